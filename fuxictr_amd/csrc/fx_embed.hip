@@ -1,0 +1,416 @@
+// fx_embed.hip — input packing, multi-field embedding gather, numeric-weight gradient,
+// FM second-order term and LR first-order term.  HBM/latency-bound kernels: one 64-byte row
+// (D=16 fp32) is read by a quad of lanes as 4 x float4, lookups of one sample are adjacent so
+// the [B,F,D] record is written as whole 128-B lines, no intermediate per-field tensors exist.
+//
+// Reference behaviour restated here (paths relative to the reference checkout):
+//   fuxictr/pytorch/layers/embeddings/feature_embedding.py:261-297 (per-feature lookup loop),
+//   :230-259 (stack/cat), fuxictr/pytorch/layers/blocks/logistic_regression.py:55-58,
+//   fuxictr/pytorch/layers/interactions/inner_product.py:55-62.
+#include "fx_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// fx_pack_columns
+// ---------------------------------------------------------------------------------------------
+#define FX_PACK_MAX_COLS 64
+struct PackArgs {
+    const void* col[FX_PACK_MAX_COLS];
+    int32_t dtype[FX_PACK_MAX_COLS];
+    int32_t width[FX_PACK_MAX_COLS];
+    int64_t out_col[FX_PACK_MAX_COLS];
+    int64_t B;
+    int64_t out_ld;
+    void* out;
+};
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_pack_columns(PackArgs a) {
+    const int c = blockIdx.y;
+    const int64_t w = a.width[c];
+    const int64_t n = a.B * w;
+    const int dt = a.dtype[c];
+    const void* src = a.col[c];
+    OutT* out = reinterpret_cast<OutT*>(a.out);
+    const int64_t oc = a.out_col[c];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / w, k = i - b * w;
+        OutT v;
+        if (dt == FX_F64) v = (OutT) reinterpret_cast<const double*>(src)[i];
+        else if (dt == FX_I64) v = (OutT) reinterpret_cast<const int64_t*>(src)[i];
+        else if (dt == FX_F32) v = (OutT) reinterpret_cast<const float*>(src)[i];
+        else v = (OutT) reinterpret_cast<const int32_t*>(src)[i];
+        out[b * a.out_ld + oc + k] = v;
+    }
+}
+
+extern "C" int fx_pack_columns(const void* const* cols_host, const int32_t* dtypes_host,
+                               const int32_t* widths_host, int32_t ncols, int64_t B,
+                               int32_t out_dtype, void* out, int64_t out_ld, int64_t out_col0,
+                               fx_stream_t stream) {
+    FX_CHECK_ARG(ncols >= 0 && ncols <= FX_PACK_MAX_COLS, "fx_pack_columns: ncols=%d not in [0,%d]",
+                 ncols, FX_PACK_MAX_COLS);
+    FX_CHECK_ARG(out_dtype == FX_I32 || out_dtype == FX_F32,
+                 "fx_pack_columns: out_dtype must be FX_I32 or FX_F32");
+    FX_CHECK_ARG(B >= 0, "fx_pack_columns: B < 0");
+    if (ncols == 0 || B == 0) return FX_OK;
+    FX_CHECK_ARG(out != nullptr && cols_host && dtypes_host && widths_host,
+                 "fx_pack_columns: null pointer");
+    PackArgs a;
+    memset(&a, 0, sizeof(a));
+    int64_t col = out_col0, maxw = 1;
+    for (int c = 0; c < ncols; ++c) {
+        FX_CHECK_ARG(cols_host[c] != nullptr, "fx_pack_columns: column %d is null", c);
+        FX_CHECK_ARG(dtypes_host[c] >= FX_F32 && dtypes_host[c] <= FX_I64,
+                     "fx_pack_columns: bad dtype %d for column %d", dtypes_host[c], c);
+        FX_CHECK_ARG(widths_host[c] >= 1, "fx_pack_columns: width of column %d < 1", c);
+        a.col[c] = cols_host[c];
+        a.dtype[c] = dtypes_host[c];
+        a.width[c] = widths_host[c];
+        a.out_col[c] = col;
+        col += widths_host[c];
+        if (widths_host[c] > maxw) maxw = widths_host[c];
+    }
+    FX_CHECK_ARG(col <= out_ld, "fx_pack_columns: columns (%lld) exceed out_ld (%lld)",
+                 (long long)col, (long long)out_ld);
+    a.B = B;
+    a.out_ld = out_ld;
+    a.out = out;
+    int64_t gx = fx_ceil_div(B * maxw, 256);
+    if (gx > 1024) gx = 1024;
+    dim3 grid((unsigned)gx, (unsigned)ncols);
+    if (out_dtype == FX_I32)
+        hipLaunchKernelGGL(k_pack_columns<int32_t>, grid, dim3(256), 0, fx_hip_stream(stream), a);
+    else
+        hipLaunchKernelGGL(k_pack_columns<float>, grid, dim3(256), 0, fx_hip_stream(stream), a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fx_emb_gather_fwd: item i -> (b = i / (C+Fd), r = i % (C+Fd)); r < C is an id lookup, else a
+// numeric expansion.  `lanes` lanes (VEC floats each) serve one item.
+// ---------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const float* table;
+    const int32_t* ids;
+    int64_t ids_ld;
+    const int64_t* col_row_base;
+    const int32_t* col_vocab;
+    const int64_t* col_out_off;
+    const float* dense;
+    int64_t dense_ld;
+    const float* num_w;
+    const int64_t* num_out_off;
+    float* out;
+    int64_t out_ld;
+    int64_t B;
+    fx_scalars* scal;
+    int32_t D, C, Fd, lanes_log2;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_gather_fwd(GatherArgs a) {
+    const int lanes = 1 << a.lanes_log2;
+    const int sub = threadIdx.x & (lanes - 1);
+    const int64_t items_per_block = 256 >> a.lanes_log2;
+    const int R = a.C + a.Fd;
+    const int64_t n_items = a.B * R;
+    const int d0 = sub * VEC;
+    const bool lane_on = d0 < a.D;
+    for (int64_t item = (int64_t)blockIdx.x * items_per_block + (threadIdx.x >> a.lanes_log2);
+         item < n_items; item += (int64_t)gridDim.x * items_per_block) {
+        const int64_t b = item / R;
+        const int r = (int)(item - b * R);
+        float val[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) val[k] = 0.f;
+        int64_t off;
+        if (r < a.C) {
+            const int32_t id = a.ids[b * a.ids_ld + r];
+            off = a.col_out_off[r];
+            if (id >= 0 && id < a.col_vocab[r]) {
+                if (lane_on) {
+                    const int64_t row = a.col_row_base[r] + id;
+                    fx_load<VEC>(a.table + row * a.D + d0, val);
+                }
+            } else if (sub == 0) {
+                atomicOr(&a.scal->err_flag, FX_FLAG_BAD_ID);
+            }
+        } else {
+            const int j = r - a.C;
+            off = a.num_out_off[j];
+            if (lane_on) {
+                const float x = a.dense[b * a.dense_ld + j];
+                float w[VEC];
+                fx_load<VEC>(a.num_w + (int64_t)j * a.D + d0, w);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) val[k] = x * w[k];
+            }
+        }
+        if (lane_on) fx_store<VEC>(a.out + b * a.out_ld + off + d0, val);
+    }
+}
+
+static int fx_log2i(int x) {
+    int l = 0;
+    while ((1 << l) < x) ++l;
+    return l;
+}
+
+extern "C" int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* ids,
+                                 int64_t ids_ld, const int64_t* col_row_base,
+                                 const int32_t* col_vocab, const int64_t* col_out_off, int32_t C,
+                                 const float* dense, int64_t dense_ld, const float* num_w,
+                                 const int64_t* num_out_off, int32_t Fd, float* out,
+                                 int64_t out_ld, int64_t B, fx_scalars* scal,
+                                 fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256, "fx_emb_gather_fwd: D=%d not in [1,256]", D);
+    FX_CHECK_ARG(C >= 0 && Fd >= 0 && B >= 0, "fx_emb_gather_fwd: negative size");
+    if (B == 0 || C + Fd == 0) return FX_OK;
+    FX_CHECK_ARG(out && scal, "fx_emb_gather_fwd: null out/scal");
+    FX_CHECK_ARG(C == 0 || (table && ids && col_row_base && col_vocab && col_out_off),
+                 "fx_emb_gather_fwd: null sparse argument");
+    FX_CHECK_ARG(Fd == 0 || (dense && num_w && num_out_off),
+                 "fx_emb_gather_fwd: null numeric argument");
+    const FxRowGeom g = fx_row_geom(D);
+    FX_CHECK_ARG(out_ld % g.vec == 0, "fx_emb_gather_fwd: out_ld=%lld not a multiple of %d",
+                 (long long)out_ld, g.vec);
+    GatherArgs a{table, ids, ids_ld, col_row_base, col_vocab, col_out_off, dense, dense_ld,
+                 num_w, num_out_off, out, out_ld, B, scal, D, C, Fd, fx_log2i(g.lanes)};
+    const int64_t items = B * (int64_t)(C + Fd);
+    int64_t blocks = fx_ceil_div(items, 256 / g.lanes);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    dim3 grid((unsigned)blocks);
+    hipStream_t s = fx_hip_stream(stream);
+    if (g.vec == 4) hipLaunchKernelGGL(k_emb_gather_fwd<4>, grid, dim3(256), 0, s, a);
+    else if (g.vec == 2) hipLaunchKernelGGL(k_emb_gather_fwd<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_emb_gather_fwd<1>, grid, dim3(256), 0, s, a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fx_emb_numeric_grad: one 1024-thread block per numeric feature j; thread (grp, d) sums rows
+// b = grp, grp + ngrp, ... then a fixed-order LDS reduction over the groups.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_emb_numeric_grad(const float* dout, int64_t dout_ld,
+                                                           const int64_t* num_out_off,
+                                                           const float* dense, int64_t dense_ld,
+                                                           int D, int Dp, int64_t B,
+                                                           float* dnum_w) {
+    __shared__ float red[1024];
+    const int j = blockIdx.x;
+    const int d = threadIdx.x % Dp;
+    const int grp = threadIdx.x / Dp;
+    const int ngrp = 1024 / Dp;
+    const int64_t off = num_out_off[j];
+    float acc = 0.f;
+    if (d < D) {
+        for (int64_t b = grp; b < B; b += ngrp)
+            acc = fmaf(dense[b * dense_ld + j], dout[b * dout_ld + off + d], acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = ngrp >> 1; s > 0; s >>= 1) {
+        if (grp < s) red[threadIdx.x] += red[threadIdx.x + s * Dp];
+        __syncthreads();
+    }
+    if (grp == 0 && d < D) dnum_w[(int64_t)j * D + d] = red[d];
+}
+
+extern "C" int fx_emb_numeric_grad(const float* dout, int64_t dout_ld,
+                                   const int64_t* num_out_off, const float* dense,
+                                   int64_t dense_ld, int32_t Fd, int32_t D, int64_t B,
+                                   float* dnum_w, fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256, "fx_emb_numeric_grad: D=%d not in [1,256]", D);
+    if (Fd <= 0) return FX_OK;
+    FX_CHECK_ARG(dout && num_out_off && dense && dnum_w, "fx_emb_numeric_grad: null pointer");
+    int Dp = 1;
+    while (Dp < D) Dp <<= 1;
+    hipLaunchKernelGGL(k_emb_numeric_grad, dim3(Fd), dim3(1024), 0, fx_hip_stream(stream), dout,
+                       dout_ld, num_out_off, dense, dense_ld, (int)D, Dp, B, dnum_w);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FM second-order term.  S lanes per sample (S = max(16, lanes-per-row)); S/lanes fields are
+// walked in parallel; per-d field sums are completed with xor shuffles across the field-parallel
+// lanes, then one more xor reduction over all S lanes gives 0.5*(sum_d s_d^2 - sum e^2).
+// ---------------------------------------------------------------------------------------------
+struct FmArgs {
+    const float* emb;
+    int64_t emb_ld;
+    const float* addend;
+    const float* g;
+    float* out;
+    float* demb;
+    int64_t demb_ld;
+    int64_t B;
+    int32_t F, D, lanes_log2, S_log2, accumulate;
+};
+
+template <int VEC, bool BWD>
+__global__ __launch_bounds__(256) void k_fm(FmArgs a) {
+    const int lanes = 1 << a.lanes_log2;
+    const int S = 1 << a.S_log2;
+    const int ls = threadIdx.x & (S - 1);        // lane within sample group
+    const int sub = ls & (lanes - 1);            // lane within row
+    const int fpar = ls >> a.lanes_log2;         // field-parallel index
+    const int nfpar = S >> a.lanes_log2;
+    const int d0 = sub * VEC;
+    const bool lane_on = d0 < a.D;
+    const int64_t spb = 256 >> a.S_log2;         // samples per block
+    // every lane of a wave must take part in the shuffles: iterate on a wave-uniform bound
+    const int64_t n_iter = (a.B + spb * gridDim.x - 1) / (spb * gridDim.x);
+    for (int64_t it = 0; it < n_iter; ++it) {
+        const int64_t b = (it * gridDim.x + blockIdx.x) * spb + (threadIdx.x >> a.S_log2);
+        const bool valid = b < a.B;
+        float s[VEC], q = 0.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) s[k] = 0.f;
+        if (valid && lane_on) {
+            const float* e = a.emb + b * a.emb_ld + d0;
+            for (int f = fpar; f < a.F; f += nfpar) {
+                float v[VEC];
+                fx_load<VEC>(e + (int64_t)f * a.D, v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    s[k] += v[k];
+                    q = fmaf(v[k], v[k], q);
+                }
+            }
+        }
+        // complete the per-d field sums across the field-parallel lanes
+        for (int off = lanes; off < S; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s[k] += __shfl_xor(s[k], off, 64);
+        }
+        if constexpr (!BWD) {
+            float t = -q;
+            if (fpar == 0) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) t = fmaf(s[k], s[k], t);
+            }
+            for (int off = 1; off < S; off <<= 1) t += __shfl_xor(t, off, 64);
+            if (valid && ls == 0) {
+                float r = 0.5f * t;
+                if (a.addend) r += a.addend[b];
+                a.out[b] = r;
+            }
+        } else {
+            if (valid && lane_on) {
+                const float gb = a.g[b];
+                const float* e = a.emb + b * a.emb_ld + d0;
+                float* de = a.demb + b * a.demb_ld + d0;
+                for (int f = fpar; f < a.F; f += nfpar) {
+                    float v[VEC], o[VEC];
+                    fx_load<VEC>(e + (int64_t)f * a.D, v);
+                    if (a.accumulate) fx_load<VEC>(de + (int64_t)f * a.D, o);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const float t = gb * (s[k] - v[k]);
+                        o[k] = a.accumulate ? o[k] + t : t;
+                    }
+                    fx_store<VEC>(de + (int64_t)f * a.D, o);
+                }
+            }
+        }
+    }
+}
+
+static int fx_fm_launch(bool bwd, FmArgs a, fx_stream_t stream) {
+    const FxRowGeom g = fx_row_geom(a.D);
+    a.lanes_log2 = fx_log2i(g.lanes);
+    int S = g.lanes < 16 ? 16 : g.lanes;
+    a.S_log2 = fx_log2i(S);
+    int64_t blocks = fx_ceil_div(a.B, 256 / S);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    dim3 grid((unsigned)blocks);
+    hipStream_t s = fx_hip_stream(stream);
+    if (!bwd) {
+        if (g.vec == 4) hipLaunchKernelGGL((k_fm<4, false>), grid, dim3(256), 0, s, a);
+        else if (g.vec == 2) hipLaunchKernelGGL((k_fm<2, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_fm<1, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (g.vec == 4) hipLaunchKernelGGL((k_fm<4, true>), grid, dim3(256), 0, s, a);
+        else if (g.vec == 2) hipLaunchKernelGGL((k_fm<2, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_fm<1, true>), grid, dim3(256), 0, s, a);
+    }
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+extern "C" int fx_fm_fwd(const float* emb, int64_t emb_ld, int32_t F, int32_t D,
+                         const float* addend, float* out, int64_t B, fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256 && F >= 1, "fx_fm_fwd: bad F=%d / D=%d", F, D);
+    if (B <= 0) return FX_OK;
+    FX_CHECK_ARG(emb && out, "fx_fm_fwd: null pointer");
+    const FxRowGeom g = fx_row_geom(D);
+    FX_CHECK_ARG(emb_ld % g.vec == 0, "fx_fm_fwd: emb_ld not a multiple of %d", g.vec);
+    FmArgs a{emb, emb_ld, addend, nullptr, out, nullptr, 0, B, F, D, 0, 0, 0};
+    return fx_fm_launch(false, a, stream);
+}
+
+extern "C" int fx_fm_bwd(const float* emb, int64_t emb_ld, int32_t F, int32_t D, const float* g,
+                         float* demb, int64_t demb_ld, int32_t accumulate, int64_t B,
+                         fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256 && F >= 1, "fx_fm_bwd: bad F=%d / D=%d", F, D);
+    if (B <= 0) return FX_OK;
+    FX_CHECK_ARG(emb && g && demb, "fx_fm_bwd: null pointer");
+    const FxRowGeom geo = fx_row_geom(D);
+    FX_CHECK_ARG(emb_ld % geo.vec == 0 && demb_ld % geo.vec == 0,
+                 "fx_fm_bwd: leading dimensions not a multiple of %d", geo.vec);
+    FmArgs a{emb, emb_ld, nullptr, g, nullptr, demb, demb_ld, B, F, D, 0, 0, accumulate};
+    return fx_fm_launch(true, a, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LR first-order term: 16 lanes per sample walk the C id columns (4-byte rows of the D=1 table)
+// and the Fd numeric columns, then an xor reduction.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lr_fwd(const float* table1, const int32_t* ids,
+                                                int64_t ids_ld, const int64_t* col_row_base,
+                                                const int32_t* col_vocab, int C,
+                                                const float* dense, int64_t dense_ld,
+                                                const float* num_w1, int Fd, const float* bias,
+                                                float* out, int64_t B, fx_scalars* scal) {
+    const int ls = threadIdx.x & 15;
+    const int64_t n_iter = (B + 16 * (int64_t)gridDim.x - 1) / (16 * (int64_t)gridDim.x);
+    for (int64_t it = 0; it < n_iter; ++it) {
+        const int64_t b = (it * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 4);
+        const bool valid = b < B;
+        float acc = 0.f;
+        if (valid) {
+            for (int c = ls; c < C; c += 16) {
+                const int32_t id = ids[b * ids_ld + c];
+                if (id >= 0 && id < col_vocab[c]) acc += table1[col_row_base[c] + id];
+                else atomicOr(&scal->err_flag, FX_FLAG_BAD_ID);
+            }
+            for (int j = ls; j < Fd; j += 16) acc = fmaf(dense[b * dense_ld + j], num_w1[j], acc);
+        }
+        for (int off = 1; off < 16; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        if (valid && ls == 0) out[b] = acc + (bias ? bias[0] : 0.f);
+    }
+}
+
+extern "C" int fx_lr_fwd(const float* table1, const int32_t* ids, int64_t ids_ld,
+                         const int64_t* col_row_base, const int32_t* col_vocab, int32_t C,
+                         const float* dense, int64_t dense_ld, const float* num_w1, int32_t Fd,
+                         const float* bias, float* out, int64_t B, fx_scalars* scal,
+                         fx_stream_t stream) {
+    FX_CHECK_ARG(C >= 0 && Fd >= 0, "fx_lr_fwd: negative size");
+    if (B <= 0) return FX_OK;
+    FX_CHECK_ARG(out && scal, "fx_lr_fwd: null out/scal");
+    FX_CHECK_ARG(C == 0 || (table1 && ids && col_row_base && col_vocab),
+                 "fx_lr_fwd: null sparse argument");
+    FX_CHECK_ARG(Fd == 0 || (dense && num_w1), "fx_lr_fwd: null numeric argument");
+    int64_t blocks = fx_ceil_div(B, 16);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_lr_fwd, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream),
+                       table1, ids, ids_ld, col_row_base, col_vocab, (int)C, dense, dense_ld,
+                       num_w1, (int)Fd, bias, out, B, scal);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}

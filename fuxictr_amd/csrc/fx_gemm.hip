@@ -1,0 +1,357 @@
+// fx_gemm.hip — fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products,
+// fp32 accumulate, 157 TFLOP/s dense peak on MI355X) with a fused epilogue, plus the column-sum
+// (bias gradient) and sigmoid+BCE kernels of the dense tower.
+//
+// Replaces the aten::addmm / relu / mul / add launches of
+//   fuxictr/pytorch/layers/blocks/mlp_block.py:96            (Linear -> ReLU stack)
+//   fuxictr/pytorch/layers/interactions/cross_net.py:126-129 (X_{i+1} = X_i + X_0 * (W X_i + b))
+// and their autograd (dX = dZ W, dW = dZ^T X, db = colsum dZ) triggered at rank_model.py:320.
+//
+// Tiling (one wave = 64 lanes, 4 waves per workgroup, one workgroup per CU at B=4096):
+//   block tile 128x128x16, LDS double-buffered, k-major tiles T[k][m] so that an MFMA operand
+//   fragment (lane l: row l&31, k = l>>5) is one conflict-free ds_read_b32;
+//   wave tile 64x64 = 2x2 MFMA tiles of 32x32 -> 4 independent accumulators (64 VGPRs);
+//   global->register prefetch of tile t+1 is issued before the MFMAs of tile t;
+//   blockIdx is remapped so the 8 n-tiles that share one A row-panel run on the same XCD (L2).
+#include "fx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FX_BM 128
+#define FX_BN 128
+#define FX_BK 16
+#define FX_LD_KC 130   // row stride of a tile filled by transposing 4-byte LDS writes (conflict-free)
+#define FX_LD_MC 132   // row stride of a tile filled by 16-byte LDS writes (keeps 16-B alignment)
+
+struct GemmArgs {
+    const float* A;
+    int64_t lda;
+    const float* B;
+    int64_t ldb;
+    float* C;
+    int64_t ldc;
+    int64_t M, N, K;
+    int64_t k_chunk;
+    fx_gemm_epilogue epi;
+    float* ws;
+    int32_t split_k;
+    int32_t tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float fx_epilogue(const fx_gemm_epilogue& e, float z, int64_t m,
+                                             int64_t n) {
+    if (e.bias) z += e.bias[n];
+    if (e.zout) e.zout[m * e.ldz + n] = z;
+    if (e.act == 1) z = fmaxf(z, 0.f);
+    if (e.mul) z *= e.mul[m * e.ldmul + n];
+    if (e.mask) z = e.mask[m * e.ldmask + n] > 0.f ? z : 0.f;
+    if (e.add) z += e.add[m * e.ldadd + n];
+    return z;
+}
+
+// Operand tile loader.  R = extent of the non-contracted dimension (M for A, N for B).
+// KC: element (r,k) at P[r*ld + k] (k contiguous) else at P[k*ld + r] (r contiguous).
+template <bool KC, bool VEC>
+struct TileLoader {
+    float4 st[2];
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int64_t r0,
+                                         int64_t R, int64_t k0, int64_t kend) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = threadIdx.x + 256 * p;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (KC) {
+                const int64_t r = r0 + (q >> 2);
+                const int64_t k = k0 + ((q & 3) << 2);
+                if (r < R) {
+                    const float* src = P + r * ld + k;
+                    if constexpr (VEC) {
+                        if (k < kend) v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (k + 0 < kend) v.x = src[0];
+                        if (k + 1 < kend) v.y = src[1];
+                        if (k + 2 < kend) v.z = src[2];
+                        if (k + 3 < kend) v.w = src[3];
+                    }
+                }
+            } else {
+                const int64_t k = k0 + (q >> 5);
+                const int64_t r = r0 + ((q & 31) << 2);
+                if (k < kend) {
+                    const float* src = P + k * ld + r;
+                    if constexpr (VEC) {
+                        if (r < R) v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (r + 0 < R) v.x = src[0];
+                        if (r + 1 < R) v.y = src[1];
+                        if (r + 2 < R) v.z = src[2];
+                        if (r + 3 < R) v.w = src[3];
+                    }
+                }
+            }
+            st[p] = v;
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ T) const {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = threadIdx.x + 256 * p;
+            if constexpr (KC) {
+                const int r = q >> 2, kq = (q & 3) << 2;
+                T[(kq + 0) * FX_LD_KC + r] = st[p].x;
+                T[(kq + 1) * FX_LD_KC + r] = st[p].y;
+                T[(kq + 2) * FX_LD_KC + r] = st[p].z;
+                T[(kq + 3) * FX_LD_KC + r] = st[p].w;
+            } else {
+                const int k = q >> 5, r = (q & 31) << 2;
+                *reinterpret_cast<float4*>(T + k * FX_LD_MC + r) = st[p];
+            }
+        }
+    }
+};
+
+template <bool A_KC, bool B_KC, bool A_VEC, bool B_VEC>
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
+    constexpr int LDA = A_KC ? FX_LD_KC : FX_LD_MC;
+    constexpr int LDB = B_KC ? FX_LD_KC : FX_LD_MC;
+    __shared__ __attribute__((aligned(16))) float As[2][FX_BK * FX_LD_MC];
+    __shared__ __attribute__((aligned(16))) float Bs[2][FX_BK * FX_LD_MC];
+
+    // XCD-aware tile mapping: workgroup L runs on XCD L % 8; give each XCD a contiguous range of
+    // tiles (row-major over (tm, tn)) so the n-tiles sharing an A panel share one L2.
+    const int64_t nwg = (int64_t)a.tiles_m * a.tiles_n;
+    const int64_t L = blockIdx.x;
+    int64_t T = L;
+    if (nwg >= 8) {
+        const int64_t q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+        T = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    }
+    const int64_t m0 = (T / a.tiles_n) * FX_BM;
+    const int64_t n0 = (T % a.tiles_n) * FX_BN;
+    const int z = blockIdx.y;
+    const int64_t kbeg = (int64_t)z * a.k_chunk;
+    const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TileLoader<A_KC, A_VEC> la;
+    TileLoader<B_KC, B_VEC> lb;
+    const int64_t nk = (kend > kbeg) ? (kend - kbeg + FX_BK - 1) / FX_BK : 0;
+    if (nk > 0) {
+        la.load(a.A, a.lda, m0, a.M, kbeg, kend);
+        lb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
+        la.store(As[0]);
+        lb.store(Bs[0]);
+    }
+    __syncthreads();
+    for (int64_t t = 0; t < nk; ++t) {
+        const int cur = (int)(t & 1);
+        if (t + 1 < nk) {
+            la.load(a.A, a.lda, m0, a.M, kbeg + (t + 1) * FX_BK, kend);
+            lb.load(a.B, a.ldb, n0, a.N, kbeg + (t + 1) * FX_BK, kend);
+        }
+        const float* as = As[cur] + half * LDA + wm * 64 + l31;
+        const float* bs = Bs[cur] + half * LDB + wn * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < FX_BK; kk += 2) {
+            const float a0 = as[kk * LDA], a1 = as[kk * LDA + 32];
+            const float b0 = bs[kk * LDB], b1 = bs[kk * LDB + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (t + 1 < nk) {
+            la.store(As[cur ^ 1]);
+            lb.store(Bs[cur ^ 1]);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= a.M) continue;
+                if (a.split_k > 1) {
+                    a.ws[((int64_t)z * a.M + m) * a.N + n] = acc[i][j][r];
+                } else {
+                    a.C[m * a.ldc + n] = fx_epilogue(a.epi, acc[i][j][r], m, n);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a) {
+    const int64_t total = a.M * a.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < a.split_k; ++z) s += a.ws[(int64_t)z * total + i];
+        const int64_t m = i / a.N, n = i - m * a.N;
+        a.C[m * a.ldc + n] = fx_epilogue(a.epi, s, m, n);
+    }
+}
+
+template <bool A_KC, bool B_KC>
+static void fx_gemm_dispatch_vec(bool av, bool bv, dim3 grid, hipStream_t s, const GemmArgs& a) {
+    if (av && bv) hipLaunchKernelGGL((k_gemm_f32<A_KC, B_KC, true, true>), grid, dim3(256), 0, s, a);
+    else if (av) hipLaunchKernelGGL((k_gemm_f32<A_KC, B_KC, true, false>), grid, dim3(256), 0, s, a);
+    else if (bv) hipLaunchKernelGGL((k_gemm_f32<A_KC, B_KC, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_f32<A_KC, B_KC, false, false>), grid, dim3(256), 0, s, a);
+}
+
+extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
+                           const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                           int64_t ldc, const fx_gemm_epilogue* epi_host, int32_t split_k,
+                           float* workspace, fx_stream_t stream) {
+    FX_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "fx_gemm_f32: negative dimension");
+    if (M == 0 || N == 0) return FX_OK;
+    FX_CHECK_ARG(A && B && C, "fx_gemm_f32: null matrix");
+    FX_CHECK_ARG(lda >= (transa ? M : K) && ldb >= (transb ? K : N) && ldc >= N,
+                 "fx_gemm_f32: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)",
+                 (long long)lda, (long long)ldb, (long long)ldc);
+    if (split_k < 1) split_k = 1;
+    FX_CHECK_ARG(split_k == 1 || workspace, "fx_gemm_f32: split_k > 1 needs a workspace");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K;
+    if (epi_host) a.epi = *epi_host;
+    // K per split, rounded up to the k-tile so every split starts on a 16-B boundary
+    int64_t kc = fx_ceil_div(fx_ceil_div(K, split_k), FX_BK) * FX_BK;
+    if (kc < FX_BK) kc = FX_BK;
+    split_k = (int32_t)fx_ceil_div(K > 0 ? K : 1, kc);
+    a.k_chunk = kc;
+    a.split_k = split_k;
+    a.ws = workspace;
+    a.tiles_m = (int32_t)fx_ceil_div(M, FX_BM);
+    a.tiles_n = (int32_t)fx_ceil_div(N, FX_BN);
+    const bool a_kc = !transa, b_kc = transb != 0;
+    const bool a_al = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool b_al = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    const bool av = a_al && (a_kc ? (K % 4 == 0) : (M % 4 == 0));
+    const bool bv = b_al && (b_kc ? (K % 4 == 0) : (N % 4 == 0));
+    dim3 grid((unsigned)((int64_t)a.tiles_m * a.tiles_n), (unsigned)split_k);
+    hipStream_t s = fx_hip_stream(stream);
+    if (a_kc && b_kc) fx_gemm_dispatch_vec<true, true>(av, bv, grid, s, a);
+    else if (a_kc) fx_gemm_dispatch_vec<true, false>(av, bv, grid, s, a);
+    else if (b_kc) fx_gemm_dispatch_vec<false, true>(av, bv, grid, s, a);
+    else fx_gemm_dispatch_vec<false, false>(av, bv, grid, s, a);
+    FX_CHECK_LAUNCH();
+    if (split_k > 1) {
+        int64_t blocks = fx_ceil_div(M * N, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        FX_CHECK_LAUNCH();
+    }
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums (bias gradient), two deterministic stages
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colsum_stage1(const float* X, int64_t ldx, int64_t M,
+                                                       int64_t N, int64_t rows_per_chunk,
+                                                       float* ws) {
+    __shared__ float red[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + tx;
+    const int64_t mb = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t me = (mb + rows_per_chunk < M) ? mb + rows_per_chunk : M;
+    float acc = 0.f;
+    if (n < N)
+        for (int64_t m = mb + ty; m < me; m += 4) acc += X[m * ldx + n];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (ty == 0 && n < N)
+        ws[(int64_t)blockIdx.y * N + n] = (red[tx] + red[tx + 64]) + (red[tx + 128] + red[tx + 192]);
+}
+
+__global__ __launch_bounds__(256) void k_colsum_stage2(const float* ws, int64_t N, int chunks,
+                                                       float* out) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += ws[(int64_t)c * N + n];
+    out[n] = s;
+}
+
+extern "C" int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out,
+                         float* workspace, fx_stream_t stream) {
+    FX_CHECK_ARG(M >= 0 && N >= 0, "fx_colsum: negative dimension");
+    if (N == 0) return FX_OK;
+    FX_CHECK_ARG(X && out && workspace, "fx_colsum: null pointer");
+    hipStream_t s = fx_hip_stream(stream);
+    const int64_t rpc = fx_ceil_div(M > 0 ? M : 1, FX_COLSUM_CHUNKS);
+    hipLaunchKernelGGL(k_colsum_stage1, dim3((unsigned)fx_ceil_div(N, 64), FX_COLSUM_CHUNKS),
+                       dim3(256), 0, s, X, ldx, M, N, rpc, workspace);
+    FX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_colsum_stage2, dim3((unsigned)fx_ceil_div(N, 256)), dim3(256), 0, s,
+                       workspace, N, (int)FX_COLSUM_CHUNKS, out);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sigmoid + binary cross entropy (mean) + dloss/dlogit, one workgroup, fixed-order reduction
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_sigmoid_bce(const float* logit, const float* y,
+                                                      int64_t B, float* prob, float* loss,
+                                                      float* dlogit) {
+    __shared__ float red[1024];
+    float acc = 0.f;
+    const float invB = 1.f / (float)B;
+    for (int64_t i = threadIdx.x; i < B; i += 1024) {
+        const float x = logit[i];
+        const float p = 1.f / (1.f + expf(-x));  // torch.sigmoid
+        const float t = y[i];
+        // F.binary_cross_entropy clamps each log term at -100
+        const float lp = fmaxf(logf(p), -100.f);
+        const float lq = fmaxf(logf(1.f - p), -100.f);
+        acc += -(t * lp + (1.f - t) * lq);
+        if (prob) prob[i] = p;
+        if (dlogit) {
+            // binary_cross_entropy_backward: (p - t) / max((1 - p) * p, 1e-12) * grad, then
+            // sigmoid_backward: * p * (1 - p)
+            const float dp = (p - t) / fmaxf((1.f - p) * p, 1e-12f) * invB;
+            dlogit[i] = dp * ((1.f - p) * p);
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) *loss = red[0] * invB;
+}
+
+extern "C" int fx_sigmoid_bce(const float* logit, const float* y, int64_t B, float* prob,
+                              float* loss, float* dlogit, fx_stream_t stream) {
+    FX_CHECK_ARG(B > 0, "fx_sigmoid_bce: B must be positive");
+    FX_CHECK_ARG(logit && y, "fx_sigmoid_bce: null pointer");
+    hipLaunchKernelGGL(k_sigmoid_bce, dim3(1), dim3(1024), 0, fx_hip_stream(stream), logit, y, B,
+                       prob, loss, dlogit);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}

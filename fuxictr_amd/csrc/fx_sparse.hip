@@ -1,0 +1,737 @@
+// fx_sparse.hip — sparse side of the training step: index de-duplication, run-wise gradient
+// reduction to unique rows, global-norm clip coefficient, sparse-row Adam / SGD with the
+// "exact" catch-up replay, and the multi-tensor dense optimizer kernels.
+//
+// What this replaces in the reference (paths relative to the reference checkout):
+//   aten::embedding_dense_backward (zero-filled [V,D] grad + index_add), triggered at
+//     fuxictr/pytorch/models/rank_model.py:320
+//   nn.utils.clip_grad_norm_ over every parameter            rank_model.py:321
+//   torch.optim.Adam / SGD step over every table row          rank_model.py:322, torch_utils.py:76
+// None of the table-sized passes exist here: the gradient only ever exists for the unique rows
+// a batch touches.  All reductions use a fixed order (stable sort by row, ascending lookup
+// position inside a run, fixed trees) so results are run-to-run deterministic.
+#include "fx_common.h"
+
+#include <rocprim/rocprim.hpp>
+
+// ---------------------------------------------------------------------------------------------
+// de-duplication
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_keys(const int32_t* ids, int64_t ids_ld, int64_t n,
+                                                    int C, const int64_t* col_row_base,
+                                                    const int32_t* col_vocab,
+                                                    const int32_t* col_pad, uint32_t sentinel,
+                                                    uint32_t* keys, uint32_t* pos) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / C;
+        const int c = (int)(i - b * C);
+        const int32_t id = ids[b * ids_ld + c];
+        uint32_t key = sentinel;
+        if (id >= 0 && id < col_vocab[c] && id != col_pad[c])
+            key = (uint32_t)(col_row_base[c] + id);
+        keys[i] = key;
+        pos[i] = (uint32_t)i;
+    }
+}
+
+struct HeadFlag {
+    const uint32_t* key;
+    uint32_t sentinel;
+    __host__ __device__ uint32_t operator()(uint32_t i) const {
+        const uint32_t k = key[i];
+        return (k != sentinel && (i == 0 || key[i - 1] != k)) ? 1u : 0u;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_scatter_unique(const uint32_t* key, const uint32_t* scan,
+                                                        int64_t n, uint32_t sentinel,
+                                                        uint32_t* uniq_row, uint32_t* seg_start,
+                                                        int32_t* n_unique) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = key[i];
+        if (k == sentinel) {
+            if (i == 0) {  // no valid lookup at all
+                *n_unique = 0;
+                seg_start[0] = 0;
+            }
+            continue;
+        }
+        const uint32_t u = scan[i];  // inclusive count of heads up to i  (>= 1 here)
+        if (i == 0 || key[i - 1] != k) {
+            uniq_row[u - 1] = k;
+            seg_start[u - 1] = (uint32_t)i;
+        }
+        if (i == n - 1 || key[i + 1] == sentinel) {  // last valid lookup
+            seg_start[u] = (uint32_t)(i + 1);
+            *n_unique = (int32_t)u;
+        }
+    }
+}
+
+static inline size_t fx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static hipError_t fx_dedup_temp_bytes(int64_t n, size_t* sort_bytes, size_t* scan_bytes) {
+    // size queries are host-only but not free; a training loop asks for the same n every step
+    static thread_local int64_t c_n = -1;
+    static thread_local size_t c_sort = 0, c_scan = 0;
+    if (n == c_n) {
+        *sort_bytes = c_sort;
+        *scan_bytes = c_scan;
+        return hipSuccess;
+    }
+    uint32_t* nul = nullptr;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, *sort_bytes, nul, nul, nul, nul, (size_t)n,
+                                             0u, 32u, (hipStream_t)0);
+    if (e != hipSuccess) return e;
+    HeadFlag hf{nullptr, 0};
+    auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), hf);
+    e = rocprim::inclusive_scan(nullptr, *scan_bytes, in, nul, (size_t)n,
+                                rocprim::plus<uint32_t>(), (hipStream_t)0);
+    if (e == hipSuccess) {
+        c_n = n;
+        c_sort = *sort_bytes;
+        c_scan = *scan_bytes;
+    }
+    return e;
+}
+
+extern "C" size_t fx_dedup_workspace_bytes(int64_t n_lookups) {
+    if (n_lookups <= 0) return 256;
+    size_t sort_bytes = 0, scan_bytes = 0;
+    if (fx_dedup_temp_bytes(n_lookups, &sort_bytes, &scan_bytes) != hipSuccess) {
+        fx_set_error("fx_dedup_workspace_bytes: rocprim size query failed (no HIP device?)");
+        return 0;
+    }
+    const size_t arr = fx_align_up((size_t)n_lookups * sizeof(uint32_t), 256);
+    const size_t tmp = fx_align_up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes, 256);
+    return 3 * arr + tmp + 256;
+}
+
+extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
+                        const int64_t* col_row_base, const int32_t* col_vocab,
+                        const int32_t* col_pad, int64_t total_rows, void* workspace,
+                        size_t workspace_bytes, uint32_t* sorted_key, uint32_t* sorted_pos,
+                        uint32_t* uniq_row, uint32_t* seg_start, int32_t* n_unique,
+                        fx_stream_t stream) {
+    FX_CHECK_ARG(B >= 0 && C >= 0, "fx_dedup: negative size");
+    FX_CHECK_ARG(total_rows > 0 && total_rows < (int64_t)0xFFFFFFFFLL,
+                 "fx_dedup: total_rows=%lld must be in (0, 2^32-1)", (long long)total_rows);
+    FX_CHECK_ARG(n_unique && seg_start, "fx_dedup: null output");
+    hipStream_t s = fx_hip_stream(stream);
+    const int64_t n = B * (int64_t)C;
+    if (n == 0) {
+        FX_CHECK_HIP(hipMemsetAsync(n_unique, 0, sizeof(int32_t), s));
+        FX_CHECK_HIP(hipMemsetAsync(seg_start, 0, sizeof(uint32_t), s));
+        return FX_OK;
+    }
+    FX_CHECK_ARG(n < (int64_t)0x7FFFFFFF, "fx_dedup: too many lookups (%lld)", (long long)n);
+    FX_CHECK_ARG(ids && col_row_base && col_vocab && col_pad && workspace && sorted_key &&
+                     sorted_pos && uniq_row,
+                 "fx_dedup: null pointer");
+    size_t sort_bytes = 0, scan_bytes = 0;
+    FX_CHECK_HIP(fx_dedup_temp_bytes(n, &sort_bytes, &scan_bytes));
+    const size_t arr = fx_align_up((size_t)n * sizeof(uint32_t), 256);
+    size_t tmp = fx_align_up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes, 256);
+    FX_CHECK_ARG(workspace_bytes >= 3 * arr + tmp, "fx_dedup: workspace too small (%zu < %zu)",
+                 workspace_bytes, 3 * arr + tmp);
+    char* w = reinterpret_cast<char*>(workspace);
+    uint32_t* keys_in = reinterpret_cast<uint32_t*>(w);
+    uint32_t* pos_in = reinterpret_cast<uint32_t*>(w + arr);
+    uint32_t* scan = reinterpret_cast<uint32_t*>(w + 2 * arr);
+    void* temp = w + 3 * arr;
+    const uint32_t sentinel = (uint32_t)total_rows;
+
+    int64_t blocks = fx_ceil_div(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_build_keys, dim3((unsigned)blocks), dim3(256), 0, s, ids, ids_ld, n,
+                       (int)C, col_row_base, col_vocab, col_pad, sentinel, keys_in, pos_in);
+    FX_CHECK_LAUNCH();
+    size_t tb = tmp;
+    FX_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, sorted_key, pos_in, sorted_pos,
+                                           (size_t)n, 0u, 32u, s));
+    HeadFlag hf{sorted_key, sentinel};
+    auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), hf);
+    tb = tmp;
+    FX_CHECK_HIP(rocprim::inclusive_scan(temp, tb, in, scan, (size_t)n,
+                                         rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_scatter_unique, dim3((unsigned)blocks), dim3(256), 0, s, sorted_key, scan,
+                       n, sentinel, uniq_row, seg_start, n_unique);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gradient reduction to unique rows.  A block of 256 threads owns RPB = 256/lanes consecutive
+// unique rows.  Phase 1: the row's lane group sums a short run (<= FX_LONG_RUN lookups) alone.
+// Phase 2: each long run of the block (hot rows of tiny tables) is summed by the whole block:
+// group g takes lookups g, g+RPB, ... and a fixed LDS tree combines the groups.  The block then
+// reduces ||G||^2 of its rows in a fixed order into one partial.
+// ---------------------------------------------------------------------------------------------
+#define FX_LONG_RUN 32
+
+struct ReduceArgs {
+    const float* dout;
+    int64_t dout_ld;
+    const int64_t* col_out_off;
+    const uint32_t* sorted_pos;
+    const uint32_t* seg_start;
+    const int32_t* n_unique;
+    float* G;
+    float* sq_partials;
+    int32_t C, D, lanes_log2;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_grad_reduce(ReduceArgs a) {
+    __shared__ float red[256 * VEC];
+    __shared__ uint32_t s_beg[256], s_end[256];
+    __shared__ float red4[4];
+    const int lanes = 1 << a.lanes_log2;
+    const int rpb = 256 >> a.lanes_log2;
+    const int sub = threadIdx.x & (lanes - 1);
+    const int grp = threadIdx.x >> a.lanes_log2;
+    const int d0 = sub * VEC;
+    const bool lane_on = d0 < a.D;
+    const int nu = *a.n_unique;
+    const int64_t u = (int64_t)blockIdx.x * rpb + grp;
+    uint32_t beg = 0, end = 0;
+    if (u < nu) {
+        beg = a.seg_start[u];
+        end = a.seg_start[u + 1];
+    }
+    if (sub == 0) {
+        s_beg[grp] = beg;
+        s_end[grp] = end;
+    }
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    const bool is_long = (end - beg) > FX_LONG_RUN;
+    if (!is_long && lane_on) {
+        for (uint32_t i = beg; i < end; ++i) {
+            const uint32_t p = a.sorted_pos[i];
+            const uint32_t b = p / (uint32_t)a.C, c = p - b * (uint32_t)a.C;
+            float v[VEC];
+            fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += v[k];
+        }
+    }
+    __syncthreads();
+    // phase 2: long runs, one at a time, whole block
+    for (int r = 0; r < rpb; ++r) {
+        const uint32_t rb = s_beg[r], re = s_end[r];
+        if (re - rb <= FX_LONG_RUN) continue;  // block-uniform
+        float part[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) part[k] = 0.f;
+        if (lane_on) {
+            for (uint32_t i = rb + grp; i < re; i += rpb) {
+                const uint32_t p = a.sorted_pos[i];
+                const uint32_t b = p / (uint32_t)a.C, c = p - b * (uint32_t)a.C;
+                float v[VEC];
+                fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) part[k] += v[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) red[k * 256 + threadIdx.x] = part[k];
+        __syncthreads();
+        for (int s = rpb >> 1; s > 0; s >>= 1) {
+            if (grp < s) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    red[k * 256 + threadIdx.x] += red[k * 256 + threadIdx.x + (s << a.lanes_log2)];
+            }
+            __syncthreads();
+        }
+        if (grp == r) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = red[k * 256 + sub];
+        }
+        __syncthreads();
+    }
+    float sq = 0.f;
+    if (u < nu && lane_on) {
+        fx_store<VEC>(a.G + u * a.D + d0, acc);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) sq = fmaf(acc[k], acc[k], sq);
+    }
+    const float tot = fx_block_sum_256(sq, red4);
+    if (threadIdx.x == 0) a.sq_partials[blockIdx.x] = tot;
+}
+
+extern "C" int64_t fx_emb_grad_reduce_partials(int64_t n_max) {
+    // worst case geometry is lanes = 64 (4 rows per block); callers size for lanes = 1 .. 64
+    // through the D they pass to fx_emb_grad_reduce, so report the count for lanes = 64.
+    return n_max <= 0 ? 1 : fx_ceil_div(n_max, 4);
+}
+
+extern "C" int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int64_t* col_out_off,
+                                  int32_t C, int32_t D, const uint32_t* sorted_pos,
+                                  const uint32_t* seg_start, const int32_t* n_unique,
+                                  int64_t n_max, float* G, float* sq_partials,
+                                  fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256 && C >= 1, "fx_emb_grad_reduce: bad C=%d / D=%d", C, D);
+    hipStream_t s = fx_hip_stream(stream);
+    const int64_t n_part = fx_emb_grad_reduce_partials(n_max);
+    FX_CHECK_ARG(sq_partials, "fx_emb_grad_reduce: null sq_partials");
+    // partial slots not written by a block below must read as zero
+    FX_CHECK_HIP(hipMemsetAsync(sq_partials, 0, (size_t)n_part * sizeof(float), s));
+    if (n_max <= 0) return FX_OK;
+    FX_CHECK_ARG(dout && col_out_off && sorted_pos && seg_start && n_unique && G,
+                 "fx_emb_grad_reduce: null pointer");
+    const FxRowGeom g = fx_row_geom(D);
+    FX_CHECK_ARG(dout_ld % g.vec == 0 || g.vec == 1,
+                 "fx_emb_grad_reduce: dout_ld not a multiple of %d", g.vec);
+    int ll = 0;
+    while ((1 << ll) < g.lanes) ++ll;
+    ReduceArgs a{dout, dout_ld, col_out_off, sorted_pos, seg_start, n_unique, G, sq_partials,
+                 C, D, ll};
+    const int64_t blocks = fx_ceil_div(n_max, 256 / g.lanes);
+    dim3 grid((unsigned)blocks);
+    if (g.vec == 4) hipLaunchKernelGGL(k_emb_grad_reduce<4>, grid, dim3(256), 0, s, a);
+    else if (g.vec == 2) hipLaunchKernelGGL(k_emb_grad_reduce<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_emb_grad_reduce<1>, grid, dim3(256), 0, s, a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer scalars
+// ---------------------------------------------------------------------------------------------
+__global__ void k_opt_begin_step(fx_scalars* sc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int t = sc->step + 1;
+        sc->step = t;
+        // python: bias_correction1 = 1 - beta1 ** step (double), step_size = lr / bias_correction1,
+        // bias_correction2_sqrt = (1 - beta2 ** step) ** 0.5
+        const double b1 = (double)sc->beta1, b2 = (double)sc->beta2;
+        const double bc1 = 1.0 - pow(b1, (double)t);
+        const double bc2 = 1.0 - pow(b2, (double)t);
+        sc->bc1 = (float)bc1;
+        sc->bc2_sqrt = (float)sqrt(bc2);
+        sc->step_size = (float)((double)sc->lr / bc1);
+    }
+}
+
+extern "C" int fx_opt_begin_step(fx_scalars* scal, fx_stream_t stream) {
+    FX_CHECK_ARG(scal, "fx_opt_begin_step: null scal");
+    hipLaunchKernelGGL(k_opt_begin_step, dim3(1), dim3(64), 0, fx_hip_stream(stream), scal);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+#define FX_CLIP_MAX_PARTS 16
+struct ClipArgs {
+    const float* part[FX_CLIP_MAX_PARTS];
+    int64_t count[FX_CLIP_MAX_PARTS];
+    int32_t n_parts;
+    fx_scalars* scal;
+};
+
+__global__ __launch_bounds__(256) void k_clip_coef(ClipArgs a) {
+    __shared__ double red[256];
+    // fixed assignment thread <- elements t, t+256, ... of every array, in array order: deterministic
+    double acc = 0.0;
+    for (int p = 0; p < a.n_parts; ++p) {
+        const float* x = a.part[p];
+        for (int64_t i = threadIdx.x; i < a.count[p]; i += 256) acc += (double)x[i];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float total = (float)sqrt(red[0]);
+        float coef = 1.f;
+        if (a.scal->max_norm > 0.f) {
+            coef = a.scal->max_norm / (total + 1e-6f);
+            if (coef > 1.f) coef = 1.f;
+        }
+        a.scal->total_norm = total;
+        a.scal->clip_coef = coef;
+    }
+}
+
+extern "C" int fx_clip_coef(const float* const* parts_host, const int64_t* counts_host,
+                            int32_t n_parts, fx_scalars* scal, fx_stream_t stream) {
+    FX_CHECK_ARG(n_parts >= 0 && n_parts <= FX_CLIP_MAX_PARTS, "fx_clip_coef: n_parts=%d > %d",
+                 n_parts, FX_CLIP_MAX_PARTS);
+    FX_CHECK_ARG(scal, "fx_clip_coef: null scal");
+    ClipArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int p = 0; p < n_parts; ++p) {
+        FX_CHECK_ARG(parts_host[p] || counts_host[p] == 0, "fx_clip_coef: null part %d", p);
+        a.part[p] = parts_host[p];
+        a.count[p] = counts_host[p];
+    }
+    a.n_parts = n_parts;
+    a.scal = scal;
+    hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(256), 0, fx_hip_stream(stream), a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sparse-row optimizers
+// ---------------------------------------------------------------------------------------------
+struct RowOptArgs {
+    float* table;
+    float* m;
+    float* v;
+    int32_t* last_step;
+    const uint32_t* uniq_row;
+    const int32_t* n_unique;
+    const float* G;
+    const fx_scalars* scal;
+    int64_t total_rows;
+    int32_t D, lanes_log2, upto_offset;
+};
+
+// torch.optim.Adam._single_tensor_adam, one element
+__device__ __forceinline__ void fx_adam_elem(float& p, float& m, float& v, float g, float w1,
+                                             float beta2, float w2, float bc2_sqrt, float eps,
+                                             float step_size) {
+    m = m + w1 * (g - m);                  // exp_avg.lerp_(grad, 1 - beta1)
+    v = fmaf(w2 * g, g, v * beta2);        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);       // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_sparse_adam(RowOptArgs a) {
+    const int lanes = 1 << a.lanes_log2;
+    const int sub = threadIdx.x & (lanes - 1);
+    const int d0 = sub * VEC;
+    const int nu = *a.n_unique;
+    const int64_t rpb = 256 >> a.lanes_log2;
+    const fx_scalars sc = *a.scal;
+    const float w1 = 1.f - sc.beta1, w2 = 1.f - sc.beta2;
+    for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2); u < nu;
+         u += (int64_t)gridDim.x * rpb) {
+        const int64_t row = a.uniq_row[u];
+        if (d0 < a.D) {
+            float p[VEC], m[VEC], v[VEC], g[VEC];
+            const int64_t o = row * a.D + d0;
+            fx_load<VEC>(a.table + o, p);
+            fx_load<VEC>(a.m + o, m);
+            fx_load<VEC>(a.v + o, v);
+            fx_load<VEC>(a.G + u * a.D + d0, g);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                fx_adam_elem(p[k], m[k], v[k], g[k] * sc.clip_coef, w1, sc.beta2, w2, sc.bc2_sqrt,
+                             sc.eps, sc.step_size);
+            fx_store<VEC>(a.table + o, p);
+            fx_store<VEC>(a.m + o, m);
+            fx_store<VEC>(a.v + o, v);
+        }
+        if (sub == 0 && a.last_step) a.last_step[row] = sc.step;
+    }
+}
+
+// Replay of the zero-gradient Adam steps a dense optimizer would have applied to a row that no
+// batch touched since last_step[row].  With g = 0 the per-step update is
+//     m *= beta1 ; v *= beta2 ; p -= lr/(1-beta1^j) * m / (sqrt(v)/sqrt(1-beta2^j) + eps)
+// whose magnitude decays like (beta1/sqrt(beta2))^j ~ 0.9^j, so after FX_REPLAY_MAX steps the
+// remaining terms are below fp32 resolution of the accumulated update; the tail only decays m, v.
+#define FX_REPLAY_MAX 256
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_adam_catchup(RowOptArgs a) {
+    const int lanes = 1 << a.lanes_log2;
+    const int sub = threadIdx.x & (lanes - 1);
+    const int d0 = sub * VEC;
+    const int64_t rpb = 256 >> a.lanes_log2;
+    const fx_scalars sc = *a.scal;
+    const int upto = sc.step + a.upto_offset;
+    const int64_t n = a.uniq_row ? (int64_t)(*a.n_unique) : a.total_rows;
+    const float w1 = 1.f - sc.beta1;
+    const double lb1 = log2((double)sc.beta1), lb2 = log2((double)sc.beta2);
+    for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2); u < n;
+         u += (int64_t)gridDim.x * rpb) {
+        const int64_t row = a.uniq_row ? (int64_t)a.uniq_row[u] : u;
+        const int last = a.last_step[row];
+        const int k_steps = upto - last;
+        if (k_steps <= 0) continue;
+        if (d0 < a.D) {
+            float p[VEC], m[VEC], v[VEC];
+            const int64_t o = row * a.D + d0;
+            fx_load<VEC>(a.m + o, m);
+            fx_load<VEC>(a.v + o, v);
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) any = any || (m[k] != 0.f) || (v[k] != 0.f);
+            if (any) {
+                fx_load<VEC>(a.table + o, p);
+                const int kk = k_steps < FX_REPLAY_MAX ? k_steps : FX_REPLAY_MAX;
+                float pw1 = (float)exp2(lb1 * (double)last);  // beta1^last
+                float pw2 = (float)exp2(lb2 * (double)last);
+                for (int j = 0; j < kk; ++j) {
+                    pw1 *= sc.beta1;
+                    pw2 *= sc.beta2;
+                    const float step_size = sc.lr / (1.f - pw1);
+                    const float bc2s = sqrtf(1.f - pw2);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        m[k] = m[k] + w1 * (0.f - m[k]);
+                        v[k] = v[k] * sc.beta2;
+                        p[k] = p[k] - step_size * (m[k] / (sqrtf(v[k]) / bc2s + sc.eps));
+                    }
+                }
+                if (k_steps > kk) {
+                    const float f1 = (float)exp2(lb1 * (double)(k_steps - kk));
+                    const float f2 = (float)exp2(lb2 * (double)(k_steps - kk));
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        m[k] *= f1;
+                        v[k] *= f2;
+                    }
+                }
+                fx_store<VEC>(a.table + o, p);
+                fx_store<VEC>(a.m + o, m);
+                fx_store<VEC>(a.v + o, v);
+            }
+        }
+        if (sub == 0) a.last_step[row] = upto;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_sparse_sgd(RowOptArgs a) {
+    const int lanes = 1 << a.lanes_log2;
+    const int sub = threadIdx.x & (lanes - 1);
+    const int d0 = sub * VEC;
+    const int nu = *a.n_unique;
+    const int64_t rpb = 256 >> a.lanes_log2;
+    const float scale = a.scal->lr * a.scal->clip_coef;
+    for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2); u < nu;
+         u += (int64_t)gridDim.x * rpb) {
+        if (d0 >= a.D) continue;
+        const int64_t row = a.uniq_row[u];
+        float p[VEC], g[VEC];
+        fx_load<VEC>(a.table + row * a.D + d0, p);
+        fx_load<VEC>(a.G + u * a.D + d0, g);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) p[k] = p[k] - scale * g[k];
+        fx_store<VEC>(a.table + row * a.D + d0, p);
+    }
+}
+
+#define FX_LAUNCH_ROWOPT(KERNEL, n_rows_max)                                             \
+    do {                                                                                 \
+        const FxRowGeom g = fx_row_geom(D);                                              \
+        int ll = 0;                                                                      \
+        while ((1 << ll) < g.lanes) ++ll;                                                \
+        a.lanes_log2 = ll;                                                               \
+        int64_t blocks = fx_ceil_div((n_rows_max), 256 / g.lanes);                       \
+        if (blocks > 256 * 64) blocks = 256 * 64;                                        \
+        if (blocks < 1) blocks = 1;                                                      \
+        dim3 grid((unsigned)blocks);                                                     \
+        hipStream_t s = fx_hip_stream(stream);                                           \
+        if (g.vec == 4) hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), 0, s, a);         \
+        else if (g.vec == 2) hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), 0, s, a);    \
+        else hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), 0, s, a);                    \
+        FX_CHECK_LAUNCH();                                                               \
+    } while (0)
+
+extern "C" int fx_sparse_adam(float* table, float* m, float* v, int32_t* last_step, int32_t D,
+                              const uint32_t* uniq_row, const int32_t* n_unique, int64_t n_max,
+                              const float* G, const fx_scalars* scal, fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256, "fx_sparse_adam: D=%d not in [1,256]", D);
+    if (n_max <= 0) return FX_OK;
+    FX_CHECK_ARG(table && m && v && uniq_row && n_unique && G && scal,
+                 "fx_sparse_adam: null pointer");
+    RowOptArgs a{table, m, v, last_step, uniq_row, n_unique, G, scal, 0, D, 0, 0};
+    FX_LAUNCH_ROWOPT(k_sparse_adam, n_max);
+    return FX_OK;
+}
+
+extern "C" int fx_adam_catchup(float* table, float* m, float* v, int32_t* last_step, int32_t D,
+                               const uint32_t* uniq_row, const int32_t* n_unique, int64_t n_max,
+                               int64_t total_rows, int32_t upto_offset, const fx_scalars* scal,
+                               fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256, "fx_adam_catchup: D=%d not in [1,256]", D);
+    FX_CHECK_ARG(table && m && v && last_step && scal, "fx_adam_catchup: null pointer");
+    FX_CHECK_ARG(uniq_row == nullptr || n_unique != nullptr,
+                 "fx_adam_catchup: uniq_row given without n_unique");
+    const int64_t rows = uniq_row ? n_max : total_rows;
+    if (rows <= 0) return FX_OK;
+    RowOptArgs a{table, m, v, last_step, uniq_row, n_unique, nullptr, scal, total_rows, D, 0,
+                 upto_offset};
+    FX_LAUNCH_ROWOPT(k_adam_catchup, rows);
+    return FX_OK;
+}
+
+extern "C" int fx_sparse_sgd(float* table, int32_t D, const uint32_t* uniq_row,
+                             const int32_t* n_unique, int64_t n_max, const float* G,
+                             const fx_scalars* scal, fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256, "fx_sparse_sgd: D=%d not in [1,256]", D);
+    if (n_max <= 0) return FX_OK;
+    FX_CHECK_ARG(table && uniq_row && n_unique && G && scal, "fx_sparse_sgd: null pointer");
+    RowOptArgs a{table, nullptr, nullptr, nullptr, uniq_row, n_unique, G, scal, 0, D, 0, 0};
+    FX_LAUNCH_ROWOPT(k_sparse_sgd, n_max);
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-tensor dense kernels (MLP / CrossNet / bias / numeric-weight parameters)
+// ---------------------------------------------------------------------------------------------
+#define FX_MT_MAX 64
+struct MtArgs {
+    float* p[FX_MT_MAX];
+    const float* g[FX_MT_MAX];
+    float* m[FX_MT_MAX];
+    float* v[FX_MT_MAX];
+    int64_t size[FX_MT_MAX];
+    const fx_scalars* scal;
+    float* sq_partials;
+};
+
+__global__ __launch_bounds__(256) void k_mt_sqnorm(MtArgs a) {
+    __shared__ float red4[4];
+    const int t = blockIdx.y;
+    const float* g = a.g[t];
+    const int64_t n = a.size[t];
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const float4 x = g4[i];
+            acc = fmaf(x.x, x.x, acc);
+            acc = fmaf(x.y, x.y, acc);
+            acc = fmaf(x.z, x.z, acc);
+            acc = fmaf(x.w, x.w, acc);
+        }
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+            acc = fmaf(g[i], g[i], acc);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+            acc = fmaf(g[i], g[i], acc);
+    }
+    const float tot = fx_block_sum_256(acc, red4);
+    if (threadIdx.x == 0) a.sq_partials[(int64_t)t * gridDim.x + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_mt_adam(MtArgs a) {
+    const int t = blockIdx.y;
+    float* p = a.p[t];
+    const float* g = a.g[t];
+    float* m = a.m[t];
+    float* v = a.v[t];
+    const int64_t n = a.size[t];
+    const fx_scalars sc = *a.scal;
+    const float w1 = 1.f - sc.beta1, w2 = 1.f - sc.beta2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+                         reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v);
+    int64_t done = 0;
+    if ((al & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            float pp[4], gg[4], mm[4], vv[4];
+            fx_load<4>(p + 4 * i, pp);
+            fx_load<4>(g + 4 * i, gg);
+            fx_load<4>(m + 4 * i, mm);
+            fx_load<4>(v + 4 * i, vv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                fx_adam_elem(pp[k], mm[k], vv[k], gg[k] * sc.clip_coef, w1, sc.beta2, w2,
+                             sc.bc2_sqrt, sc.eps, sc.step_size);
+            fx_store<4>(p + 4 * i, pp);
+            fx_store<4>(m + 4 * i, mm);
+            fx_store<4>(v + 4 * i, vv);
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        fx_adam_elem(pp, mm, vv, g[i] * sc.clip_coef, w1, sc.beta2, w2, sc.bc2_sqrt, sc.eps,
+                     sc.step_size);
+        p[i] = pp;
+        m[i] = mm;
+        v[i] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mt_sgd(MtArgs a) {
+    const int t = blockIdx.y;
+    float* p = a.p[t];
+    const float* g = a.g[t];
+    const int64_t n = a.size[t];
+    const float scale = a.scal->lr * a.scal->clip_coef;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        p[i] = p[i] - scale * g[i];
+}
+
+extern "C" int fx_mt_sqnorm(const float* const* grads_host, const int64_t* sizes_host, int32_t n,
+                            float* sq_partials, fx_stream_t stream) {
+    FX_CHECK_ARG(n >= 0 && n <= FX_MT_MAX, "fx_mt_sqnorm: n=%d not in [0,%d]", n, FX_MT_MAX);
+    if (n == 0) return FX_OK;
+    FX_CHECK_ARG(grads_host && sizes_host && sq_partials, "fx_mt_sqnorm: null pointer");
+    MtArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) {
+        FX_CHECK_ARG(grads_host[i] || sizes_host[i] == 0, "fx_mt_sqnorm: null grad %d", i);
+        a.g[i] = grads_host[i];
+        a.size[i] = sizes_host[i];
+    }
+    a.sq_partials = sq_partials;
+    hipLaunchKernelGGL(k_mt_sqnorm, dim3(FX_MT_BLOCKS, n), dim3(256), 0, fx_hip_stream(stream), a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+extern "C" int fx_mt_adam(float* const* params_host, const float* const* grads_host,
+                          float* const* m_host, float* const* v_host, const int64_t* sizes_host,
+                          int32_t n, const fx_scalars* scal, fx_stream_t stream) {
+    FX_CHECK_ARG(n >= 0 && n <= FX_MT_MAX, "fx_mt_adam: n=%d not in [0,%d]", n, FX_MT_MAX);
+    if (n == 0) return FX_OK;
+    FX_CHECK_ARG(params_host && grads_host && m_host && v_host && sizes_host && scal,
+                 "fx_mt_adam: null pointer");
+    MtArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) {
+        FX_CHECK_ARG(sizes_host[i] == 0 ||
+                         (params_host[i] && grads_host[i] && m_host[i] && v_host[i]),
+                     "fx_mt_adam: null tensor %d", i);
+        a.p[i] = params_host[i];
+        a.g[i] = grads_host[i];
+        a.m[i] = m_host[i];
+        a.v[i] = v_host[i];
+        a.size[i] = sizes_host[i];
+    }
+    a.scal = scal;
+    hipLaunchKernelGGL(k_mt_adam, dim3(FX_MT_BLOCKS, n), dim3(256), 0, fx_hip_stream(stream), a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+extern "C" int fx_mt_sgd(float* const* params_host, const float* const* grads_host,
+                         const int64_t* sizes_host, int32_t n, const fx_scalars* scal,
+                         fx_stream_t stream) {
+    FX_CHECK_ARG(n >= 0 && n <= FX_MT_MAX, "fx_mt_sgd: n=%d not in [0,%d]", n, FX_MT_MAX);
+    if (n == 0) return FX_OK;
+    FX_CHECK_ARG(params_host && grads_host && sizes_host && scal, "fx_mt_sgd: null pointer");
+    MtArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) {
+        FX_CHECK_ARG(sizes_host[i] == 0 || (params_host[i] && grads_host[i]),
+                     "fx_mt_sgd: null tensor %d", i);
+        a.p[i] = params_host[i];
+        a.g[i] = grads_host[i];
+        a.size[i] = sizes_host[i];
+    }
+    a.scal = scal;
+    hipLaunchKernelGGL(k_mt_sgd, dim3(FX_MT_BLOCKS, n), dim3(256), 0, fx_hip_stream(stream), a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}

@@ -1,0 +1,245 @@
+/*
+ * fxctr.h — C-ABI of the MI355X-native CTR hot path (libfxctr.so, gfx950 only).
+ *
+ * Drop-in boundary.  The reference (reczoo/FuxiCTR) has no FFI: its hot path is a Python class
+ * API (fuxictr.pytorch FeatureEmbedding / BaseModel) that dispatches to stock ATen ops.  Every
+ * entry point below replaces the ATen work issued by the reference lines cited next to it
+ * (paths relative to the reference checkout).  The Python shim in fuxictr_amd/ binds these with
+ * ctypes and mirrors the reference class API on top.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a hipStream_t passed as void*; no torch types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - every function returns FX_OK (0) or an FX_ERR_* code; fx_last_error() gives the message
+ *     (thread-local).  No exceptions cross the ABI.  The caller owns all memory.
+ *   - all launches are asynchronous on `stream`; nothing here synchronises, allocates or frees,
+ *     so every call is hipGraph-capturable.  Per-step dynamic scalars (step, lr, clip
+ *     coefficient, unique-row count) live in device memory for the same reason.
+ *   - matrices are row-major fp32; "ld" = leading dimension (row stride) in elements.
+ */
+#ifndef FXCTR_H
+#define FXCTR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_ABI_VERSION 1
+
+typedef void* fx_stream_t; /* hipStream_t; NULL = the null stream */
+
+enum { FX_OK = 0, FX_ERR_INVALID = 1, FX_ERR_HIP = 2, FX_ERR_UNSUPPORTED = 3 };
+enum { FX_F32 = 0, FX_F64 = 1, FX_I32 = 2, FX_I64 = 3 };
+
+/* bits of fx_scalars.err_flag (sticky, set by kernels, read by the host at its own sync points) */
+enum { FX_FLAG_BAD_ID = 1 };
+
+/* Device-resident per-step scalars (64 bytes; the shim allocates it as 16 x 4-byte words).
+ * Mirrors the python-side scalars of torch.optim.Adam._single_tensor_adam and
+ * torch.nn.utils.clip_grad_norm_ as used by rank_model.py:321-322. */
+typedef struct fx_scalars {
+    int32_t step;      /*  0: optimizer step t, 1-based after fx_opt_begin_step */
+    int32_t err_flag;  /*  1 */
+    float lr;          /*  2: written by the host when lr changes (rank_model.py:221-234) */
+    float beta1;       /*  3 */
+    float beta2;       /*  4 */
+    float eps;         /*  5 */
+    float bc1;         /*  6: 1 - beta1^t */
+    float bc2_sqrt;    /*  7: sqrt(1 - beta2^t) */
+    float step_size;   /*  8: lr / bc1 */
+    float clip_coef;   /*  9: min(1, max_norm / (total_norm + 1e-6)) */
+    float total_norm;  /* 10 */
+    float max_norm;    /* 11: <= 0 disables clipping (coef = 1) */
+    float loss;        /* 12: scratch for the fused loss kernel */
+    float pad[3];
+} fx_scalars;
+
+int fx_abi_version(void);
+const char* fx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Input packing.  Replaces the per-feature `.long()` / `.float().view(-1,1)` casts of
+ * fuxictr/pytorch/layers/embeddings/feature_embedding.py:280-291 (39 tiny ATen casts per
+ * forward at Criteo shape) by one launch: ncols device columns, column c being a contiguous
+ * [B, widths[c]] array of dtype dtypes[c], are converted and written side by side into
+ * out[b*out_ld + out_col0 + (running column offset)].  out_dtype is FX_I32 (ids) or FX_F32.
+ * cols_host / dtypes_host / widths_host are HOST arrays (<= 64 columns per call).
+ * ------------------------------------------------------------------------------------------ */
+int fx_pack_columns(const void* const* cols_host, const int32_t* dtypes_host,
+                    const int32_t* widths_host, int32_t ncols, int64_t B, int32_t out_dtype,
+                    void* out, int64_t out_ld, int64_t out_col0, fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-field embedding lookup, forward.  Replaces FeatureEmbeddingDict.forward +
+ * dict2tensor (feature_embedding.py:261-297, :230-259): C id-columns gather D-float rows from
+ * one packed table, Fd numeric columns are expanded by their nn.Linear(1,D,bias=False) weight
+ * (feature_embedding.py:153-154, :280-282), everything is written straight into its final slot
+ * of the per-sample output record (no stack/cat pass):
+ *     out[b*out_ld + col_out_off[c] + d] = table[(col_row_base[c] + ids[b,c]) * D + d]
+ *     out[b*out_ld + num_out_off[j] + d] = dense[b,j] * num_w[j*D + d]
+ * ids outside [0, col_vocab[c]) set FX_FLAG_BAD_ID in scal->err_flag and read as a zero row.
+ * ------------------------------------------------------------------------------------------ */
+int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* ids, int64_t ids_ld,
+                      const int64_t* col_row_base, const int32_t* col_vocab,
+                      const int64_t* col_out_off, int32_t C, const float* dense,
+                      int64_t dense_ld, const float* num_w, const int64_t* num_out_off,
+                      int32_t Fd, float* out, int64_t out_ld, int64_t B, fx_scalars* scal,
+                      fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Index de-duplication for the sparse backward/update.  Builds, for the B*C lookups of a batch,
+ * the list of unique packed-table rows and the (stable) sorted lookup positions of each:
+ *     key(b,c) = col_row_base[c] + ids[b,c]       (0xFFFFFFFF for padding_idx / bad ids)
+ *     sorted_key/sorted_pos = stable radix sort of (key, pos=b*C+c) by key
+ *     uniq_row[u], seg_start[u]..seg_start[u+1] = the u-th distinct key and its run in sorted_*
+ *     *n_unique = number of distinct non-sentinel keys
+ * This replaces the zero-filled dense [V,D] gradient + index_add of aten::embedding_dense_backward
+ * (triggered at rank_model.py:320) — no dense gradient ever exists.  Deterministic.
+ * Packed tables are limited to < 2^32 - 1 rows.
+ * ------------------------------------------------------------------------------------------ */
+size_t fx_dedup_workspace_bytes(int64_t n_lookups);
+int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
+             const int64_t* col_row_base, const int32_t* col_vocab, const int32_t* col_pad,
+             int64_t total_rows, void* workspace, size_t workspace_bytes, uint32_t* sorted_key,
+             uint32_t* sorted_pos, uint32_t* uniq_row, uint32_t* seg_start, int32_t* n_unique,
+             fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding backward, sparse side: G[u,:] = sum over the run of unique row u of
+ * dout[b*dout_ld + col_out_off[c] + :], summed in ascending lookup position (deterministic).
+ * Also writes per-block partial sums of ||G||^2 into sq_partials[0..n_partials) (n_partials is
+ * returned by fx_emb_grad_reduce_partials(n_max)); rows >= *n_unique are not touched.
+ * ------------------------------------------------------------------------------------------ */
+int64_t fx_emb_grad_reduce_partials(int64_t n_max);
+int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int64_t* col_out_off, int32_t C,
+                       int32_t D, const uint32_t* sorted_pos, const uint32_t* seg_start,
+                       const int32_t* n_unique, int64_t n_max, float* G, float* sq_partials,
+                       fx_stream_t stream);
+
+/* Numeric-feature weight gradient: dnum_w[j,d] = sum_b dense[b,j] * dout[b*dout_ld + num_out_off[j] + d]
+ * (autograd of the nn.Linear(1,D) at feature_embedding.py:280-282).  Deterministic tree sum. */
+int fx_emb_numeric_grad(const float* dout, int64_t dout_ld, const int64_t* num_out_off,
+                        const float* dense, int64_t dense_ld, int32_t Fd, int32_t D, int64_t B,
+                        float* dnum_w, fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer scalars.  fx_opt_begin_step: step += 1 and the bias corrections of
+ * torch.optim.Adam (bias_correction1/2, step_size; computed in double like the Python side).
+ * fx_clip_coef: total_norm = sqrt(sum of all given partial arrays), clip_coef as
+ * torch.nn.utils.clip_grad_norm_ (rank_model.py:321).  parts_host: HOST array of n_parts device
+ * pointers, counts_host their lengths (<= 16 arrays).
+ * ------------------------------------------------------------------------------------------ */
+int fx_opt_begin_step(fx_scalars* scal, fx_stream_t stream);
+int fx_clip_coef(const float* const* parts_host, const int64_t* counts_host, int32_t n_parts,
+                 fx_scalars* scal, fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse-row optimizers on the packed table (replace the dense torch.optim step over every row,
+ * rank_model.py:322 / torch_utils.py:76).  All take the unique rows of fx_dedup and the reduced
+ * gradient rows G (scaled by scal->clip_coef inside).
+ *  fx_sparse_adam   : p,m,v of the touched rows, Adam step t = scal->step; last_step[row] = t.
+ *  fx_adam_catchup  : "exact" mode — dense Adam also moves rows whose gradient is zero (their
+ *                     m/(sqrt(v)+eps) is non-zero once touched).  Replays the zero-gradient
+ *                     steps last_step[row]+1 .. upto for the given rows (uniq_row != NULL) or for
+ *                     all rows [0,total_rows) (uniq_row == NULL, flush before evaluate/save), so
+ *                     the table equals the reference's dense-Adam table.  upto_offset is added
+ *                     to scal->step (-1: bring rows to t-1 before the forward of step t; 0: flush).
+ *  fx_sparse_sgd    : p -= lr * clip * g (exactly the dense SGD result).
+ * ------------------------------------------------------------------------------------------ */
+int fx_sparse_adam(float* table, float* m, float* v, int32_t* last_step, int32_t D,
+                   const uint32_t* uniq_row, const int32_t* n_unique, int64_t n_max,
+                   const float* G, const fx_scalars* scal, fx_stream_t stream);
+int fx_adam_catchup(float* table, float* m, float* v, int32_t* last_step, int32_t D,
+                    const uint32_t* uniq_row, const int32_t* n_unique, int64_t n_max,
+                    int64_t total_rows, int32_t upto_offset, const fx_scalars* scal,
+                    fx_stream_t stream);
+int fx_sparse_sgd(float* table, int32_t D, const uint32_t* uniq_row, const int32_t* n_unique,
+                  int64_t n_max, const float* G, const fx_scalars* scal, fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense (multi-tensor) side of clip + Adam/SGD for the MLP / CrossNet / bias parameters.
+ * ptr arrays are HOST arrays of n device pointers (<= 64 per call), sizes_host element counts.
+ *  fx_mt_sqnorm : sq_partials[i*FX_MT_BLOCKS + k] = partial ||g_i||^2   (FX_MT_BLOCKS per tensor)
+ *  fx_mt_adam   : torch.optim.Adam single-tensor formulas with g * clip_coef
+ *  fx_mt_sgd    : p -= lr * clip_coef * g
+ * ------------------------------------------------------------------------------------------ */
+#define FX_MT_BLOCKS 32
+int fx_mt_sqnorm(const float* const* grads_host, const int64_t* sizes_host, int32_t n,
+                 float* sq_partials, fx_stream_t stream);
+int fx_mt_adam(float* const* params_host, const float* const* grads_host, float* const* m_host,
+               float* const* v_host, const int64_t* sizes_host, int32_t n, const fx_scalars* scal,
+               fx_stream_t stream);
+int fx_mt_sgd(float* const* params_host, const float* const* grads_host,
+              const int64_t* sizes_host, int32_t n, const fx_scalars* scal, fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FM second-order term + LR first-order term (DeepFM / FM / xDeepFM).
+ *  fx_fm_fwd : out[b] = 0.5 * sum_d ((sum_f e[b,f,d])^2 - sum_f e[b,f,d]^2) (+ addend[b])
+ *              (fuxictr/pytorch/layers/interactions/inner_product.py:55-62, "product_sum";
+ *              the addend fuses factorization_machine.py:58).
+ *  fx_fm_bwd : demb[b,f,d] (+)= g[b] * (sum_f e[b,f,d] - e[b,f,d])   (accumulate != 0: +=)
+ *  fx_lr_fwd : out[b] = sum_c table1[col_row_base[c] + ids[b,c]] + sum_j dense[b,j]*num_w1[j] + bias
+ *              (logistic_regression.py:55-58: a D=1 FeatureEmbedding summed over fields).
+ * ------------------------------------------------------------------------------------------ */
+int fx_fm_fwd(const float* emb, int64_t emb_ld, int32_t F, int32_t D, const float* addend,
+              float* out, int64_t B, fx_stream_t stream);
+int fx_fm_bwd(const float* emb, int64_t emb_ld, int32_t F, int32_t D, const float* g,
+              float* demb, int64_t demb_ld, int32_t accumulate, int64_t B, fx_stream_t stream);
+int fx_lr_fwd(const float* table1, const int32_t* ids, int64_t ids_ld,
+              const int64_t* col_row_base, const int32_t* col_vocab, int32_t C,
+              const float* dense, int64_t dense_ld, const float* num_w1, int32_t Fd,
+              const float* bias, float* out, int64_t B, fx_scalars* scal, fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM with fused epilogue (MLP_Block / CrossNetV2 / fc layers and their backward:
+ * mlp_block.py:96, cross_net.py:126-129, autograd of aten::addmm).  Row-major:
+ *     acc[M,N] = op(A)[M,K] . op(B)[K,N]
+ *     transa = 0: A stored [M,K] (lda)   transa = 1: A stored [K,M]
+ *     transb = 0: B stored [K,N] (ldb)   transb = 1: B stored [N,K]   (nn.Linear weight)
+ * Uses v_mfma_f32_32x32x2_f32: exact fp32 products and fp32 accumulation (no TF32/bf16).
+ * Epilogue, in this order (NULL members are skipped):
+ *     z = acc + bias[n];  zout[m,n] = z;  act(z) (1 = relu);  z *= mul[m,n];
+ *     z = mask[m,n] > 0 ? z : 0;  z += add[m,n];  C[m,n] = z
+ * split_k > 1 splits K over blocks; partials go to workspace[split_k][M][N] and a second
+ * (deterministic) kernel reduces them and applies the epilogue.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fx_gemm_epilogue {
+    const float* bias;
+    float* zout;
+    int64_t ldz;
+    int32_t act;
+    const float* mul;
+    int64_t ldmul;
+    const float* mask;
+    int64_t ldmask;
+    const float* add;
+    int64_t ldadd;
+} fx_gemm_epilogue;
+
+int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K, const float* A,
+                int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                const fx_gemm_epilogue* epi_host, int32_t split_k, float* workspace,
+                fx_stream_t stream);
+
+/* Column sums (bias gradients): out[n] = sum_m X[m,n] * (mask == NULL ? 1 : mask[m,n] > 0).
+ * Two-stage deterministic reduction; workspace >= FX_COLSUM_CHUNKS * N floats. */
+#define FX_COLSUM_CHUNKS 32
+int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, float* workspace,
+              fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Output activation + loss, fused: p = sigmoid(logit); loss = mean BCE(p, y) with torch's
+ * log clamp at -100 (BaseModel.get_output_activation rank_model.py:447-448 +
+ * F.binary_cross_entropy torch_utils.py:95-98); dlogit = dloss/dlogit (torch's two-step
+ * backward: (p-y)/max(p(1-p),1e-12)/B * p(1-p)).  prob/loss/dlogit may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+int fx_sigmoid_bce(const float* logit, const float* y, int64_t B, float* prob, float* loss,
+                   float* dlogit, fx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FXCTR_H */
