@@ -313,6 +313,56 @@ extern "C" int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, floa
 }
 
 // ---------------------------------------------------------------------------------------------
+// relu backward mask (only for a tower whose last layer is activated)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mask_mul(const float* dy, const float* y, float* out,
+                                                  int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+extern "C" int fx_mask_mul(const float* dy, const float* y, float* out, int64_t n,
+                           fx_stream_t stream) {
+    if (n <= 0) return FX_OK;
+    FX_CHECK_ARG(dy && y && out, "fx_mask_mul: null pointer");
+    int64_t blocks = fx_ceil_div(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_mask_mul, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), dy,
+                       y, out, n);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CrossNetV2 backward glue
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cross_bwd_prep(const float* dxn, const float* x0,
+                                                        const float* z, float* t, float* dx0,
+                                                        int64_t n, int init, int add_dxn) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * 256) {
+        const float d = dxn[i];
+        t[i] = d * x0[i];
+        float term = d * z[i];
+        if (add_dxn) term += d;
+        dx0[i] = init ? term : dx0[i] + term;
+    }
+}
+
+extern "C" int fx_cross_bwd_prep(const float* dxn, const float* x0, const float* z, float* t,
+                                 float* dx0, int64_t n, int32_t init, int32_t add_dxn,
+                                 fx_stream_t stream) {
+    if (n <= 0) return FX_OK;
+    FX_CHECK_ARG(dxn && x0 && z && t && dx0, "fx_cross_bwd_prep: null pointer");
+    int64_t blocks = fx_ceil_div(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_cross_bwd_prep, dim3((unsigned)blocks), dim3(256), 0,
+                       fx_hip_stream(stream), dxn, x0, z, t, dx0, n, (int)init, (int)add_dxn);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // sigmoid + binary cross entropy (mean) + dloss/dlogit, one workgroup, fixed-order reduction
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_sigmoid_bce(const float* logit, const float* y,
@@ -324,12 +374,13 @@ __global__ __launch_bounds__(1024) void k_sigmoid_bce(const float* logit, const 
     for (int64_t i = threadIdx.x; i < B; i += 1024) {
         const float x = logit[i];
         const float p = 1.f / (1.f + expf(-x));  // torch.sigmoid
+        if (prob) prob[i] = p;
+        if (!y) continue;  // activation only
         const float t = y[i];
         // F.binary_cross_entropy clamps each log term at -100
         const float lp = fmaxf(logf(p), -100.f);
         const float lq = fmaxf(logf(1.f - p), -100.f);
         acc += -(t * lp + (1.f - t) * lq);
-        if (prob) prob[i] = p;
         if (dlogit) {
             // binary_cross_entropy_backward: (p - t) / max((1 - p) * p, 1e-12) * grad, then
             // sigmoid_backward: * p * (1 - p)
@@ -349,7 +400,8 @@ __global__ __launch_bounds__(1024) void k_sigmoid_bce(const float* logit, const 
 extern "C" int fx_sigmoid_bce(const float* logit, const float* y, int64_t B, float* prob,
                               float* loss, float* dlogit, fx_stream_t stream) {
     FX_CHECK_ARG(B > 0, "fx_sigmoid_bce: B must be positive");
-    FX_CHECK_ARG(logit && y, "fx_sigmoid_bce: null pointer");
+    FX_CHECK_ARG(logit, "fx_sigmoid_bce: null logit");
+    FX_CHECK_ARG(y || (!loss && !dlogit), "fx_sigmoid_bce: loss/dlogit need labels");
     hipLaunchKernelGGL(k_sigmoid_bce, dim3(1), dim3(1024), 0, fx_hip_stream(stream), logit, y, B,
                        prob, loss, dlogit);
     FX_CHECK_LAUNCH();

@@ -1,0 +1,1014 @@
+"""Native (MI355X) drop-ins for the reference's hot-path layers.
+
+Same class names, constructor signatures, forward signatures and state_dict keys as
+`fuxictr.pytorch.layers` (reference paths cited per class), but every op on the path is a call
+into libfxctr.so (include/fxctr.h):
+
+  FeatureEmbeddingDict / FeatureEmbedding   feature_embedding.py:30-297
+      one packed [sum(V_f), D] table per embedding dim, ONE gather launch for all fields that
+      writes the final [B, F, D] record (dict entries are views of it; dict2tensor returns the
+      record itself), sparse backward to unique rows, sparse-row Adam/SGD.
+  LogisticRegression / FactorizationMachine / InnerProductInteraction
+      logistic_regression.py:24-59, factorization_machine.py:25-59, inner_product.py:23-70
+  MLP_Block                                 mlp_block.py:24-96  (one autograd node, fp32 MFMA GEMMs)
+  CrossNetV2                                cross_net.py:95-129 (one autograd node, fused epilogue)
+
+torch is used for device memory, streams, nn.Module bookkeeping and the autograd tape only.
+"""
+from collections import OrderedDict
+from functools import partial  # noqa: F401  (used by eval'ed initializer strings)
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+_DEFAULT_DEVICE = None
+
+
+def set_default_device(device):
+    """Device on which native layers allocate their tables (set by BaseModel.__init__)."""
+    global _DEFAULT_DEVICE
+    _DEFAULT_DEVICE = torch.device(device) if device is not None else None
+
+
+def _alloc_device():
+    if _DEFAULT_DEVICE is not None:
+        return _DEFAULT_DEVICE
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+        else torch.device("cpu")
+
+
+def not_in_whitelist(element, whitelist=[]):
+    """fuxictr/utils.py:209"""
+    if not whitelist:
+        return False
+    if not isinstance(whitelist, list):
+        return element != whitelist
+    return element not in whitelist
+
+
+def get_initializer(initializer):
+    """fuxictr/pytorch/torch_utils.py:175-194 (string -> callable via eval)."""
+    if isinstance(initializer, str):
+        try:
+            initializer = eval(initializer)
+        except Exception:
+            raise ValueError("initializer={} is not supported.".format(initializer))
+    return initializer
+
+
+class FeatureDict(dict):
+    """Batch dict with a per-batch cache (packed id matrices, de-dup results) shared by the
+    embedding layers of one model, so the main and the LR tables pack / sort the ids once."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.cache = {}
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling encoders (torch ops; SURVEY §8f-3 "next" row) — fuxictr/pytorch/layers/pooling.py:23-73
+# ------------------------------------------------------------------------------------------------
+class MaskedAveragePooling(nn.Module):
+    def forward(self, embedding_matrix, mask=None):
+        sum_out = torch.sum(embedding_matrix, dim=1)
+        if mask is None:
+            mask = embedding_matrix.sum(dim=-1) != 0
+        return sum_out / (mask.float().sum(-1, keepdim=True) + 1e-12)
+
+
+class MaskedSumPooling(nn.Module):
+    def forward(self, embedding_matrix):
+        return torch.sum(embedding_matrix, dim=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# packed tables
+# ------------------------------------------------------------------------------------------------
+class _TableView(nn.Module):
+    """state_dict-compatible stand-in for the per-feature nn.Embedding: `.weight` is a
+    [vocab_size, D] view of the packed table (key `embedding_layers.<feature>.weight`)."""
+
+    def __init__(self, weight_view, padding_idx):
+        super().__init__()
+        self.weight = nn.Parameter(weight_view, requires_grad=True)
+        self.padding_idx = padding_idx
+        self.num_embeddings, self.embedding_dim = weight_view.shape
+
+    def forward(self, ids):  # convenience only; the layer never goes through here
+        raise RuntimeError("_TableView is storage only; call FeatureEmbeddingDict.forward")
+
+
+class _NumericView(nn.Module):
+    """Stand-in for nn.Linear(1, D, bias=False): `.weight` is a [D, 1] view of the packed
+    numeric-weight matrix (key `embedding_layers.<feature>.weight`)."""
+
+    def __init__(self, weight_view):
+        super().__init__()
+        self.weight = nn.Parameter(weight_view, requires_grad=True)
+        self.bias = None
+        self.in_features, self.out_features = 1, weight_view.shape[0]
+
+
+class _Plan(object):
+    """Launch plan of one table group for one set of present features."""
+    pass
+
+
+class _PendingGrad(object):
+    __slots__ = ("dd", "G", "sq")
+
+    def __init__(self, dd, G, sq):
+        self.dd, self.G, self.sq = dd, G, sq
+
+
+class _TableGroup(object):
+    """All id/numeric features of one FeatureEmbeddingDict that share an embedding dim D."""
+
+    def __init__(self, D, device):
+        self.D = D
+        self.device = device
+        self.tables = OrderedDict()   # owning feature -> (row_base, vocab, padding_idx)
+        self.alias = {}               # feature -> owning feature (share_embedding)
+        self.widths = {}              # id feature -> 1 or max_len
+        self.numeric = []             # numeric features, row order of num_w
+        self.total_rows = 0
+        self.table = None             # [total_rows, D]
+        self.num_w = None             # [len(numeric), D]
+        self.plans = {}
+        # optimizer attachment
+        self.scal = None
+        self.opt_kind = None          # None | "adam" | "sgd"
+        self.exact = False
+        self.m = self.v = self.last_step = None
+        self.num_grad = None
+        self.pending = []
+        self.dedup_ws = None
+
+    # -- construction -----------------------------------------------------------------------
+    def add_table(self, feature, vocab, padding_idx, width):
+        self.tables[feature] = (self.total_rows, int(vocab), padding_idx)
+        self.widths[feature] = width
+        self.total_rows += int(vocab)
+
+    def add_alias(self, feature, owner, width):
+        self.alias[feature] = self.alias.get(owner, owner)
+        self.widths[feature] = width
+
+    def add_numeric(self, feature):
+        self.numeric.append(feature)
+
+    def allocate(self):
+        if self.total_rows >= 2 ** 32 - 1:
+            raise NotImplementedError("packed table with %d rows exceeds the 2^32-1 row limit "
+                                      "of the sparse path" % self.total_rows)
+        if self.total_rows > 0:
+            self.table = torch.empty(self.total_rows, self.D, dtype=torch.float32,
+                                     device=self.device)
+        if self.numeric:
+            self.num_w = torch.empty(len(self.numeric), self.D, dtype=torch.float32,
+                                     device=self.device)
+
+    def table_of(self, feature):
+        return self.tables[self.alias.get(feature, feature)]
+
+    def ensure_scal(self):
+        if self.scal is None:
+            self.scal = ops.new_scalars(self.device)
+        return self.scal
+
+    # -- plans ------------------------------------------------------------------------------
+    def plan_for(self, ordered_features):
+        """ordered_features: features of this group to embed, in feature_map order."""
+        key = tuple(ordered_features)
+        plan = self.plans.get(key)
+        if plan is not None:
+            return plan
+        p = _Plan()
+        D = self.D
+        p.id_feats, p.num_feats = [], []
+        p.slot = {}
+        row_base, vocab, pad, out_off, num_off = [], [], [], [], []
+        slot = 0
+        for f in ordered_features:
+            if f in self.widths:
+                w = self.widths[f]
+                base, V, pidx = self.table_of(f)
+                p.id_feats.append((f, w))
+                for k in range(w):
+                    row_base.append(base)
+                    vocab.append(V)
+                    pad.append(-1 if pidx is None else int(pidx))
+                    out_off.append((slot + k) * D)
+                p.slot[f] = (slot, w)
+                slot += w
+            else:
+                p.num_feats.append(f)
+                num_off.append(slot * D)
+                p.slot[f] = (slot, 1)
+                slot += 1
+        p.n_slots = slot
+        p.C = len(row_base)
+        p.Fd = len(p.num_feats)
+        dev = self.device
+        p.col_row_base = torch.tensor(row_base, dtype=torch.int64, device=dev)
+        p.col_vocab = torch.tensor(vocab, dtype=torch.int32, device=dev)
+        p.col_pad = torch.tensor(pad, dtype=torch.int32, device=dev)
+        p.col_out_off = torch.tensor(out_off, dtype=torch.int64, device=dev)
+        p.col_zero_off = torch.zeros(max(p.C, 1), dtype=torch.int64, device=dev)
+        p.num_out_off = torch.tensor(num_off, dtype=torch.int64, device=dev)
+        p.num_zero_off = torch.zeros(max(p.Fd, 1), dtype=torch.int64, device=dev)
+        p.num_rows = [self.numeric.index(f) for f in p.num_feats]
+        p.num_full = p.num_rows == list(range(len(self.numeric)))
+        p.sig = (tuple(p.id_feats), tuple(row_base), tuple(pad))
+        p.pack_sig = (tuple(p.id_feats), tuple(p.num_feats))
+        self.plans[key] = p
+        return p
+
+    # -- per-batch helpers ------------------------------------------------------------------
+    def pack_inputs(self, plan, inputs):
+        """-> (ids int32 [B, C] or None, dense fp32 [B, Fd] or None); cached on a FeatureDict."""
+        cache = getattr(inputs, "cache", None)
+        ckey = ("pack", plan.pack_sig)
+        if cache is not None and ckey in cache:
+            return cache[ckey]
+        first = inputs[plan.id_feats[0][0] if plan.id_feats else plan.num_feats[0]]
+        B = first.shape[0]
+        ids = dense = None
+        if plan.C:
+            ids = torch.empty(B, plan.C, dtype=torch.int32, device=self.device)
+            ops.pack_columns([inputs[f] for f, _ in plan.id_feats], ids)
+        if plan.Fd:
+            dense = torch.empty(B, plan.Fd, dtype=torch.float32, device=self.device)
+            ops.pack_columns([inputs[f] for f in plan.num_feats], dense)
+        if cache is not None:
+            cache[ckey] = (ids, dense)
+        return ids, dense
+
+    def dedup(self, plan, ids, inputs):
+        cache = getattr(inputs, "cache", None)
+        ckey = ("dedup", plan.sig, self.total_rows)
+        if cache is not None and ckey in cache:
+            return cache[ckey]
+        n = ids.shape[0] * ids.shape[1]
+        if self.dedup_ws is None or self.dedup_ws[0] != n:
+            self.dedup_ws = (n, torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8,
+                                            device=self.device))
+        dd = ops.dedup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad, self.total_rows,
+                       self.dedup_ws[1])
+        if cache is not None:
+            cache[ckey] = dd
+        return dd
+
+    def select_num_w(self, plan):
+        if plan.Fd == 0:
+            return None
+        if plan.num_full:
+            return self.num_w
+        idx = torch.tensor(plan.num_rows, dtype=torch.int64, device=self.device)
+        return self.num_w.index_select(0, idx)
+
+    def prepare_train(self, plan, ids, inputs):
+        """De-dup the batch's rows; in exact mode bring them up to date before they are read."""
+        if plan.C == 0 or self.opt_kind is None:
+            return None
+        dd = self.dedup(plan, ids, inputs)
+        if self.exact and self.opt_kind == "adam":
+            ops.adam_catchup(self.table, self.m, self.v, self.last_step, self.D, dd,
+                             self.total_rows, -1, self.scal)
+        return dd
+
+    def backward(self, plan, ids, dense, dout, dout_ld, col_off, num_off, dd, inputs_cache):
+        """Sparse + numeric gradients of one forward call (dout: grad of the output record)."""
+        D = self.D
+        if plan.Fd:
+            g = torch.empty(plan.Fd, D, dtype=torch.float32, device=self.device)
+            ops.emb_numeric_grad(dout, dout_ld, num_off, dense, D, g)
+            if plan.num_full and self.num_grad is None:
+                self.num_grad = g
+            else:
+                if self.num_grad is None:
+                    self.num_grad = torch.zeros_like(self.num_w)
+                idx = torch.tensor(plan.num_rows, dtype=torch.int64, device=self.device)
+                self.num_grad.index_add_(0, idx, g)
+        if plan.C:
+            if dd is None:
+                dd = self.dedup(plan, ids, inputs_cache)
+            G = torch.empty(dd.n_max, D, dtype=torch.float32, device=self.device)
+            sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max), dtype=torch.float32,
+                             device=self.device)
+            ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G, sq)
+            self.pending.append(_PendingGrad(dd, G, sq))
+
+    def flush(self):
+        """exact mode: replay pending zero-gradient Adam steps for EVERY row (before eval/save)."""
+        if self.exact and self.opt_kind == "adam" and self.table is not None:
+            ops.adam_catchup(self.table, self.m, self.v, self.last_step, self.D, None,
+                             self.total_rows, 0, self.scal)
+
+
+class _EmbGatherFn(torch.autograd.Function):
+    """One launch: all id columns + numeric columns of a group -> [B, n_slots * D]."""
+
+    @staticmethod
+    def forward(ctx, anchor, group, plan, ids, dense, dd, inputs):
+        B = (ids if ids is not None else dense).shape[0]
+        out = torch.empty(B, plan.n_slots * group.D, dtype=torch.float32, device=group.device)
+        ops.emb_gather_fwd(group.table, group.D, ids, plan.col_row_base, plan.col_vocab,
+                           plan.col_out_off, dense, group.select_num_w(plan), plan.num_out_off,
+                           out, group.ensure_scal())
+        ctx.group, ctx.plan, ctx.ids, ctx.dense, ctx.dd = group, plan, ids, dense, dd
+        ctx.inputs = inputs if hasattr(inputs, "cache") else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        ctx.group.backward(ctx.plan, ctx.ids, ctx.dense, dout, dout.stride(0),
+                           ctx.plan.col_out_off, ctx.plan.num_out_off, ctx.dd, ctx.inputs)
+        return None, None, None, None, None, None, None
+
+
+class FeatureEmbeddingDict(nn.Module):
+    """Native drop-in for feature_embedding.py:91-297 (same ctor / forward / dict2tensor)."""
+
+    def __init__(self,
+                 feature_map,
+                 embedding_dim,
+                 embedding_initializer="partial(nn.init.normal_, std=1e-4)",
+                 required_feature_columns=None,
+                 not_required_feature_columns=None,
+                 use_pretrain=True,
+                 use_sharing=True):
+        super(FeatureEmbeddingDict, self).__init__()
+        self._feature_map = feature_map
+        self.required_feature_columns = required_feature_columns
+        self.not_required_feature_columns = not_required_feature_columns
+        self.use_pretrain = use_pretrain
+        self.embedding_initializer = get_initializer(embedding_initializer)
+        self.embedding_layers = nn.ModuleDict()
+        self.feature_encoders = nn.ModuleDict()
+        self._device = _alloc_device()
+        self._groups = OrderedDict()   # D -> _TableGroup
+        self._feat_group = {}          # feature -> D
+        self._torch_feats = set()      # features served by stock torch modules ("embedding" type)
+        lr_mode = (not (use_pretrain and use_sharing)) and embedding_dim == 1
+        for feature, spec in self._feature_map.features.items():
+            if not self.is_required(feature):
+                continue
+            ftype = spec["type"]
+            if lr_mode:
+                feat_dim = 1  # the LR trick, feature_embedding.py:135-138
+                if ftype == "sequence":
+                    self.feature_encoders[feature] = MaskedSumPooling()
+            else:
+                feat_dim = spec.get("embedding_dim", embedding_dim)
+                if spec.get("feature_encoder", None):
+                    self.feature_encoders[feature] = self.get_feature_encoder(spec["feature_encoder"])
+                elif ftype == "embedding":
+                    pretrain_dim = spec.get("pretrain_dim", feat_dim)
+                    self.feature_encoders[feature] = nn.Linear(pretrain_dim, feat_dim, bias=False)
+            if ftype in ("categorical", "sequence") and use_pretrain and "pretrained_emb" in spec:
+                raise NotImplementedError(
+                    "feature '%s': pretrained_emb tables are outside the native hot path "
+                    "(SURVEY.md §2 row 14); drop `pretrained_emb` or pass use_pretrain=False"
+                    % feature)
+            width = spec["max_len"] if ftype == "sequence" else 1
+            if ftype in ("categorical", "sequence", "numeric"):
+                grp = self._groups.get(feat_dim)
+                if grp is None:
+                    grp = self._groups[feat_dim] = _TableGroup(feat_dim, self._device)
+                self._feat_group[feature] = feat_dim
+            share = spec.get("share_embedding")
+            if use_sharing and share in self._feat_group and ftype in ("categorical", "sequence"):
+                if self._feat_group[share] != feat_dim:
+                    raise NotImplementedError("share_embedding across different embedding dims")
+                grp.add_alias(feature, share, width)
+                continue
+            if ftype == "numeric":
+                grp.add_numeric(feature)
+            elif ftype in ("categorical", "sequence"):
+                grp.add_table(feature, spec["vocab_size"], spec.get("padding_idx", None), width)
+            elif ftype == "embedding":
+                self.embedding_layers[feature] = nn.Identity()
+                self._torch_feats.add(feature)
+            else:
+                raise NotImplementedError("feature type={} is not supported.".format(ftype))
+        for grp in self._groups.values():
+            grp.allocate()
+        self._bind_views()
+        self._default_init()
+        self.init_weights()
+
+    # -- storage ----------------------------------------------------------------------------
+    def _bind_views(self):
+        """(Re)point the per-feature Parameters at views of the packed storage."""
+        for grp in self._groups.values():
+            for feature, (base, V, pidx) in grp.tables.items():
+                view = grp.table[base:base + V]
+                if feature in self.embedding_layers:
+                    self.embedding_layers[feature].weight.data = view
+                else:
+                    self.embedding_layers[feature] = _TableView(view, pidx)
+            for feature, owner in grp.alias.items():
+                self.embedding_layers[feature] = self.embedding_layers[owner]
+            for j, feature in enumerate(grp.numeric):
+                view = grp.num_w[j].view(grp.D, 1)
+                if feature in self.embedding_layers:
+                    self.embedding_layers[feature].weight.data = view
+                else:
+                    self.embedding_layers[feature] = _NumericView(view)
+
+    def _apply(self, fn, recurse=True):
+        # nn.Module.to()/cuda()/float(): move the packed storages, then re-bind the views so the
+        # per-feature Parameters keep aliasing one table (a per-Parameter move would split it).
+        for grp in self._groups.values():
+            for name in ("table", "num_w", "m", "v", "last_step", "scal"):
+                t = getattr(grp, name)
+                if t is not None:
+                    setattr(grp, name, fn(t))
+            ref = grp.table if grp.table is not None else grp.num_w
+            if ref is not None and ref.device != grp.device:
+                grp.device = ref.device
+                grp.plans = {}
+                grp.dedup_ws = None
+        devs = [g.device for g in self._groups.values()]
+        if devs:
+            self._device = devs[0]
+        self._bind_views()
+        for module in self.feature_encoders.values():
+            module._apply(fn)
+        for f in self._torch_feats:
+            self.embedding_layers[f]._apply(fn)
+        return self
+
+    def _default_init(self):
+        """What the stock modules would hold before init_weights(): nn.Embedding ~ N(0,1) with a
+        zero padding row, nn.Linear(1,D) ~ kaiming-uniform (both are overwritten right after by
+        init_weights / BaseModel.reset_parameters, as in the reference)."""
+        with torch.no_grad():
+            for grp in self._groups.values():
+                if grp.table is not None:
+                    grp.table.normal_(0.0, 1.0)
+                    for _, (base, V, pidx) in grp.tables.items():
+                        if pidx is not None:
+                            grp.table[base + pidx].zero_()
+                if grp.num_w is not None:
+                    grp.num_w.uniform_(-1.0, 1.0)
+
+    def get_feature_encoder(self, encoder):
+        from . import layers  # noqa: F401  (encoder strings say "layers.MaskedAveragePooling()")
+        try:
+            if isinstance(encoder, list):
+                return nn.Sequential(*[eval(enc) for enc in encoder])
+            return eval(encoder)
+        except Exception:
+            raise ValueError("feature_encoder={} is not supported.".format(encoder))
+
+    def init_weights(self):
+        """feature_embedding.py:205-216 — initializer on rows 1.. when a padding_idx exists."""
+        with torch.no_grad():
+            for k, v in self.embedding_layers.items():
+                if "share_embedding" in self._feature_map.features[k]:
+                    continue
+                if isinstance(v, _TableView):
+                    if v.padding_idx is not None:
+                        self.embedding_initializer(v.weight[1:, :])
+                    else:
+                        self.embedding_initializer(v.weight)
+
+    def is_required(self, feature):
+        spec = self._feature_map.features[feature]
+        if spec["type"] == "meta":
+            return False
+        elif self.required_feature_columns and (feature not in self.required_feature_columns):
+            return False
+        elif self.not_required_feature_columns and (feature in self.not_required_feature_columns):
+            return False
+        return True
+
+    # -- forward ----------------------------------------------------------------------------
+    def forward(self, inputs, feature_source=[], feature_type=[]):
+        """-> OrderedDict name -> [B, D] (or [B, L, D]); values are views of one [B, F, D] record
+        per embedding dim, written by a single gather launch."""
+        fmap = self._feature_map.features
+        present = []
+        for feature in inputs.keys():
+            spec = fmap.get(feature)
+            if spec is None:
+                continue
+            if feature_source and not_in_whitelist(spec["source"], feature_source):
+                continue
+            if feature_type and not_in_whitelist(spec["type"], feature_type):
+                continue
+            if feature in self.embedding_layers:
+                present.append(feature)
+        present_set = set(present)
+        emb = {}
+        for D, grp in self._groups.items():
+            feats = [f for f in fmap if f in present_set and self._feat_group.get(f) == D]
+            if not feats:
+                continue
+            plan = grp.plan_for(feats)
+            ids, dense = grp.pack_inputs(plan, inputs)
+            track = torch.is_grad_enabled() and self.training
+            dd = grp.prepare_train(plan, ids, inputs) if track else None
+            anchor = self._anchor(grp)
+            out = _EmbGatherFn.apply(anchor, grp, plan, ids, dense, dd, inputs)
+            rec = out.view(out.shape[0], plan.n_slots, D)
+            for f in feats:
+                s, w = plan.slot[f]
+                if fmap[f]["type"] == "sequence":
+                    emb[f] = rec[:, s:s + w, :]
+                else:
+                    emb[f] = rec[:, s, :]
+            emb[("__record__", D)] = (rec, plan)
+        for f in present:
+            if f in self._torch_feats:
+                emb[f] = self.embedding_layers[f](inputs[f].float())
+        feature_emb_dict = _EmbDict()
+        for f in present:  # reference order = order of `inputs`
+            e = emb[f]
+            if f in self.feature_encoders:
+                e = self.feature_encoders[f](e)
+                feature_emb_dict._encoded.add(f)
+            feature_emb_dict[f] = e
+        feature_emb_dict._records = [v for k, v in emb.items() if isinstance(k, tuple)]
+        return feature_emb_dict
+
+    def _anchor(self, grp):
+        for f in grp.tables:
+            return self.embedding_layers[f].weight
+        return self.embedding_layers[grp.numeric[0]].weight
+
+    def dict2tensor(self, embedding_dict, flatten_emb=False, feature_list=[], feature_source=[],
+                    feature_type=[]):
+        """feature_embedding.py:230-259.  When the selection is a contiguous slot range of the
+        gather record the record itself is returned (no stack/cat pass)."""
+        names = []
+        for feature, spec in self._feature_map.features.items():
+            if feature_list and not_in_whitelist(feature, feature_list):
+                continue
+            if feature_source and not_in_whitelist(spec["source"], feature_source):
+                continue
+            if feature_type and not_in_whitelist(spec["type"], feature_type):
+                continue
+            if feature in embedding_dict:
+                names.append(feature)
+        fast = self._record_slice(embedding_dict, names)
+        if fast is not None:
+            return fast.flatten(start_dim=1) if flatten_emb else fast
+        tensors = [embedding_dict[f] for f in names]
+        if flatten_emb:
+            return torch.cat(tensors, dim=-1)
+        return torch.stack(tensors, dim=1)
+
+    @staticmethod
+    def _record_slice(embedding_dict, names):
+        records = getattr(embedding_dict, "_records", None)
+        if not records or len(records) != 1 or not names:
+            return None
+        rec, plan = records[0]
+        lo = None
+        nxt = None
+        for f in names:
+            if f not in plan.slot or f in embedding_dict._encoded:
+                return None
+            s, w = plan.slot[f]
+            if w != 1:
+                return None
+            if lo is None:
+                lo = s
+            elif s != nxt:
+                return None
+            nxt = s + 1
+        if lo == 0 and nxt == plan.n_slots:
+            return rec
+        return rec[:, lo:nxt, :]
+
+    # -- optimizer hooks --------------------------------------------------------------------
+    def table_groups(self):
+        return list(self._groups.values())
+
+    def table_parameters(self):
+        """Parameters that are views of packed tables (handled by the sparse-row optimizer)."""
+        seen, out = set(), []
+        for m in self.embedding_layers.values():
+            if isinstance(m, _TableView) and id(m.weight) not in seen:
+                seen.add(id(m.weight))
+                out.append(m.weight)
+        return out
+
+    def numeric_parameters(self):
+        return [m.weight for m in self.embedding_layers.values() if isinstance(m, _NumericView)]
+
+
+class _EmbDict(OrderedDict):
+    """OrderedDict of embeddings that remembers the gather record(s) it is a view of."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._records = []
+        self._encoded = set()
+
+
+class FeatureEmbedding(nn.Module):
+    """feature_embedding.py:30-88."""
+
+    def __init__(self,
+                 feature_map,
+                 embedding_dim,
+                 embedding_initializer="partial(nn.init.normal_, std=1e-4)",
+                 required_feature_columns=None,
+                 not_required_feature_columns=None,
+                 use_pretrain=True,
+                 use_sharing=True):
+        super(FeatureEmbedding, self).__init__()
+        self.embedding_layer = FeatureEmbeddingDict(
+            feature_map, embedding_dim, embedding_initializer=embedding_initializer,
+            required_feature_columns=required_feature_columns,
+            not_required_feature_columns=not_required_feature_columns,
+            use_pretrain=use_pretrain, use_sharing=use_sharing)
+
+    def forward(self, X, feature_source=[], feature_type=[], flatten_emb=False):
+        feature_emb_dict = self.embedding_layer(X, feature_source=feature_source,
+                                                feature_type=feature_type)
+        return self.embedding_layer.dict2tensor(feature_emb_dict, flatten_emb=flatten_emb)
+
+
+# ------------------------------------------------------------------------------------------------
+# LR / FM
+# ------------------------------------------------------------------------------------------------
+class _LRFn(torch.autograd.Function):
+    """out[b] = sum of the D=1 rows + numeric terms + bias, one launch (logistic_regression.py:55-58)."""
+
+    @staticmethod
+    def forward(ctx, anchor, bias, group, plan, ids, dense, dd, inputs):
+        B = (ids if ids is not None else dense).shape[0]
+        out = torch.empty(B, 1, dtype=torch.float32, device=group.device)
+        num_w1 = group.select_num_w(plan)
+        ops.lr_fwd(group.table, ids, plan.col_row_base, plan.col_vocab, dense, num_w1, bias, out,
+                   group.ensure_scal())
+        ctx.group, ctx.plan, ctx.ids, ctx.dense, ctx.dd = group, plan, ids, dense, dd
+        ctx.inputs = inputs if hasattr(inputs, "cache") else None
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        # every column of a sample receives the same upstream value: ld = 1, offsets = 0
+        ctx.group.backward(ctx.plan, ctx.ids, ctx.dense, dout, 1, ctx.plan.col_zero_off,
+                           ctx.plan.num_zero_off, ctx.dd, ctx.inputs)
+        dbias = dout.sum().reshape(1) if ctx.has_bias else None
+        return None, dbias, None, None, None, None, None, None
+
+
+class LogisticRegression(nn.Module):
+    """logistic_regression.py:24-59."""
+
+    def __init__(self, feature_map, use_bias=True):
+        super(LogisticRegression, self).__init__()
+        self.bias = nn.Parameter(torch.zeros(1, device=_alloc_device()), requires_grad=True) \
+            if use_bias else None
+        self.embedding_layer = FeatureEmbedding(feature_map, 1, use_pretrain=False,
+                                                use_sharing=False)
+
+    def forward(self, X):
+        layer = self.embedding_layer.embedding_layer
+        groups = layer.table_groups()
+        fmap = layer._feature_map.features
+        feats = [f for f in fmap if f in X and f in layer.embedding_layers]
+        native = (len(groups) == 1 and not layer._torch_feats
+                  and all(f in layer._feat_group for f in feats))
+        if not native:
+            embed_weights = self.embedding_layer(X)
+            output = embed_weights.sum(dim=1)
+            if self.bias is not None:
+                output = output + self.bias
+            return output
+        grp = groups[0]
+        plan = grp.plan_for(feats)
+        ids, dense = grp.pack_inputs(plan, X)
+        track = torch.is_grad_enabled() and self.training
+        dd = grp.prepare_train(plan, ids, X) if track else None
+        return _LRFn.apply(layer._anchor(grp), self.bias, grp, plan, ids, dense, dd, X)
+
+
+class _FMFn(torch.autograd.Function):
+    """0.5 * sum_d((sum_f e)^2 - sum_f e^2) (+ addend), inner_product.py:55-62."""
+
+    @staticmethod
+    def forward(ctx, emb, addend):
+        emb = emb.contiguous()
+        B, F, D = emb.shape
+        out = torch.empty(B, 1, dtype=torch.float32, device=emb.device)
+        ops.fm_fwd(emb.view(B, F * D), F, D, addend, out)
+        ctx.save_for_backward(emb)
+        ctx.has_add = addend is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (emb,) = ctx.saved_tensors
+        B, F, D = emb.shape
+        g = g.contiguous()
+        demb = torch.empty_like(emb)
+        ops.fm_bwd(emb.view(B, F * D), F, D, g, demb.view(B, F * D), accumulate=False)
+        return demb, (g if ctx.has_add else None)
+
+
+class InnerProductInteraction(nn.Module):
+    """inner_product.py:23-70.  `product_sum` is native; the other outputs run the reference's
+    torch formulas (not on the BASELINE path)."""
+
+    def __init__(self, num_fields, output="product_sum"):
+        super(InnerProductInteraction, self).__init__()
+        self._output_type = output
+        if output not in ["product_sum", "bi_interaction", "inner_product", "elementwise_product"]:
+            raise ValueError("InnerProductInteraction output={} is not supported.".format(output))
+        dev = _alloc_device()
+        if output == "inner_product":
+            self.interaction_units = int(num_fields * (num_fields - 1) / 2)
+            self.triu_mask = nn.Parameter(
+                torch.triu(torch.ones(num_fields, num_fields, device=dev), 1).bool(),
+                requires_grad=False)
+        elif output == "elementwise_product":
+            self.triu_index = nn.Parameter(
+                torch.triu_indices(num_fields, num_fields, offset=1).to(dev), requires_grad=False)
+
+    def forward(self, feature_emb):
+        if self._output_type == "product_sum":
+            return _FMFn.apply(feature_emb, None)
+        if self._output_type == "bi_interaction":
+            sum_of_square = torch.sum(feature_emb, dim=1) ** 2
+            square_of_sum = torch.sum(feature_emb ** 2, dim=1)
+            return (sum_of_square - square_of_sum) * 0.5
+        if self._output_type == "inner_product":
+            ipm = torch.bmm(feature_emb, feature_emb.transpose(1, 2))
+            return torch.masked_select(ipm, self.triu_mask).view(-1, self.interaction_units)
+        emb1 = torch.index_select(feature_emb, 1, self.triu_index[0])
+        emb2 = torch.index_select(feature_emb, 1, self.triu_index[1])
+        return emb1 * emb2
+
+
+class FactorizationMachine(nn.Module):
+    """factorization_machine.py:25-59; fm + lr fused into the FM kernel's addend."""
+
+    def __init__(self, feature_map):
+        super(FactorizationMachine, self).__init__()
+        self.fm_layer = InnerProductInteraction(feature_map.num_fields, output="product_sum")
+        self.lr_layer = LogisticRegression(feature_map, use_bias=True)
+
+    def forward(self, X, feature_emb):
+        lr_out = self.lr_layer(X)
+        return _FMFn.apply(feature_emb, lr_out)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense tower
+# ------------------------------------------------------------------------------------------------
+def _split_k_for(M, N, K):
+    """Split the contraction when the output grid alone cannot fill 256 CUs (weight gradients)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 192:
+        return 1
+    s = max(1, min(256 // tiles, K // 256))
+    return min(s, 16)
+
+
+class _Workspace(object):
+    """Grow-only fp32 scratch per device for split-K slabs and column-sum partials."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, device, n):
+        buf = cls._bufs.get(device)
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
+            cls._bufs[device] = buf
+        return buf
+
+
+def linear_weight_grads(dz, x, W_shape, need_bias):
+    """dW[N_out, K_in] = dz^T x (split-K), db[N_out] = colsum(dz)."""
+    Bsz, N_out = dz.shape
+    K_in = x.shape[1]
+    dW = torch.empty(N_out, K_in, dtype=torch.float32, device=dz.device)
+    sk = _split_k_for(N_out, K_in, Bsz)
+    ws = _Workspace.get(dz.device, max(sk * N_out * K_in, _lib.FX_COLSUM_CHUNKS * N_out))
+    ops.gemm(dz, x, dW, transa=True, transb=False, split_k=sk, workspace=ws)
+    db = None
+    if need_bias:
+        db = torch.empty(N_out, dtype=torch.float32, device=dz.device)
+        ops.colsum(dz, db, ws)
+    return dW, db
+
+
+class _MLPFn(torch.autograd.Function):
+    """Whole Linear(+ReLU) stack as ONE autograd node: forward = one GEMM per layer with
+    bias+ReLU in the epilogue; backward = dX GEMM with the ReLU mask of the layer below in its
+    epilogue, split-K dW GEMM, column-sum db.  args = (x, acts, W0, b0, W1, b1, ...)."""
+
+    @staticmethod
+    def forward(ctx, x, acts, *wb):
+        x = x.contiguous()
+        n = len(acts)
+        hs = [x]
+        h = x
+        for i in range(n):
+            W, b = wb[2 * i], wb[2 * i + 1]
+            y = torch.empty(h.shape[0], W.shape[0], dtype=torch.float32, device=h.device)
+            ops.gemm(h, W, y, transa=False, transb=True, bias=b, act=1 if acts[i] else 0)
+            hs.append(y)
+            h = y
+        ctx.acts = acts
+        ctx.wb = wb
+        ctx.hs = hs
+        ctx.need_dx = x.requires_grad
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        acts, wb, hs = ctx.acts, ctx.wb, ctx.hs
+        n = len(acts)
+        dz = dy.contiguous()
+        if acts[n - 1]:
+            dz = ops.mask_mul(dz, hs[n], torch.empty_like(dz))
+        grads = [None] * (2 * n)
+        dx = None
+        for i in range(n - 1, -1, -1):
+            W, b = wb[2 * i], wb[2 * i + 1]
+            h_in = hs[i]
+            dW, db = linear_weight_grads(dz, h_in, W.shape, b is not None)
+            grads[2 * i], grads[2 * i + 1] = dW, db
+            if i > 0 or ctx.need_dx:
+                dh = torch.empty_like(h_in)
+                mask = h_in if (i > 0 and acts[i - 1]) else None
+                ops.gemm(dz, W, dh, transa=False, transb=False, mask=mask)
+                if i > 0:
+                    dz = dh
+                else:
+                    dx = dh
+        return (dx, None) + tuple(grads)
+
+
+class FxLinear(nn.Linear):
+    """nn.Linear whose forward/backward run on the fp32 MFMA GEMM (same parameters/keys)."""
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        y = _MLPFn.apply(x.reshape(-1, x.shape[-1]), (False,), self.weight, self.bias)
+        return y.reshape(*lead, self.out_features)
+
+
+def get_activation(activation, hidden_units=None):
+    """fuxictr/pytorch/torch_utils.py:137-173."""
+    if isinstance(activation, str):
+        if activation.lower() in ["prelu", "dice"]:
+            assert type(hidden_units) == int
+        if activation.lower() == "relu":
+            return nn.ReLU()
+        elif activation.lower() == "sigmoid":
+            return nn.Sigmoid()
+        elif activation.lower() == "tanh":
+            return nn.Tanh()
+        elif activation.lower() == "softmax":
+            return nn.Softmax(dim=-1)
+        elif activation.lower() == "prelu":
+            return nn.PReLU(hidden_units, init=0.1)
+        elif activation.lower() == "dice":
+            raise NotImplementedError("activation=dice: DIN path is not built yet (SURVEY §8 a10)")
+        else:
+            return getattr(nn, activation)()
+    elif isinstance(activation, list):
+        if hidden_units is not None:
+            assert len(activation) == len(hidden_units)
+            return [get_activation(act, units) for act, units in zip(activation, hidden_units)]
+        return [get_activation(act) for act in activation]
+    return activation
+
+
+class MLP_Block(nn.Module):
+    """mlp_block.py:24-96 — same `self.mlp` nn.Sequential (so the same state_dict keys); when the
+    stack is only Linear / ReLU (the BASELINE configs) forward is a single fused node."""
+
+    def __init__(self,
+                 input_dim,
+                 hidden_units=[],
+                 hidden_activations="ReLU",
+                 output_dim=None,
+                 output_activation=None,
+                 dropout_rates=0.0,
+                 batch_norm=False,
+                 bn_only_once=False,
+                 use_bias=True):
+        super(MLP_Block, self).__init__()
+        dev = _alloc_device()
+        dense_layers = []
+        if not isinstance(dropout_rates, list):
+            dropout_rates = [dropout_rates] * len(hidden_units)
+        if not isinstance(hidden_activations, list):
+            hidden_activations = [hidden_activations] * len(hidden_units)
+        hidden_activations = get_activation(hidden_activations, hidden_units)
+        hidden_units = [input_dim] + hidden_units
+        if batch_norm and bn_only_once:
+            dense_layers.append(nn.BatchNorm1d(input_dim, device=dev))
+        for idx in range(len(hidden_units) - 1):
+            dense_layers.append(FxLinear(hidden_units[idx], hidden_units[idx + 1], bias=use_bias,
+                                         device=dev))
+            if batch_norm and not bn_only_once:
+                dense_layers.append(nn.BatchNorm1d(hidden_units[idx + 1], device=dev))
+            if hidden_activations[idx]:
+                dense_layers.append(hidden_activations[idx])
+            if dropout_rates[idx] > 0:
+                dense_layers.append(nn.Dropout(p=dropout_rates[idx]))
+        if output_dim is not None:
+            dense_layers.append(FxLinear(hidden_units[-1], output_dim, bias=use_bias, device=dev))
+        if output_activation is not None:
+            dense_layers.append(get_activation(output_activation))
+        self.mlp = nn.Sequential(*dense_layers)
+        self._fused = self._fusable()
+
+    def _fusable(self):
+        """(list of (FxLinear, relu?)) if the stack is Linear[/ReLU] only, else None."""
+        mods = list(self.mlp)
+        stack = []
+        i = 0
+        while i < len(mods):
+            if not isinstance(mods[i], FxLinear):
+                return None
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            stack.append((mods[i], relu))
+            i += 2 if relu else 1
+        return stack or None
+
+    def forward(self, inputs):
+        if self._fused is None or inputs.dim() != 2:
+            return self.mlp(inputs)
+        acts = tuple(r for _, r in self._fused)
+        wb = []
+        for lin, _ in self._fused:
+            wb += [lin.weight, lin.bias]
+        return _MLPFn.apply(inputs, acts, *wb)
+
+
+class _CrossNetV2Fn(torch.autograd.Function):
+    """X_{i+1} = X_i + X_0 * (W_i X_i + b_i), cross_net.py:126-129; one GEMM per layer with the
+    bias / Hadamard / residual in its epilogue.  args = (x0, W0, b0, W1, b1, ...)."""
+
+    @staticmethod
+    def forward(ctx, x0, *wb):
+        x0 = x0.contiguous()
+        n = len(wb) // 2
+        xs, zs = [x0], []
+        xi = x0
+        for i in range(n):
+            W, b = wb[2 * i], wb[2 * i + 1]
+            z = torch.empty_like(x0)
+            xn = torch.empty_like(x0)
+            ops.gemm(xi, W, xn, transa=False, transb=True, bias=b, zout=z, mul=x0, add=xi)
+            xs.append(xn)
+            zs.append(z)
+            xi = xn
+        ctx.wb, ctx.xs, ctx.zs = wb, xs, zs
+        return xi
+
+    @staticmethod
+    def backward(ctx, dxn):
+        wb, xs, zs = ctx.wb, ctx.xs, ctx.zs
+        n = len(wb) // 2
+        x0 = xs[0]
+        dxn = dxn.contiguous()
+        dx0 = torch.empty_like(x0)
+        t = torch.empty_like(x0)
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            W, b = wb[2 * i], wb[2 * i + 1]
+            # t = dxn * x0 (grad of W x_i + b); dx0 (+)= dxn * z_i; at the first layer x_i IS x_0,
+            # so its residual gradient dxn joins dx0 and the last GEMM adds dx0 in its epilogue.
+            ops.cross_bwd_prep(dxn, x0, zs[i], t, dx0, init=(i == n - 1), add_dxn=(i == 0))
+            dW, db = linear_weight_grads(t, xs[i], W.shape, b is not None)
+            grads[2 * i], grads[2 * i + 1] = dW, db
+            dxi = torch.empty_like(x0)
+            ops.gemm(t, W, dxi, transa=False, transb=False, add=(dx0 if i == 0 else dxn))
+            dxn = dxi
+        return (dxn,) + tuple(grads)
+
+
+class CrossNetV2(nn.Module):
+    """cross_net.py:95-129."""
+
+    def __init__(self, input_dim, num_layers):
+        super(CrossNetV2, self).__init__()
+        self.num_layers = num_layers
+        dev = _alloc_device()
+        self.cross_layers = nn.ModuleList(FxLinear(input_dim, input_dim, device=dev)
+                                          for _ in range(self.num_layers))
+
+    def forward(self, X_0):
+        wb = []
+        for lin in self.cross_layers:
+            wb += [lin.weight, lin.bias]
+        return _CrossNetV2Fn.apply(X_0, *wb)

@@ -1,0 +1,279 @@
+"""Thin tensor-level wrappers over the C-ABI (include/fxctr.h).
+
+torch is plumbing here: it owns device memory and the stream; every computation below is a call
+into libfxctr.so.  All functions require CUDA(HIP) fp32/int32 contiguous tensors and raise
+otherwise — there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr, vp
+
+_DT = {torch.float32: _lib.FX_F32, torch.float64: _lib.FX_F64,
+       torch.int32: _lib.FX_I32, torch.int64: _lib.FX_I64}
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise _lib.FxError("%s must live on the GPU: the native path has no CPU fallback "
+                           "(got device %s)" % (name, t.device))
+
+
+def new_scalars(device, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.0):
+    """Allocate and initialise a device-resident fx_scalars block (16 x 4-byte words)."""
+    host = torch.zeros(_lib.SC_WORDS, dtype=torch.float32)
+    host[_lib.SC_LR] = lr
+    host[_lib.SC_BETA1] = beta1
+    host[_lib.SC_BETA2] = beta2
+    host[_lib.SC_EPS] = eps
+    host[_lib.SC_CLIP] = 1.0
+    host[_lib.SC_MAX_NORM] = max_norm
+    return host.to(device)
+
+
+def pack_columns(cols, out, out_col0=0):
+    """cols: list of [B] or [B, w] device tensors -> out[:, out_col0:...] (int32 or float32)."""
+    lib = _lib.load()
+    B = out.shape[0]
+    i = 0
+    col = out_col0
+    while i < len(cols):
+        chunk = cols[i:i + _lib.FX_PACK_MAX_COLS]
+        keep = []
+        dts, ws = [], []
+        for t in chunk:
+            _need_cuda(t, "input column")
+            if t.dtype not in _DT:
+                raise _lib.FxError("unsupported input dtype %s" % t.dtype)
+            if not t.is_contiguous():
+                t = t.contiguous()
+            if t.shape[0] != B:
+                raise _lib.FxError("input column has %d rows, expected %d" % (t.shape[0], B))
+            keep.append(t)
+            dts.append(_DT[t.dtype])
+            ws.append(1 if t.dim() == 1 else int(t.shape[1]))
+        check(lib.fx_pack_columns(_lib.ptr_array(keep), _lib.i32_array(dts), _lib.i32_array(ws),
+                                  len(keep), B, _DT[out.dtype], ptr(out), out.stride(0), col,
+                                  stream_ptr(out.device)), "fx_pack_columns")
+        col += sum(ws)
+        i += len(chunk)
+    return out
+
+
+def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w,
+                   num_out_off, out, scal):
+    lib = _lib.load()
+    B = out.shape[0]
+    C_ = 0 if ids is None else ids.shape[1]
+    Fd = 0 if dense is None else dense.shape[1]
+    check(lib.fx_emb_gather_fwd(ptr(table), D, ptr(ids), 0 if ids is None else ids.stride(0),
+                                ptr(col_row_base), ptr(col_vocab), ptr(col_out_off), C_,
+                                ptr(dense), 0 if dense is None else dense.stride(0), ptr(num_w),
+                                ptr(num_out_off), Fd, ptr(out), out.stride(0), B, ptr(scal),
+                                stream_ptr(out.device)), "fx_emb_gather_fwd")
+    return out
+
+
+def dedup_workspace_bytes(n):
+    lib = _lib.load()
+    nbytes = lib.fx_dedup_workspace_bytes(n)
+    if nbytes == 0:
+        check(1, "fx_dedup_workspace_bytes")
+    return int(nbytes)
+
+
+class DedupResult(object):
+    """Unique rows of a batch's lookups (device resident; count stays on the device)."""
+    __slots__ = ("sorted_key", "sorted_pos", "uniq_row", "seg_start", "n_unique", "n_max", "C")
+
+    def __init__(self, n, C_, device):
+        self.sorted_key = torch.empty(n, dtype=torch.int32, device=device)
+        self.sorted_pos = torch.empty(n, dtype=torch.int32, device=device)
+        self.uniq_row = torch.empty(n, dtype=torch.int32, device=device)
+        self.seg_start = torch.empty(n + 1, dtype=torch.int32, device=device)
+        self.n_unique = torch.zeros(1, dtype=torch.int32, device=device)
+        self.n_max = n
+        self.C = C_
+
+
+def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None):
+    lib = _lib.load()
+    B, C_ = ids.shape
+    if result is None:
+        result = DedupResult(B * C_, C_, ids.device)
+    check(lib.fx_dedup(ptr(ids), ids.stride(0), B, C_, ptr(col_row_base), ptr(col_vocab),
+                       ptr(col_pad), total_rows, ptr(workspace), workspace.numel(),
+                       ptr(result.sorted_key), ptr(result.sorted_pos), ptr(result.uniq_row),
+                       ptr(result.seg_start), ptr(result.n_unique), stream_ptr(ids.device)),
+          "fx_dedup")
+    return result
+
+
+def emb_grad_reduce_partials(n_max):
+    return int(_lib.load().fx_emb_grad_reduce_partials(n_max))
+
+
+def emb_grad_reduce(dout, dout_ld, col_out_off, C_, D, dd, G, sq_partials):
+    lib = _lib.load()
+    check(lib.fx_emb_grad_reduce(ptr(dout), dout_ld, ptr(col_out_off), C_, D, ptr(dd.sorted_pos),
+                                 ptr(dd.seg_start), ptr(dd.n_unique), dd.n_max, ptr(G),
+                                 ptr(sq_partials), stream_ptr(dout.device)),
+          "fx_emb_grad_reduce")
+
+
+def emb_numeric_grad(dout, dout_ld, num_out_off, dense, D, dnum_w):
+    lib = _lib.load()
+    B, Fd = dense.shape
+    check(lib.fx_emb_numeric_grad(ptr(dout), dout_ld, ptr(num_out_off), ptr(dense),
+                                  dense.stride(0), Fd, D, B, ptr(dnum_w),
+                                  stream_ptr(dout.device)), "fx_emb_numeric_grad")
+
+
+def opt_begin_step(scal):
+    check(_lib.load().fx_opt_begin_step(ptr(scal), stream_ptr(scal.device)), "fx_opt_begin_step")
+
+
+def clip_coef(parts, scal):
+    """parts: list of fp32 device tensors holding partial sums of squared gradient norms."""
+    lib = _lib.load()
+    if len(parts) > _lib.FX_CLIP_MAX_PARTS:
+        raise _lib.FxError("too many partial-norm arrays (%d)" % len(parts))
+    check(lib.fx_clip_coef(_lib.ptr_array(parts), _lib.i64_array([p.numel() for p in parts]),
+                           len(parts), ptr(scal), stream_ptr(scal.device)), "fx_clip_coef")
+
+
+def sparse_adam(table, m, v, last_step, D, dd, G, scal):
+    check(_lib.load().fx_sparse_adam(ptr(table), ptr(m), ptr(v), ptr(last_step), D,
+                                     ptr(dd.uniq_row), ptr(dd.n_unique), dd.n_max, ptr(G),
+                                     ptr(scal), stream_ptr(table.device)), "fx_sparse_adam")
+
+
+def adam_catchup(table, m, v, last_step, D, dd, total_rows, upto_offset, scal):
+    """dd=None: every row of the table (flush); else only the unique rows of dd."""
+    lib = _lib.load()
+    if dd is None:
+        check(lib.fx_adam_catchup(ptr(table), ptr(m), ptr(v), ptr(last_step), D, vp(0), vp(0), 0,
+                                  total_rows, upto_offset, ptr(scal), stream_ptr(table.device)),
+              "fx_adam_catchup")
+    else:
+        check(lib.fx_adam_catchup(ptr(table), ptr(m), ptr(v), ptr(last_step), D,
+                                  ptr(dd.uniq_row), ptr(dd.n_unique), dd.n_max, total_rows,
+                                  upto_offset, ptr(scal), stream_ptr(table.device)),
+              "fx_adam_catchup")
+
+
+def sparse_sgd(table, D, dd, G, scal):
+    check(_lib.load().fx_sparse_sgd(ptr(table), D, ptr(dd.uniq_row), ptr(dd.n_unique), dd.n_max,
+                                    ptr(G), ptr(scal), stream_ptr(table.device)),
+          "fx_sparse_sgd")
+
+
+def _chunks(n):
+    i = 0
+    while i < n:
+        yield i, min(n, i + _lib.FX_MT_MAX)
+        i += _lib.FX_MT_MAX
+
+
+def mt_sqnorm(grads, sq_partials):
+    """sq_partials: fp32 [len(grads) * FX_MT_BLOCKS]."""
+    lib = _lib.load()
+    sizes = [g.numel() for g in grads]
+    for a, b in _chunks(len(grads)):
+        out = sq_partials[a * _lib.FX_MT_BLOCKS:]
+        check(lib.fx_mt_sqnorm(_lib.ptr_array(grads[a:b]), _lib.i64_array(sizes[a:b]), b - a,
+                               ptr(out), stream_ptr(sq_partials.device)), "fx_mt_sqnorm")
+
+
+def mt_adam(params, grads, ms, vs, scal):
+    lib = _lib.load()
+    sizes = [p.numel() for p in params]
+    for a, b in _chunks(len(params)):
+        check(lib.fx_mt_adam(_lib.ptr_array(params[a:b]), _lib.ptr_array(grads[a:b]),
+                             _lib.ptr_array(ms[a:b]), _lib.ptr_array(vs[a:b]),
+                             _lib.i64_array(sizes[a:b]), b - a, ptr(scal),
+                             stream_ptr(scal.device)), "fx_mt_adam")
+
+
+def mt_sgd(params, grads, scal):
+    lib = _lib.load()
+    sizes = [p.numel() for p in params]
+    for a, b in _chunks(len(params)):
+        check(lib.fx_mt_sgd(_lib.ptr_array(params[a:b]), _lib.ptr_array(grads[a:b]),
+                            _lib.i64_array(sizes[a:b]), b - a, ptr(scal),
+                            stream_ptr(scal.device)), "fx_mt_sgd")
+
+
+def fm_fwd(emb, F, D, addend, out):
+    B = emb.shape[0]
+    check(_lib.load().fx_fm_fwd(ptr(emb), emb.stride(0), F, D, ptr(addend), ptr(out), B,
+                                stream_ptr(emb.device)), "fx_fm_fwd")
+    return out
+
+
+def fm_bwd(emb, F, D, g, demb, accumulate=False):
+    B = emb.shape[0]
+    check(_lib.load().fx_fm_bwd(ptr(emb), emb.stride(0), F, D, ptr(g), ptr(demb), demb.stride(0),
+                                1 if accumulate else 0, B, stream_ptr(emb.device)), "fx_fm_bwd")
+    return demb
+
+
+def lr_fwd(table1, ids, col_row_base, col_vocab, dense, num_w1, bias, out, scal):
+    B = out.shape[0]
+    C_ = 0 if ids is None else ids.shape[1]
+    Fd = 0 if dense is None else dense.shape[1]
+    check(_lib.load().fx_lr_fwd(ptr(table1), ptr(ids), 0 if ids is None else ids.stride(0),
+                                ptr(col_row_base), ptr(col_vocab), C_, ptr(dense),
+                                0 if dense is None else dense.stride(0), ptr(num_w1), Fd,
+                                ptr(bias), ptr(out), B, ptr(scal), stream_ptr(out.device)),
+          "fx_lr_fwd")
+    return out
+
+
+def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul=None, mask=None,
+         add=None, split_k=1, workspace=None):
+    """C = epilogue(op(A) . op(B)).  A, B, C: 2-D fp32 with unit inner stride."""
+    lib = _lib.load()
+    M, N = C_.shape
+    K = A.shape[0] if transa else A.shape[1]
+    epi = _lib.GemmEpilogue()
+    epi.bias = bias.data_ptr() if bias is not None else None
+    epi.act = act
+    if zout is not None:
+        epi.zout, epi.ldz = zout.data_ptr(), zout.stride(0)
+    if mul is not None:
+        epi.mul, epi.ldmul = mul.data_ptr(), mul.stride(0)
+    if mask is not None:
+        epi.mask, epi.ldmask = mask.data_ptr(), mask.stride(0)
+    if add is not None:
+        epi.add, epi.ldadd = add.data_ptr(), add.stride(0)
+    check(lib.fx_gemm_f32(1 if transa else 0, 1 if transb else 0, M, N, K, ptr(A), A.stride(0),
+                          ptr(B_), B_.stride(0), ptr(C_), C_.stride(0), C.byref(epi), split_k,
+                          ptr(workspace), stream_ptr(C_.device)), "fx_gemm_f32")
+    return C_
+
+
+def colsum(X, out, workspace):
+    M, N = X.shape
+    check(_lib.load().fx_colsum(ptr(X), X.stride(0), M, N, ptr(out), ptr(workspace),
+                                stream_ptr(X.device)), "fx_colsum")
+    return out
+
+
+def mask_mul(dy, y, out):
+    check(_lib.load().fx_mask_mul(ptr(dy), ptr(y), ptr(out), dy.numel(), stream_ptr(dy.device)),
+          "fx_mask_mul")
+    return out
+
+
+def cross_bwd_prep(dxn, x0, z, t, dx0, init, add_dxn):
+    check(_lib.load().fx_cross_bwd_prep(ptr(dxn), ptr(x0), ptr(z), ptr(t), ptr(dx0), dxn.numel(),
+                                        1 if init else 0, 1 if add_dxn else 0,
+                                        stream_ptr(dxn.device)), "fx_cross_bwd_prep")
+
+
+def sigmoid_bce(logit, y, prob=None, loss=None, dlogit=None):
+    check(_lib.load().fx_sigmoid_bce(ptr(logit), ptr(y), logit.numel(), ptr(prob), ptr(loss),
+                                     ptr(dlogit), stream_ptr(logit.device)), "fx_sigmoid_bce")

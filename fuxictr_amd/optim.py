@@ -1,0 +1,196 @@
+"""Native optimizers: global-norm clip + Adam/SGD as fused kernels, sparse rows for the tables.
+
+Replaces, for one training step (reference lines):
+    nn.utils.clip_grad_norm_(self.parameters(), max_norm)   rank_model.py:321
+    self.optimizer.step()  (torch.optim.Adam / SGD over ALL parameters, torch_utils.py:76)
+The reference's tables are dense-gradient nn.Embedding, so its Adam moves every row each step.
+`sparse_update="exact"` (default) reproduces exactly that trajectory while touching only the rows a
+batch reads: a row's missed zero-gradient steps are replayed in registers when it is next read
+(fx_adam_catchup), and `flush()` replays all rows before evaluate/save/lr change.
+`sparse_update="lazy"` is torch.optim.SparseAdam semantics (rows move only when touched).
+Plain SGD is identical sparse or dense.
+
+The object is a torch.optim.Optimizer so `param_groups[*]["lr"]` (BaseModel.lr_decay,
+rank_model.py:221-234) and zero_grad() keep working.
+"""
+import torch
+
+from . import _lib, ops
+from .layers import FeatureEmbeddingDict
+
+
+class _NativeOptimizer(torch.optim.Optimizer):
+    kind = None
+
+    def __init__(self, params, lr, model=None, sparse_update="exact", betas=(0.9, 0.999),
+                 eps=1e-8):
+        if sparse_update not in ("exact", "lazy"):
+            raise ValueError("sparse_update={} is not supported.".format(sparse_update))
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.sparse_update = sparse_update
+        self._groups = []
+        self._table_param_ids = set()
+        self._numeric_param_ids = set()
+        self.device = None
+        if model is not None:
+            for mod in model.modules():
+                if isinstance(mod, FeatureEmbeddingDict):
+                    self._groups += mod.table_groups()
+                    self._table_param_ids.update(id(p) for p in mod.table_parameters())
+                    self._numeric_param_ids.update(id(p) for p in mod.numeric_parameters())
+        for p in params:
+            if p.is_cuda:
+                self.device = p.device
+                break
+        if self.device is None:
+            raise _lib.FxError("native optimizer needs parameters on the GPU (no CPU fallback)")
+        self.scal = ops.new_scalars(self.device, lr=lr, beta1=betas[0], beta2=betas[1], eps=eps)
+        self._lr_dev = float(lr)
+        self._max_norm = 0.0
+        self._state_dense = {}   # id(tensor) -> (m, v)
+        self._sq_dense = None
+        for grp in self._groups:
+            self._attach(grp)
+
+    # -- setup --------------------------------------------------------------------------------
+    def _attach(self, grp):
+        grp.scal = self.scal
+        grp.opt_kind = self.kind
+        grp.exact = self.kind == "adam" and self.sparse_update == "exact"
+        if self.kind == "adam" and grp.table is not None:
+            grp.m = torch.zeros_like(grp.table)
+            grp.v = torch.zeros_like(grp.table)
+            grp.last_step = torch.zeros(grp.total_rows, dtype=torch.int32, device=grp.device)
+
+    def set_max_norm(self, max_norm):
+        max_norm = float(max_norm) if max_norm else 0.0
+        if max_norm != self._max_norm:
+            self.scal[_lib.SC_MAX_NORM:_lib.SC_MAX_NORM + 1].fill_(max_norm)
+            self._max_norm = max_norm
+
+    def sync_lr(self):
+        """Push a host-side lr change (lr_decay) to the device; exact mode first replays every
+        pending row with the OLD lr, since the replay uses the lr in the scalar block."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_dev:
+            self.flush()
+            self.scal[_lib.SC_LR:_lib.SC_LR + 1].fill_(lr)
+            self._lr_dev = lr
+
+    def begin_step(self):
+        """Call before the forward of a training step: t += 1, Adam bias corrections."""
+        self.sync_lr()
+        ops.opt_begin_step(self.scal)
+
+    def flush(self):
+        for grp in self._groups:
+            grp.flush()
+
+    def check_errors(self):
+        """Host sync: raise if a kernel saw an id outside its table (reference: IndexError)."""
+        flag = int(self.scal.view(torch.int32)[_lib.SC_ERR].item())
+        if flag & _lib.FX_FLAG_BAD_ID:
+            raise IndexError("embedding id out of range (native gather flagged FX_FLAG_BAD_ID)")
+
+    # -- step ---------------------------------------------------------------------------------
+    def _dense_lists(self):
+        ps, gs = [], []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if id(p) in self._table_param_ids or id(p) in self._numeric_param_ids:
+                    continue
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                if not p.is_contiguous():
+                    raise _lib.FxError("non-contiguous dense parameter")
+                ps.append(p.data)
+                gs.append(g)
+        for grp in self._groups:
+            if grp.num_w is not None and grp.num_grad is not None:
+                ps.append(grp.num_w)
+                gs.append(grp.num_grad)
+        return ps, gs
+
+    def _moments(self, ps):
+        ms, vs = [], []
+        for p in ps:
+            st = self._state_dense.get(p.data_ptr())
+            if st is None:
+                st = (torch.zeros_like(p), torch.zeros_like(p))
+                self._state_dense[p.data_ptr()] = st
+            ms.append(st[0])
+            vs.append(st[1])
+        return ms, vs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closure is not supported by the native optimizer")
+        ps, gs = self._dense_lists()
+        parts = []
+        if ps:
+            need = len(ps) * _lib.FX_MT_BLOCKS
+            if self._sq_dense is None or self._sq_dense.numel() != need:
+                self._sq_dense = torch.empty(need, dtype=torch.float32, device=self.device)
+            ops.mt_sqnorm(gs, self._sq_dense)
+            parts.append(self._sq_dense)
+        for grp in self._groups:
+            if len(grp.pending) > 1:
+                raise NotImplementedError(
+                    "a table group was looked up %d times in one training step; merging several "
+                    "sparse gradients per step is not implemented" % len(grp.pending))
+            for rec in grp.pending:
+                parts.append(rec.sq)
+        ops.clip_coef(parts, self.scal)
+        if ps:
+            self._dense_update(ps, gs)
+        for grp in self._groups:
+            for rec in grp.pending:
+                self._sparse_update(grp, rec)
+            grp.pending = []
+            grp.num_grad = None
+        return None
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=set_to_none)
+        for grp in self._groups:
+            grp.pending = []
+            grp.num_grad = None
+
+
+class NativeAdam(_NativeOptimizer):
+    """torch.optim.Adam(params, lr) defaults (betas 0.9/0.999, eps 1e-8, no weight decay)."""
+    kind = "adam"
+
+    def _dense_update(self, ps, gs):
+        ms, vs = self._moments(ps)
+        ops.mt_adam(ps, gs, ms, vs, self.scal)
+
+    def _sparse_update(self, grp, rec):
+        ops.sparse_adam(grp.table, grp.m, grp.v, grp.last_step, grp.D, rec.dd, rec.G, self.scal)
+
+
+class NativeSGD(_NativeOptimizer):
+    """torch.optim.SGD(params, lr) defaults (no momentum, no weight decay)."""
+    kind = "sgd"
+
+    def _dense_update(self, ps, gs):
+        ops.mt_sgd(ps, gs, self.scal)
+
+    def _sparse_update(self, grp, rec):
+        ops.sparse_sgd(grp.table, grp.D, rec.dd, rec.G, self.scal)
+
+
+def get_optimizer(optimizer, params, lr, model=None, sparse_update="exact"):
+    """fuxictr/pytorch/torch_utils.py:58-79 — string -> optimizer; Adam and SGD are native."""
+    if isinstance(optimizer, str):
+        name = optimizer.lower()
+        if name == "adam":
+            return NativeAdam(params, lr, model=model, sparse_update=sparse_update)
+        if name == "sgd":
+            return NativeSGD(params, lr, model=model, sparse_update=sparse_update)
+    raise NotImplementedError("optimizer={} is not supported.".format(optimizer))

@@ -1,0 +1,431 @@
+"""`BaseModel` — host-side mirror of fuxictr/pytorch/models/rank_model.py:31-470 with the
+training step re-plumbed onto the native kernels.
+
+Kept verbatim (names, arguments, behaviour): ctor kwargs, compile, fit, train_epoch, train_step,
+evaluate, predict, lr_decay, checkpoint_and_earlystop, save/load_weights, count_parameters, and
+the per-model contract forward(inputs) -> {"y_pred": Tensor[B,1]}.
+
+What changed underneath train_step (rank_model.py:307-323):
+    zero_grad / forward / loss / backward     same Python shape, native autograd nodes
+    clip_grad_norm_ + optimizer.step()        fused into the native optimizer (optim.py)
+    sigmoid + binary_cross_entropy            one fused kernel (fx_sigmoid_bce)
+"""
+import logging
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, layers, ops
+from .layers import FeatureDict, FeatureEmbeddingDict, FxLinear, _NumericView, not_in_whitelist
+from .optim import get_optimizer
+
+
+# -- small host utilities mirrored from fuxictr/utils.py:166-206 and fuxictr/metrics.py:26-51 ------
+class Monitor(object):
+    def __init__(self, kv):
+        if isinstance(kv, str):
+            kv = {kv: 1}
+        self.kv_pairs = kv
+
+    def get_value(self, logs):
+        return sum(logs.get(k, 0) * v for k, v in self.kv_pairs.items())
+
+    def get_metrics(self):
+        return list(self.kv_pairs.keys())
+
+
+def evaluate_metrics(y_true, y_pred, metrics, group_id=None):
+    """logloss / AUC through scikit-learn on float64, exactly as the reference (metrics.py:49-51),
+    so "AUC to 4 decimals" compares like with like.  Group metrics are out of scope."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    out = OrderedDict()
+    for metric in metrics:
+        if metric in ["logloss", "binary_crossentropy"]:
+            out[metric] = log_loss(y_true, y_pred)
+        elif metric == "AUC":
+            out[metric] = roc_auc_score(y_true, y_pred)
+        elif metric in ["gAUC", "avgAUC", "MRR"] or metric.startswith("NDCG"):
+            raise NotImplementedError("metrics={} not implemented.".format(metric))
+        else:
+            raise ValueError("metric={} not supported.".format(metric))
+    return out
+
+
+def get_device(gpu=-1):
+    """torch_utils.py:42-56, except that the native path REQUIRES a GPU."""
+    if gpu >= 0 and torch.cuda.is_available():
+        return torch.device("cuda:" + str(gpu))
+    raise _lib.FxError("fuxictr_amd runs on an MI355X only: pass gpu>=0 on a machine with a "
+                       "visible HIP device (gpu=%s, cuda available=%s)"
+                       % (gpu, torch.cuda.is_available()))
+
+
+def get_regularizer(reg):
+    """torch_utils.py:106-135."""
+    reg_pair = []
+    if isinstance(reg, float):
+        reg_pair.append((2, reg))
+    elif isinstance(reg, str):
+        try:
+            if reg.startswith("l1(") or reg.startswith("l2("):
+                reg_pair.append((int(reg[1]), float(reg.rstrip(")").split("(")[-1])))
+            elif reg.startswith("l1_l2"):
+                l1_reg, l2_reg = reg.rstrip(")").split("(")[-1].split(",")
+                reg_pair.append((1, float(l1_reg)))
+                reg_pair.append((2, float(l2_reg)))
+            else:
+                raise NotImplementedError
+        except Exception:
+            raise NotImplementedError("regularizer={} is not supported.".format(reg))
+    return reg_pair
+
+
+# -- fused output activation + loss ----------------------------------------------------------------
+class _SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logit):
+        logit = logit.contiguous()
+        p = torch.empty_like(logit)
+        ops.sigmoid_bce(logit, None, prob=p)
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        return dp * p * (1 - p)  # only reached by custom losses; the BCE path never comes here
+
+
+class FxSigmoid(nn.Module):
+    """nn.Sigmoid whose input logit is remembered so that the BCE loss can be fused with it."""
+
+    def forward(self, x):
+        p = _SigmoidFn.apply(x)
+        p._fx_logit = x
+        return p
+
+
+class _SigmoidBCEFn(torch.autograd.Function):
+    """loss = mean BCE(sigmoid(logit), y); forward also produces dloss/dlogit."""
+
+    @staticmethod
+    def forward(ctx, logit, y):
+        logit = logit.contiguous()
+        y = y.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=logit.device)
+        dlogit = torch.empty_like(logit)
+        ops.sigmoid_bce(logit, y, loss=loss, dlogit=dlogit)
+        ctx.save_for_backward(dlogit)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogit,) = ctx.saved_tensors
+        return dlogit * g, None
+
+
+def _bce_loss(y_pred, y_true, reduction="mean"):
+    logit = getattr(y_pred, "_fx_logit", None)
+    if logit is not None and reduction == "mean":
+        return _SigmoidBCEFn.apply(logit, y_true)
+    return torch.nn.functional.binary_cross_entropy(y_pred, y_true, reduction=reduction)
+
+
+def get_loss(loss):
+    """torch_utils.py:81-104."""
+    if isinstance(loss, str):
+        if loss in ["bce", "binary_crossentropy", "binary_cross_entropy"]:
+            return _bce_loss
+        try:
+            return getattr(torch.nn.functional, loss)
+        except AttributeError:
+            raise NotImplementedError("loss={} is not supported.".format(loss))
+    return loss
+
+
+class BaseModel(nn.Module):
+    def __init__(self,
+                 feature_map,
+                 model_id="BaseModel",
+                 task="binary_classification",
+                 gpu=-1,
+                 monitor="AUC",
+                 save_best_only=True,
+                 monitor_mode="max",
+                 early_stop_patience=2,
+                 eval_steps=None,
+                 embedding_regularizer=None,
+                 net_regularizer=None,
+                 reduce_lr_on_plateau=True,
+                 **kwargs):
+        super(BaseModel, self).__init__()
+        self.device = get_device(gpu)
+        torch.cuda.set_device(self.device)
+        layers.set_default_device(self.device)  # native layers allocate their tables here
+        self._monitor = Monitor(kv=monitor)
+        self._monitor_mode = monitor_mode
+        self._early_stop_patience = early_stop_patience
+        self._eval_steps = eval_steps
+        self._save_best_only = save_best_only
+        self._embedding_regularizer = embedding_regularizer
+        self._net_regularizer = net_regularizer
+        self._reduce_lr_on_plateau = reduce_lr_on_plateau
+        self._verbose = kwargs["verbose"]
+        self._sparse_update = kwargs.get("sparse_update", "exact")
+        self._max_gradient_norm = 10.
+        self.feature_map = feature_map
+        self.output_activation = self.get_output_activation(task)
+        self.model_id = model_id
+        self.model_dir = os.path.join(kwargs["model_root"], feature_map.dataset_id)
+        self.checkpoint = os.path.abspath(os.path.join(self.model_dir, self.model_id + ".model"))
+        self.validation_metrics = kwargs["metrics"]
+        if self._embedding_regularizer:
+            raise NotImplementedError(
+                "embedding_regularizer={} needs a dense pass over every table row each step "
+                "(rank_model.py:106-112); the sparse-row path supports 0/None only for now"
+                .format(embedding_regularizer))
+
+    def compile(self, optimizer, loss, lr):
+        self.optimizer = get_optimizer(optimizer, self.parameters(), lr, model=self,
+                                       sparse_update=self._sparse_update)
+        self.loss_fn = get_loss(loss)
+
+    def regularization_loss(self):
+        """rank_model.py:95-118 for the non-embedding parameters."""
+        reg_term = 0
+        if self._net_regularizer:
+            net_reg = get_regularizer(self._net_regularizer)
+            emb_params = set()
+            for m_name, module in self.named_modules():
+                if type(module) == FeatureEmbeddingDict:
+                    for p_name, _ in module.named_parameters():
+                        emb_params.add(".".join([m_name, p_name]))
+            for name, param in self.named_parameters():
+                if param.requires_grad and name not in emb_params:
+                    for net_p, net_lambda in net_reg:
+                        reg_term += (net_lambda / net_p) * torch.norm(param, net_p) ** net_p
+        return reg_term
+
+    def add_loss(self, return_dict, y_true):
+        return self.loss_fn(return_dict["y_pred"], y_true, reduction='mean')
+
+    def compute_loss(self, return_dict, y_true):
+        return self.add_loss(return_dict, y_true) + self.regularization_loss()
+
+    def reset_parameters(self):
+        """rank_model.py:146-167: xavier_normal_ on Linear/Conv1d, then every init_weights()."""
+        def default_reset_params(m):
+            if type(m) in [nn.Linear, nn.Conv1d, FxLinear, _NumericView]:
+                nn.init.xavier_normal_(m.weight)
+                if m.bias is not None:
+                    m.bias.data.fill_(0)
+
+        def custom_reset_params(m):
+            if hasattr(m, 'init_weights'):
+                m.init_weights()
+        self.apply(default_reset_params)
+        self.apply(custom_reset_params)
+
+    def get_inputs(self, inputs, feature_source=None):
+        """rank_model.py:169-189; returns a FeatureDict so the embedding layers of this model can
+        share the packed id matrix and the de-dup of the batch."""
+        if isinstance(inputs, FeatureDict) and getattr(inputs, "_fx_ready", False):
+            return inputs
+        X_dict = FeatureDict()
+        for feature in inputs.keys():
+            if feature in self.feature_map.labels:
+                continue
+            spec = self.feature_map.features[feature]
+            if spec["type"] == "meta":
+                continue
+            if feature_source and not_in_whitelist(spec["source"], feature_source):
+                continue
+            X_dict[feature] = inputs[feature].to(self.device)
+        return X_dict
+
+    def get_labels(self, inputs):
+        labels = self.feature_map.labels
+        y = inputs[labels[0]].to(self.device)
+        return y.float().view(-1, 1)
+
+    def get_group_id(self, inputs):
+        return inputs[self.feature_map.group_id]
+
+    def model_to_device(self):
+        self.to(device=self.device)
+
+    def lr_decay(self, factor=0.1, min_lr=1e-6):
+        for param_group in self.optimizer.param_groups:
+            reduced_lr = max(param_group["lr"] * factor, min_lr)
+            param_group["lr"] = reduced_lr
+        return reduced_lr
+
+    def fit(self, data_generator, epochs=1, validation_data=None,
+            max_gradient_norm=10., **kwargs):
+        self.valid_gen = validation_data
+        self._max_gradient_norm = max_gradient_norm
+        self._best_metric = np.inf if self._monitor_mode == "min" else -np.inf
+        self._stopping_steps = 0
+        self._stop_training = False
+        self._steps_per_epoch = len(data_generator)
+        self._total_steps = 0
+        self._batch_index = 0
+        self._epoch_index = 0
+        if self._eval_steps is None:
+            self._eval_steps = self._steps_per_epoch
+        logging.info("Start training: {} batches/epoch".format(self._steps_per_epoch))
+        logging.info("************ Epoch=1 start ************")
+        for epoch in range(epochs):
+            self._epoch_index = epoch
+            self.train_epoch(data_generator)
+            if self._stop_training:
+                break
+            else:
+                logging.info("************ Epoch={} end ************".format(self._epoch_index + 1))
+        logging.info("Training finished.")
+        logging.info("Load best model: {}".format(self.checkpoint))
+        self.load_weights(self.checkpoint)
+
+    def checkpoint_and_earlystop(self, logs, min_delta=1e-6):
+        monitor_value = self._monitor.get_value(logs)
+        if (self._monitor_mode == "min" and monitor_value > self._best_metric - min_delta) or \
+           (self._monitor_mode == "max" and monitor_value < self._best_metric + min_delta):
+            self._stopping_steps += 1
+            logging.info("Monitor({})={:.6f} STOP!".format(self._monitor_mode, monitor_value))
+            if self._reduce_lr_on_plateau:
+                current_lr = self.lr_decay()
+                logging.info("Reduce learning rate on plateau: {:.6f}".format(current_lr))
+        else:
+            self._stopping_steps = 0
+            self._best_metric = monitor_value
+            if self._save_best_only:
+                logging.info("Save best model: monitor({})={:.6f}"
+                             .format(self._monitor_mode, monitor_value))
+                self.save_weights(self.checkpoint)
+        if self._stopping_steps >= self._early_stop_patience:
+            self._stop_training = True
+            logging.info("********* Epoch={} early stop *********".format(self._epoch_index + 1))
+        if not self._save_best_only:
+            self.save_weights(self.checkpoint)
+
+    def eval_step(self):
+        logging.info('Evaluation @epoch {} - batch {}: '.format(self._epoch_index + 1,
+                                                                 self._batch_index + 1))
+        val_logs = self.evaluate(self.valid_gen, metrics=self._monitor.get_metrics())
+        self.checkpoint_and_earlystop(val_logs)
+        self.train()
+
+    def train(self, mode=True):
+        """Leaving training mode makes the tables consistent first: in exact mode rows that were
+        not read recently still owe their zero-gradient Adam steps (optim.py)."""
+        if not mode and getattr(self, "optimizer", None) is not None \
+                and hasattr(self.optimizer, "flush"):
+            self.optimizer.flush()
+        return super().train(mode)
+
+    def train_step(self, batch_data):
+        """rank_model.py:307-323 on the native path."""
+        opt = self.optimizer
+        opt.set_max_norm(self._max_gradient_norm)
+        opt.begin_step()
+        opt.zero_grad()
+        return_dict = self.forward(batch_data)
+        y_true = self.get_labels(batch_data)
+        loss = self.compute_loss(return_dict, y_true)
+        loss.backward()
+        opt.step()  # global-norm clip (rank_model.py:321) is fused into the update kernels
+        return loss
+
+    def train_epoch(self, data_generator):
+        self._batch_index = 0
+        train_loss = 0
+        self.train()
+        if self._verbose == 0:
+            batch_iterator = data_generator
+        else:
+            from tqdm import tqdm
+            batch_iterator = tqdm(data_generator, disable=False, file=sys.stdout)
+        for batch_index, batch_data in enumerate(batch_iterator):
+            self._batch_index = batch_index
+            self._total_steps += 1
+            loss = self.train_step(batch_data)
+            train_loss += loss.item()
+            if self._total_steps % self._eval_steps == 0:
+                logging.info("Train loss: {:.6f}".format(train_loss / self._eval_steps))
+                train_loss = 0
+                self.eval_step()
+            if self._stop_training:
+                break
+        self.optimizer.check_errors()
+
+    def evaluate(self, data_generator, metrics=None):
+        self.eval()
+        with torch.no_grad():
+            y_pred, y_true, group_id = [], [], []
+            if self._verbose > 0:
+                from tqdm import tqdm
+                data_generator = tqdm(data_generator, disable=False, file=sys.stdout)
+            for batch_data in data_generator:
+                return_dict = self.forward(batch_data)
+                y_pred.extend(return_dict["y_pred"].data.cpu().numpy().reshape(-1))
+                y_true.extend(self.get_labels(batch_data).data.cpu().numpy().reshape(-1))
+                if self.feature_map.group_id is not None:
+                    group_id.extend(self.get_group_id(batch_data).numpy().reshape(-1))
+            y_pred = np.array(y_pred, np.float64)
+            y_true = np.array(y_true, np.float64)
+            group_id = np.array(group_id) if len(group_id) > 0 else None
+            if metrics is not None:
+                val_logs = self.evaluate_metrics(y_true, y_pred, metrics, group_id)
+            else:
+                val_logs = self.evaluate_metrics(y_true, y_pred, self.validation_metrics, group_id)
+            logging.info('[Metrics] ' + ' - '.join('{}: {:.6f}'.format(k, v)
+                                                   for k, v in val_logs.items()))
+            return val_logs
+
+    def predict(self, data_generator):
+        self.eval()
+        with torch.no_grad():
+            y_pred = []
+            if self._verbose > 0:
+                from tqdm import tqdm
+                data_generator = tqdm(data_generator, disable=False, file=sys.stdout)
+            for batch_data in data_generator:
+                return_dict = self.forward(batch_data)
+                y_pred.extend(return_dict["y_pred"].data.cpu().numpy().reshape(-1))
+            return np.array(y_pred, np.float64)
+
+    def evaluate_metrics(self, y_true, y_pred, metrics, group_id=None):
+        return evaluate_metrics(y_true, y_pred, metrics, group_id)
+
+    def save_weights(self, checkpoint):
+        if hasattr(self.optimizer, "flush"):
+            self.optimizer.flush()
+        os.makedirs(os.path.dirname(checkpoint), exist_ok=True)
+        torch.save(self.state_dict(), checkpoint)
+
+    def load_weights(self, checkpoint):
+        self.to(self.device)
+        state_dict = torch.load(checkpoint, map_location="cpu")
+        self.load_state_dict(state_dict)
+
+    def get_output_activation(self, task):
+        if task == "binary_classification":
+            return FxSigmoid()
+        elif task == "regression":
+            return nn.Identity()
+        else:
+            raise NotImplementedError("task={} is not supported.".format(task))
+
+    def count_parameters(self, count_embedding=True):
+        total_params = 0
+        for name, param in self.named_parameters():
+            if not count_embedding and "embedding" in name:
+                continue
+            if param.requires_grad:
+                total_params += param.numel()
+        logging.info("Total number of parameters: {}.".format(total_params))
+        return total_params

@@ -1,0 +1,98 @@
+"""The callers of the hot path that BASELINE.json's configs name — DeepFM and DCNv2 — written
+against the native drop-in layers exactly as the reference's model_zoo writes them against
+`fuxictr.pytorch.layers` (model_zoo/DeepFM/DeepFM_torch/src/DeepFM.py:41-88,
+model_zoo/DCNv2/src/DCNv2.py:44-132).  They exist here because /root/reference does not travel to
+the GPU box; with the reference installed, its own model_zoo classes run unmodified on these
+layers through `fuxictr_amd.patch.install()`.
+"""
+import torch
+from torch import nn
+
+from .layers import (CrossNetV2, FactorizationMachine, FeatureEmbedding, FxLinear, MLP_Block)
+from .rank_model import BaseModel
+
+
+class DeepFM(BaseModel):
+    def __init__(self, feature_map, model_id="DeepFM", gpu=-1, learning_rate=1e-3,
+                 embedding_dim=10, hidden_units=[64, 64, 64], hidden_activations="ReLU",
+                 net_dropout=0, batch_norm=False, embedding_regularizer=None,
+                 net_regularizer=None, **kwargs):
+        super(DeepFM, self).__init__(feature_map, model_id=model_id, gpu=gpu,
+                                     embedding_regularizer=embedding_regularizer,
+                                     net_regularizer=net_regularizer, **kwargs)
+        self.embedding_layer = FeatureEmbedding(feature_map, embedding_dim)
+        self.fm = FactorizationMachine(feature_map)
+        self.mlp = MLP_Block(input_dim=feature_map.sum_emb_out_dim(), output_dim=1,
+                             hidden_units=hidden_units, hidden_activations=hidden_activations,
+                             output_activation=None, dropout_rates=net_dropout,
+                             batch_norm=batch_norm)
+        self.compile(kwargs["optimizer"], kwargs["loss"], learning_rate)
+        self.reset_parameters()
+        self.model_to_device()
+
+    def forward(self, inputs):
+        X = self.get_inputs(inputs)
+        feature_emb = self.embedding_layer(X)
+        y_pred = self.fm(X, feature_emb)
+        y_pred += self.mlp(feature_emb.flatten(start_dim=1))
+        y_pred = self.output_activation(y_pred)
+        return {"y_pred": y_pred}
+
+
+class DCNv2(BaseModel):
+    def __init__(self, feature_map, model_id="DCNv2", gpu=-1, model_structure="parallel",
+                 use_low_rank_mixture=False, low_rank=32, num_experts=4, learning_rate=1e-3,
+                 embedding_dim=10, stacked_dnn_hidden_units=[], parallel_dnn_hidden_units=[],
+                 dnn_activations="ReLU", num_cross_layers=3, net_dropout=0, batch_norm=False,
+                 embedding_regularizer=None, net_regularizer=None, **kwargs):
+        super(DCNv2, self).__init__(feature_map, model_id=model_id, gpu=gpu,
+                                    embedding_regularizer=embedding_regularizer,
+                                    net_regularizer=net_regularizer, **kwargs)
+        self.embedding_layer = FeatureEmbedding(feature_map, embedding_dim)
+        input_dim = feature_map.sum_emb_out_dim()
+        if use_low_rank_mixture:
+            raise NotImplementedError("CrossNetMix is outside the hot-path scope (SURVEY §2 #5)")
+        self.crossnet = CrossNetV2(input_dim, num_cross_layers)
+        self.model_structure = model_structure
+        assert self.model_structure in ["crossnet_only", "stacked", "parallel", "stacked_parallel"], \
+            "model_structure={} not supported!".format(self.model_structure)
+        if self.model_structure in ["stacked", "stacked_parallel"]:
+            self.stacked_dnn = MLP_Block(input_dim=input_dim, output_dim=None,
+                                         hidden_units=stacked_dnn_hidden_units,
+                                         hidden_activations=dnn_activations,
+                                         output_activation=None, dropout_rates=net_dropout,
+                                         batch_norm=batch_norm)
+            final_dim = stacked_dnn_hidden_units[-1]
+        if self.model_structure in ["parallel", "stacked_parallel"]:
+            self.parallel_dnn = MLP_Block(input_dim=input_dim, output_dim=None,
+                                          hidden_units=parallel_dnn_hidden_units,
+                                          hidden_activations=dnn_activations,
+                                          output_activation=None, dropout_rates=net_dropout,
+                                          batch_norm=batch_norm)
+            final_dim = input_dim + parallel_dnn_hidden_units[-1]
+        if self.model_structure == "stacked_parallel":
+            final_dim = stacked_dnn_hidden_units[-1] + parallel_dnn_hidden_units[-1]
+        if self.model_structure == "crossnet_only":
+            final_dim = input_dim
+        self.fc = FxLinear(final_dim, 1, device=self.device)
+        self.compile(kwargs["optimizer"], kwargs["loss"], learning_rate)
+        self.reset_parameters()
+        self.model_to_device()
+
+    def forward(self, inputs):
+        X = self.get_inputs(inputs)
+        feature_emb = self.embedding_layer(X, flatten_emb=True)
+        cross_out = self.crossnet(feature_emb)
+        if self.model_structure == "crossnet_only":
+            final_out = cross_out
+        elif self.model_structure == "stacked":
+            final_out = self.stacked_dnn(cross_out)
+        elif self.model_structure == "parallel":
+            dnn_out = self.parallel_dnn(feature_emb)
+            final_out = torch.cat([cross_out, dnn_out], dim=-1)
+        elif self.model_structure == "stacked_parallel":
+            final_out = torch.cat([self.stacked_dnn(cross_out), self.parallel_dnn(feature_emb)],
+                                  dim=-1)
+        y_pred = self.fc(final_out)
+        y_pred = self.output_activation(y_pred)
+        return {"y_pred": y_pred}

@@ -92,7 +92,7 @@ int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* ids, int64_t
 /* ------------------------------------------------------------------------------------------
  * Index de-duplication for the sparse backward/update.  Builds, for the B*C lookups of a batch,
  * the list of unique packed-table rows and the (stable) sorted lookup positions of each:
- *     key(b,c) = col_row_base[c] + ids[b,c]       (0xFFFFFFFF for padding_idx / bad ids)
+ *     key(b,c) = col_row_base[c] + ids[b,c]       (sentinel total_rows for padding_idx / bad ids)
  *     sorted_key/sorted_pos = stable radix sort of (key, pos=b*C+c) by key
  *     uniq_row[u], seg_start[u]..seg_start[u+1] = the u-th distinct key and its run in sorted_*
  *     *n_unique = number of distinct non-sentinel keys
@@ -224,17 +224,30 @@ int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
                 const fx_gemm_epilogue* epi_host, int32_t split_k, float* workspace,
                 fx_stream_t stream);
 
-/* Column sums (bias gradients): out[n] = sum_m X[m,n] * (mask == NULL ? 1 : mask[m,n] > 0).
+/* Column sums (bias gradients): out[n] = sum_m X[m,n].
  * Two-stage deterministic reduction; workspace >= FX_COLSUM_CHUNKS * N floats. */
 #define FX_COLSUM_CHUNKS 32
 int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, float* workspace,
               fx_stream_t stream);
 
+/* ReLU backward for a tower whose LAST layer is activated (e.g. DCNv2 parallel_dnn,
+ * mlp_block.py:80-81 with output_dim=None): out[i] = y[i] > 0 ? dy[i] : 0.  (Inner layers get
+ * this mask for free in the dX GEMM epilogue.) */
+int fx_mask_mul(const float* dy, const float* y, float* out, int64_t n, fx_stream_t stream);
+
+/* CrossNetV2 backward glue (autograd of cross_net.py:128), one pass over [n] elements:
+ *     t[i]   = dxn[i] * x0[i]                         (gradient of W x_i + b)
+ *     term   = dxn[i] * z[i] (+ dxn[i] if add_dxn)    (gradient reaching x_0 through the Hadamard)
+ *     dx0[i] = init ? term : dx0[i] + term */
+int fx_cross_bwd_prep(const float* dxn, const float* x0, const float* z, float* t, float* dx0,
+                      int64_t n, int32_t init, int32_t add_dxn, fx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Output activation + loss, fused: p = sigmoid(logit); loss = mean BCE(p, y) with torch's
  * log clamp at -100 (BaseModel.get_output_activation rank_model.py:447-448 +
  * F.binary_cross_entropy torch_utils.py:95-98); dlogit = dloss/dlogit (torch's two-step
- * backward: (p-y)/max(p(1-p),1e-12)/B * p(1-p)).  prob/loss/dlogit may be NULL.
+ * backward: (p-y)/max(p(1-p),1e-12)/B * p(1-p)).  prob/loss/dlogit may be NULL; y == NULL
+ * computes the activation only (evaluate / predict).
  * ------------------------------------------------------------------------------------------ */
 int fx_sigmoid_bce(const float* logit, const float* y, int64_t B, float* prob, float* loss,
                    float* dlogit, fx_stream_t stream);

@@ -1,0 +1,206 @@
+"""CPU oracle: a torch-fp32 restatement of the reference hot path.
+
+*** TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import this file; the product (fuxictr_amd/) never does. ***
+
+Where the arithmetic lives: the reference (reczoo/FuxiCTR v2.3.10) is pure Python on top of
+PyTorch (not vendored, unpinned: requirements.txt lists no torch; README.md:112 says >=2.7.1), so
+its numerics ARE the ATen CPU kernels.  This file restates the reference's algorithm as explicit
+functional torch-CPU code — per-field lookups, stack, LR, FM, MLP, CrossNetV2, sigmoid+BCE,
+clip_grad_norm_, dense Adam — each function citing the reference lines it follows (paths
+relative to the reference checkout).  It deliberately keeps the reference's cost structure (dense
+[V, D] gradients, dense Adam over every row), so timing `train_step` is a fair "port" baseline.
+
+Pinned against the real reference: tests/golden/*.npz were produced by importing the actual
+reference modules from /root/reference in the build container (tests/golden/make_golden.py) and
+tests/test_oracle_golden.py checks every function here against them.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+EMB = "embedding_layer.embedding_layer.embedding_layers."
+LR_EMB = "fm.lr_layer.embedding_layer.embedding_layer.embedding_layers."
+
+
+# ---------------------------------------------------------------------------------------------
+# layers
+# ---------------------------------------------------------------------------------------------
+def feature_embedding(state, prefix, features, X):
+    """FeatureEmbeddingDict.forward, feature_embedding.py:261-297 -> OrderedDict name -> tensor.
+    numeric: x.float().view(-1,1) @ W[D,1]^T (:280-282); categorical/sequence: W[ids.long()]
+    (:283-288).  `share_embedding` aliases are resolved by the state_dict (both keys exist)."""
+    out = OrderedDict()
+    for name, spec in features.items():
+        if name not in X or spec["type"] == "meta":
+            continue
+        w = state[prefix + name + ".weight"]
+        if spec["type"] == "numeric":
+            out[name] = F.linear(X[name].float().view(-1, 1), w)
+        elif spec["type"] in ("categorical", "sequence"):
+            out[name] = F.embedding(X[name].long(), w, padding_idx=spec.get("padding_idx", None))
+        else:
+            raise NotImplementedError(spec["type"])
+    return out
+
+
+def dict2tensor(features, emb, flatten_emb=False):
+    """FeatureEmbeddingDict.dict2tensor, feature_embedding.py:230-259 (no filters)."""
+    lst = [emb[f] for f in features if f in emb]
+    return torch.cat(lst, dim=-1) if flatten_emb else torch.stack(lst, dim=1)
+
+
+def logistic_regression(state, features, X, emb_prefix=LR_EMB, bias_key="fm.lr_layer.bias"):
+    """LogisticRegression.forward, logistic_regression.py:46-59: a D=1 FeatureEmbedding summed over
+    fields + bias (sequence features are sum-pooled first, feature_embedding.py:135-138)."""
+    emb = feature_embedding(state, emb_prefix, features, X)
+    for name, spec in features.items():
+        if name in emb and spec["type"] == "sequence":
+            emb[name] = emb[name].sum(dim=1)
+    w = dict2tensor(features, emb)       # [B, F, 1]
+    out = w.sum(dim=1)
+    if bias_key in state:
+        out = out + state[bias_key]
+    return out
+
+
+def fm_product_sum(feature_emb):
+    """InnerProductInteraction 'product_sum', inner_product.py:55-62."""
+    sum_of_square = torch.sum(feature_emb, dim=1) ** 2
+    square_of_sum = torch.sum(feature_emb ** 2, dim=1)
+    return ((sum_of_square - square_of_sum) * 0.5).sum(dim=-1, keepdim=True)
+
+
+def mlp_block(state, prefix, x, n_hidden, has_output):
+    """MLP_Block.forward, mlp_block.py:53-96 for Linear+ReLU stacks (no BN / dropout): the
+    nn.Sequential indices are 0,2,4,... for the hidden Linears and 2*n_hidden for the output."""
+    h = x
+    for i in range(n_hidden):
+        h = F.relu(F.linear(h, state[prefix + "mlp.%d.weight" % (2 * i)],
+                            state[prefix + "mlp.%d.bias" % (2 * i)]))
+    if has_output:
+        k = 2 * n_hidden
+        h = F.linear(h, state[prefix + "mlp.%d.weight" % k], state[prefix + "mlp.%d.bias" % k])
+    return h
+
+
+def crossnet_v2(state, prefix, x0, n_layers):
+    """CrossNetV2.forward, cross_net.py:117-129: X_{i+1} = X_i + X_0 * (W_i X_i + b_i)."""
+    xi = x0
+    for i in range(n_layers):
+        xi = xi + x0 * F.linear(xi, state[prefix + "cross_layers.%d.weight" % i],
+                                state[prefix + "cross_layers.%d.bias" % i])
+    return xi
+
+
+# ---------------------------------------------------------------------------------------------
+# models (logit before the output activation)
+# ---------------------------------------------------------------------------------------------
+def deepfm_logit(state, features, X, n_hidden):
+    """DeepFM.forward, model_zoo/DeepFM/DeepFM_torch/src/DeepFM.py:73-88."""
+    emb = dict2tensor(features, feature_embedding(state, EMB, features, X))
+    y = fm_product_sum(emb) + logistic_regression(state, features, X)   # factorization_machine.py:46-59
+    return y + mlp_block(state, "mlp.", emb.flatten(start_dim=1), n_hidden, True)
+
+
+def dcnv2_logit(state, features, X, n_cross, n_hidden):
+    """DCNv2.forward (model_structure='parallel'), model_zoo/DCNv2/src/DCNv2.py:108-132."""
+    emb = dict2tensor(features, feature_embedding(state, EMB, features, X), flatten_emb=True)
+    cross = crossnet_v2(state, "crossnet.", emb, n_cross)
+    dnn = mlp_block(state, "parallel_dnn.", emb, n_hidden, False)
+    return F.linear(torch.cat([cross, dnn], dim=-1), state["fc.weight"], state["fc.bias"])
+
+
+def model_logit(cfg, state, features, X):
+    if cfg["model"] == "DeepFM":
+        return deepfm_logit(state, features, X, cfg["n_hidden"])
+    if cfg["model"] == "DCNv2":
+        return dcnv2_logit(state, features, X, cfg["n_cross"], cfg["n_hidden"])
+    raise NotImplementedError(cfg["model"])
+
+
+def predict(cfg, state, features, X):
+    """y_pred = sigmoid(logit), rank_model.py:447-448."""
+    with torch.no_grad():
+        return torch.sigmoid(model_logit(cfg, state, features, X))
+
+
+# ---------------------------------------------------------------------------------------------
+# training step with the reference's dense semantics
+# ---------------------------------------------------------------------------------------------
+def bce_mean(y_pred, y_true):
+    """F.binary_cross_entropy(..., reduction='mean'), torch_utils.py:95-98 / rank_model.py:130."""
+    return F.binary_cross_entropy(y_pred, y_true, reduction="mean")
+
+
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (rank_model.py:321): total = || [ ||g_i||_2 ] ||_2,
+    coef = clamp(max_norm / (total + 1e-6), max=1); grads scaled in place.  Returns total."""
+    norms = [torch.linalg.vector_norm(g, 2) for g in grads]
+    total = torch.linalg.vector_norm(torch.stack(norms), 2)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return float(total)
+
+
+def adam_dense(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam._single_tensor_adam (the optimizer rank_model.py:322 steps; defaults from
+    torch_utils.py:72-76), applied to EVERY element — untouched table rows included."""
+    m.lerp_(g, 1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    step_size = lr / bc1
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-step_size)
+
+
+class OracleTrainer(object):
+    """State + dense Adam, one `train_step` == BaseModel.train_step (rank_model.py:307-323)."""
+
+    def __init__(self, cfg, state, features, lr=1e-3, max_norm=10.0, optimizer="adam"):
+        self.cfg, self.features = cfg, features
+        self.lr, self.max_norm, self.kind = lr, max_norm, optimizer
+        self.state = OrderedDict()
+        # share_embedding (feature_embedding.py:149-151): in the main table dict the sharing
+        # feature's key is the SAME Parameter as its target's key
+        alias = {EMB + f + ".weight": EMB + spec["share_embedding"] + ".weight"
+                 for f, spec in features.items() if spec.get("share_embedding")}
+        for k, t in state.items():
+            if k in alias and alias[k] in self.state:
+                self.state[k] = self.state[alias[k]]
+                continue
+            t = torch.as_tensor(t)
+            self.state[k] = t.detach().clone().float().requires_grad_(True)
+        self.params = []
+        seen = set()
+        for t in self.state.values():
+            if id(t) not in seen:
+                seen.add(id(t))
+                self.params.append(t)
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.step = 0
+
+    def train_step(self, X, y):
+        for p in self.params:
+            p.grad = None                                   # optimizer.zero_grad()
+        prob = torch.sigmoid(model_logit(self.cfg, self.state, self.features, X))
+        loss = bce_mean(prob, y.float().view(-1, 1))
+        loss.backward()                                     # dense [V, D] embedding grads
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        total = clip_grad_norm(grads, self.max_norm)
+        self.step += 1
+        with torch.no_grad():
+            for p, g, m, v in zip(self.params, grads, self.m, self.v):
+                if self.kind == "adam":
+                    adam_dense(p, g, m, v, self.step, self.lr)
+                else:
+                    p.add_(g, alpha=-self.lr)               # torch.optim.SGD defaults
+        return float(loss), total
+
+    def predict(self, X):
+        return predict(self.cfg, self.state, self.features, X)

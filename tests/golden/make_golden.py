@@ -1,0 +1,163 @@
+"""Generate golden vectors by running the REAL reference (reczoo/FuxiCTR at /root/reference).
+
+Run in the build container only (the reference does not travel to the GPU box):
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python3 -B /root/repo/tests/golden/make_golden.py
+It imports fuxictr + model_zoo from /root/reference (with empty stub modules for polars / h5py /
+keras_preprocessing, none of which is touched on this path — SURVEY.md §8c), builds the reference's
+own DeepFM / DCNv2 on CPU, runs forward + `train_step` (rank_model.py:307-323) on small seeded
+synthetic batches and stores inputs, initial weights and the reference's outputs in
+tests/golden/<case>.npz.  Nothing is written inside /root/reference.
+"""
+import json
+import os
+import sys
+import types
+
+OUT_DIR = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+TMP = "/tmp/fx_golden"
+
+
+def _import_reference():
+    for name in ["polars", "h5py", "keras_preprocessing", "keras_preprocessing.sequence"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["keras_preprocessing.sequence"].pad_sequences = lambda *a, **k: None
+    sys.modules["keras_preprocessing"].sequence = sys.modules["keras_preprocessing.sequence"]
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+
+
+def small_criteo_spec(dataset_id, n_dense, cards):
+    feats = []
+    for j in range(n_dense):
+        feats.append({"I%d" % (j + 1): {"source": "", "type": "numeric"}})
+    for c, card in enumerate(cards):
+        feats.append({"C%d" % (c + 1): {"source": "", "type": "categorical", "padding_idx": 0,
+                                       "vocab_size": int(card) + 1}})
+    return {"dataset_id": dataset_id, "num_fields": len(feats), "total_features": 0,
+            "input_length": len(feats), "labels": ["label"], "features": feats}
+
+
+def make_batches(rng, spec, B, n, pad_frac=0.02):
+    import numpy as np
+    batches = []
+    for _ in range(n):
+        b = {}
+        for item in spec["features"]:
+            (name, fs), = item.items()
+            if fs["type"] == "numeric":
+                b[name] = rng.random(B, dtype=np.float32)
+            else:
+                card = fs["vocab_size"] - 1
+                ids = np.floor(card * rng.random(B) ** 3).astype(np.int64) + 1
+                ids = np.minimum(ids, card)
+                ids[rng.random(B) < pad_frac] = 0     # padding_idx occurrences
+                b[name] = ids
+        b["label"] = (rng.random(B) < 0.3).astype(np.float32)
+        batches.append(b)
+    return batches
+
+
+def run_case(case):
+    import numpy as np
+    import torch
+    from fuxictr.features import FeatureMap
+    from fuxictr.pytorch.torch_utils import seed_everything
+    name = case["name"]
+    spec = small_criteo_spec(name, case["n_dense"], case["cards"])
+    os.makedirs(os.path.join(TMP, name), exist_ok=True)
+    fm_path = os.path.join(TMP, name, "feature_map.json")
+    with open(fm_path, "w") as f:
+        json.dump(spec, f)
+    seed_everything(case["seed"])
+    torch.set_num_threads(8)
+    fmap = FeatureMap(name, os.path.join(TMP, name))
+    fmap.load(fm_path, {"embedding_dim": case["embedding_dim"]})
+    common = dict(gpu=-1, embedding_dim=case["embedding_dim"], learning_rate=case["lr"],
+                  optimizer=case["optimizer"], loss="binary_crossentropy",
+                  task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
+                  model_root=TMP, embedding_regularizer=0, net_regularizer=0)
+    if case["model"] == "DeepFM":
+        from model_zoo.DeepFM.DeepFM_torch.src import DeepFM
+        model = DeepFM(fmap, model_id=name, hidden_units=case["hidden"], **common)
+    else:
+        from model_zoo import DCNv2
+        model = DCNv2(fmap, model_id=name, model_structure="parallel",
+                      num_cross_layers=case["n_cross"],
+                      parallel_dnn_hidden_units=case["hidden"], **common)
+    # make the (1e-4 std) tables matter numerically: rescale so logits are O(1)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "embedding_layers" in k and "lr_layer" not in k and p.shape[0] > 1 \
+                    and p.dim() == 2 and p.shape[1] > 1:
+                p.mul_(case.get("emb_scale", 1.0))
+            if "lr_layer" in k and "embedding_layers" in k and p.shape[0] > 1:
+                p.mul_(case.get("lr_scale", 1.0))
+    model._max_gradient_norm = case["max_norm"]          # what fit() would set (rank_model.py:251)
+    logits = []
+    model.output_activation.register_forward_pre_hook(lambda m, inp: logits.append(inp[0].detach().clone()))
+    rng = np.random.default_rng(case["seed"])
+    batches = make_batches(rng, spec, case["B"], case["steps"] + 1)
+    out = {}
+    for k, v in model.state_dict().items():
+        out["state0/" + k] = v.detach().cpu().numpy().copy()
+    def to_torch(b):
+        return {k: torch.from_numpy(v) for k, v in b.items()}
+    model.eval()
+    with torch.no_grad():
+        p0 = model.forward(to_torch(batches[-1]))["y_pred"]
+    out["expect/pred0"] = p0.numpy().reshape(-1).copy()
+    out["expect/logit0"] = logits[-1].numpy().reshape(-1).copy()
+    model.train()
+    losses, norms = [], []
+    for i in range(case["steps"]):
+        b = to_torch(batches[i])
+        # total grad norm of this step, measured the way clip_grad_norm_ does
+        loss = model.train_step(b)
+        losses.append(float(loss.item()))
+    out["expect/loss"] = np.asarray(losses, dtype=np.float64)
+    model.eval()
+    with torch.no_grad():
+        p1 = model.forward(to_torch(batches[-1]))["y_pred"]
+    out["expect/pred1"] = p1.numpy().reshape(-1).copy()
+    out["expect/logit1"] = logits[-1].numpy().reshape(-1).copy()
+    for k, v in model.state_dict().items():
+        out["state1/" + k] = v.detach().cpu().numpy().copy()
+    for i, b in enumerate(batches):
+        for k, v in b.items():
+            out["batch%d/%s" % (i, k)] = v
+    meta = dict(case)
+    meta["spec"] = spec
+    meta["torch"] = torch.__version__
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "loss", losses, "pred0[:3]", out["expect/pred0"][:3], "pred1[:3]",
+          out["expect/pred1"][:3], "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+CARDS = [37, 13, 1500, 900, 11, 5, 211, 19, 3, 401, 97, 1200, 53, 7]
+CASES = [
+    dict(name="deepfm_adam", model="DeepFM", n_dense=5, cards=CARDS, embedding_dim=8,
+         hidden=[64, 32], B=192, steps=6, lr=1e-2, optimizer="adam", max_norm=10.0, seed=2019,
+         emb_scale=1000.0, lr_scale=1000.0),
+    dict(name="deepfm_adam_clip", model="DeepFM", n_dense=5, cards=CARDS, embedding_dim=8,
+         hidden=[64, 32], B=192, steps=4, lr=1e-2, optimizer="adam", max_norm=0.05, seed=7,
+         emb_scale=1000.0, lr_scale=1000.0),
+    dict(name="deepfm_sgd", model="DeepFM", n_dense=5, cards=CARDS, embedding_dim=8,
+         hidden=[64, 32], B=192, steps=4, lr=5e-2, optimizer="SGD", max_norm=10.0, seed=11,
+         emb_scale=1000.0, lr_scale=1000.0),
+    dict(name="deepfm_d10", model="DeepFM", n_dense=3, cards=CARDS[:9], embedding_dim=10,
+         hidden=[48], B=100, steps=3, lr=1e-2, optimizer="adam", max_norm=10.0, seed=3,
+         emb_scale=1000.0, lr_scale=1000.0),
+    dict(name="dcnv2_adam", model="DCNv2", n_dense=5, cards=CARDS, embedding_dim=8,
+         hidden=[64, 32], n_cross=3, B=192, steps=5, lr=1e-2, optimizer="adam", max_norm=10.0,
+         seed=2019, emb_scale=1000.0),
+]
+
+if __name__ == "__main__":
+    _import_reference()
+    only = sys.argv[1:]
+    for case in CASES:
+        if not only or case["name"] in only:
+            run_case(case)
