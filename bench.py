@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: samples/sec of the native DeepFM training step on synthetic Criteo-shaped
+input (BASELINE.json configs[1]: 26 sparse + 13 dense fields, 33.76 M rows, emb_dim 16, MLP
+4x1024, Adam, batch 4096 per GPU).  One step = pack -> de-dup -> catch-up -> gather -> FM/LR ->
+MLP fwd -> sigmoid+BCE -> MLP bwd -> sparse grad reduce -> global-norm clip -> dense + sparse-row
+Adam, nothing skipped.  Inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel: the fp32 MFMA GEMM, timed live
+with HIP events inside the timed region) and `cpu_baseline` (the oracle's dense-semantics step —
+a restatement of the reference — timed on this box's host cores; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0           # HBM3E spec (6.3 TB/s measured streaming ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
+    ap.add_argument("--model", default="DeepFM", choices=["DeepFM", "DCNv2"])
+    ap.add_argument("--dist", default="powerlaw", choices=["powerlaw", "uniform"])
+    ap.add_argument("--sparse-update", default="exact", choices=["exact", "lazy"])
+    ap.add_argument("--vocab-scale", type=float, default=1.0, help="debug: shrink the tables")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(args, device_index, cards):
+    from fuxictr_amd import synthetic, zoo
+    fmap, spec = synthetic.criteo_feature_map(cards=cards, embedding_dim=16)
+    common = dict(gpu=device_index, embedding_dim=16, learning_rate=1e-3, optimizer="adam",
+                  loss="binary_crossentropy", task="binary_classification",
+                  metrics=["logloss", "AUC"], verbose=0, model_root="/tmp/fx_bench",
+                  sparse_update=args.sparse_update)
+    torch.manual_seed(2019)
+    if args.model == "DeepFM":
+        model = zoo.DeepFM(fmap, model_id="bench", hidden_units=[1024] * 4, **common)
+    else:
+        model = zoo.DCNv2(fmap, model_id="bench", model_structure="parallel", num_cross_layers=3,
+                          parallel_dnn_hidden_units=[1024] * 4, **common)
+    return model, fmap, spec
+
+
+def cpu_baseline(args, cards, n_steps):
+    """The oracle (restatement of the reference, dense [V,D] grads + dense Adam over every row)
+    on the host cores, same workload shape, a bounded number of steps."""
+    from fuxictr_amd import synthetic
+    from oracle import ctr_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    g = torch.Generator().manual_seed(0)
+    _, spec = synthetic.criteo_feature_map(cards=cards, embedding_dim=16)
+    features = {k: v for item in spec["features"] for k, v in item.items()}
+    state = {}
+    D = 16
+    for f, fs in features.items():
+        if fs["type"] == "numeric":
+            state[O.EMB + f + ".weight"] = torch.randn(D, 1, generator=g) * 0.3
+            state[O.LR_EMB + f + ".weight"] = torch.randn(1, 1, generator=g) * 0.3
+        else:
+            state[O.EMB + f + ".weight"] = torch.randn(fs["vocab_size"], D, generator=g) * 1e-4
+            state[O.LR_EMB + f + ".weight"] = torch.randn(fs["vocab_size"], 1, generator=g) * 1e-4
+    state["fm.lr_layer.bias"] = torch.zeros(1)
+    dims = [39 * D] + [1024] * 4
+    if args.model == "DeepFM":
+        for i in range(4):
+            state["mlp.mlp.%d.weight" % (2 * i)] = torch.randn(dims[i + 1], dims[i], generator=g) * 0.03
+            state["mlp.mlp.%d.bias" % (2 * i)] = torch.zeros(dims[i + 1])
+        state["mlp.mlp.8.weight"] = torch.randn(1, 1024, generator=g) * 0.03
+        state["mlp.mlp.8.bias"] = torch.zeros(1)
+        cfg = {"model": "DeepFM", "n_hidden": 4}
+    else:
+        for k in list(state):
+            if k.startswith("fm."):
+                del state[k]
+        for i in range(3):
+            state["crossnet.cross_layers.%d.weight" % i] = torch.randn(624, 624, generator=g) * 0.03
+            state["crossnet.cross_layers.%d.bias" % i] = torch.zeros(624)
+        for i in range(4):
+            state["parallel_dnn.mlp.%d.weight" % (2 * i)] = torch.randn(dims[i + 1], dims[i], generator=g) * 0.03
+            state["parallel_dnn.mlp.%d.bias" % (2 * i)] = torch.zeros(dims[i + 1])
+        state["fc.weight"] = torch.randn(1, 624 + 1024, generator=g) * 0.03
+        state["fc.bias"] = torch.zeros(1)
+        cfg = {"model": "DCNv2", "n_hidden": 4, "n_cross": 3}
+    tr = O.OracleTrainer(cfg, state, features, lr=1e-3, max_norm=10.0)
+    del state
+    rng = np.random.default_rng(1)
+    batches = [{k: torch.from_numpy(v) for k, v in
+                synthetic.criteo_batch(rng, args.batch, cards=cards, dist=args.dist).items()}
+               for _ in range(n_steps + 1)]
+    tr.train_step(batches[0], batches[0]["label"])          # warm-up (allocates grads/moments)
+    t0 = time.perf_counter()
+    for b in batches[1:]:
+        tr.train_step(b, b["label"])
+    dt = time.perf_counter() - t0
+    return {"value": args.batch * n_steps / dt, "unit": "samples/sec",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d dense-Adam training steps of the oracle (%s, batch %d, full vocab) "
+                      "after 1 warm-up, %.1f s" % (n_steps, args.model, args.batch, dt),
+            "ms_per_step": 1e3 * dt / n_steps}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fuxictr_amd import ops, synthetic
+    from fuxictr_amd.layers import FeatureDict
+    cards = [max(3, int(c * args.vocab_scale)) for c in synthetic.CRITEO_CARDS]
+    model, fmap, spec = build_model(args, local_rank, cards)
+    model.train()
+
+    # synthetic batches, resident in HBM (ids int64 / dense fp32 / label fp32 — what the
+    # reference's get_inputs would hold after .to(device)); distinct per rank and per step
+    rng = np.random.default_rng(1000 + rank)
+    n_pool = 8
+    pool = []
+    for _ in range(n_pool):
+        b = synthetic.criteo_batch(rng, args.batch, cards=cards, dist=args.dist)
+        pool.append({k: torch.from_numpy(v).to(dev) for k, v in b.items()})
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    step_i = 0
+    for _ in range(args.warmup):
+        model.train_step(pool[step_i % n_pool])
+        step_i += 1
+    sync()
+    ops.KernelTimer.reset()
+    ops.KernelTimer.enabled = not args.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.train_step(pool[step_i % n_pool])
+        step_i += 1
+    sync()
+    dt = time.perf_counter() - t0
+    ops.KernelTimer.enabled = False
+    model.optimizer.check_errors()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ktimes = ops.KernelTimer.summary()
+
+    if rank == 0:
+        global_batch = args.batch * world
+        value = global_batch * args.steps / dt
+        out = {
+            "metric": "samples/sec at batch 4096, Criteo-shape DeepFM/DCNv2, 1/2/4/8 MI355X",
+            "value": value, "unit": "samples/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %s on synthetic Criteo (26 sparse + 13 dense, "
+                                   "%d rows, emb_dim 16, MLP 4x1024), Adam, full training step"
+                                   % (args.model, sum(cards) + len(cards)),
+                       "global_batch": global_batch, "per_gpu_batch": args.batch,
+                       "id_distribution": args.dist, "sparse_update": args.sparse_update,
+                       "parallelism": "single GPU" if world == 1 else
+                                      "%d independent replicas (row-sharded all-to-all path not "
+                                      "built yet; no data-path collective)" % world},
+        }
+        g = ktimes.get("k_gemm_f32")
+        if g and g["total_ms"] > 0:
+            ach = g["work"] / (g["total_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "k_gemm_f32 (fp32 MFMA GEMM, MLP/CrossNet fwd+bwd)",
+                               "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                               "traffic": None, "launches": g["launches"],
+                               "avg_launch_us": g["avg_us"],
+                               "share_of_step": g["total_ms"] / (1e3 * dt)}
+        e = ktimes.get("k_emb_gather_fwd")
+        if e and e["total_ms"] > 0:
+            ach = e["work"] / (e["total_ms"] * 1e-3) / 1e9
+            out["roofline_gather"] = {"kernel": "k_emb_gather_fwd", "bound": "hbm", "achieved": ach,
+                                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                                      "launches": e["launches"], "avg_launch_us": e["avg_us"]}
+        if world == 1 and not args.no_cpu_baseline:
+            del pool
+            out["cpu_baseline"] = cpu_baseline(args, cards, args.cpu_baseline_steps)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,45 @@ _DT = {torch.float32: _lib.FX_F32, torch.float64: _lib.FX_F64,
        torch.int32: _lib.FX_I32, torch.int64: _lib.FX_I64}
 
 
+class KernelTimer(object):
+    """Opt-in HIP-event timing of individual launches on torch's current stream (the stream the
+    kernels are launched on).  bench.py enables it to measure the roofline kernels live inside the
+    timed region; it is off (zero cost) otherwise."""
+    enabled = False
+    records = {}     # name -> list of (start_event, end_event, work)
+
+    @classmethod
+    def start(cls):
+        if not cls.enabled:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    @classmethod
+    def stop(cls, name, ev, work):
+        if ev is None:
+            return
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        cls.records.setdefault(name, []).append((ev, end, work))
+
+    @classmethod
+    def summary(cls):
+        """name -> dict(launches, total_ms, avg_us, work) after a device synchronize."""
+        out = {}
+        for name, recs in cls.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            out[name] = {"launches": len(recs), "total_ms": ms,
+                         "avg_us": 1e3 * ms / max(len(recs), 1),
+                         "work": float(sum(w for _, _, w in recs))}
+        return out
+
+    @classmethod
+    def reset(cls):
+        cls.records = {}
+
+
 def _need_cuda(t, name):
     if not t.is_cuda:
         raise _lib.FxError("%s must live on the GPU: the native path has no CPU fallback "
@@ -68,11 +107,15 @@ def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, n
     B = out.shape[0]
     C_ = 0 if ids is None else ids.shape[1]
     Fd = 0 if dense is None else dense.shape[1]
+    ev = KernelTimer.start()
     check(lib.fx_emb_gather_fwd(ptr(table), D, ptr(ids), 0 if ids is None else ids.stride(0),
                                 ptr(col_row_base), ptr(col_vocab), ptr(col_out_off), C_,
                                 ptr(dense), 0 if dense is None else dense.stride(0), ptr(num_w),
                                 ptr(num_out_off), Fd, ptr(out), out.stride(0), B, ptr(scal),
                                 stream_ptr(out.device)), "fx_emb_gather_fwd")
+    # algorithmic bytes: rows + ids + dense in, the [B,F,D] record out
+    KernelTimer.stop("k_emb_gather_fwd", ev,
+                     B * (C_ * (4 * D + 4) + Fd * 4 + (C_ + Fd) * 4 * D) if ev else 0)
     return out
 
 
@@ -249,9 +292,11 @@ def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul
         epi.mask, epi.ldmask = mask.data_ptr(), mask.stride(0)
     if add is not None:
         epi.add, epi.ldadd = add.data_ptr(), add.stride(0)
+    ev = KernelTimer.start()
     check(lib.fx_gemm_f32(1 if transa else 0, 1 if transb else 0, M, N, K, ptr(A), A.stride(0),
                           ptr(B_), B_.stride(0), ptr(C_), C_.stride(0), C.byref(epi), split_k,
                           ptr(workspace), stream_ptr(C_.device)), "fx_gemm_f32")
+    KernelTimer.stop("k_gemm_f32", ev, 2.0 * M * N * K if ev else 0)
     return C_
 
 

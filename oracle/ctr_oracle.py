@@ -200,7 +200,7 @@ class OracleTrainer(object):
                     adam_dense(p, g, m, v, self.step, self.lr)
                 else:
                     p.add_(g, alpha=-self.lr)               # torch.optim.SGD defaults
-        return float(loss), total
+        return float(loss.detach()), total
 
     def predict(self, X):
         return predict(self.cfg, self.state, self.features, X)

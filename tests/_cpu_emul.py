@@ -1,0 +1,266 @@
+"""TEST INFRASTRUCTURE: torch-CPU emulation of the libfxctr entry points, with the same
+signatures as fuxictr_amd.ops.  tests/test_host_wiring.py monkeypatches it in so the HOST logic
+(layer bookkeeping, autograd wiring, optimizer sequencing, BaseModel loop) can be exercised in the
+GPU-less build container.  It is never importable from the product package."""
+import math
+
+import numpy as np
+import torch
+
+from fuxictr_amd import _lib
+
+SC = _lib
+
+
+def new_scalars(device, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.0):
+    s = torch.zeros(_lib.SC_WORDS, dtype=torch.float32)
+    s[SC.SC_LR], s[SC.SC_BETA1], s[SC.SC_BETA2], s[SC.SC_EPS] = lr, beta1, beta2, eps
+    s[SC.SC_CLIP], s[SC.SC_MAX_NORM] = 1.0, max_norm
+    return s
+
+
+def _step(scal):
+    return int(scal.view(torch.int32)[SC.SC_STEP])
+
+
+def pack_columns(cols, out, out_col0=0):
+    c = out_col0
+    for t in cols:
+        t2 = t.reshape(t.shape[0], -1)
+        out[:, c:c + t2.shape[1]] = t2.to(out.dtype)
+        c += t2.shape[1]
+    return out
+
+
+def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w,
+                   num_out_off, out, scal):
+    if ids is not None:
+        for c in range(ids.shape[1]):
+            rows = ids[:, c].long() + int(col_row_base[c])
+            o = int(col_out_off[c])
+            out[:, o:o + D] = table[rows]
+    if dense is not None:
+        for j in range(dense.shape[1]):
+            o = int(num_out_off[j])
+            out[:, o:o + D] = dense[:, j:j + 1] * num_w[j]
+    return out
+
+
+def dedup_workspace_bytes(n):
+    return 256
+
+
+class DedupResult(object):
+    pass
+
+
+def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None):
+    B, C = ids.shape
+    keys = ids.long() + col_row_base.view(1, -1)
+    valid = (ids != col_pad.view(1, -1)) & (ids >= 0) & (ids < col_vocab.view(1, -1))
+    keys = torch.where(valid, keys, torch.full_like(keys, total_rows)).reshape(-1)
+    skey, spos = torch.sort(keys, stable=True)
+    nvalid = int(valid.sum())
+    uniq, counts = torch.unique_consecutive(skey[:nvalid], return_counts=True)
+    dd = DedupResult()
+    n = B * C
+    dd.sorted_key, dd.sorted_pos = skey.int(), spos.int()
+    dd.uniq_row = torch.zeros(n, dtype=torch.int32)
+    dd.uniq_row[:len(uniq)] = uniq.int()
+    dd.seg_start = torch.zeros(n + 1, dtype=torch.int32)
+    dd.seg_start[1:len(uniq) + 1] = torch.cumsum(counts, 0).int()
+    dd.n_unique = torch.tensor([len(uniq)], dtype=torch.int32)
+    dd.n_max, dd.C = n, C
+    return dd
+
+
+def emb_grad_reduce_partials(n_max):
+    return max(1, (n_max + 3) // 4)
+
+
+def emb_grad_reduce(dout, dout_ld, col_out_off, C, D, dd, G, sq_partials):
+    nu = int(dd.n_unique)
+    flat = dout.reshape(-1)
+    sq_partials.zero_()
+    for u in range(nu):
+        acc = torch.zeros(D)
+        for i in range(int(dd.seg_start[u]), int(dd.seg_start[u + 1])):
+            p = int(dd.sorted_pos[i])
+            b, c = divmod(p, C)
+            o = b * dout_ld + int(col_out_off[c])
+            acc += flat[o:o + D]
+        G[u] = acc
+    sq_partials[0] = float((G[:nu].double() ** 2).sum())
+
+
+def emb_numeric_grad(dout, dout_ld, num_out_off, dense, D, dnum_w):
+    B = dense.shape[0]
+    flat = dout.reshape(-1)
+    for j in range(dense.shape[1]):
+        o = int(num_out_off[j])
+        idx = (torch.arange(B) * dout_ld + o).view(-1, 1) + torch.arange(D).view(1, -1)
+        dnum_w[j] = (dense[:, j:j + 1] * flat[idx]).sum(0)
+
+
+def opt_begin_step(scal):
+    t = _step(scal) + 1
+    scal.view(torch.int32)[SC.SC_STEP] = t
+    b1, b2 = float(scal[SC.SC_BETA1]), float(scal[SC.SC_BETA2])
+    bc1 = 1 - b1 ** t
+    scal[SC.SC_BC1] = bc1
+    scal[SC.SC_BC2S] = math.sqrt(1 - b2 ** t)
+    scal[SC.SC_STEP_SIZE] = float(scal[SC.SC_LR]) / bc1
+
+
+def clip_coef(parts, scal):
+    total = math.sqrt(sum(float(p.double().sum()) for p in parts))
+    mx = float(scal[SC.SC_MAX_NORM])
+    scal[SC.SC_TOTAL_NORM] = total
+    scal[SC.SC_CLIP] = min(1.0, mx / (total + 1e-6)) if mx > 0 else 1.0
+
+
+def _adam(p, m, v, g, scal):
+    b1, b2, eps = scal[SC.SC_BETA1], scal[SC.SC_BETA2], scal[SC.SC_EPS]
+    m += (1 - b1) * (g - m)
+    v.mul_(b2).add_((1 - b2) * g * g)
+    p -= scal[SC.SC_STEP_SIZE] * (m / (v.sqrt() / scal[SC.SC_BC2S] + eps))
+
+
+def sparse_adam(table, m, v, last_step, D, dd, G, scal):
+    nu = int(dd.n_unique)
+    rows = dd.uniq_row[:nu].long()
+    p, mm, vv = table[rows], m[rows], v[rows]
+    _adam(p, mm, vv, G[:nu] * scal[SC.SC_CLIP], scal)
+    table[rows], m[rows], v[rows] = p, mm, vv
+    last_step[rows] = _step(scal)
+
+
+def adam_catchup(table, m, v, last_step, D, dd, total_rows, upto_offset, scal):
+    rows = torch.arange(total_rows) if dd is None else dd.uniq_row[:int(dd.n_unique)].long()
+    upto = _step(scal) + upto_offset
+    b1, b2, eps, lr = (float(scal[SC.SC_BETA1]), float(scal[SC.SC_BETA2]),
+                       float(scal[SC.SC_EPS]), float(scal[SC.SC_LR]))
+    for r in rows.tolist():
+        last = int(last_step[r])
+        for t in range(last + 1, upto + 1):
+            m[r] *= b1
+            v[r] *= b2
+            table[r] -= lr / (1 - b1 ** t) * (m[r] / (v[r].sqrt() / math.sqrt(1 - b2 ** t) + eps))
+        if upto > last:
+            last_step[r] = upto
+
+
+def sparse_sgd(table, D, dd, G, scal):
+    nu = int(dd.n_unique)
+    rows = dd.uniq_row[:nu].long()
+    table[rows] -= scal[SC.SC_LR] * scal[SC.SC_CLIP] * G[:nu]
+
+
+def mt_sqnorm(grads, sq_partials):
+    sq_partials.zero_()
+    for i, g in enumerate(grads):
+        sq_partials[i * _lib.FX_MT_BLOCKS] = float((g.double() ** 2).sum())
+
+
+def mt_adam(params, grads, ms, vs, scal):
+    for p, g, m, v in zip(params, grads, ms, vs):
+        _adam(p, m, v, g * scal[SC.SC_CLIP], scal)
+
+
+def mt_sgd(params, grads, scal):
+    for p, g in zip(params, grads):
+        p -= scal[SC.SC_LR] * scal[SC.SC_CLIP] * g
+
+
+def fm_fwd(emb, F, D, addend, out):
+    e = emb.view(-1, F, D)
+    r = 0.5 * ((e.sum(1) ** 2) - (e ** 2).sum(1)).sum(-1, keepdim=True)
+    out.copy_(r + (addend if addend is not None else 0))
+    return out
+
+
+def fm_bwd(emb, F, D, g, demb, accumulate=False):
+    e = emb.view(-1, F, D)
+    d = g.view(-1, 1, 1) * (e.sum(1, keepdim=True) - e)
+    d = d.reshape(demb.shape)
+    demb.copy_(demb + d if accumulate else d)
+    return demb
+
+
+def lr_fwd(table1, ids, col_row_base, col_vocab, dense, num_w1, bias, out, scal):
+    acc = torch.zeros(out.shape[0], 1)
+    if ids is not None:
+        for c in range(ids.shape[1]):
+            acc += table1[ids[:, c].long() + int(col_row_base[c])]
+    if dense is not None:
+        acc += dense @ num_w1.reshape(-1, 1)
+    out.copy_(acc + (bias if bias is not None else 0))
+    return out
+
+
+def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul=None, mask=None,
+         add=None, split_k=1, workspace=None):
+    a = A.t() if transa else A
+    b = B_.t() if transb else B_
+    z = a @ b
+    if bias is not None:
+        z = z + bias
+    if zout is not None:
+        zout.copy_(z)
+    if act == 1:
+        z = z.clamp(min=0)
+    if mul is not None:
+        z = z * mul
+    if mask is not None:
+        z = torch.where(mask > 0, z, torch.zeros(()))
+    if add is not None:
+        z = z + add
+    C_.copy_(z)
+    return C_
+
+
+def colsum(X, out, workspace):
+    out.copy_(X.sum(0))
+    return out
+
+
+def mask_mul(dy, y, out):
+    out.copy_(torch.where(y > 0, dy, torch.zeros(())))
+    return out
+
+
+def cross_bwd_prep(dxn, x0, z, t, dx0, init, add_dxn):
+    t.copy_(dxn * x0)
+    term = dxn * z + (dxn if add_dxn else 0)
+    dx0.copy_(term if init else dx0 + term)
+
+
+def sigmoid_bce(logit, y, prob=None, loss=None, dlogit=None):
+    p = torch.sigmoid(logit)
+    if prob is not None:
+        prob.copy_(p)
+    if y is None:
+        return
+    if loss is not None:
+        loss.copy_(torch.nn.functional.binary_cross_entropy(p, y))
+    if dlogit is not None:
+        dlogit.copy_((p - y) / torch.clamp((1 - p) * p, min=1e-12) / logit.numel() * (p * (1 - p)))
+
+
+class KernelTimer(object):
+    enabled = False
+
+
+def install(monkeypatch):
+    """Route fuxictr_amd.ops.* to this module and let BaseModel live on the CPU."""
+    import fuxictr_amd.ops as real
+    import fuxictr_amd.rank_model as rm
+    me = globals()
+    for name in ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes", "dedup",
+                 "emb_grad_reduce_partials", "emb_grad_reduce", "emb_numeric_grad",
+                 "opt_begin_step", "clip_coef", "sparse_adam", "adam_catchup", "sparse_sgd",
+                 "mt_sqnorm", "mt_adam", "mt_sgd", "fm_fwd", "fm_bwd", "lr_fwd", "gemm", "colsum",
+                 "mask_mul", "cross_bwd_prep", "sigmoid_bce"]:
+        monkeypatch.setattr(real, name, me[name])
+    monkeypatch.setattr(rm, "get_device", lambda gpu=-1: torch.device("cpu"))
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)

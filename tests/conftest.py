@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+if GOLDEN not in sys.path:
+    sys.path.insert(0, GOLDEN)      # make_golden.py's batch generator is reused by tests
 
 
 def pytest_configure(config):
@@ -43,6 +45,18 @@ class Golden(object):
     def cfg(self):
         m = self.meta
         return {"model": m["model"], "n_hidden": len(m["hidden"]), "n_cross": m.get("n_cross", 0)}
+
+
+def assert_weights_close(got, ref, lr, steps, name, tol=2e-5):
+    """Weights after k optimizer steps.  Adam's update lr*m/(sqrt(v)+eps) is ill-conditioned for the
+    few elements whose gradient is a cancellation residue of magnitude ~eps (1e-8): a 1e-10
+    difference in such a gradient (fp32 summation order) moves the element by up to ~lr.  The
+    reference itself is only reproducible to that level across BLAS builds, so: every element
+    within `tol`, except at most 0.1% of a tensor which must still be within lr * steps."""
+    err = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64))
+    bad = int((err > tol).sum())
+    assert bad <= max(1, int(1e-3 * err.size)), (name, bad, err.size, float(err.max()))
+    assert float(err.max()) <= lr * steps + tol, (name, float(err.max()))
 
 
 GOLDEN_CASES = ["deepfm_adam", "deepfm_adam_clip", "deepfm_sgd", "deepfm_d10", "dcnv2_adam"]

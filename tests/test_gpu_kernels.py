@@ -1,0 +1,412 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against the oracle / a torch-CPU
+restatement on the same seeded inputs.  Bit-exact for index and gather work; fp32 tolerances are
+written next to each check."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fuxictr_amd import _lib, ops  # noqa: E402
+from oracle import ctr_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _dev(x, dtype=None):
+    t = torch.as_tensor(x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+def test_pack_columns_all_dtypes():
+    g = torch.Generator().manual_seed(0)
+    B = 1000
+    cols = [torch.randint(0, 1 << 20, (B,), generator=g).double(),
+            torch.randint(0, 1 << 20, (B,), generator=g),
+            torch.randint(0, 1 << 20, (B, 5), generator=g).int(),
+            torch.randint(0, 100, (B,), generator=g).float()]
+    out = torch.full((B, 10), -1, dtype=torch.int32, device=DEV)
+    ops.pack_columns([c.to(DEV) for c in cols], out, out_col0=1)
+    ref = torch.cat([c.reshape(B, -1).to(torch.int32) for c in cols], dim=1)
+    assert torch.equal(out[:, 1:9].cpu(), ref)
+    assert int(out[:, 0].max()) == -1 and int(out[:, 9].max()) == -1
+    f = torch.empty(B, 2, dtype=torch.float32, device=DEV)
+    d = torch.rand(B, generator=g, dtype=torch.float64)
+    ops.pack_columns([d.to(DEV), cols[3].to(DEV)], f)
+    assert torch.equal(f.cpu(), torch.stack([d.float(), cols[3]], dim=1))
+
+
+@pytest.mark.parametrize("D", [16, 8, 10, 1, 40, 128])
+def test_gather_fwd_bit_exact(D):
+    g = torch.Generator().manual_seed(D)
+    vocabs = [50, 3, 1000, 7, 20011]
+    bases = np.concatenate([[0], np.cumsum(vocabs)[:-1]])
+    R = int(sum(vocabs))
+    B, C, Fd = 777, len(vocabs), 3
+    table = torch.randn(R, D, generator=g)
+    num_w = torch.randn(Fd, D, generator=g)
+    ids = torch.stack([torch.randint(0, v, (B,), generator=g) for v in vocabs], dim=1).int()
+    dense = torch.rand(B, Fd, generator=g)
+    # slots: interleave numeric and categorical
+    slots_c, slots_n = [1, 2, 4, 5, 7], [0, 3, 6]
+    n_slots = 8
+    out = torch.full((B, n_slots * D), 7.0, device=DEV)
+    scal = ops.new_scalars(DEV)
+    ops.emb_gather_fwd(_dev(table), D, _dev(ids), _dev(bases, torch.int64), _dev(vocabs, torch.int32),
+                       _dev([s * D for s in slots_c], torch.int64), _dev(dense), _dev(num_w),
+                       _dev([s * D for s in slots_n], torch.int64), out, scal)
+    ref = torch.zeros(B, n_slots, D)
+    for c in range(C):
+        ref[:, slots_c[c]] = table[ids[:, c].long() + int(bases[c])]
+    for j in range(Fd):
+        ref[:, slots_n[j]] = dense[:, j:j + 1] * num_w[j]
+    assert torch.equal(out.cpu().view(B, n_slots, D), ref)
+    assert int(scal.view(torch.int32)[_lib.SC_ERR]) == 0
+
+
+def test_gather_flags_bad_ids():
+    D, B = 16, 64
+    table = torch.randn(10, D)
+    ids = torch.randint(0, 10, (B, 1)).int()
+    ids[5, 0] = 10
+    ids[9, 0] = -1
+    out = torch.empty(B, D, device=DEV)
+    scal = ops.new_scalars(DEV)
+    ops.emb_gather_fwd(_dev(table), D, _dev(ids), _dev([0], torch.int64), _dev([10], torch.int32),
+                       _dev([0], torch.int64), None, None, None, out, scal)
+    assert int(scal.view(torch.int32)[_lib.SC_ERR]) & _lib.FX_FLAG_BAD_ID
+    o = out.cpu()
+    assert float(o[5].abs().sum()) == 0 and float(o[9].abs().sum()) == 0
+    assert torch.equal(o[0], table[ids[0, 0]])
+
+
+def _dedup(ids, vocabs, pads):
+    bases = np.concatenate([[0], np.cumsum(vocabs)[:-1]]).astype(np.int64)
+    R = int(sum(vocabs))
+    B, C = ids.shape
+    ws = torch.empty(ops.dedup_workspace_bytes(B * C), dtype=torch.uint8, device=DEV)
+    dd = ops.dedup(_dev(ids, torch.int32), _dev(bases, torch.int64), _dev(vocabs, torch.int32),
+                   _dev(pads, torch.int32), R, ws)
+    return dd, bases, R
+
+
+@pytest.mark.parametrize("B", [1, 63, 4096])
+def test_dedup_matches_numpy_unique(B):
+    rng = np.random.default_rng(B)
+    vocabs = [4, 100, 50000, 9]
+    pads = [0, 0, -1, 3]
+    ids = np.stack([rng.integers(0, v, B) for v in vocabs], axis=1)
+    dd, bases, R = _dedup(ids, vocabs, pads)
+    keys = ids + bases[None, :]
+    valid = np.ones_like(ids, dtype=bool)
+    for c, p in enumerate(pads):
+        if p >= 0:
+            valid[:, c] = ids[:, c] != p
+    flat_keys = keys.reshape(-1)
+    flat_valid = valid.reshape(-1)
+    uniq, counts = np.unique(flat_keys[flat_valid], return_counts=True)
+    nu = int(dd.n_unique.item())
+    assert nu == len(uniq)
+    assert np.array_equal(dd.uniq_row[:nu].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, uniq)
+    seg = dd.seg_start[:nu + 1].cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.diff(seg), counts)
+    pos = dd.sorted_pos.cpu().numpy().astype(np.int64)
+    for u in [0, nu // 2, nu - 1]:
+        run = pos[seg[u]:seg[u + 1]]
+        assert np.all(np.diff(run) > 0)                       # stable: ascending lookup position
+        assert np.all(flat_keys[run] == uniq[u])
+
+
+def test_dedup_all_padding_and_all_same():
+    ids = np.zeros((128, 2), dtype=np.int64)
+    dd, _, _ = _dedup(ids, [5, 5], [0, 0])
+    assert int(dd.n_unique.item()) == 0 and int(dd.seg_start[0].item()) == 0
+    ids = np.full((4096, 1), 2, dtype=np.int64)
+    dd, _, _ = _dedup(ids, [5], [0])
+    assert int(dd.n_unique.item()) == 1
+    assert dd.seg_start[:2].cpu().tolist() == [0, 4096] and int(dd.uniq_row[0]) == 2
+
+
+@pytest.mark.parametrize("D,vocabs", [(16, [3, 10, 70000, 500]), (1, [3, 10, 70000, 500]),
+                                      (10, [40, 7]), (40, [3, 100])])
+def test_grad_reduce_matches_index_add(D, vocabs):
+    rng = np.random.default_rng(D)
+    B, C = 4096, len(vocabs)
+    pads = [0] * C
+    ids = np.stack([np.minimum((v * rng.random(B) ** 3).astype(np.int64), v - 1) for v in vocabs], 1)
+    dd, bases, R = _dedup(ids, vocabs, pads)
+    n_slots = C + 1
+    dout = torch.randn(B, n_slots * D, generator=torch.Generator().manual_seed(1))
+    offs = [(c + 1) * D for c in range(C)]
+    G = torch.zeros(dd.n_max, D, device=DEV)
+    sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max), device=DEV)
+    ops.emb_grad_reduce(_dev(dout), n_slots * D, _dev(offs, torch.int64), C, D, dd, G, sq)
+    ref = torch.zeros(R, D, dtype=torch.float64)
+    d3 = dout.view(B, n_slots, D).double()
+    for c in range(C):
+        keep = torch.from_numpy(ids[:, c] != 0)
+        ref.index_add_(0, torch.from_numpy(ids[:, c] + bases[c])[keep], d3[keep, c + 1])
+    nu = int(dd.n_unique.item())
+    rows = dd.uniq_row[:nu].cpu().long()
+    got = G[:nu].cpu().double()
+    err = (got - ref[rows]).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-6 * max(scale, 1.0), (err, scale)      # fp32 sums of <= 4096 terms
+    total = float(sq.double().sum())
+    np.testing.assert_allclose(total, float((ref ** 2).sum()), rtol=1e-5)
+    # run-to-run determinism
+    G2 = torch.zeros_like(G)
+    sq2 = torch.empty_like(sq)
+    ops.emb_grad_reduce(_dev(dout), n_slots * D, _dev(offs, torch.int64), C, D, dd, G2, sq2)
+    assert torch.equal(G[:nu], G2[:nu]) and torch.equal(sq, sq2)
+
+
+def test_numeric_grad():
+    g = torch.Generator().manual_seed(3)
+    B, Fd, D, n_slots = 4096, 13, 16, 39
+    dout = torch.randn(B, n_slots * D, generator=g)
+    dense = torch.rand(B, Fd, generator=g)
+    offs = [2 * j * D for j in range(Fd)]
+    out = torch.empty(Fd, D, device=DEV)
+    ops.emb_numeric_grad(_dev(dout), n_slots * D, _dev(offs, torch.int64), _dev(dense), D, out)
+    ref = torch.stack([(dense[:, j:j + 1].double() * dout.view(B, n_slots, D)[:, 2 * j].double()).sum(0)
+                       for j in range(Fd)])
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def _adam_ref_step(p, g, m, v, t, lr):
+    O.adam_dense(p, g, m, v, t, lr)
+
+
+@pytest.mark.parametrize("D", [16, 1, 10])
+def test_sparse_adam_exact_mode_equals_dense_adam(D):
+    """The heart of the 'exact' claim: touched-rows-only updates + catch-up replay reproduce the
+    reference's dense Adam over the WHOLE table (rows idle for > FX_REPLAY_MAX steps included)."""
+    rng = np.random.default_rng(5)
+    R, lr = 400, 1e-2
+    table0 = torch.randn(R, D, generator=torch.Generator().manual_seed(2))
+    p_ref, m_ref, v_ref = table0.clone(), torch.zeros(R, D), torch.zeros(R, D)
+    table, m, v = _dev(table0), torch.zeros(R, D, device=DEV), torch.zeros(R, D, device=DEV)
+    last = torch.zeros(R, dtype=torch.int32, device=DEV)
+    scal = ops.new_scalars(DEV, lr=lr)
+    ws = torch.empty(ops.dedup_workspace_bytes(64), dtype=torch.uint8, device=DEV)
+    n_steps = 330
+    for t in range(1, n_steps + 1):
+        # rows 0..9 are touched only at t = 1 and t = 320 (idle > 256 steps); others randomly
+        if t in (1, 320):
+            ids = np.arange(64) % 10
+        else:
+            ids = rng.integers(10, R, 64)
+        ids = ids.reshape(64, 1)
+        ops.opt_begin_step(scal)
+        dd = ops.dedup(_dev(ids, torch.int32), _dev([0], torch.int64), _dev([R], torch.int32),
+                       _dev([-1], torch.int32), R, ws)
+        ops.adam_catchup(table, m, v, last, D, dd, R, -1, scal)
+        nu = int(dd.n_unique.item())
+        rows = dd.uniq_row[:nu].cpu().long()
+        # the rows a forward would read now equal the dense-Adam table after t-1 steps
+        if t in (2, 100, 320):
+            assert (table[rows.to(DEV)].cpu() - p_ref[rows]).abs().max().item() <= 2e-6
+        G = torch.zeros(dd.n_max, D)
+        G[:nu] = torch.randn(nu, D, generator=torch.Generator().manual_seed(t)) * 0.1
+        g_dense = torch.zeros(R, D)
+        g_dense[rows] = G[:nu]
+        _adam_ref_step(p_ref, g_dense, m_ref, v_ref, t, lr)
+        ops.sparse_adam(table, m, v, last, D, dd, _dev(G), scal)
+    ops.adam_catchup(table, m, v, last, D, None, R, 0, scal)       # flush
+    assert int(last.min()) == n_steps
+    assert (table.cpu() - p_ref).abs().max().item() <= 5e-6
+    assert (m.cpu() - m_ref).abs().max().item() <= 1e-6
+    assert (v.cpu() - v_ref).abs().max().item() <= 1e-6
+
+
+def test_sparse_sgd_and_clip():
+    R, D = 50, 16
+    table0 = torch.randn(R, D)
+    table = _dev(table0)
+    scal = ops.new_scalars(DEV, lr=0.5, max_norm=1.0)
+    ids = np.array([[3], [7], [3], [9]])
+    ws = torch.empty(ops.dedup_workspace_bytes(4), dtype=torch.uint8, device=DEV)
+    dd = ops.dedup(_dev(ids, torch.int32), _dev([0], torch.int64), _dev([R], torch.int32),
+                   _dev([-1], torch.int32), R, ws)
+    G = torch.zeros(4, D)
+    G[:3] = torch.randn(3, D)
+    sq = _dev([(G ** 2).sum().item()], torch.float32)
+    ops.clip_coef([sq], scal)
+    total = G.norm().item()
+    coef = min(1.0, 1.0 / (total + 1e-6))
+    np.testing.assert_allclose(float(scal[_lib.SC_CLIP]), coef, rtol=1e-6)
+    np.testing.assert_allclose(float(scal[_lib.SC_TOTAL_NORM]), total, rtol=1e-6)
+    ops.sparse_sgd(table, D, dd, _dev(G), scal)
+    ref = table0.clone()
+    ref[[3, 7, 9]] -= 0.5 * coef * G[:3]
+    assert (table.cpu() - ref).abs().max().item() <= 1e-6
+
+
+def test_multi_tensor_adam_sqnorm_clip():
+    g = torch.Generator().manual_seed(9)
+    shapes = [(1024, 624), (1024,), (1, 1024), (1,), (13, 16), (37,)]
+    ps = [torch.randn(*s, generator=g) for s in shapes]
+    gs = [torch.randn(*s, generator=g) for s in shapes]
+    dp = [_dev(p) for p in ps]
+    dg = [_dev(x) for x in gs]
+    dm = [torch.zeros_like(p) for p in dp]
+    dv = [torch.zeros_like(p) for p in dp]
+    rm = [torch.zeros_like(p) for p in ps]
+    rv = [torch.zeros_like(p) for p in ps]
+    scal = ops.new_scalars(DEV, lr=1e-3, max_norm=10.0)
+    sq = torch.empty(len(ps) * _lib.FX_MT_BLOCKS, device=DEV)
+    for t in range(1, 4):
+        ops.opt_begin_step(scal)
+        ops.mt_sqnorm(dg, sq)
+        ops.clip_coef([sq], scal)
+        ops.mt_adam(dp, dg, dm, dv, scal)
+        grads = [x.clone() for x in gs]
+        total = O.clip_grad_norm(grads, 10.0)
+        np.testing.assert_allclose(float(scal[_lib.SC_TOTAL_NORM]), total, rtol=2e-6)
+        for p, x, m, v in zip(ps, grads, rm, rv):
+            O.adam_dense(p, x, m, v, t, 1e-3)
+    for a, b in zip(dp, ps):
+        assert (a.cpu() - b).abs().max().item() <= 2e-6
+    ops.mt_sgd(dp, dg, scal)
+    coef = float(scal[_lib.SC_CLIP])
+    for a, b, x in zip(dp, ps, gs):
+        assert (a.cpu() - (b - 1e-3 * coef * x)).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("F,D", [(39, 16), (19, 8), (12, 10), (5, 40)])
+def test_fm_forward_backward(F, D):
+    g = torch.Generator().manual_seed(F)
+    B = 517
+    emb = torch.randn(B, F, D, generator=g) * 0.3
+    add = torch.randn(B, 1, generator=g)
+    out = torch.empty(B, 1, device=DEV)
+    ops.fm_fwd(_dev(emb).view(B, F * D), F, D, _dev(add), out)
+    e = emb.clone().requires_grad_(True)
+    ref = O.fm_product_sum(e) + add
+    assert (out.cpu() - ref.detach()).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    gout = torch.randn(B, 1, generator=g)
+    ref.backward(gout)
+    demb = torch.empty(B, F * D, device=DEV)
+    ops.fm_bwd(_dev(emb).view(B, F * D), F, D, _dev(gout), demb)
+    assert (demb.cpu().view(B, F, D) - e.grad).abs().max().item() <= 1e-5 * e.grad.abs().max().item()
+    demb2 = torch.ones(B, F * D, device=DEV)
+    ops.fm_bwd(_dev(emb).view(B, F * D), F, D, _dev(gout), demb2, accumulate=True)
+    assert (demb2 - 1 - demb).abs().max().item() <= 1e-5
+
+
+def test_lr_forward():
+    g = torch.Generator().manual_seed(4)
+    vocabs = [50, 3, 1000, 7] * 6 + [11, 13]
+    bases = np.concatenate([[0], np.cumsum(vocabs)[:-1]])
+    B, C, Fd = 1000, len(vocabs), 13
+    table = torch.randn(int(sum(vocabs)), 1, generator=g)
+    ids = torch.stack([torch.randint(0, v, (B,), generator=g) for v in vocabs], dim=1).int()
+    dense = torch.rand(B, Fd, generator=g)
+    w1 = torch.randn(Fd, 1, generator=g)
+    bias = torch.randn(1, generator=g)
+    out = torch.empty(B, 1, device=DEV)
+    scal = ops.new_scalars(DEV)
+    ops.lr_fwd(_dev(table), _dev(ids), _dev(bases, torch.int64), _dev(vocabs, torch.int32),
+               _dev(dense), _dev(w1), _dev(bias), out, scal)
+    ref = sum(table[ids[:, c].long() + int(bases[c])] for c in range(C)) + dense @ w1 + bias
+    assert (out.cpu() - ref).abs().max().item() <= 1e-5
+
+
+GEMM_SHAPES = [(4096, 1024, 624), (4096, 1024, 1024), (4096, 1, 1024), (100, 70, 50), (257, 129, 17),
+               (1, 1, 1), (64, 624, 4096), (130, 1648, 33)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_all_layouts(M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(_dev(A), _dev(Bm), C, transa=ta, transb=tb)
+    a = A.t() if ta else A
+    b = Bm.t() if tb else Bm
+    ref = a.double() @ b.double()
+    bound = (a.abs().double() @ b.abs().double()).max().item()
+    err = (C.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-6 * bound, (err, bound)             # fp32 accumulate over K terms
+
+
+def test_gemm_mfma_layout_is_not_transposed():
+    """A = I with an ASYMMETRIC B catches a swapped C/D fragment mapping."""
+    n = 128
+    A = torch.eye(n)
+    Bm = torch.arange(n * n, dtype=torch.float32).view(n, n) / 100.0
+    C = torch.empty(n, n, device=DEV)
+    ops.gemm(_dev(A), _dev(Bm), C)
+    assert torch.equal(C.cpu(), Bm)
+
+
+def test_gemm_epilogues_and_split_k():
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 515, 200, 3000
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    mul = torch.randn(M, N, generator=g)
+    add = torch.randn(M, N, generator=g)
+    msk = torch.randn(M, N, generator=g)
+    z_ref = (A.double() @ W.double().t() + bias.double())
+    tol = 3e-6 * (A.abs().double() @ W.abs().double().t()).max().item()
+    for sk in (1, 5):
+        ws = torch.empty(sk * M * N, device=DEV)
+        C = torch.empty(M, N, device=DEV)
+        Z = torch.empty(M, N, device=DEV)
+        ops.gemm(_dev(A), _dev(W), C, transb=True, bias=_dev(bias), act=1, split_k=sk, workspace=ws)
+        assert (C.cpu().double() - z_ref.clamp(min=0)).abs().max().item() <= tol
+        ops.gemm(_dev(A), _dev(W), C, transb=True, bias=_dev(bias), zout=Z, mul=_dev(mul),
+                 add=_dev(add), split_k=sk, workspace=ws)
+        assert (Z.cpu().double() - z_ref).abs().max().item() <= tol
+        assert (C.cpu().double() - (z_ref * mul.double() + add.double())).abs().max().item() <= 3 * tol
+        ops.gemm(_dev(A), _dev(W), C, transb=True, mask=_dev(msk), split_k=sk, workspace=ws)
+        ref = torch.where(msk > 0, (A.double() @ W.double().t()), torch.zeros((), dtype=torch.float64))
+        assert (C.cpu().double() - ref).abs().max().item() <= tol
+
+
+def test_colsum_mask_cross_prep_bce():
+    g = torch.Generator().manual_seed(8)
+    M, N = 4096, 1000
+    X = torch.randn(M, N, generator=g)
+    out = torch.empty(N, device=DEV)
+    ws = torch.empty(_lib.FX_COLSUM_CHUNKS * N, device=DEV)
+    ops.colsum(_dev(X), out, ws)
+    assert (out.cpu().double() - X.double().sum(0)).abs().max().item() <= 2e-4
+    Y = torch.randn(M, N, generator=g)
+    o = ops.mask_mul(_dev(X), _dev(Y), torch.empty(M, N, device=DEV))
+    assert torch.equal(o.cpu(), torch.where(Y > 0, X, torch.zeros(())))
+    Z = torch.randn(M, N, generator=g)
+    t = torch.empty(M, N, device=DEV)
+    dx0 = torch.ones(M, N, device=DEV)
+    ops.cross_bwd_prep(_dev(X), _dev(Y), _dev(Z), t, dx0, init=False, add_dxn=True)
+    assert torch.allclose(t.cpu(), X * Y, atol=0, rtol=0)
+    assert (dx0.cpu() - (1 + X * Z + X)).abs().max().item() <= 1e-5
+    ops.cross_bwd_prep(_dev(X), _dev(Y), _dev(Z), t, dx0, init=True, add_dxn=False)
+    assert torch.equal(dx0.cpu(), X * Z)
+    # sigmoid + BCE: value and gradient against torch autograd on the reference's two ops
+    B = 4096
+    logit = (torch.randn(B, 1, generator=g) * 4).requires_grad_(True)
+    logit.data[0] = 40.0
+    logit.data[1] = -40.0       # exercise the log clamp at -100
+    y = (torch.rand(B, 1, generator=g) < 0.3).float()
+    y[0] = 0.0
+    y[1] = 1.0
+    p_ref = torch.sigmoid(logit)
+    loss_ref = O.bce_mean(p_ref, y)
+    loss_ref.backward()
+    prob = torch.empty(B, 1, device=DEV)
+    loss = torch.empty((), device=DEV)
+    dl = torch.empty(B, 1, device=DEV)
+    ops.sigmoid_bce(_dev(logit.detach()), _dev(y), prob=prob, loss=loss, dlogit=dl)
+    assert (prob.cpu() - p_ref.detach()).abs().max().item() <= 2e-7
+    np.testing.assert_allclose(float(loss), float(loss_ref), rtol=2e-6)
+    assert (dl.cpu() - logit.grad).abs().max().item() <= 1e-9 + 2e-6 * logit.grad.abs().max().item()
+    ops.sigmoid_bce(_dev(logit.detach()), None, prob=prob)
+    assert (prob.cpu() - p_ref.detach()).abs().max().item() <= 2e-7

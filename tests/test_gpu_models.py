@@ -1,0 +1,223 @@
+"""End-to-end parity on a real MI355X: the native DeepFM / DCNv2 (fuxictr_amd.zoo on the native
+layers, every op through libfxctr.so) against golden vectors recorded from the REAL reference
+(tests/golden/, made by make_golden.py) and against the oracle on the same inputs.
+
+Stated tolerances (BASELINE.json north_star: logits within 1e-4 fp32 of the reference forward):
+  forward logits        |d| <= 1e-4   (observed ~1e-6: exact-fp32 MFMA, same formulas)
+  loss trajectory       |d| <= 1e-4 per step over the recorded steps (dense-Adam semantics, `exact`)
+  weights after k steps |d| <= 2e-5 (see conftest.assert_weights_close for Adam's eps-conditioning)
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import Golden, assert_weights_close  # noqa: E402
+from fuxictr_amd import synthetic, zoo  # noqa: E402
+from fuxictr_amd.features import FeatureMap  # noqa: E402
+from oracle import ctr_oracle as O  # noqa: E402
+
+LOGIT_TOL = 1e-4
+
+
+def build_native(g, tmp_path, sparse_update="exact", optimizer=None):
+    m = g.meta
+    fmap = FeatureMap(g.spec["dataset_id"], str(tmp_path))
+    fmap.load_dict(g.spec, {"embedding_dim": m["embedding_dim"]})
+    common = dict(gpu=0, embedding_dim=m["embedding_dim"], learning_rate=m["lr"],
+                  optimizer=optimizer or m["optimizer"], loss="binary_crossentropy",
+                  task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
+                  model_root=str(tmp_path), embedding_regularizer=0, net_regularizer=0,
+                  sparse_update=sparse_update)
+    if m["model"] == "DeepFM":
+        model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"], **common)
+    else:
+        model = zoo.DCNv2(fmap, model_id=m["name"], model_structure="parallel",
+                          num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"],
+                          **common)
+    sd = {k: torch.from_numpy(v) for k, v in g.state0.items()}
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())   # reference checkpoint keys
+    model.load_state_dict(sd)
+    model._max_gradient_norm = m["max_norm"]
+    return model
+
+
+def tb(b):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in b.items()}
+
+
+def test_forward_logits_match_reference(golden, tmp_path):
+    model = build_native(golden, tmp_path)
+    model.eval()
+    with torch.no_grad():
+        p = model.forward(tb(golden.batches[-1]))["y_pred"]
+    logit = p._fx_logit.reshape(-1).cpu().numpy()
+    err = np.abs(logit - golden.expect["logit0"]).max()
+    assert err <= LOGIT_TOL, err
+    assert err <= 2e-5, "fp32 MFMA path is expected to be far inside the 1e-4 budget: %g" % err
+    np.testing.assert_allclose(p.reshape(-1).cpu().numpy(), golden.expect["pred0"], atol=2e-6)
+
+
+def test_training_trajectory_matches_reference(golden, tmp_path):
+    """`exact` sparse update == the reference's dense clip + Adam/SGD over every parameter."""
+    model = build_native(golden, tmp_path)
+    model.train()
+    losses = []
+    for i in range(golden.meta["steps"]):
+        losses.append(float(model.train_step(tb(golden.batches[i])).item()))
+    np.testing.assert_allclose(losses, golden.expect["loss"], rtol=0, atol=1e-4)
+    model.eval()                                   # flushes pending zero-gradient steps
+    with torch.no_grad():
+        p = model.forward(tb(golden.batches[-1]))["y_pred"]
+    assert np.abs(p._fx_logit.reshape(-1).cpu().numpy() - golden.expect["logit1"]).max() <= LOGIT_TOL
+    np.testing.assert_allclose(p.reshape(-1).cpu().numpy(), golden.expect["pred1"], atol=2e-5)
+    sd = model.state_dict()
+    for k, ref in golden.state1.items():
+        assert_weights_close(sd[k].cpu().numpy(), ref, golden.meta["lr"], golden.meta["steps"], k)
+    model.optimizer.check_errors()
+
+
+def test_auc_matches_oracle_to_4_decimals(tmp_path):
+    """Train native and oracle from the same weights on the same batches; AUC/logloss of a held
+    out set agree to 4 decimals (sklearn on float64 on both sides, like metrics.py:49-51)."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    g = Golden("deepfm_adam")
+    m = g.meta
+    model = build_native(g, tmp_path)
+    tr = O.OracleTrainer(g.cfg(), g.state0, g.features, lr=m["lr"], max_norm=m["max_norm"])
+    rng = np.random.default_rng(123)
+    from make_golden import make_batches
+    train = make_batches(rng, g.spec, 256, 12)
+    # teacher labels so that AUC is far from 0.5
+    w = rng.normal(size=len(g.features))
+    def relabel(b):
+        s = sum(w[i] * (np.asarray(b[f], dtype=np.float64) % 7 - 3) / 3.0
+                for i, f in enumerate(g.features))
+        b["label"] = (rng.random(len(s)) < 1 / (1 + np.exp(-s))).astype(np.float32)
+        return b
+    train = [relabel(b) for b in train]
+    test = [relabel(b) for b in make_batches(rng, g.spec, 2048, 2)]
+    model.train()
+    for b in train:
+        t = tb(b)
+        model.train_step(t)
+        tr.train_step(t, t["label"])
+    model.eval()
+    y = np.concatenate([b["label"] for b in test]).astype(np.float64)
+    with torch.no_grad():
+        pn = np.concatenate([model.forward(tb(b))["y_pred"].reshape(-1).cpu().numpy() for b in test])
+    po = np.concatenate([tr.predict(tb(b)).reshape(-1).numpy() for b in test])
+    auc_n, auc_o = roc_auc_score(y, pn.astype(np.float64)), roc_auc_score(y, po.astype(np.float64))
+    ll_n, ll_o = log_loss(y, pn.astype(np.float64)), log_loss(y, po.astype(np.float64))
+    assert abs(auc_n - auc_o) < 5e-5, (auc_n, auc_o)
+    assert abs(ll_n - ll_o) < 5e-5, (ll_n, ll_o)
+    assert auc_n > 0.55
+    assert np.abs(pn - po).max() <= 1e-4
+
+
+def test_lazy_mode_runs_and_differs_only_on_idle_rows(tmp_path):
+    g = Golden("deepfm_adam")
+    exact = build_native(g, tmp_path, "exact")
+    lazy = build_native(g, tmp_path, "lazy")
+    for model in (exact, lazy):
+        model.train()
+        for i in range(g.meta["steps"]):
+            loss = model.train_step(tb(g.batches[i]))
+        assert np.isfinite(float(loss.item()))
+        model.eval()
+    k = "mlp.mlp.0.weight"
+    d_dense = (exact.state_dict()[k] - lazy.state_dict()[k]).abs().max().item()
+    assert d_dense < 5e-2           # same model family, small documented deviation
+    # step 1 is identical in both modes (no row has pending steps yet)
+    e1, l1 = build_native(g, tmp_path, "exact"), build_native(g, tmp_path, "lazy")
+    a = float(e1.train_step(tb(g.batches[0])).item())
+    b = float(l1.train_step(tb(g.batches[0])).item())
+    assert a == b
+
+
+def test_bad_id_raises_like_the_reference(tmp_path):
+    g = Golden("deepfm_d10")
+    model = build_native(g, tmp_path)
+    b = tb(g.batches[0])
+    b["C3"] = b["C3"].clone()
+    b["C3"][0] = 10 ** 6
+    model.train()
+    model.train_step(b)
+    with pytest.raises(IndexError):
+        model.optimizer.check_errors()
+
+
+def test_fit_evaluate_checkpoint_roundtrip(tmp_path):
+    """BaseModel.fit / evaluate / save_weights / load_weights on the native path (rank_model.py
+    :236-270, :350-381, :417-433), driven like run_expid.py does."""
+    g = Golden("dcnv2_adam")
+    model = build_native(g, tmp_path)
+
+    class Gen(list):
+        pass
+    train = Gen(tb(b) for b in g.batches[:-1])
+    valid = Gen([tb(g.batches[-1])])
+    model.fit(train, epochs=2, validation_data=valid, max_gradient_norm=10.0)
+    logs = model.evaluate(valid)
+    assert set(logs) == {"logloss", "AUC"} and 0 < logs["logloss"] < 1
+    pred = model.predict(valid)
+    assert pred.shape == (len(g.batches[-1]["label"]),) and pred.dtype == np.float64
+    other = build_native(g, tmp_path)
+    other.load_weights(model.checkpoint)
+    np.testing.assert_array_equal(other.predict(valid), pred)
+    assert model.count_parameters() == sum(v.size for v in g.state0.values())
+
+
+@pytest.mark.parametrize("dist", ["powerlaw", "uniform"])
+def test_full_criteo_scale_properties(tmp_path, dist):
+    """BASELINE config c2 at full size (33.76 M rows, D=16, B=4096, MLP 4x1024): the oracle is too
+    slow here, so check size-independent properties: gather == table rows bit-exact, only rows of
+    the batch move in a step (checksum of all other rows unchanged), determinism across runs."""
+    fmap, _ = synthetic.criteo_feature_map(embedding_dim=16)
+    def make():
+        torch.manual_seed(0)
+        return zoo.DeepFM(fmap, model_id="c2", gpu=0, embedding_dim=16, hidden_units=[1024] * 4,
+                          optimizer="adam", loss="binary_crossentropy", learning_rate=1e-3,
+                          task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
+                          model_root=str(tmp_path), sparse_update="exact")
+    model = make()
+    rng = np.random.default_rng(0)
+    batches = [tb(synthetic.criteo_batch(rng, 4096, dist=dist)) for _ in range(3)]
+    layer = model.embedding_layer.embedding_layer
+    grp = layer.table_groups()[0]
+    assert grp.total_rows == 33762577 + 26
+    # (1) gather is bit-exact against direct indexing of the packed table
+    model.eval()
+    with torch.no_grad():
+        X = model.get_inputs(batches[0])
+        rec = model.embedding_layer(X)
+    assert rec.shape == (4096, 39, 16)
+    plan = list(grp.plans.values())[0]
+    for f in ["C1", "C3", "C26"]:
+        s, _ = plan.slot[f]
+        base = grp.table_of(f)[0]
+        rows = batches[0][f].to("cuda:0") + base
+        assert torch.equal(rec[:, s], grp.table[rows])
+    j, _ = plan.slot["I5"]
+    assert torch.equal(rec[:, j], batches[0]["I5"].to("cuda:0").view(-1, 1) * grp.num_w[4])
+    # (2) a step moves only rows of the batch
+    table_before = grp.table.clone()
+    model.train()
+    losses = [float(model.train_step(b).item()) for b in batches]
+    assert all(np.isfinite(losses))
+    touched = torch.zeros(grp.total_rows, dtype=torch.bool, device="cuda:0")
+    for b in batches:
+        for f, (base, V, _) in grp.tables.items():
+            touched[b[f].to("cuda:0") + base] = True
+    changed = (grp.table != table_before).any(dim=1)
+    assert not bool((changed & ~touched).any())
+    assert int(changed.sum()) > 0.5 * int(touched.sum())
+    model.optimizer.check_errors()
+    # (3) determinism: a second model from the same seed reproduces the losses bit for bit
+    del table_before
+    model2 = make()
+    model2.train()
+    losses2 = [float(model2.train_step(b).item()) for b in batches]
+    assert losses == losses2
+    assert torch.equal(model2.embedding_layer.embedding_layer.table_groups()[0].table, grp.table)
