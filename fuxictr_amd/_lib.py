@@ -84,6 +84,12 @@ def load():
         raise FxError(
             "libfxctr.so not found at %s — build it with `python -m fuxictr_amd.build` "
             "(hipcc --offload-arch=gfx950). The native path has no fallback." % LIB_PATH)
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the one already
+    # resident when libfxctr.so resolves libamdhip64.so.7, or two runtimes end up in the process
+    # and launches fail with "no ROCm-capable device is detected".
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

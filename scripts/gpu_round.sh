@@ -3,6 +3,7 @@
 # Usage (from the repo root on the GPU box):  bash scripts/gpu_round.sh [tag] [steps]
 TAG=${1:-r01}
 STEPS=${2:-30}
+REPO=$PWD
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -21,7 +22,7 @@ tail -5 $OUT/bench_$TAG.err | tee -a $OUT/summary_$TAG.txt
 echo "== rocprofv3 kernel trace" | tee -a $OUT/summary_$TAG.txt
 rm -rf $OUT/prof_$TAG
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- \
-    python $PWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err)
+    python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err)
 echo "rocprof exit $?" | tee -a $OUT/summary_$TAG.txt
 cat $OUT/prof_bench_$TAG.json | tee -a $OUT/summary_$TAG.txt
 STATS=$(find $OUT/prof_$TAG -name '*kernel_stats.csv' | head -1)

@@ -264,8 +264,12 @@ def test_multi_tensor_adam_sqnorm_clip():
         ops.clip_coef([sq], scal)
         ops.mt_adam(dp, dg, dm, dv, scal)
         grads = [x.clone() for x in gs]
+        truth = float(torch.sqrt(sum((x.double() ** 2).sum() for x in gs)))
         total = O.clip_grad_norm(grads, 10.0)
-        np.testing.assert_allclose(float(scal[_lib.SC_TOTAL_NORM]), total, rtol=2e-6)
+        # native: fp32 partials, fp64 final sum -> within 1e-6 of the fp64 truth; torch's CPU
+        # vector_norm (the reference's arithmetic) is itself only ~1e-5 accurate at this size
+        np.testing.assert_allclose(float(scal[_lib.SC_TOTAL_NORM]), truth, rtol=1e-6)
+        np.testing.assert_allclose(total, truth, rtol=2e-5)
         for p, x, m, v in zip(ps, grads, rm, rv):
             O.adam_dense(p, x, m, v, t, 1e-3)
     for a, b in zip(dp, ps):
@@ -406,7 +410,7 @@ def test_colsum_mask_cross_prep_bce():
     dl = torch.empty(B, 1, device=DEV)
     ops.sigmoid_bce(_dev(logit.detach()), _dev(y), prob=prob, loss=loss, dlogit=dl)
     assert (prob.cpu() - p_ref.detach()).abs().max().item() <= 2e-7
-    np.testing.assert_allclose(float(loss), float(loss_ref), rtol=2e-6)
+    np.testing.assert_allclose(float(loss), float(loss_ref.detach()), rtol=2e-6)
     assert (dl.cpu() - logit.grad).abs().max().item() <= 1e-9 + 2e-6 * logit.grad.abs().max().item()
     ops.sigmoid_bce(_dev(logit.detach()), None, prob=prob)
     assert (prob.cpu() - p_ref.detach()).abs().max().item() <= 2e-7
