@@ -8,7 +8,7 @@
 // and their autograd (dX = dZ W, dW = dZ^T X, db = colsum dZ) triggered at rank_model.py:320.
 //
 // Tiling (one wave = 64 lanes, 4 waves per workgroup, one workgroup per CU at B=4096):
-//   block tile 128x128x16, LDS double-buffered, k-major tiles T[k][m] so that an MFMA operand
+//   block tile 128x128x32, LDS double-buffered (67.5 KB), k-major tiles T[k][m] so that an MFMA operand
 //   fragment (lane l: row l&31, k = l>>5) is one conflict-free ds_read_b32;
 //   wave tile 64x64 = 2x2 MFMA tiles of 32x32 -> 4 independent accumulators (64 VGPRs);
 //   global->register prefetch of tile t+1 is issued before the MFMAs of tile t;
@@ -19,9 +19,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FX_BM 128
 #define FX_BN 128
-#define FX_BK 16
-#define FX_LD_KC 130   // row stride of a tile filled by transposing 4-byte LDS writes (conflict-free)
+#define FX_BK 32
+#define FX_LD_KC 129   // row stride of a tile filled by transposing 4-byte LDS writes (conflict-free)
 #define FX_LD_MC 132   // row stride of a tile filled by 16-byte LDS writes (keeps 16-B alignment)
+#define FX_STAGE 4     // float4 staging registers per operand per thread (128 x 32 tile / 256 threads)
 
 struct GemmArgs {
     const float* A;
@@ -53,17 +54,17 @@ __device__ __forceinline__ float fx_epilogue(const fx_gemm_epilogue& e, float z,
 // KC: element (r,k) at P[r*ld + k] (k contiguous) else at P[k*ld + r] (r contiguous).
 template <bool KC, bool VEC>
 struct TileLoader {
-    float4 st[2];
+    float4 st[FX_STAGE];
 
     __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int64_t r0,
                                          int64_t R, int64_t k0, int64_t kend) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < FX_STAGE; ++p) {
             const int q = threadIdx.x + 256 * p;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (KC) {
-                const int64_t r = r0 + (q >> 2);
-                const int64_t k = k0 + ((q & 3) << 2);
+                const int64_t r = r0 + (q >> 3);
+                const int64_t k = k0 + ((q & 7) << 2);
                 if (r < R) {
                     const float* src = P + r * ld + k;
                     if constexpr (VEC) {
@@ -96,10 +97,10 @@ struct TileLoader {
 
     __device__ __forceinline__ void store(float* __restrict__ T) const {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < FX_STAGE; ++p) {
             const int q = threadIdx.x + 256 * p;
             if constexpr (KC) {
-                const int r = q >> 2, kq = (q & 3) << 2;
+                const int r = q >> 3, kq = (q & 7) << 2;
                 T[(kq + 0) * FX_LD_KC + r] = st[p].x;
                 T[(kq + 1) * FX_LD_KC + r] = st[p].y;
                 T[(kq + 2) * FX_LD_KC + r] = st[p].z;
@@ -164,14 +165,34 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
         }
         const float* as = As[cur] + half * LDA + wm * 64 + l31;
         const float* bs = Bs[cur] + half * LDB + wn * 64 + l31;
+        // Software-pipelined fragment reads, two k-pairs deep: the ds_read2_b32 pair of k-pair
+        // s+2 is issued right after the four MFMAs of k-pair s (same register set), so an LDS
+        // latency is always covered by 4-8 MFMAs.  Pinned with sched_group_barrier — left alone,
+        // hipcc sinks every read next to its use and pays a full LDS latency per 4 MFMAs.
+        float fa[2][2], fb[2][2];
 #pragma unroll
-        for (int kk = 0; kk < FX_BK; kk += 2) {
-            const float a0 = as[kk * LDA], a1 = as[kk * LDA + 32];
-            const float b0 = bs[kk * LDB], b1 = bs[kk * LDB + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int s2 = 0; s2 < 2; ++s2) {
+            fa[s2][0] = as[(2 * s2) * LDA];
+            fa[s2][1] = as[(2 * s2) * LDA + 32];
+            fb[s2][0] = bs[(2 * s2) * LDB];
+            fb[s2][1] = bs[(2 * s2) * LDB + 32];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < FX_BK / 2; ++s2) {
+            const int c = s2 & 1;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (s2 + 2 < FX_BK / 2) {
+                fa[c][0] = as[(2 * s2 + 4) * LDA];
+                fa[c][1] = as[(2 * s2 + 4) * LDA + 32];
+                fb[c][0] = bs[(2 * s2 + 4) * LDB];
+                fb[c][1] = bs[(2 * s2 + 4) * LDB + 32];
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
         }
         if (t + 1 < nk) {
             la.store(As[cur ^ 1]);
@@ -212,6 +233,69 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Skinny shapes.  Every CTR tower ends in Linear(hidden -> 1): its forward (N = 1), weight
+// gradient (M = 1) and input gradient (K = 1) would each occupy a full 128-wide MFMA tile per
+// block for one useful row/column, so they run as bandwidth-bound kernels instead.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fx_a_at(const GemmArgs& a, int ta, int64_t m, int64_t k) {
+    return ta ? a.A[k * a.lda + m] : a.A[m * a.lda + k];
+}
+__device__ __forceinline__ float fx_b_at(const GemmArgs& a, int tb, int64_t k, int64_t n) {
+    return tb ? a.B[n * a.ldb + k] : a.B[k * a.ldb + n];
+}
+
+// K <= 8: one thread per output element
+__global__ __launch_bounds__(256) void k_gemm_small_k(GemmArgs a, int ta, int tb) {
+    const int64_t total = a.M * a.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / a.N, n = i - m * a.N;
+        float acc = 0.f;
+        for (int64_t k = 0; k < a.K; ++k) acc = fmaf(fx_a_at(a, ta, m, k), fx_b_at(a, tb, k, n), acc);
+        a.C[m * a.ldc + n] = fx_epilogue(a.epi, acc, m, n);
+    }
+}
+
+// N <= 4, A stored [M,K]: one wave per output row, lanes stride k (coalesced), xor reduction
+__global__ __launch_bounds__(256) void k_gemm_small_n(GemmArgs a, int tb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < a.M; m += waves) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = a.A + m * a.lda;
+        for (int64_t k = lane; k < a.K; k += 64) {
+            const float x = arow[k];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < a.N) acc[n] = fmaf(x, fx_b_at(a, tb, k, n), acc[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = fx_wave_sum(acc[n]);
+        if (lane == 0)
+            for (int n = 0; n < a.N; ++n) a.C[m * a.ldc + n] = fx_epilogue(a.epi, acc[n], m, n);
+    }
+}
+
+// M <= 4, A stored [K,M], B stored [K,N]: thread per column n, K split over blockIdx.y into
+// workspace slabs (reduced, with the epilogue, by k_splitk_reduce)
+__global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int z = blockIdx.y;
+    const int64_t kbeg = (int64_t)z * a.k_chunk;
+    const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
+    if (n >= a.N) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t k = kbeg; k < kend; ++k) {
+        const float b = a.B[k * a.ldb + n];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m < a.M) acc[m] = fmaf(a.A[k * a.lda + m], b, acc[m]);
+    }
+    for (int m = 0; m < a.M; ++m) a.ws[((int64_t)z * a.M + m) * a.N + n] = acc[m];
+}
+
 template <bool A_KC, bool B_KC>
 static void fx_gemm_dispatch_vec(bool av, bool bv, dim3 grid, hipStream_t s, const GemmArgs& a) {
     if (av && bv) hipLaunchKernelGGL((k_gemm_f32<A_KC, B_KC, true, true>), grid, dim3(256), 0, s, a);
@@ -246,13 +330,47 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     a.ws = workspace;
     a.tiles_m = (int32_t)fx_ceil_div(M, FX_BM);
     a.tiles_n = (int32_t)fx_ceil_div(N, FX_BN);
+    hipStream_t s = fx_hip_stream(stream);
+    if (K <= 8) {
+        a.split_k = 1;
+        int64_t blocks = fx_ceil_div(M * N, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_gemm_small_k, dim3((unsigned)blocks), dim3(256), 0, s, a,
+                           (int)(transa != 0), (int)(transb != 0));
+        FX_CHECK_LAUNCH();
+        return FX_OK;
+    }
+    if (N <= 4 && !transa) {
+        a.split_k = 1;
+        int64_t blocks = fx_ceil_div(M, 4);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_gemm_small_n, dim3((unsigned)blocks), dim3(256), 0, s, a,
+                           (int)(transb != 0));
+        FX_CHECK_LAUNCH();
+        return FX_OK;
+    }
+    if (M <= 4 && transa && !transb && workspace) {
+        // finer K split than the MFMA path wants: this kernel is a column-parallel reduction
+        int64_t want = split_k > 1 ? split_k : 1;
+        int64_t kc2 = fx_ceil_div(K, want);
+        if (kc2 < 1) kc2 = 1;
+        a.k_chunk = kc2;
+        a.split_k = (int32_t)fx_ceil_div(K, kc2);
+        hipLaunchKernelGGL(k_gemm_small_m, dim3((unsigned)fx_ceil_div(N, 256), (unsigned)a.split_k),
+                           dim3(256), 0, s, a);
+        FX_CHECK_LAUNCH();
+        int64_t blocks = fx_ceil_div(M * N, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        FX_CHECK_LAUNCH();
+        return FX_OK;
+    }
     const bool a_kc = !transa, b_kc = transb != 0;
     const bool a_al = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_al = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
     const bool av = a_al && (a_kc ? (K % 4 == 0) : (M % 4 == 0));
     const bool bv = b_al && (b_kc ? (K % 4 == 0) : (N % 4 == 0));
     dim3 grid((unsigned)((int64_t)a.tiles_m * a.tiles_n), (unsigned)split_k);
-    hipStream_t s = fx_hip_stream(stream);
     if (a_kc && b_kc) fx_gemm_dispatch_vec<true, true>(av, bv, grid, s, a);
     else if (a_kc) fx_gemm_dispatch_vec<true, false>(av, bv, grid, s, a);
     else if (b_kc) fx_gemm_dispatch_vec<false, true>(av, bv, grid, s, a);
@@ -287,6 +405,34 @@ __global__ __launch_bounds__(256) void k_colsum_stage1(const float* X, int64_t l
         ws[(int64_t)blockIdx.y * N + n] = (red[tx] + red[tx + 64]) + (red[tx + 128] + red[tx + 192]);
 }
 
+// vectorised variant: a thread owns 4 adjacent columns (N % 4 == 0, 16-B aligned rows)
+__global__ __launch_bounds__(256) void k_colsum_stage1_v4(const float* X, int64_t ldx, int64_t M,
+                                                          int64_t N, int64_t rows_per_chunk,
+                                                          float* ws) {
+    __shared__ float4 red[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t n = ((int64_t)blockIdx.x * 64 + tx) * 4;
+    const int64_t mb = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t me = (mb + rows_per_chunk < M) ? mb + rows_per_chunk : M;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N)
+        for (int64_t m = mb + ty; m < me; m += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(X + m * ldx + n);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        const float4 a0 = red[tx], a1 = red[tx + 64], a2 = red[tx + 128], a3 = red[tx + 192];
+        float4 r;
+        r.x = (a0.x + a1.x) + (a2.x + a3.x);
+        r.y = (a0.y + a1.y) + (a2.y + a3.y);
+        r.z = (a0.z + a1.z) + (a2.z + a3.z);
+        r.w = (a0.w + a1.w) + (a2.w + a3.w);
+        *reinterpret_cast<float4*>(ws + (int64_t)blockIdx.y * N + n) = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_colsum_stage2(const float* ws, int64_t N, int chunks,
                                                        float* out) {
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -303,8 +449,15 @@ extern "C" int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, floa
     FX_CHECK_ARG(X && out && workspace, "fx_colsum: null pointer");
     hipStream_t s = fx_hip_stream(stream);
     const int64_t rpc = fx_ceil_div(M > 0 ? M : 1, FX_COLSUM_CHUNKS);
-    hipLaunchKernelGGL(k_colsum_stage1, dim3((unsigned)fx_ceil_div(N, 64), FX_COLSUM_CHUNKS),
-                       dim3(256), 0, s, X, ldx, M, N, rpc, workspace);
+    const bool vec = (N % 4 == 0) && (ldx % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_colsum_stage1_v4, dim3((unsigned)fx_ceil_div(N, 256), FX_COLSUM_CHUNKS),
+                           dim3(256), 0, s, X, ldx, M, N, rpc, workspace);
+    else
+        hipLaunchKernelGGL(k_colsum_stage1, dim3((unsigned)fx_ceil_div(N, 64), FX_COLSUM_CHUNKS),
+                           dim3(256), 0, s, X, ldx, M, N, rpc, workspace);
     FX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_colsum_stage2, dim3((unsigned)fx_ceil_div(N, 256)), dim3(256), 0, s,
                        workspace, N, (int)FX_COLSUM_CHUNKS, out);

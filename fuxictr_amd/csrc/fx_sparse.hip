@@ -163,11 +163,13 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
 }
 
 // ---------------------------------------------------------------------------------------------
-// gradient reduction to unique rows.  A block of 256 threads owns RPB = 256/lanes consecutive
-// unique rows.  Phase 1: the row's lane group sums a short run (<= FX_LONG_RUN lookups) alone.
-// Phase 2: each long run of the block (hot rows of tiny tables) is summed by the whole block:
-// group g takes lookups g, g+RPB, ... and a fixed LDS tree combines the groups.  The block then
-// reduces ||G||^2 of its rows in a fixed order into one partial.
+// gradient reduction to unique rows, three launches:
+//   short : a lane group (D/VEC lanes) owns one unique row and sums its run when it has at most
+//           FX_LONG_RUN lookups; longer runs (hot rows of tiny tables: a 3-row table at B=4096
+//           has runs of ~1365) are appended to a list (order of the list is irrelevant to results)
+//   long  : one workgroup per listed row, group g sums lookups g, g+RPB, ... and a fixed LDS
+//           tree combines the groups, so a hot row costs ~run/RPB load rounds instead of `run`
+//   sqnorm: block b reduces ||G||^2 of rows [b*RPB, (b+1)*RPB) in a fixed order -> partial[b]
 // ---------------------------------------------------------------------------------------------
 #define FX_LONG_RUN 32
 
@@ -180,63 +182,61 @@ struct ReduceArgs {
     const int32_t* n_unique;
     float* G;
     float* sq_partials;
+    int32_t* scratch;   // [0] = number of long rows, [1..] = their unique-row indices
     int32_t C, D, lanes_log2;
 };
 
 template <int VEC>
-__global__ __launch_bounds__(256) void k_emb_grad_reduce(ReduceArgs a) {
+__device__ __forceinline__ void fx_accum_lookup(const ReduceArgs& a, uint32_t i, int d0,
+                                                float (&acc)[VEC]) {
+    const uint32_t p = a.sorted_pos[i];
+    const uint32_t b = p / (uint32_t)a.C, c = p - b * (uint32_t)a.C;
+    float v[VEC];
+    fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += v[k];
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_grad_reduce_short(ReduceArgs a) {
+    const int lanes = 1 << a.lanes_log2;
+    const int rpb = 256 >> a.lanes_log2;
+    const int sub = threadIdx.x & (lanes - 1);
+    const int d0 = sub * VEC;
+    const int nu = *a.n_unique;
+    const int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2);
+    if (u >= nu) return;
+    const uint32_t beg = a.seg_start[u], end = a.seg_start[u + 1];
+    if (end - beg > FX_LONG_RUN) {
+        if (sub == 0) a.scratch[1 + atomicAdd(&a.scratch[0], 1)] = (int32_t)u;
+        return;
+    }
+    if (d0 >= a.D) return;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (uint32_t i = beg; i < end; ++i) fx_accum_lookup<VEC>(a, i, d0, acc);
+    fx_store<VEC>(a.G + u * a.D + d0, acc);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_grad_reduce_long(ReduceArgs a) {
     __shared__ float red[256 * VEC];
-    __shared__ uint32_t s_beg[256], s_end[256];
-    __shared__ float red4[4];
     const int lanes = 1 << a.lanes_log2;
     const int rpb = 256 >> a.lanes_log2;
     const int sub = threadIdx.x & (lanes - 1);
     const int grp = threadIdx.x >> a.lanes_log2;
     const int d0 = sub * VEC;
     const bool lane_on = d0 < a.D;
-    const int nu = *a.n_unique;
-    const int64_t u = (int64_t)blockIdx.x * rpb + grp;
-    uint32_t beg = 0, end = 0;
-    if (u < nu) {
-        beg = a.seg_start[u];
-        end = a.seg_start[u + 1];
-    }
-    if (sub == 0) {
-        s_beg[grp] = beg;
-        s_end[grp] = end;
-    }
-    float acc[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-    const bool is_long = (end - beg) > FX_LONG_RUN;
-    if (!is_long && lane_on) {
-        for (uint32_t i = beg; i < end; ++i) {
-            const uint32_t p = a.sorted_pos[i];
-            const uint32_t b = p / (uint32_t)a.C, c = p - b * (uint32_t)a.C;
-            float v[VEC];
-            fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] += v[k];
-        }
-    }
-    __syncthreads();
-    // phase 2: long runs, one at a time, whole block
-    for (int r = 0; r < rpb; ++r) {
-        const uint32_t rb = s_beg[r], re = s_end[r];
-        if (re - rb <= FX_LONG_RUN) continue;  // block-uniform
+    const int n_long = a.scratch[0];
+    for (int li = blockIdx.x; li < n_long; li += gridDim.x) {   // block-uniform
+        const int64_t u = a.scratch[1 + li];
+        const uint32_t beg = a.seg_start[u], end = a.seg_start[u + 1];
         float part[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) part[k] = 0.f;
-        if (lane_on) {
-            for (uint32_t i = rb + grp; i < re; i += rpb) {
-                const uint32_t p = a.sorted_pos[i];
-                const uint32_t b = p / (uint32_t)a.C, c = p - b * (uint32_t)a.C;
-                float v[VEC];
-                fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) part[k] += v[k];
-            }
-        }
+        if (lane_on)
+            for (uint32_t i = beg + grp; i < end; i += rpb) fx_accum_lookup<VEC>(a, i, d0, part);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) red[k * 256 + threadIdx.x] = part[k];
         __syncthreads();
@@ -248,40 +248,56 @@ __global__ __launch_bounds__(256) void k_emb_grad_reduce(ReduceArgs a) {
             }
             __syncthreads();
         }
-        if (grp == r) {
+        if (grp == 0 && lane_on) {
+            float out[VEC];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = red[k * 256 + sub];
+            for (int k = 0; k < VEC; ++k) out[k] = red[k * 256 + sub];
+            fx_store<VEC>(a.G + u * a.D + d0, out);
         }
         __syncthreads();
     }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_rows_sqnorm(ReduceArgs a) {
+    __shared__ float red4[4];
+    const int lanes = 1 << a.lanes_log2;
+    const int rpb = 256 >> a.lanes_log2;
+    const int d0 = (threadIdx.x & (lanes - 1)) * VEC;
+    const int nu = *a.n_unique;
+    const int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2);
     float sq = 0.f;
-    if (u < nu && lane_on) {
-        fx_store<VEC>(a.G + u * a.D + d0, acc);
+    if (u < nu && d0 < a.D) {
+        float g[VEC];
+        fx_load<VEC>(a.G + u * a.D + d0, g);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) sq = fmaf(acc[k], acc[k], sq);
+        for (int k = 0; k < VEC; ++k) sq = fmaf(g[k], g[k], sq);
     }
     const float tot = fx_block_sum_256(sq, red4);
     if (threadIdx.x == 0) a.sq_partials[blockIdx.x] = tot;
 }
 
-extern "C" int64_t fx_emb_grad_reduce_partials(int64_t n_max) {
-    // worst case geometry is lanes = 64 (4 rows per block); callers size for lanes = 1 .. 64
-    // through the D they pass to fx_emb_grad_reduce, so report the count for lanes = 64.
-    return n_max <= 0 ? 1 : fx_ceil_div(n_max, 4);
+extern "C" int64_t fx_emb_grad_reduce_partials(int64_t n_max, int32_t D) {
+    if (n_max <= 0 || D < 1 || D > 256) return 1;
+    return fx_ceil_div(n_max, 256 / fx_row_geom(D).lanes);
+}
+
+extern "C" int64_t fx_emb_grad_reduce_scratch_ints(int64_t n_max) {
+    return (n_max <= 0 ? 0 : n_max / (FX_LONG_RUN + 1)) + 2;
 }
 
 extern "C" int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int64_t* col_out_off,
                                   int32_t C, int32_t D, const uint32_t* sorted_pos,
                                   const uint32_t* seg_start, const int32_t* n_unique,
-                                  int64_t n_max, float* G, float* sq_partials,
+                                  int64_t n_max, float* G, float* sq_partials, int32_t* scratch,
                                   fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256 && C >= 1, "fx_emb_grad_reduce: bad C=%d / D=%d", C, D);
     hipStream_t s = fx_hip_stream(stream);
-    const int64_t n_part = fx_emb_grad_reduce_partials(n_max);
-    FX_CHECK_ARG(sq_partials, "fx_emb_grad_reduce: null sq_partials");
-    // partial slots not written by a block below must read as zero
-    FX_CHECK_HIP(hipMemsetAsync(sq_partials, 0, (size_t)n_part * sizeof(float), s));
-    if (n_max <= 0) return FX_OK;
+    FX_CHECK_ARG(sq_partials && scratch, "fx_emb_grad_reduce: null sq_partials / scratch");
+    if (n_max <= 0) {
+        FX_CHECK_HIP(hipMemsetAsync(sq_partials, 0, sizeof(float), s));
+        return FX_OK;
+    }
     FX_CHECK_ARG(dout && col_out_off && sorted_pos && seg_start && n_unique && G,
                  "fx_emb_grad_reduce: null pointer");
     const FxRowGeom g = fx_row_geom(D);
@@ -290,12 +306,18 @@ extern "C" int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int6
     int ll = 0;
     while ((1 << ll) < g.lanes) ++ll;
     ReduceArgs a{dout, dout_ld, col_out_off, sorted_pos, seg_start, n_unique, G, sq_partials,
-                 C, D, ll};
+                 scratch, C, D, ll};
+    FX_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(int32_t), s));
     const int64_t blocks = fx_ceil_div(n_max, 256 / g.lanes);
-    dim3 grid((unsigned)blocks);
-    if (g.vec == 4) hipLaunchKernelGGL(k_emb_grad_reduce<4>, grid, dim3(256), 0, s, a);
-    else if (g.vec == 2) hipLaunchKernelGGL(k_emb_grad_reduce<2>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_emb_grad_reduce<1>, grid, dim3(256), 0, s, a);
+    dim3 grid((unsigned)blocks), grid_long(512);
+#define FX_REDUCE_LAUNCH(V)                                                              \
+    hipLaunchKernelGGL(k_emb_grad_reduce_short<V>, grid, dim3(256), 0, s, a);            \
+    hipLaunchKernelGGL(k_emb_grad_reduce_long<V>, grid_long, dim3(256), 0, s, a);        \
+    hipLaunchKernelGGL(k_rows_sqnorm<V>, grid, dim3(256), 0, s, a);
+    if (g.vec == 4) { FX_REDUCE_LAUNCH(4) }
+    else if (g.vec == 2) { FX_REDUCE_LAUNCH(2) }
+    else { FX_REDUCE_LAUNCH(1) }
+#undef FX_REDUCE_LAUNCH
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
@@ -333,17 +355,17 @@ struct ClipArgs {
     fx_scalars* scal;
 };
 
-__global__ __launch_bounds__(256) void k_clip_coef(ClipArgs a) {
-    __shared__ double red[256];
-    // fixed assignment thread <- elements t, t+256, ... of every array, in array order: deterministic
+__global__ __launch_bounds__(1024) void k_clip_coef(ClipArgs a) {
+    __shared__ double red[1024];
+    // fixed assignment thread <- elements t, t+1024, ... of every array, in array order: deterministic
     double acc = 0.0;
     for (int p = 0; p < a.n_parts; ++p) {
         const float* x = a.part[p];
-        for (int64_t i = threadIdx.x; i < a.count[p]; i += 256) acc += (double)x[i];
+        for (int64_t i = threadIdx.x; i < a.count[p]; i += 1024) acc += (double)x[i];
     }
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 512; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
@@ -373,7 +395,7 @@ extern "C" int fx_clip_coef(const float* const* parts_host, const int64_t* count
     }
     a.n_parts = n_parts;
     a.scal = scal;
-    hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(256), 0, fx_hip_stream(stream), a);
+    hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(1024), 0, fx_hip_stream(stream), a);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

@@ -296,9 +296,11 @@ class _TableGroup(object):
             if dd is None:
                 dd = self.dedup(plan, ids, inputs_cache)
             G = torch.empty(dd.n_max, D, dtype=torch.float32, device=self.device)
-            sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max), dtype=torch.float32,
+            sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max, D), dtype=torch.float32,
                              device=self.device)
-            ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G, sq)
+            scratch = torch.empty(ops.emb_grad_reduce_scratch_ints(dd.n_max), dtype=torch.int32,
+                                  device=self.device)
+            ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G, sq, scratch)
             self.pending.append(_PendingGrad(dd, G, sq))
 
     def flush(self):
@@ -771,6 +773,8 @@ class FactorizationMachine(nn.Module):
 # ------------------------------------------------------------------------------------------------
 def _split_k_for(M, N, K):
     """Split the contraction when the output grid alone cannot fill 256 CUs (weight gradients)."""
+    if M <= 4:                      # skinny weight gradient: column-parallel reduction kernel
+        return max(1, min(64, K // 64))
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 192:
         return 1

@@ -154,15 +154,19 @@ def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=N
     return result
 
 
-def emb_grad_reduce_partials(n_max):
-    return int(_lib.load().fx_emb_grad_reduce_partials(n_max))
+def emb_grad_reduce_partials(n_max, D):
+    return int(_lib.load().fx_emb_grad_reduce_partials(n_max, D))
 
 
-def emb_grad_reduce(dout, dout_ld, col_out_off, C_, D, dd, G, sq_partials):
+def emb_grad_reduce_scratch_ints(n_max):
+    return int(_lib.load().fx_emb_grad_reduce_scratch_ints(n_max))
+
+
+def emb_grad_reduce(dout, dout_ld, col_out_off, C_, D, dd, G, sq_partials, scratch):
     lib = _lib.load()
     check(lib.fx_emb_grad_reduce(ptr(dout), dout_ld, ptr(col_out_off), C_, D, ptr(dd.sorted_pos),
                                  ptr(dd.seg_start), ptr(dd.n_unique), dd.n_max, ptr(G),
-                                 ptr(sq_partials), stream_ptr(dout.device)),
+                                 ptr(sq_partials), ptr(scratch), stream_ptr(dout.device)),
           "fx_emb_grad_reduce")
 
 

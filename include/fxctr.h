@@ -109,15 +109,18 @@ int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
 
 /* ------------------------------------------------------------------------------------------
  * Embedding backward, sparse side: G[u,:] = sum over the run of unique row u of
- * dout[b*dout_ld + col_out_off[c] + :], summed in ascending lookup position (deterministic).
- * Also writes per-block partial sums of ||G||^2 into sq_partials[0..n_partials) (n_partials is
- * returned by fx_emb_grad_reduce_partials(n_max)); rows >= *n_unique are not touched.
+ * dout[b*dout_ld + col_out_off[c] + :], summed in a fixed order (deterministic; runs longer than
+ * 32 lookups — hot rows of tiny tables — are reduced by a whole workgroup each).
+ * Also writes per-block partial sums of ||G||^2 into sq_partials[0..n_partials), n_partials =
+ * fx_emb_grad_reduce_partials(n_max, D); rows >= *n_unique are not touched.
+ * scratch: fx_emb_grad_reduce_scratch_ints(n_max) int32 words of device scratch.
  * ------------------------------------------------------------------------------------------ */
-int64_t fx_emb_grad_reduce_partials(int64_t n_max);
+int64_t fx_emb_grad_reduce_partials(int64_t n_max, int32_t D);
+int64_t fx_emb_grad_reduce_scratch_ints(int64_t n_max);
 int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int64_t* col_out_off, int32_t C,
                        int32_t D, const uint32_t* sorted_pos, const uint32_t* seg_start,
                        const int32_t* n_unique, int64_t n_max, float* G, float* sq_partials,
-                       fx_stream_t stream);
+                       int32_t* scratch, fx_stream_t stream);
 
 /* Numeric-feature weight gradient: dnum_w[j,d] = sum_b dense[b,j] * dout[b*dout_ld + num_out_off[j] + d]
  * (autograd of the nn.Linear(1,D) at feature_embedding.py:280-282).  Deterministic tree sum. */
@@ -204,7 +207,9 @@ int fx_lr_fwd(const float* table1, const int32_t* ids, int64_t ids_ld,
  *     z = acc + bias[n];  zout[m,n] = z;  act(z) (1 = relu);  z *= mul[m,n];
  *     z = mask[m,n] > 0 ? z : 0;  z += add[m,n];  C[m,n] = z
  * split_k > 1 splits K over blocks; partials go to workspace[split_k][M][N] and a second
- * (deterministic) kernel reduces them and applies the epilogue.
+ * (deterministic) kernel reduces them and applies the epilogue.  Skinny shapes (K <= 8; N <= 4
+ * with transa = 0; M <= 4 with transa = 1, transb = 0 and a workspace) — the Linear(hidden -> 1)
+ * head of every tower and its gradients — run on bandwidth-bound kernels instead of MFMA tiles.
  * ------------------------------------------------------------------------------------------ */
 typedef struct fx_gemm_epilogue {
     const float* bias;
@@ -226,7 +231,7 @@ int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
 
 /* Column sums (bias gradients): out[n] = sum_m X[m,n].
  * Two-stage deterministic reduction; workspace >= FX_COLSUM_CHUNKS * N floats. */
-#define FX_COLSUM_CHUNKS 32
+#define FX_COLSUM_CHUNKS 64
 int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, float* workspace,
               fx_stream_t stream);
 

@@ -74,11 +74,15 @@ def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=N
     return dd
 
 
-def emb_grad_reduce_partials(n_max):
+def emb_grad_reduce_partials(n_max, D):
     return max(1, (n_max + 3) // 4)
 
 
-def emb_grad_reduce(dout, dout_ld, col_out_off, C, D, dd, G, sq_partials):
+def emb_grad_reduce_scratch_ints(n_max):
+    return n_max // 33 + 2
+
+
+def emb_grad_reduce(dout, dout_ld, col_out_off, C, D, dd, G, sq_partials, scratch):
     nu = int(dd.n_unique)
     flat = dout.reshape(-1)
     sq_partials.zero_()
@@ -257,7 +261,8 @@ def install(monkeypatch):
     import fuxictr_amd.rank_model as rm
     me = globals()
     for name in ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes", "dedup",
-                 "emb_grad_reduce_partials", "emb_grad_reduce", "emb_numeric_grad",
+                 "emb_grad_reduce_partials", "emb_grad_reduce_scratch_ints", "emb_grad_reduce",
+                 "emb_numeric_grad",
                  "opt_begin_step", "clip_coef", "sparse_adam", "adam_catchup", "sparse_sgd",
                  "mt_sqnorm", "mt_adam", "mt_sgd", "fm_fwd", "fm_bwd", "lr_fwd", "gemm", "colsum",
                  "mask_mul", "cross_bwd_prep", "sigmoid_bce"]:

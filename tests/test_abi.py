@@ -46,7 +46,9 @@ def test_argument_validation_without_gpu():
     assert st == 1 and b"D=0" in lib.fx_last_error()
     st = lib.fx_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 1, None, None)
     assert st == 1 and b"null matrix" in lib.fx_last_error()
-    assert lib.fx_emb_grad_reduce_partials(1024) == 256
+    assert lib.fx_emb_grad_reduce_partials(1024, 16) == 16
+    assert lib.fx_emb_grad_reduce_partials(1024, 128) == 128
+    assert lib.fx_emb_grad_reduce_scratch_ints(3300) == 102
 
 
 def test_struct_layout_matches_header():

@@ -141,8 +141,9 @@ def test_grad_reduce_matches_index_add(D, vocabs):
     dout = torch.randn(B, n_slots * D, generator=torch.Generator().manual_seed(1))
     offs = [(c + 1) * D for c in range(C)]
     G = torch.zeros(dd.n_max, D, device=DEV)
-    sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max), device=DEV)
-    ops.emb_grad_reduce(_dev(dout), n_slots * D, _dev(offs, torch.int64), C, D, dd, G, sq)
+    sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max, D), device=DEV)
+    scr = torch.empty(ops.emb_grad_reduce_scratch_ints(dd.n_max), dtype=torch.int32, device=DEV)
+    ops.emb_grad_reduce(_dev(dout), n_slots * D, _dev(offs, torch.int64), C, D, dd, G, sq, scr)
     ref = torch.zeros(R, D, dtype=torch.float64)
     d3 = dout.view(B, n_slots, D).double()
     for c in range(C):
@@ -159,7 +160,7 @@ def test_grad_reduce_matches_index_add(D, vocabs):
     # run-to-run determinism
     G2 = torch.zeros_like(G)
     sq2 = torch.empty_like(sq)
-    ops.emb_grad_reduce(_dev(dout), n_slots * D, _dev(offs, torch.int64), C, D, dd, G2, sq2)
+    ops.emb_grad_reduce(_dev(dout), n_slots * D, _dev(offs, torch.int64), C, D, dd, G2, sq2, scr)
     assert torch.equal(G[:nu], G2[:nu]) and torch.equal(sq, sq2)
 
 
