@@ -15,14 +15,11 @@
 //   blockIdx is remapped so the 8 n-tiles that share one A row-panel run on the same XCD (L2).
 #include "fx_common.h"
 
+#include <stdlib.h>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define FX_BM 128
-#define FX_BN 128
 #define FX_BK 32
-#define FX_LD_KC 129   // row stride of a tile filled by transposing 4-byte LDS writes (conflict-free)
-#define FX_LD_MC 132   // row stride of a tile filled by 16-byte LDS writes (keeps 16-B alignment)
-#define FX_STAGE 4     // float4 staging registers per operand per thread (128 x 32 tile / 256 threads)
 
 struct GemmArgs {
     const float* A;
@@ -50,22 +47,26 @@ __device__ __forceinline__ float fx_epilogue(const fx_gemm_epilogue& e, float z,
     return z;
 }
 
-// Operand tile loader.  R = extent of the non-contracted dimension (M for A, N for B).
+// Operand tile loader for an R x 32 tile (R = 64 or 128 rows of the non-contracted dimension).
 // KC: element (r,k) at P[r*ld + k] (k contiguous) else at P[k*ld + r] (r contiguous).
-template <bool KC, bool VEC>
+// LDS image is always k-major T[k][LD]: LD = R+1 when filled by transposing 4-byte writes
+// (conflict-free), R+4 when filled by 16-byte writes (keeps 16-B alignment).
+template <int R, bool KC, bool VEC>
 struct TileLoader {
-    float4 st[FX_STAGE];
+    static constexpr int NST = R / 32;            // float4 staging registers per thread
+    static constexpr int LD = KC ? R + 1 : R + 4;
+    float4 st[NST];
 
     __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int64_t r0,
-                                         int64_t R, int64_t k0, int64_t kend) {
+                                         int64_t Rext, int64_t k0, int64_t kend) {
 #pragma unroll
-        for (int p = 0; p < FX_STAGE; ++p) {
+        for (int p = 0; p < NST; ++p) {
             const int q = threadIdx.x + 256 * p;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (KC) {
                 const int64_t r = r0 + (q >> 3);
                 const int64_t k = k0 + ((q & 7) << 2);
-                if (r < R) {
+                if (r < Rext) {
                     const float* src = P + r * ld + k;
                     if constexpr (VEC) {
                         if (k < kend) v = *reinterpret_cast<const float4*>(src);
@@ -77,17 +78,17 @@ struct TileLoader {
                     }
                 }
             } else {
-                const int64_t k = k0 + (q >> 5);
-                const int64_t r = r0 + ((q & 31) << 2);
+                const int64_t k = k0 + q / (R / 4);
+                const int64_t r = r0 + ((q % (R / 4)) << 2);
                 if (k < kend) {
                     const float* src = P + k * ld + r;
                     if constexpr (VEC) {
-                        if (r < R) v = *reinterpret_cast<const float4*>(src);
+                        if (r < Rext) v = *reinterpret_cast<const float4*>(src);
                     } else {
-                        if (r + 0 < R) v.x = src[0];
-                        if (r + 1 < R) v.y = src[1];
-                        if (r + 2 < R) v.z = src[2];
-                        if (r + 3 < R) v.w = src[3];
+                        if (r + 0 < Rext) v.x = src[0];
+                        if (r + 1 < Rext) v.y = src[1];
+                        if (r + 2 < Rext) v.z = src[2];
+                        if (r + 3 < Rext) v.w = src[3];
                     }
                 }
             }
@@ -97,28 +98,35 @@ struct TileLoader {
 
     __device__ __forceinline__ void store(float* __restrict__ T) const {
 #pragma unroll
-        for (int p = 0; p < FX_STAGE; ++p) {
+        for (int p = 0; p < NST; ++p) {
             const int q = threadIdx.x + 256 * p;
             if constexpr (KC) {
                 const int r = q >> 3, kq = (q & 7) << 2;
-                T[(kq + 0) * FX_LD_KC + r] = st[p].x;
-                T[(kq + 1) * FX_LD_KC + r] = st[p].y;
-                T[(kq + 2) * FX_LD_KC + r] = st[p].z;
-                T[(kq + 3) * FX_LD_KC + r] = st[p].w;
+                T[(kq + 0) * LD + r] = st[p].x;
+                T[(kq + 1) * LD + r] = st[p].y;
+                T[(kq + 2) * LD + r] = st[p].z;
+                T[(kq + 3) * LD + r] = st[p].w;
             } else {
-                const int k = q >> 5, r = (q & 31) << 2;
-                *reinterpret_cast<float4*>(T + k * FX_LD_MC + r) = st[p];
+                const int k = q / (R / 4), r = (q % (R / 4)) << 2;
+                *reinterpret_cast<float4*>(T + k * LD + r) = st[p];
             }
         }
     }
 };
 
-template <bool A_KC, bool B_KC, bool A_VEC, bool B_VEC>
+// BM x BN x 32 block tile, 4 waves as 2 (m) x 2 (n); a wave owns (BM/2) x (BN/2) = MI x NJ MFMA
+// tiles of 32x32.  128x128 (one workgroup per CU at 67.5 KB LDS... two fit) is the efficient
+// shape when the grid has >= 2 workgroups per CU; at B = 4096 the towers give exactly 256 such
+// tiles, so 128x64 / 64x64 are used there to keep 2-4 workgroups per CU in flight: the barrier /
+// LDS-refill bubble of one workgroup is then covered by the MFMAs of another.
+template <int BM, int BN, bool A_KC, bool B_KC, bool A_VEC, bool B_VEC>
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
-    constexpr int LDA = A_KC ? FX_LD_KC : FX_LD_MC;
-    constexpr int LDB = B_KC ? FX_LD_KC : FX_LD_MC;
-    __shared__ __attribute__((aligned(16))) float As[2][FX_BK * FX_LD_MC];
-    __shared__ __attribute__((aligned(16))) float Bs[2][FX_BK * FX_LD_MC];
+    using LoaderA = TileLoader<BM, A_KC, A_VEC>;
+    using LoaderB = TileLoader<BN, B_KC, B_VEC>;
+    constexpr int LDA = LoaderA::LD, LDB = LoaderB::LD;
+    constexpr int MI = BM / 64, NJ = BN / 64;
+    __shared__ __attribute__((aligned(16))) float As[2][FX_BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][FX_BK * LDB];
 
     // XCD-aware tile mapping: workgroup L runs on XCD L % 8; give each XCD a contiguous range of
     // tiles (row-major over (tm, tn)) so the n-tiles sharing an A panel share one L2.
@@ -129,8 +137,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
         const int64_t q = nwg >> 3, r = nwg & 7, xcd = L & 7;
         T = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
     }
-    const int64_t m0 = (T / a.tiles_n) * FX_BM;
-    const int64_t n0 = (T % a.tiles_n) * FX_BN;
+    const int64_t m0 = (T / a.tiles_n) * BM;
+    const int64_t n0 = (T % a.tiles_n) * BN;
     const int z = blockIdx.y;
     const int64_t kbeg = (int64_t)z * a.k_chunk;
     const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
@@ -139,16 +147,16 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    TileLoader<A_KC, A_VEC> la;
-    TileLoader<B_KC, B_VEC> lb;
+    LoaderA la;
+    LoaderB lb;
     const int64_t nk = (kend > kbeg) ? (kend - kbeg + FX_BK - 1) / FX_BK : 0;
     if (nk > 0) {
         la.load(a.A, a.lda, m0, a.M, kbeg, kend);
@@ -163,34 +171,36 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
             la.load(a.A, a.lda, m0, a.M, kbeg + (t + 1) * FX_BK, kend);
             lb.load(a.B, a.ldb, n0, a.N, kbeg + (t + 1) * FX_BK, kend);
         }
-        const float* as = As[cur] + half * LDA + wm * 64 + l31;
-        const float* bs = Bs[cur] + half * LDB + wn * 64 + l31;
-        // Software-pipelined fragment reads, two k-pairs deep: the ds_read2_b32 pair of k-pair
-        // s+2 is issued right after the four MFMAs of k-pair s (same register set), so an LDS
-        // latency is always covered by 4-8 MFMAs.  Pinned with sched_group_barrier — left alone,
-        // hipcc sinks every read next to its use and pays a full LDS latency per 4 MFMAs.
-        float fa[2][2], fb[2][2];
+        const float* as = As[cur] + half * LDA + wm * (BM / 2) + l31;
+        const float* bs = Bs[cur] + half * LDB + wn * (BN / 2) + l31;
+        // Software-pipelined fragment reads, two k-pairs deep: the LDS reads of k-pair s+2 are
+        // issued right after the MFMAs of k-pair s (same register set), so an LDS latency is
+        // always covered by MFMAs.  Pinned with sched_group_barrier — left alone, hipcc sinks
+        // every read next to its use and pays a full LDS latency per MFMA group.
+        float fa[2][MI], fb[2][NJ];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            fa[s2][0] = as[(2 * s2) * LDA];
-            fa[s2][1] = as[(2 * s2) * LDA + 32];
-            fb[s2][0] = bs[(2 * s2) * LDB];
-            fb[s2][1] = bs[(2 * s2) * LDB + 32];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[s2][i] = as[(2 * s2) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[s2][j] = bs[(2 * s2) * LDB + 32 * j];
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
         for (int s2 = 0; s2 < FX_BK / 2; ++s2) {
             const int c = s2 & 1;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j],
+                                                                     acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);
             if (s2 + 2 < FX_BK / 2) {
-                fa[c][0] = as[(2 * s2 + 4) * LDA];
-                fa[c][1] = as[(2 * s2 + 4) * LDA + 32];
-                fb[c][0] = bs[(2 * s2 + 4) * LDB];
-                fb[c][1] = bs[(2 * s2 + 4) * LDB + 32];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[c][i] = as[(2 * s2 + 4) * LDA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[c][j] = bs[(2 * s2 + 4) * LDB + 32 * j];
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
         }
@@ -203,14 +213,14 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t n = n0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < NJ; ++j) {
+            const int64_t n = n0 + wn * (BN / 2) + j * 32 + l31;
             if (n >= a.N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int64_t m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= a.M) continue;
                 if (a.split_k > 1) {
                     a.ws[((int64_t)z * a.M + m) * a.N + n] = acc[i][j][r];
@@ -296,12 +306,25 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs a) {
     for (int m = 0; m < a.M; ++m) a.ws[((int64_t)z * a.M + m) * a.N + n] = acc[m];
 }
 
-template <bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC>
 static void fx_gemm_dispatch_vec(bool av, bool bv, dim3 grid, hipStream_t s, const GemmArgs& a) {
-    if (av && bv) hipLaunchKernelGGL((k_gemm_f32<A_KC, B_KC, true, true>), grid, dim3(256), 0, s, a);
-    else if (av) hipLaunchKernelGGL((k_gemm_f32<A_KC, B_KC, true, false>), grid, dim3(256), 0, s, a);
-    else if (bv) hipLaunchKernelGGL((k_gemm_f32<A_KC, B_KC, false, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_f32<A_KC, B_KC, false, false>), grid, dim3(256), 0, s, a);
+    if (av && bv)
+        hipLaunchKernelGGL((k_gemm_f32<BM, BN, A_KC, B_KC, true, true>), grid, dim3(256), 0, s, a);
+    else if (av)
+        hipLaunchKernelGGL((k_gemm_f32<BM, BN, A_KC, B_KC, true, false>), grid, dim3(256), 0, s, a);
+    else if (bv)
+        hipLaunchKernelGGL((k_gemm_f32<BM, BN, A_KC, B_KC, false, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_gemm_f32<BM, BN, A_KC, B_KC, false, false>), grid, dim3(256), 0, s, a);
+}
+
+template <int BM, int BN>
+static void fx_gemm_dispatch_layout(bool a_kc, bool b_kc, bool av, bool bv, dim3 grid,
+                                    hipStream_t s, const GemmArgs& a) {
+    if (a_kc && b_kc) fx_gemm_dispatch_vec<BM, BN, true, true>(av, bv, grid, s, a);
+    else if (a_kc) fx_gemm_dispatch_vec<BM, BN, true, false>(av, bv, grid, s, a);
+    else if (b_kc) fx_gemm_dispatch_vec<BM, BN, false, true>(av, bv, grid, s, a);
+    else fx_gemm_dispatch_vec<BM, BN, false, false>(av, bv, grid, s, a);
 }
 
 extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
@@ -328,8 +351,27 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     a.k_chunk = kc;
     a.split_k = split_k;
     a.ws = workspace;
-    a.tiles_m = (int32_t)fx_ceil_div(M, FX_BM);
-    a.tiles_n = (int32_t)fx_ceil_div(N, FX_BN);
+    // tile shape: the largest one that still gives ~2 workgroups per CU (256 CUs)
+    int bm = 128, bn = 128;
+    {
+        static const int forced = []() {   // FX_GEMM_TILE=128x128|128x64|64x64 (experiments)
+            const char* e = getenv("FX_GEMM_TILE");
+            if (!e) return 0;
+            if (!strcmp(e, "128x128")) return 1;
+            if (!strcmp(e, "128x64")) return 2;
+            if (!strcmp(e, "64x64")) return 3;
+            return 0;
+        }();
+        const int64_t want = 448;
+        if (forced == 2) { bn = 64; }
+        else if (forced == 3) { bm = 64; bn = 64; }
+        else if (forced == 0 && fx_ceil_div(M, 128) * fx_ceil_div(N, 128) * split_k < want) {
+            bn = 64;
+            if (fx_ceil_div(M, 128) * fx_ceil_div(N, 64) * split_k < want) bm = 64;
+        }
+    }
+    a.tiles_m = (int32_t)fx_ceil_div(M, bm);
+    a.tiles_n = (int32_t)fx_ceil_div(N, bn);
     hipStream_t s = fx_hip_stream(stream);
     if (K <= 8) {
         a.split_k = 1;
@@ -371,10 +413,9 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     const bool av = a_al && (a_kc ? (K % 4 == 0) : (M % 4 == 0));
     const bool bv = b_al && (b_kc ? (K % 4 == 0) : (N % 4 == 0));
     dim3 grid((unsigned)((int64_t)a.tiles_m * a.tiles_n), (unsigned)split_k);
-    if (a_kc && b_kc) fx_gemm_dispatch_vec<true, true>(av, bv, grid, s, a);
-    else if (a_kc) fx_gemm_dispatch_vec<true, false>(av, bv, grid, s, a);
-    else if (b_kc) fx_gemm_dispatch_vec<false, true>(av, bv, grid, s, a);
-    else fx_gemm_dispatch_vec<false, false>(av, bv, grid, s, a);
+    if (bm == 128 && bn == 128) fx_gemm_dispatch_layout<128, 128>(a_kc, b_kc, av, bv, grid, s, a);
+    else if (bm == 128) fx_gemm_dispatch_layout<128, 64>(a_kc, b_kc, av, bv, grid, s, a);
+    else fx_gemm_dispatch_layout<64, 64>(a_kc, b_kc, av, bv, grid, s, a);
     FX_CHECK_LAUNCH();
     if (split_k > 1) {
         int64_t blocks = fx_ceil_div(M * N, 256);
@@ -435,11 +476,15 @@ __global__ __launch_bounds__(256) void k_colsum_stage1_v4(const float* X, int64_
 
 __global__ __launch_bounds__(256) void k_colsum_stage2(const float* ws, int64_t N, int chunks,
                                                        float* out) {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += ws[(int64_t)c * N + n];
-    out[n] = s;
+    if (n < N)
+        for (int c = ty; c < chunks; c += 4) s += ws[(int64_t)c * N + n];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) out[n] = (red[tx] + red[tx + 64]) + (red[tx + 128] + red[tx + 192]);
 }
 
 extern "C" int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out,
@@ -459,7 +504,7 @@ extern "C" int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, floa
         hipLaunchKernelGGL(k_colsum_stage1, dim3((unsigned)fx_ceil_div(N, 64), FX_COLSUM_CHUNKS),
                            dim3(256), 0, s, X, ldx, M, N, rpc, workspace);
     FX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_colsum_stage2, dim3((unsigned)fx_ceil_div(N, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_colsum_stage2, dim3((unsigned)fx_ceil_div(N, 64)), dim3(256), 0, s,
                        workspace, N, (int)FX_COLSUM_CHUNKS, out);
     FX_CHECK_LAUNCH();
     return FX_OK;
