@@ -60,6 +60,7 @@ struct TileLoader {
     static constexpr int NST = R / 32;
     static constexpr int LD = KC ? R + 1 : R + 4;
     const float* ptr[NST];
+    const float* fbk[NST];   // always-valid per-thread address used when the chunk is out of range
     float4 st[NST];
     int koff[NST];
     int64_t rrem[NST];   // rows (elements of the non-contracted dim) left from this chunk's row
@@ -85,6 +86,10 @@ struct TileLoader {
                 ptr[p] = P + (kbeg + koff[p]) * ld + r;
             }
             rrem[p] = Rext - r;
+            // Out-of-range chunks still issue a load (branch-free) and must not all hit ONE
+            // address — 130k lanes hammering a single L2 line costs ~25 us per launch.  Use this
+            // thread's own chunk of the first k-tile (in range whenever its row is).
+            fbk[p] = (rrem[p] > 0) ? ptr[p] : P;   // rows past the edge: only in edge tiles
         }
     }
 
@@ -94,7 +99,7 @@ struct TileLoader {
         const int64_t krem = kend - (k0 + koff[p]);   // contraction elements left from this chunk
         if constexpr (VEC) {
             const bool ok = (rrem[p] > 0) && (krem > 0);
-            st[p] = *reinterpret_cast<const float4*>(ok ? ptr[p] : P);
+            st[p] = *reinterpret_cast<const float4*>(ok ? ptr[p] : fbk[p]);
             okm = ok ? (okm | (1u << p)) : (okm & ~(1u << p));
         } else {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
