@@ -51,111 +51,66 @@ __device__ __forceinline__ float fx_epilogue(const fx_gemm_epilogue& e, float z,
 // KC: element (r,k) at P[r*ld + k] (k contiguous) else at P[k*ld + r] (r contiguous).
 // LDS image is always k-major T[k][LD]: LD = R+1 when filled by transposing 4-byte writes
 // (conflict-free), R+4 when filled by 16-byte writes (keeps 16-B alignment).
-// A thread owns NST float4 "chunks" of the tile; chunk-granular load_one/store_one let the main
-// loop interleave the refill with the MFMA stream.  Vector loads are branch-free: the address is
-// selected (valid ? src : base) and the validity bit is applied only when the chunk is written
-// to LDS, so no wait sits next to the load.
 template <int R, bool KC, bool VEC>
 struct TileLoader {
-    static constexpr int NST = R / 32;
+    static constexpr int NST = R / 32;            // float4 staging registers per thread
     static constexpr int LD = KC ? R + 1 : R + 4;
-    const float* ptr[NST];
-    const float* fbk[NST];   // always-valid per-thread address used when the chunk is out of range
     float4 st[NST];
-    int koff[NST];
-    int64_t rrem[NST];   // rows (elements of the non-contracted dim) left from this chunk's row
-    int64_t kstep, ld_;
-    uint32_t okm;
 
-    __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int64_t r0,
-                                         int64_t Rext, int64_t kbeg) {
-        ld_ = ld;
-        okm = 0;
-        kstep = KC ? (int64_t)FX_BK : (int64_t)FX_BK * ld;
+    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int64_t r0,
+                                         int64_t Rext, int64_t k0, int64_t kend) {
 #pragma unroll
         for (int p = 0; p < NST; ++p) {
             const int q = threadIdx.x + 256 * p;
-            int64_t r;
-            if constexpr (KC) {
-                r = r0 + (q >> 3);
-                koff[p] = (q & 7) << 2;
-                ptr[p] = P + r * ld + kbeg + koff[p];
-            } else {
-                r = r0 + ((q % (R / 4)) << 2);
-                koff[p] = q / (R / 4);
-                ptr[p] = P + (kbeg + koff[p]) * ld + r;
-            }
-            rrem[p] = Rext - r;
-            // Out-of-range chunks still issue a load (branch-free) and must not all hit ONE
-            // address — 130k lanes hammering a single L2 line costs ~25 us per launch.  Use this
-            // thread's own chunk of the first k-tile (in range whenever its row is).
-            fbk[p] = (rrem[p] > 0) ? ptr[p] : P;   // rows past the edge: only in edge tiles
-        }
-    }
-
-    // fetch chunk p of the k-tile starting at k0 (ptr[] must point into that tile)
-    __device__ __forceinline__ void load_one(int p, const float* __restrict__ P, int64_t k0,
-                                             int64_t kend) {
-        const int64_t krem = kend - (k0 + koff[p]);   // contraction elements left from this chunk
-        if constexpr (VEC) {
-            const bool ok = (rrem[p] > 0) && (krem > 0);
-            st[p] = *reinterpret_cast<const float4*>(ok ? ptr[p] : fbk[p]);
-            okm = ok ? (okm | (1u << p)) : (okm & ~(1u << p));
-        } else {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float* src = ptr[p];
             if constexpr (KC) {
-                if (rrem[p] > 0) {
-                    if (krem > 0) v.x = src[0];
-                    if (krem > 1) v.y = src[1];
-                    if (krem > 2) v.z = src[2];
-                    if (krem > 3) v.w = src[3];
+                const int64_t r = r0 + (q >> 3);
+                const int64_t k = k0 + ((q & 7) << 2);
+                if (r < Rext) {
+                    const float* src = P + r * ld + k;
+                    if constexpr (VEC) {
+                        if (k < kend) v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (k + 0 < kend) v.x = src[0];
+                        if (k + 1 < kend) v.y = src[1];
+                        if (k + 2 < kend) v.z = src[2];
+                        if (k + 3 < kend) v.w = src[3];
+                    }
                 }
             } else {
-                if (krem > 0) {
-                    if (rrem[p] > 0) v.x = src[0];
-                    if (rrem[p] > 1) v.y = src[1];
-                    if (rrem[p] > 2) v.z = src[2];
-                    if (rrem[p] > 3) v.w = src[3];
+                const int64_t k = k0 + q / (R / 4);
+                const int64_t r = r0 + ((q % (R / 4)) << 2);
+                if (k < kend) {
+                    const float* src = P + k * ld + r;
+                    if constexpr (VEC) {
+                        if (r < Rext) v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (r + 0 < Rext) v.x = src[0];
+                        if (r + 1 < Rext) v.y = src[1];
+                        if (r + 2 < Rext) v.z = src[2];
+                        if (r + 3 < Rext) v.w = src[3];
+                    }
                 }
             }
             st[p] = v;
-            okm |= (1u << p);
         }
     }
 
-    __device__ __forceinline__ void advance() {
+    __device__ __forceinline__ void store(float* __restrict__ T) const {
 #pragma unroll
-        for (int p = 0; p < NST; ++p) ptr[p] += kstep;
-    }
-
-    __device__ __forceinline__ void store_one(int p, float* __restrict__ T) const {
-        const bool ok = (okm >> p) & 1u;
-        float4 v;
-        v.x = ok ? st[p].x : 0.f;
-        v.y = ok ? st[p].y : 0.f;
-        v.z = ok ? st[p].z : 0.f;
-        v.w = ok ? st[p].w : 0.f;
-        const int q = threadIdx.x + 256 * p;
-        if constexpr (KC) {
-            const int r = q >> 3, kq = (q & 7) << 2;
-            T[(kq + 0) * LD + r] = v.x;
-            T[(kq + 1) * LD + r] = v.y;
-            T[(kq + 2) * LD + r] = v.z;
-            T[(kq + 3) * LD + r] = v.w;
-        } else {
-            const int k = q / (R / 4), r = (q % (R / 4)) << 2;
-            *reinterpret_cast<float4*>(T + k * LD + r) = v;
+        for (int p = 0; p < NST; ++p) {
+            const int q = threadIdx.x + 256 * p;
+            if constexpr (KC) {
+                const int r = q >> 3, kq = (q & 7) << 2;
+                T[(kq + 0) * LD + r] = st[p].x;
+                T[(kq + 1) * LD + r] = st[p].y;
+                T[(kq + 2) * LD + r] = st[p].z;
+                T[(kq + 3) * LD + r] = st[p].w;
+            } else {
+                const int k = q / (R / 4), r = (q % (R / 4)) << 2;
+                *reinterpret_cast<float4*>(T + k * LD + r) = st[p];
+            }
         }
-    }
-
-    __device__ __forceinline__ void load_all(const float* __restrict__ P, int64_t k0, int64_t kend) {
-#pragma unroll
-        for (int p = 0; p < NST; ++p) load_one(p, P, k0, kend);
-    }
-    __device__ __forceinline__ void store_all(float* __restrict__ T) const {
-#pragma unroll
-        for (int p = 0; p < NST; ++p) store_one(p, T);
     }
 };
 
@@ -203,35 +158,25 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     LoaderA la;
     LoaderB lb;
     const int64_t nk = (kend > kbeg) ? (kend - kbeg + FX_BK - 1) / FX_BK : 0;
-    // Pipeline: LDS[cur] holds k-tile t, the staging registers hold k-tile t+1 (fetched during
-    // iteration t-1).  Inside iteration t, between the MFMAs: registers -> LDS[cur^1] (k-pair
-    // steps 0..), then the global loads of k-tile t+2 (steps 8..).  Neither the global-load issue
-    // nor the LDS refill sits between the last MFMA of one k-tile and the first MFMA of the
-    // next — only the barrier and one LDS read latency do.
-    la.init(a.A, a.lda, m0, a.M, kbeg);
-    lb.init(a.B, a.ldb, n0, a.N, kbeg);
     if (nk > 0) {
-        la.load_all(a.A, kbeg, kend);
-        lb.load_all(a.B, kbeg, kend);
-        la.store_all(As[0]);
-        lb.store_all(Bs[0]);
-        la.advance();
-        lb.advance();
-        la.load_all(a.A, kbeg + FX_BK, kend);   // flagged invalid (-> zeros) when there is no tile 1
-        lb.load_all(a.B, kbeg + FX_BK, kend);
-        la.advance();
-        lb.advance();
+        la.load(a.A, a.lda, m0, a.M, kbeg, kend);
+        lb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
+        la.store(As[0]);
+        lb.store(Bs[0]);
     }
     __syncthreads();
-    constexpr int NCH = LoaderA::NST + LoaderB::NST;   // refill chunks per thread (<= 8)
     for (int64_t t = 0; t < nk; ++t) {
         const int cur = (int)(t & 1);
+        if (t + 1 < nk) {
+            la.load(a.A, a.lda, m0, a.M, kbeg + (t + 1) * FX_BK, kend);
+            lb.load(a.B, a.ldb, n0, a.N, kbeg + (t + 1) * FX_BK, kend);
+        }
         const float* as = As[cur] + half * LDA + wm * (BM / 2) + l31;
         const float* bs = Bs[cur] + half * LDB + wn * (BN / 2) + l31;
-        const int64_t k2 = kbeg + (t + 2) * FX_BK;
-        // Fragment reads are software-pipelined two k-pairs deep (left alone, hipcc sinks every
-        // read next to its use and pays a full LDS latency per MFMA group); sched_barrier(0)
-        // keeps each k-pair step's work — MFMAs, the reads of step+2 and one refill chunk — together.
+        // Software-pipelined fragment reads, two k-pairs deep: the LDS reads of k-pair s+2 are
+        // issued right after the MFMAs of k-pair s (same register set), so an LDS latency is
+        // always covered by MFMAs.  Pinned with sched_group_barrier — left alone, hipcc sinks
+        // every read next to its use and pays a full LDS latency per MFMA group.
         float fa[2][MI], fb[2][NJ];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -240,7 +185,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) fb[s2][j] = bs[(2 * s2) * LDB + 32 * j];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
         for (int s2 = 0; s2 < FX_BK / 2; ++s2) {
             const int c = s2 & 1;
@@ -250,24 +195,19 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j],
                                                                      acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);
             if (s2 + 2 < FX_BK / 2) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) fa[c][i] = as[(2 * s2 + 4) * LDA + 32 * i];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) fb[c][j] = bs[(2 * s2 + 4) * LDB + 32 * j];
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
-            if (s2 < NCH) {                      // k-tile t+1: registers -> the other LDS buffer
-                if (s2 < LoaderA::NST) la.store_one(s2, As[cur ^ 1]);
-                else lb.store_one(s2 - LoaderA::NST, Bs[cur ^ 1]);
-            } else if (s2 >= 8 && s2 - 8 < NCH) {  // k-tile t+2: global -> registers
-                const int ch = s2 - 8;
-                if (ch < LoaderA::NST) la.load_one(ch, a.A, k2, kend);
-                else lb.load_one(ch - LoaderA::NST, a.B, k2, kend);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
-        la.advance();
-        lb.advance();
+        if (t + 1 < nk) {
+            la.store(As[cur ^ 1]);
+            lb.store(Bs[cur ^ 1]);
+        }
         __syncthreads();
     }
 
