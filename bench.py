@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch the step eagerly instead of replaying a captured hipGraph")
     return ap.parse_args()
 
 
@@ -51,7 +53,7 @@ def build_model(args, device_index, cards):
     common = dict(gpu=device_index, embedding_dim=16, learning_rate=1e-3, optimizer="adam",
                   loss="binary_crossentropy", task="binary_classification",
                   metrics=["logloss", "AUC"], verbose=0, model_root="/tmp/fx_bench",
-                  sparse_update=args.sparse_update)
+                  sparse_update=args.sparse_update, hip_graph=not args.no_graph)
     torch.manual_seed(2019)
     if args.model == "DeepFM":
         model = zoo.DeepFM(fmap, model_id="bench", hidden_units=[1024] * 4, **common)
@@ -182,12 +184,15 @@ def main():
             torch.cuda.synchronize(dev)
 
     step_i = 0
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 5 if not args.no_graph else 0)):   # >= 5: 3 eager + capture
         model.train_step(pool[step_i % n_pool])
         step_i += 1
     sync()
     ops.KernelTimer.reset()
-    ops.KernelTimer.enabled = not args.no_kernel_timing
+    # eager mode: the roofline kernels are timed with HIP events inside the timed region itself;
+    # graph mode: events cannot sit inside a replayed graph, so the same kernels are timed in an
+    # instrumented eager pass right after the timed region (same process, same buffers)
+    ops.KernelTimer.enabled = args.no_graph and not args.no_kernel_timing
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.train_step(pool[step_i % n_pool])
@@ -196,6 +201,19 @@ def main():
     dt = time.perf_counter() - t0
     ops.KernelTimer.enabled = False
     model.optimizer.check_errors()
+    timing_mode = "hip events inside the timed region (eager launches)"
+    if not args.no_graph and not args.no_kernel_timing:
+        model._use_graph = False
+        ops.KernelTimer.enabled = True
+        for _ in range(min(args.steps, 20)):
+            model.train_step(pool[step_i % n_pool])
+            step_i += 1
+        sync()
+        ops.KernelTimer.enabled = False
+        model._use_graph = True
+        timing_mode = ("hip events around the same kernels in an eager pass of %d steps right "
+                       "after the timed region (the timed region replays a hipGraph)"
+                       % min(args.steps, 20))
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,6 +234,7 @@ def main():
                                    % (args.model, sum(cards) + len(cards)),
                        "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "id_distribution": args.dist, "sparse_update": args.sparse_update,
+                       "launch": "eager" if args.no_graph else "hipGraph replay",
                        "parallelism": "single GPU" if world == 1 else
                                       "%d independent replicas (row-sharded all-to-all path not "
                                       "built yet; no data-path collective)" % world},
@@ -227,8 +246,9 @@ def main():
                                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                                "traffic": None, "launches": g["launches"],
-                               "avg_launch_us": g["avg_us"],
-                               "share_of_step": g["total_ms"] / (1e3 * dt)}
+                               "avg_launch_us": g["avg_us"], "timing": timing_mode,
+                               "gemm_us_per_step": 1e3 * g["total_ms"] * 15.0 / g["launches"]
+                               if args.model == "DeepFM" else None}
         e = ktimes.get("k_emb_gather_fwd")
         if e and e["total_ms"] > 0:
             ach = e["work"] / (e["total_ms"] * 1e-3) / 1e9

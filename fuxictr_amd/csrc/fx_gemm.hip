@@ -362,12 +362,15 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
             if (!strcmp(e, "64x64")) return 3;
             return 0;
         }();
+        // Measured on MI355X (profiles/r01_gemm_tiles.txt): when 128x128 tiles cannot give ~2
+        // workgroups per CU, 64x64 (4 workgroups per CU, 33 KB LDS each) beats 128x64 on every
+        // tower shape of the B=4096 step (e.g. 4096x1024x624: 85.9 vs 79.1 TFLOP/s).
         const int64_t want = 448;
         if (forced == 2) { bn = 64; }
         else if (forced == 3) { bm = 64; bn = 64; }
         else if (forced == 0 && fx_ceil_div(M, 128) * fx_ceil_div(N, 128) * split_k < want) {
+            bm = 64;
             bn = 64;
-            if (fx_ceil_div(M, 128) * fx_ceil_div(N, 64) * split_k < want) bm = 64;
         }
     }
     a.tiles_m = (int32_t)fx_ceil_div(M, bm);

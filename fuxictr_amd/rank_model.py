@@ -147,6 +147,63 @@ def get_loss(loss):
     return loss
 
 
+class _GraphStep(object):
+    """One captured training step with static input buffers."""
+
+    def __init__(self, model, batch):
+        self.model = model
+        dev = model.device
+        label = model.feature_map.labels[0]
+        self.label = label
+        self.B = batch[label].shape[0]
+        # which packed id / dense matrices the model's embedding layers ask for: run one eager
+        # step on a FeatureDict and read its cache
+        probe = model.get_inputs(batch)
+        probe._fx_ready = True
+        probe[label] = batch[label].to(dev)
+        model._step_body(probe)
+        self.packs = []      # (sig, id feature names, numeric feature names, ids, dense)
+        static = FeatureDict()
+        static._fx_ready = True
+        for key, (ids, dense) in probe.cache.items():
+            if key[0] != "pack":
+                continue
+            id_feats, num_feats = key[1]
+            s_ids = torch.zeros_like(ids) if ids is not None else None
+            s_dense = torch.zeros_like(dense) if dense is not None else None
+            self.packs.append((key, [f for f, _ in id_feats], list(num_feats), s_ids, s_dense))
+            static.cache[key] = (s_ids, s_dense)
+            col = 0
+            for f, w in id_feats:
+                static[f] = s_ids[:, col] if w == 1 else s_ids[:, col:col + w]
+                col += w
+            for j, f in enumerate(num_feats):
+                static[f] = s_dense[:, j]
+        for f in probe.keys():
+            if f not in static and f != label:
+                static[f] = probe[f].clone()
+        self.y = torch.zeros(self.B, 1, dtype=torch.float32, device=dev)
+        static[label] = self.y.view(-1)
+        self.static = static
+        self._pack_keys = {k for k, *_ in self.packs}
+        self.fill(batch)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = model._step_body(static)
+        # the capture only recorded the step; drop per-batch caches created while recording
+        static.cache = {k: v for k, v in static.cache.items() if k in self._pack_keys}
+
+    def fill(self, batch):
+        dev = self.model.device
+        for _, id_names, num_names, s_ids, s_dense in self.packs:
+            if s_ids is not None:
+                ops.pack_columns([batch[f].to(dev) for f in id_names], s_ids)
+            if s_dense is not None:
+                ops.pack_columns([batch[f].to(dev) for f in num_names], s_dense)
+        ops.pack_columns([batch[self.label].to(dev)], self.y)
+
+
 class BaseModel(nn.Module):
     def __init__(self,
                  feature_map,
@@ -176,6 +233,9 @@ class BaseModel(nn.Module):
         self._reduce_lr_on_plateau = reduce_lr_on_plateau
         self._verbose = kwargs["verbose"]
         self._sparse_update = kwargs.get("sparse_update", "exact")
+        self._use_graph = bool(kwargs.get("hip_graph", False))
+        self._graph_state = None
+        self._graph_warm = 0
         self._max_gradient_norm = 10.
         self.feature_map = feature_map
         self.output_activation = self.get_output_activation(task)
@@ -327,11 +387,9 @@ class BaseModel(nn.Module):
             self.optimizer.flush()
         return super().train(mode)
 
-    def train_step(self, batch_data):
-        """rank_model.py:307-323 on the native path."""
+    def _step_body(self, batch_data):
         opt = self.optimizer
-        opt.set_max_norm(self._max_gradient_norm)
-        opt.begin_step()
+        ops.opt_begin_step(opt.scal)     # t += 1, Adam bias corrections (device side)
         opt.zero_grad()
         return_dict = self.forward(batch_data)
         y_true = self.get_labels(batch_data)
@@ -339,6 +397,33 @@ class BaseModel(nn.Module):
         loss.backward()
         opt.step()  # global-norm clip (rank_model.py:321) is fused into the update kernels
         return loss
+
+    def train_step(self, batch_data):
+        """rank_model.py:307-323 on the native path.  With `hip_graph: true` the whole step
+        (about 60 launches) is captured once into a hipGraph and replayed: every per-step scalar
+        (step counter, lr, clip coefficient, unique-row count) already lives in device memory."""
+        opt = self.optimizer
+        opt.set_max_norm(self._max_gradient_norm)
+        opt.sync_lr()
+        if self._use_graph:
+            return self._train_step_graph(batch_data)
+        return self._step_body(batch_data)
+
+    # -- hipGraph replay of the training step ----------------------------------------------------
+    def _train_step_graph(self, batch_data):
+        st = self._graph_state
+        label = self.feature_map.labels[0]
+        B = batch_data[label].shape[0]
+        if st is None:
+            if self._graph_warm < 3:          # eager warm-up: allocations, plans, workspaces
+                self._graph_warm += 1
+                return self._step_body(batch_data)
+            st = self._graph_state = _GraphStep(self, batch_data)
+        if B != st.B:
+            return self._step_body(batch_data)   # e.g. the last, shorter batch of an epoch
+        st.fill(batch_data)
+        st.graph.replay()
+        return st.loss
 
     def train_epoch(self, data_generator):
         self._batch_index = 0

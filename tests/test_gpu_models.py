@@ -21,7 +21,7 @@ from oracle import ctr_oracle as O  # noqa: E402
 LOGIT_TOL = 1e-4
 
 
-def build_native(g, tmp_path, sparse_update="exact", optimizer=None):
+def build_native(g, tmp_path, sparse_update="exact", optimizer=None, hip_graph=False):
     m = g.meta
     fmap = FeatureMap(g.spec["dataset_id"], str(tmp_path))
     fmap.load_dict(g.spec, {"embedding_dim": m["embedding_dim"]})
@@ -29,7 +29,7 @@ def build_native(g, tmp_path, sparse_update="exact", optimizer=None):
                   optimizer=optimizer or m["optimizer"], loss="binary_crossentropy",
                   task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
                   model_root=str(tmp_path), embedding_regularizer=0, net_regularizer=0,
-                  sparse_update=sparse_update)
+                  sparse_update=sparse_update, hip_graph=hip_graph)
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"], **common)
     else:
@@ -134,6 +134,29 @@ def test_lazy_mode_runs_and_differs_only_on_idle_rows(tmp_path):
     a = float(e1.train_step(tb(g.batches[0])).item())
     b = float(l1.train_step(tb(g.batches[0])).item())
     assert a == b
+
+
+@pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam", "deepfm_sgd"])
+def test_hip_graph_replay_is_bit_identical_to_eager(case, tmp_path):
+    """`hip_graph: true` replays the captured step; same kernels, same order -> same bits."""
+    g = Golden(case)
+    eager = build_native(g, tmp_path, hip_graph=False)
+    graph = build_native(g, tmp_path, hip_graph=True)
+    eager.train()
+    graph.train()
+    n = len(g.batches)
+    for i in range(9):                       # 3 eager warm-ups + probe + replays
+        b = tb(g.batches[i % n])
+        le = float(eager.train_step(b).item())
+        lg = float(graph.train_step(b).item())
+        assert le == lg, (i, le, lg)
+    assert graph._graph_state is not None
+    eager.eval()
+    graph.eval()
+    se, sg = eager.state_dict(), graph.state_dict()
+    for k in se:
+        assert torch.equal(se[k], sg[k]), k
+    graph.optimizer.check_errors()
 
 
 def test_bad_id_raises_like_the_reference(tmp_path):
