@@ -165,9 +165,10 @@ class _GraphStep(object):
         self.packs = []      # (sig, id feature names, numeric feature names, ids, dense)
         static = FeatureDict()
         static._fx_ready = True
-        for key, (ids, dense) in probe.cache.items():
+        for key, val in probe.cache.items():
             if key[0] != "pack":
                 continue
+            ids, dense = val
             id_feats, num_feats = key[1]
             s_ids = torch.zeros_like(ids) if ids is not None else None
             s_dense = torch.zeros_like(dense) if dense is not None else None
