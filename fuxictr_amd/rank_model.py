@@ -161,7 +161,7 @@ class _GraphStep(object):
         probe = model.get_inputs(batch)
         probe._fx_ready = True
         probe[label] = batch[label].to(dev)
-        model._step_body(probe)
+        model._side_stream_step(probe)
         self.packs = []      # (sig, id feature names, numeric feature names, ids, dense)
         static = FeatureDict()
         static._fx_ready = True
@@ -190,7 +190,7 @@ class _GraphStep(object):
         self.fill(batch)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=model._graph_stream):
             self.loss = model._step_body(static)
         # the capture only recorded the step; drop per-batch caches created while recording
         static.cache = {k: v for k, v in static.cache.items() if k in self._pack_keys}
@@ -411,6 +411,19 @@ class BaseModel(nn.Module):
         return self._step_body(batch_data)
 
     # -- hipGraph replay of the training step ----------------------------------------------------
+    def _side_stream_step(self, batch_data):
+        """Warm-up steps of graph mode run on the stream the capture will use, so autograd's
+        AccumulateGrad nodes (created at the first backward, remembered per parameter) are not
+        tied to the default stream — a capture may not depend on it."""
+        if getattr(self, "_graph_stream", None) is None:
+            self._graph_stream = torch.cuda.Stream(self.device)
+        s = self._graph_stream
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            loss = self._step_body(batch_data)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        return loss
+
     def _train_step_graph(self, batch_data):
         st = self._graph_state
         label = self.feature_map.labels[0]
@@ -418,7 +431,7 @@ class BaseModel(nn.Module):
         if st is None:
             if self._graph_warm < 3:          # eager warm-up: allocations, plans, workspaces
                 self._graph_warm += 1
-                return self._step_body(batch_data)
+                return self._side_stream_step(batch_data)
             st = self._graph_state = _GraphStep(self, batch_data)
         if B != st.B:
             return self._step_body(batch_data)   # e.g. the last, shorter batch of an epoch
