@@ -161,7 +161,7 @@ class _GraphStep(object):
         probe = model.get_inputs(batch)
         probe._fx_ready = True
         probe[label] = batch[label].to(dev)
-        model._side_stream_step(probe)
+        self.probe_loss = model._side_stream_step(probe)
         self.packs = []      # (sig, id feature names, numeric feature names, ids, dense)
         static = FeatureDict()
         static._fx_ready = True
@@ -433,6 +433,7 @@ class BaseModel(nn.Module):
                 self._graph_warm += 1
                 return self._side_stream_step(batch_data)
             st = self._graph_state = _GraphStep(self, batch_data)
+            return st.probe_loss              # the probe inside _GraphStep WAS this batch's step
         if B != st.B:
             return self._step_body(batch_data)   # e.g. the last, shorter batch of an epoch
         st.fill(batch_data)
