@@ -42,18 +42,20 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: run independent replicas instead of the row-sharded model")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the step eagerly instead of replaying a captured hipGraph")
     return ap.parse_args()
 
 
-def build_model(args, device_index, cards):
+def build_model(args, device_index, cards, shard=None):
     from fuxictr_amd import synthetic, zoo
     fmap, spec = synthetic.criteo_feature_map(cards=cards, embedding_dim=16)
     common = dict(gpu=device_index, embedding_dim=16, learning_rate=1e-3, optimizer="adam",
                   loss="binary_crossentropy", task="binary_classification",
                   metrics=["logloss", "AUC"], verbose=0, model_root="/tmp/fx_bench",
-                  sparse_update=args.sparse_update, hip_graph=not args.no_graph)
+                  sparse_update=args.sparse_update, hip_graph=not args.no_graph, shard=shard)
     torch.manual_seed(2019)
     if args.model == "DeepFM":
         model = zoo.DeepFM(fmap, model_id="bench", hidden_units=[1024] * 4, **common)
@@ -154,18 +156,36 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # debug hook for 1-GPU boxes: FX_BENCH_BACKEND=gloo puts every rank on cuda:0 and stages the
+    # collectives through the host (RCCL refuses two ranks on one device)
+    backend = os.environ.get("FX_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from fuxictr_amd import ops, synthetic
     from fuxictr_amd.layers import FeatureDict
     cards = [max(3, int(c * args.vocab_scale)) for c in synthetic.CRITEO_CARDS]
-    model, fmap, spec = build_model(args, local_rank, cards)
+    parallelism = "single GPU"
+    if world > 1 and not args.replicas:
+        # row-sharded tables (row % world) + all-to-all exchange + dense all-reduce, eager launches
+        model, fmap, spec = build_model(args, local_rank, cards, shard="row")
+        parallelism = ("tables row-sharded over %d ranks (RCCL all-to-all ids/rows/row-grads), "
+                       "towers data-parallel (one flat all-reduce), global clip; eager launches"
+                       % world)
+    else:
+        model, fmap, spec = build_model(args, local_rank, cards)
+        if world > 1:
+            parallelism = "%d independent replicas (--replicas; no data-path collective)" % world
     model.train()
 
     # synthetic batches, resident in HBM (ids int64 / dense fp32 / label fp32 — what the
@@ -184,7 +204,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     step_i = 0
-    for _ in range(max(args.warmup, 5 if not args.no_graph else 0)):   # >= 5: 3 eager + capture
+    for _ in range(max(args.warmup, 5 if model._use_graph else 0)):   # >= 5: 3 eager + capture
         model.train_step(pool[step_i % n_pool])
         step_i += 1
     sync()
@@ -192,7 +212,7 @@ def main():
     # eager mode: the roofline kernels are timed with HIP events inside the timed region itself;
     # graph mode: events cannot sit inside a replayed graph, so the same kernels are timed in an
     # instrumented eager pass right after the timed region (same process, same buffers)
-    ops.KernelTimer.enabled = args.no_graph and not args.no_kernel_timing
+    ops.KernelTimer.enabled = (not model._use_graph) and not args.no_kernel_timing
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.train_step(pool[step_i % n_pool])
@@ -202,7 +222,7 @@ def main():
     ops.KernelTimer.enabled = False
     model.optimizer.check_errors()
     timing_mode = "hip events inside the timed region (eager launches)"
-    if not args.no_graph and not args.no_kernel_timing:
+    if model._use_graph and not args.no_kernel_timing:
         model._use_graph = False
         ops.KernelTimer.enabled = True
         for _ in range(min(args.steps, 20)):
@@ -234,10 +254,8 @@ def main():
                                    % (args.model, sum(cards) + len(cards)),
                        "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "id_distribution": args.dist, "sparse_update": args.sparse_update,
-                       "launch": "eager" if args.no_graph else "hipGraph replay",
-                       "parallelism": "single GPU" if world == 1 else
-                                      "%d independent replicas (row-sharded all-to-all path not "
-                                      "built yet; no data-path collective)" % world},
+                       "launch": "hipGraph replay" if model._use_graph else "eager",
+                       "parallelism": parallelism},
         }
         g = ktimes.get("k_gemm_f32")
         if g and g["total_ms"] > 0:

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libfxctr.so")
 FX_OK = 0
 FX_F32, FX_F64, FX_I32, FX_I64 = 0, 1, 2, 3
 FX_FLAG_BAD_ID = 1
+FX_FLAG_A2A_OVERFLOW = 2
 FX_MT_BLOCKS = 32
 FX_MT_MAX = 64
 FX_COLSUM_CHUNKS = 64
@@ -44,7 +45,11 @@ SIGNATURES = {
     "fx_emb_gather_fwd": (i32, [vp, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, vp, i32, vp, i64,
                                 i64, vp, vp]),
     "fx_dedup_workspace_bytes": (C.c_size_t, [i64]),
-    "fx_dedup": (i32, [vp, i64, i64, i32, vp, vp, vp, i64, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]),
+    "fx_dedup": (i32, [vp, i64, i64, i32, vp, vp, vp, i64, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
+                       i32, vp]),
+    "fx_shard_plan": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, vp, vp, vp, vp, vp]),
+    "fx_scatter_rows": (i32, [vp, vp, vp, i64, i32, vp, vp]),
+    "fx_sum_parts": (i32, [C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
     "fx_emb_grad_reduce_partials": (i64, [i64, i32]),
     "fx_emb_grad_reduce_scratch_ints": (i64, [i64]),
     "fx_emb_grad_reduce": (i32, [vp, i64, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp]),

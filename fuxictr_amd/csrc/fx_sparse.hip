@@ -17,10 +17,14 @@
 // ---------------------------------------------------------------------------------------------
 // de-duplication
 // ---------------------------------------------------------------------------------------------
+// key = global packed row g, or — with the table row-sharded over n_shards ranks — the
+// owner-major pair (g % n_shards) * rows_per_shard + g / n_shards, so that a sort groups the
+// lookups by owning rank and the key itself carries (owner, local row).
 __global__ __launch_bounds__(256) void k_build_keys(const int32_t* ids, int64_t ids_ld, int64_t n,
                                                     int C, const int64_t* col_row_base,
                                                     const int32_t* col_vocab,
                                                     const int32_t* col_pad, uint32_t sentinel,
+                                                    uint32_t n_shards, uint32_t rows_per_shard,
                                                     uint32_t* keys, uint32_t* pos) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -28,8 +32,10 @@ __global__ __launch_bounds__(256) void k_build_keys(const int32_t* ids, int64_t 
         const int c = (int)(i - b * C);
         const int32_t id = ids[b * ids_ld + c];
         uint32_t key = sentinel;
-        if (id >= 0 && id < col_vocab[c] && id != col_pad[c])
-            key = (uint32_t)(col_row_base[c] + id);
+        if (id >= 0 && id < col_vocab[c] && id != col_pad[c]) {
+            const uint32_t g = (uint32_t)(col_row_base[c] + id);
+            key = n_shards > 1 ? (g % n_shards) * rows_per_shard + g / n_shards : g;
+        }
         keys[i] = key;
         pos[i] = (uint32_t)i;
     }
@@ -47,11 +53,12 @@ struct HeadFlag {
 __global__ __launch_bounds__(256) void k_scatter_unique(const uint32_t* key, const uint32_t* scan,
                                                         int64_t n, uint32_t sentinel,
                                                         uint32_t* uniq_row, uint32_t* seg_start,
-                                                        int32_t* n_unique) {
+                                                        int32_t* n_unique, uint32_t* sorted_uid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t k = key[i];
         if (k == sentinel) {
+            if (sorted_uid) sorted_uid[i] = 0xFFFFFFFFu;
             if (i == 0) {  // no valid lookup at all
                 *n_unique = 0;
                 seg_start[0] = 0;
@@ -59,6 +66,7 @@ __global__ __launch_bounds__(256) void k_scatter_unique(const uint32_t* key, con
             continue;
         }
         const uint32_t u = scan[i];  // inclusive count of heads up to i  (>= 1 here)
+        if (sorted_uid) sorted_uid[i] = u - 1;
         if (i == 0 || key[i - 1] != k) {
             uniq_row[u - 1] = k;
             seg_start[u - 1] = (uint32_t)i;
@@ -114,10 +122,14 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
                         const int32_t* col_pad, int64_t total_rows, void* workspace,
                         size_t workspace_bytes, uint32_t* sorted_key, uint32_t* sorted_pos,
                         uint32_t* uniq_row, uint32_t* seg_start, int32_t* n_unique,
-                        fx_stream_t stream) {
+                        uint32_t* sorted_uid, int32_t n_shards, fx_stream_t stream) {
     FX_CHECK_ARG(B >= 0 && C >= 0, "fx_dedup: negative size");
     FX_CHECK_ARG(total_rows > 0 && total_rows < (int64_t)0xFFFFFFFFLL,
                  "fx_dedup: total_rows=%lld must be in (0, 2^32-1)", (long long)total_rows);
+    FX_CHECK_ARG(n_shards >= 1, "fx_dedup: n_shards must be >= 1");
+    const int64_t rows_per_shard = fx_ceil_div(total_rows, n_shards);
+    FX_CHECK_ARG(rows_per_shard * n_shards < (int64_t)0xFFFFFFFFLL,
+                 "fx_dedup: sharded key space exceeds 32 bits");
     FX_CHECK_ARG(n_unique && seg_start, "fx_dedup: null output");
     hipStream_t s = fx_hip_stream(stream);
     const int64_t n = B * (int64_t)C;
@@ -141,12 +153,13 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
     uint32_t* pos_in = reinterpret_cast<uint32_t*>(w + arr);
     uint32_t* scan = reinterpret_cast<uint32_t*>(w + 2 * arr);
     void* temp = w + 3 * arr;
-    const uint32_t sentinel = (uint32_t)total_rows;
+    const uint32_t sentinel = (uint32_t)(n_shards > 1 ? rows_per_shard * n_shards : total_rows);
 
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_build_keys, dim3((unsigned)blocks), dim3(256), 0, s, ids, ids_ld, n,
-                       (int)C, col_row_base, col_vocab, col_pad, sentinel, keys_in, pos_in);
+                       (int)C, col_row_base, col_vocab, col_pad, sentinel, (uint32_t)n_shards,
+                       (uint32_t)rows_per_shard, keys_in, pos_in);
     FX_CHECK_LAUNCH();
     size_t tb = tmp;
     FX_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, sorted_key, pos_in, sorted_pos,
@@ -157,7 +170,7 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
     FX_CHECK_HIP(rocprim::inclusive_scan(temp, tb, in, scan, (size_t)n,
                                          rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(k_scatter_unique, dim3((unsigned)blocks), dim3(256), 0, s, sorted_key, scan,
-                       n, sentinel, uniq_row, seg_start, n_unique);
+                       n, sentinel, uniq_row, seg_start, n_unique, sorted_uid);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
@@ -323,6 +336,135 @@ extern "C" int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int6
 }
 
 // ---------------------------------------------------------------------------------------------
+// row-sharded tables: routing of a rank's unique keys to their owners (fixed-capacity buckets so
+// the all-to-all needs no host-side counts and the step stays free of host round trips)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fx_lower_bound(const uint32_t* a, int n, uint32_t x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// e = o*cap + j over the padded send buffer: local row of the j-th unique key owned by rank o,
+// or `pad_row` past the bucket's end
+__global__ __launch_bounds__(256) void k_shard_send_idx(const uint32_t* uniq_key,
+                                                        const int32_t* n_unique, int n_shards,
+                                                        uint32_t rows_per_shard, int cap,
+                                                        int32_t pad_row, int32_t* send_idx,
+                                                        fx_scalars* scal) {
+    const int nu = *n_unique;
+    const int64_t total = (int64_t)n_shards * cap;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * 256) {
+        const int o = (int)(e / cap), j = (int)(e - (int64_t)o * cap);
+        const int s0 = fx_lower_bound(uniq_key, nu, (uint32_t)o * rows_per_shard);
+        const int s1 = fx_lower_bound(uniq_key, nu, (uint32_t)(o + 1) * rows_per_shard);
+        send_idx[e] = (j < s1 - s0) ? (int32_t)(uniq_key[s0 + j] - (uint32_t)o * rows_per_shard)
+                                    : pad_row;
+        if (j == 0 && s1 - s0 > cap) atomicOr(&scal->err_flag, FX_FLAG_A2A_OVERFLOW);
+    }
+}
+
+// slot of unique key u inside the padded [n_shards*cap] buffers (pad slot on overflow)
+__global__ __launch_bounds__(256) void k_shard_uniq_slot(const uint32_t* uniq_key,
+                                                         const int32_t* n_unique, int n_shards,
+                                                         uint32_t rows_per_shard, int cap,
+                                                         int64_t n_max, int32_t* uniq_slot) {
+    const int nu = *n_unique;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < n_max;
+         u += (int64_t)gridDim.x * 256) {
+        int32_t slot = n_shards * cap;   // pad slot
+        if (u < nu) {
+            const uint32_t k = uniq_key[u];
+            const int o = (int)(k / rows_per_shard);
+            const int j = (int)u - fx_lower_bound(uniq_key, nu, (uint32_t)o * rows_per_shard);
+            if (j < cap) slot = o * cap + j;
+        }
+        uniq_slot[u] = slot;
+    }
+}
+
+// per lookup (b,c): where its row sits in the received-rows buffer
+__global__ __launch_bounds__(256) void k_shard_lookup_slot(const uint32_t* sorted_pos,
+                                                           const uint32_t* sorted_uid,
+                                                           const int32_t* uniq_slot, int64_t n,
+                                                           int32_t pad_slot, int32_t* lookup_slot) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t uid = sorted_uid[i];
+        lookup_slot[sorted_pos[i]] = (uid == 0xFFFFFFFFu) ? pad_slot : uniq_slot[uid];
+    }
+}
+
+extern "C" int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique,
+                             const uint32_t* sorted_pos, const uint32_t* sorted_uid,
+                             int64_t n_lookups, int32_t n_shards, int64_t total_rows, int32_t cap,
+                             int32_t* send_idx, int32_t* uniq_slot, int32_t* lookup_slot,
+                             fx_scalars* scal, fx_stream_t stream) {
+    FX_CHECK_ARG(n_shards >= 1 && cap >= 1 && n_lookups >= 0, "fx_shard_plan: bad sizes");
+    FX_CHECK_ARG(uniq_key && n_unique && sorted_pos && sorted_uid && send_idx && uniq_slot &&
+                     lookup_slot && scal,
+                 "fx_shard_plan: null pointer");
+    const int64_t rps = fx_ceil_div(total_rows, n_shards);
+    hipStream_t s = fx_hip_stream(stream);
+    const int64_t total = (int64_t)n_shards * cap;
+    int64_t b1 = fx_ceil_div(total, 256);
+    if (b1 > 4096) b1 = 4096;
+    hipLaunchKernelGGL(k_shard_send_idx, dim3((unsigned)b1), dim3(256), 0, s, uniq_key, n_unique,
+                       (int)n_shards, (uint32_t)rps, (int)cap, (int32_t)rps, send_idx, scal);
+    if (n_lookups > 0) {
+        int64_t b2 = fx_ceil_div(n_lookups, 256);
+        if (b2 > 4096) b2 = 4096;
+        hipLaunchKernelGGL(k_shard_uniq_slot, dim3((unsigned)b2), dim3(256), 0, s, uniq_key,
+                           n_unique, (int)n_shards, (uint32_t)rps, (int)cap, n_lookups, uniq_slot);
+        hipLaunchKernelGGL(k_shard_lookup_slot, dim3((unsigned)b2), dim3(256), 0, s, sorted_pos,
+                           sorted_uid, uniq_slot, n_lookups, (int32_t)total, lookup_slot);
+    }
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// dst[row_map[u], :] = src[u, :] for u < *n_rows (row gradients into their all-to-all slots)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_scatter_rows(const float* src, const int32_t* row_map,
+                                                      const int32_t* n_rows, int D, int lanes_log2,
+                                                      float* dst) {
+    const int lanes = 1 << lanes_log2;
+    const int d0 = (threadIdx.x & (lanes - 1)) * VEC;
+    const int64_t rpb = 256 >> lanes_log2;
+    const int n = *n_rows;
+    for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> lanes_log2); u < n;
+         u += (int64_t)gridDim.x * rpb) {
+        if (d0 >= D) continue;
+        float v[VEC];
+        fx_load<VEC>(src + u * D + d0, v);
+        fx_store<VEC>(dst + (int64_t)row_map[u] * D + d0, v);
+    }
+}
+
+extern "C" int fx_scatter_rows(const float* src, const int32_t* row_map, const int32_t* n_rows,
+                               int64_t n_max, int32_t D, float* dst, fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256, "fx_scatter_rows: D=%d not in [1,256]", D);
+    if (n_max <= 0) return FX_OK;
+    FX_CHECK_ARG(src && row_map && n_rows && dst, "fx_scatter_rows: null pointer");
+    const FxRowGeom g = fx_row_geom(D);
+    int ll = 0;
+    while ((1 << ll) < g.lanes) ++ll;
+    int64_t blocks = fx_ceil_div(n_max, 256 / g.lanes);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    dim3 grid((unsigned)blocks);
+    hipStream_t s = fx_hip_stream(stream);
+    if (g.vec == 4) hipLaunchKernelGGL(k_scatter_rows<4>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst);
+    else if (g.vec == 2) hipLaunchKernelGGL(k_scatter_rows<2>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst);
+    else hipLaunchKernelGGL(k_scatter_rows<1>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // optimizer scalars
 // ---------------------------------------------------------------------------------------------
 __global__ void k_opt_begin_step(fx_scalars* sc) {
@@ -379,6 +521,42 @@ __global__ __launch_bounds__(1024) void k_clip_coef(ClipArgs a) {
         a.scal->total_norm = total;
         a.scal->clip_coef = coef;
     }
+}
+
+// out[0] = sum of the given partial arrays (fixed order): the rank-local table part of the
+// global gradient norm, all-reduced by the host before fx_clip_coef
+__global__ __launch_bounds__(1024) void k_sum_parts(ClipArgs a, float* out) {
+    __shared__ double red[1024];
+    double acc = 0.0;
+    for (int p = 0; p < a.n_parts; ++p) {
+        const float* x = a.part[p];
+        for (int64_t i = threadIdx.x; i < a.count[p]; i += 1024) acc += (double)x[i];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+extern "C" int fx_sum_parts(const float* const* parts_host, const int64_t* counts_host,
+                            int32_t n_parts, float* out, fx_stream_t stream) {
+    FX_CHECK_ARG(n_parts >= 0 && n_parts <= FX_CLIP_MAX_PARTS, "fx_sum_parts: n_parts=%d > %d",
+                 n_parts, FX_CLIP_MAX_PARTS);
+    FX_CHECK_ARG(out, "fx_sum_parts: null out");
+    ClipArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int p = 0; p < n_parts; ++p) {
+        FX_CHECK_ARG(parts_host[p] || counts_host[p] == 0, "fx_sum_parts: null part %d", p);
+        a.part[p] = parts_host[p];
+        a.count[p] = counts_host[p];
+    }
+    a.n_parts = n_parts;
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1024), 0, fx_hip_stream(stream), a, out);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
 }
 
 extern "C" int fx_clip_coef(const float* const* parts_host, const int64_t* counts_host,

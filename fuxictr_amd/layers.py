@@ -24,6 +24,13 @@ from torch import nn
 from . import _lib, ops
 
 _DEFAULT_DEVICE = None
+_DIST = None    # DistContext when tables are row-sharded over the ranks of one node
+
+
+def set_dist_context(ctx):
+    """Row-shard every table built from now on over ctx's ranks (set by BaseModel(shard='row'))."""
+    global _DIST
+    _DIST = ctx
 
 
 def set_default_device(device):
@@ -116,6 +123,11 @@ class _Plan(object):
     pass
 
 
+class _ShardExchange(object):
+    """Per-batch routing state of the row-sharded path (see _TableGroup.shard_exchange_ids)."""
+    pass
+
+
 class _PendingGrad(object):
     __slots__ = ("dd", "G", "sq")
 
@@ -145,6 +157,13 @@ class _TableGroup(object):
         self.num_grad = None
         self.pending = []
         self.dedup_ws = None
+        # row sharding (owner = row % world, local row = row // world)
+        self.dist = _DIST
+        self.n_shards = _DIST.world if _DIST is not None else 1
+        self.rank = _DIST.rank if _DIST is not None else 0
+        self.rows_per_shard = 0
+        self.a2a_factor = 1.5
+        self.owner_ws = None
 
     # -- construction -----------------------------------------------------------------------
     def add_table(self, feature, vocab, padding_idx, width):
@@ -163,7 +182,13 @@ class _TableGroup(object):
         if self.total_rows >= 2 ** 32 - 1:
             raise NotImplementedError("packed table with %d rows exceeds the 2^32-1 row limit "
                                       "of the sparse path" % self.total_rows)
-        if self.total_rows > 0:
+        if self.total_rows > 0 and self.n_shards > 1:
+            # local shard + one all-zero pad row (index rows_per_shard) that padded all-to-all
+            # slots point at; it is never part of a de-dup result, so it is never updated
+            self.rows_per_shard = -(-self.total_rows // self.n_shards)
+            self.table = torch.zeros(self.rows_per_shard + 1, self.D, dtype=torch.float32,
+                                     device=self.device)
+        elif self.total_rows > 0:
             self.table = torch.empty(self.total_rows, self.D, dtype=torch.float32,
                                      device=self.device)
         if self.numeric:
@@ -172,6 +197,22 @@ class _TableGroup(object):
 
     def table_of(self, feature):
         return self.tables[self.alias.get(feature, feature)]
+
+    def local_range(self, feature):
+        """Rows of this rank's shard that belong to `feature` (contiguous): [lo, hi)."""
+        base, V, _ = self.table_of(feature)
+        if self.n_shards == 1:
+            return base, base + V
+        n, r = self.n_shards, self.rank
+        lo = max(0, -(-(base - r) // n))
+        hi = (base + V - 1 - r) // n + 1 if base + V - 1 >= r else 0
+        return lo, max(lo, hi)
+
+    def local_row(self, g):
+        """Local index of global packed row g if this rank owns it, else None."""
+        if self.n_shards == 1:
+            return g
+        return g // self.n_shards if g % self.n_shards == self.rank else None
 
     def ensure_scal(self):
         if self.scal is None:
@@ -279,7 +320,8 @@ class _TableGroup(object):
                              self.total_rows, -1, self.scal)
         return dd
 
-    def backward(self, plan, ids, dense, dout, dout_ld, col_off, num_off, dd, inputs_cache):
+    def backward(self, plan, ids, dense, dout, dout_ld, col_off, num_off, dd, inputs_cache,
+                 sx=None):
         """Sparse + numeric gradients of one forward call (dout: grad of the output record)."""
         D = self.D
         if plan.Fd:
@@ -292,7 +334,9 @@ class _TableGroup(object):
                     self.num_grad = torch.zeros_like(self.num_w)
                 idx = torch.tensor(plan.num_rows, dtype=torch.int64, device=self.device)
                 self.num_grad.index_add_(0, idx, g)
-        if plan.C:
+        if plan.C and sx is not None:
+            self.shard_backward(plan, sx, dout, dout_ld, col_off)
+        elif plan.C:
             if dd is None:
                 dd = self.dedup(plan, ids, inputs_cache)
             G = torch.empty(dd.n_max, D, dtype=torch.float32, device=self.device)
@@ -303,24 +347,117 @@ class _TableGroup(object):
             ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G, sq, scratch)
             self.pending.append(_PendingGrad(dd, G, sq))
 
+    # -- row-sharded exchange --------------------------------------------------------------
+    def a2a_cap(self, n_lookups):
+        per_peer = -(-n_lookups // self.n_shards)
+        return int(-(-int(per_peer * self.a2a_factor) // 64) * 64 + 64)
+
+    def shard_exchange_ids(self, plan, ids, inputs):
+        """De-dup the local lookups owner-major, route the unique keys to their owners (one
+        all-to-all) and de-dup what this rank received as an owner.  Shared by table groups with
+        the same id columns / row bases (the D=16 and the D=1 LR tables)."""
+        cache = getattr(inputs, "cache", None)
+        ckey = ("shard", plan.sig, self.total_rows, self.n_shards)
+        if cache is not None and ckey in cache:
+            return cache[ckey]
+        dev, N = self.device, self.n_shards
+        n = ids.shape[0] * ids.shape[1]
+        if self.dedup_ws is None or self.dedup_ws[0] != n:
+            self.dedup_ws = (n, torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8,
+                                            device=dev))
+        dd = ops.dedup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad, self.total_rows,
+                       self.dedup_ws[1], n_shards=N, want_uid=True)
+        cap = self.a2a_cap(n)
+        sx = _ShardExchange()
+        sx.dd, sx.cap = dd, cap
+        sx.send_idx = torch.empty(N * cap, dtype=torch.int32, device=dev)
+        sx.uniq_slot = torch.empty(n, dtype=torch.int32, device=dev)
+        sx.lookup_slot = torch.empty(ids.shape[0], ids.shape[1], dtype=torch.int32, device=dev)
+        ops.shard_plan(dd, N, self.total_rows, cap, sx.send_idx, sx.uniq_slot, sx.lookup_slot,
+                       self.ensure_scal())
+        sx.recv_idx = self.dist.all_to_all(sx.send_idx).view(N * cap, 1)
+        if self.owner_ws is None or self.owner_ws[0] != N * cap:
+            self.owner_ws = (N * cap, torch.empty(ops.dedup_workspace_bytes(N * cap),
+                                                  dtype=torch.uint8, device=dev))
+        rps = self.rows_per_shard
+        sx.own_base = torch.zeros(1, dtype=torch.int64, device=dev)
+        sx.own_vocab = torch.tensor([rps + 1], dtype=torch.int32, device=dev)
+        sx.own_pad = torch.tensor([rps], dtype=torch.int32, device=dev)
+        sx.owner_dd = ops.dedup(sx.recv_idx, sx.own_base, sx.own_vocab, sx.own_pad, rps + 1,
+                                self.owner_ws[1])
+        # lookups gather from the received-rows buffer [N*cap + 1, D] (last row = zeros)
+        C = ids.shape[1]
+        sx.slot_base = torch.zeros(C, dtype=torch.int64, device=dev)
+        sx.slot_vocab = torch.full((C,), N * cap + 1, dtype=torch.int32, device=dev)
+        if cache is not None:
+            cache[ckey] = sx
+        return sx
+
+    def shard_fetch_rows(self, sx, track):
+        """Owner side: bring the requested rows up to date (exact mode), gather them, send them
+        back.  -> [N*cap + 1, D] rows in the slot order of sx.lookup_slot."""
+        N, cap, D = self.n_shards, sx.cap, self.D
+        if track and self.exact and self.opt_kind == "adam":
+            ops.adam_catchup(self.table, self.m, self.v, self.last_step, D, sx.owner_dd,
+                             self.rows_per_shard + 1, -1, self.scal)
+        rows_send = torch.empty(N * cap, D, dtype=torch.float32, device=self.device)
+        ops.emb_gather_fwd(self.table, D, sx.recv_idx, sx.own_base, sx.own_vocab, sx.own_base,
+                           None, None, None, rows_send, self.ensure_scal())
+        rows = torch.zeros(N * cap + 1, D, dtype=torch.float32, device=self.device)
+        rows[:N * cap] = self.dist.all_to_all(rows_send)
+        return rows
+
+    def shard_backward(self, plan, sx, dout, dout_ld, col_off):
+        """Requester: reduce to local unique keys, ship to owners; owner: reduce across ranks."""
+        N, cap, D = self.n_shards, sx.cap, self.D
+        dd = sx.dd
+        G_loc = torch.empty(dd.n_max, D, dtype=torch.float32, device=self.device)
+        sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max, D), dtype=torch.float32,
+                         device=self.device)
+        scratch = torch.empty(ops.emb_grad_reduce_scratch_ints(dd.n_max), dtype=torch.int32,
+                              device=self.device)
+        ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G_loc, sq, scratch)
+        gsend = torch.zeros(N * cap + 1, D, dtype=torch.float32, device=self.device)
+        ops.scatter_rows(G_loc, sx.uniq_slot, dd.n_unique, dd.n_max, D, gsend)
+        grecv = self.dist.all_to_all(gsend[:N * cap])
+        odd = sx.owner_dd
+        G_own = torch.empty(odd.n_max, D, dtype=torch.float32, device=self.device)
+        sq_own = torch.empty(ops.emb_grad_reduce_partials(odd.n_max, D), dtype=torch.float32,
+                             device=self.device)
+        scratch2 = torch.empty(ops.emb_grad_reduce_scratch_ints(odd.n_max), dtype=torch.int32,
+                               device=self.device)
+        ops.emb_grad_reduce(grecv, D, sx.own_base, 1, D, odd, G_own, sq_own, scratch2)
+        self.pending.append(_PendingGrad(odd, G_own, sq_own))
+
     def flush(self):
         """exact mode: replay pending zero-gradient Adam steps for EVERY row (before eval/save)."""
         if self.exact and self.opt_kind == "adam" and self.table is not None:
+            rows = self.rows_per_shard + 1 if self.n_shards > 1 else self.total_rows
             ops.adam_catchup(self.table, self.m, self.v, self.last_step, self.D, None,
-                             self.total_rows, 0, self.scal)
+                             rows, 0, self.scal)
 
 
 class _EmbGatherFn(torch.autograd.Function):
     """One launch: all id columns + numeric columns of a group -> [B, n_slots * D]."""
 
     @staticmethod
-    def forward(ctx, anchor, group, plan, ids, dense, dd, inputs):
+    def forward(ctx, anchor, group, plan, ids, dense, dd, inputs, track):
         B = (ids if ids is not None else dense).shape[0]
         out = torch.empty(B, plan.n_slots * group.D, dtype=torch.float32, device=group.device)
-        ops.emb_gather_fwd(group.table, group.D, ids, plan.col_row_base, plan.col_vocab,
-                           plan.col_out_off, dense, group.select_num_w(plan), plan.num_out_off,
-                           out, group.ensure_scal())
-        ctx.group, ctx.plan, ctx.ids, ctx.dense, ctx.dd = group, plan, ids, dense, dd
+        sx = None
+        if group.n_shards > 1 and plan.C:
+            # row-sharded: ids -> owners, rows <- owners, then the same gather kernel reads the
+            # received rows through the per-lookup slot matrix
+            sx = group.shard_exchange_ids(plan, ids, inputs)
+            rows = group.shard_fetch_rows(sx, track)
+            ops.emb_gather_fwd(rows, group.D, sx.lookup_slot, sx.slot_base, sx.slot_vocab,
+                               plan.col_out_off, dense, group.select_num_w(plan),
+                               plan.num_out_off, out, group.ensure_scal())
+        else:
+            ops.emb_gather_fwd(group.table, group.D, ids, plan.col_row_base, plan.col_vocab,
+                               plan.col_out_off, dense, group.select_num_w(plan),
+                               plan.num_out_off, out, group.ensure_scal())
+        ctx.group, ctx.plan, ctx.ids, ctx.dense, ctx.dd, ctx.sx = group, plan, ids, dense, dd, sx
         ctx.inputs = inputs if hasattr(inputs, "cache") else None
         return out
 
@@ -328,8 +465,9 @@ class _EmbGatherFn(torch.autograd.Function):
     def backward(ctx, dout):
         dout = dout.contiguous()
         ctx.group.backward(ctx.plan, ctx.ids, ctx.dense, dout, dout.stride(0),
-                           ctx.plan.col_out_off, ctx.plan.num_out_off, ctx.dd, ctx.inputs)
-        return None, None, None, None, None, None, None
+                           ctx.plan.col_out_off, ctx.plan.num_out_off, ctx.dd, ctx.inputs,
+                           sx=ctx.sx)
+        return None, None, None, None, None, None, None, None
 
 
 class FeatureEmbeddingDict(nn.Module):
@@ -408,7 +546,8 @@ class FeatureEmbeddingDict(nn.Module):
         """(Re)point the per-feature Parameters at views of the packed storage."""
         for grp in self._groups.values():
             for feature, (base, V, pidx) in grp.tables.items():
-                view = grp.table[base:base + V]
+                lo, hi = grp.local_range(feature)
+                view = grp.table[lo:hi]
                 if feature in self.embedding_layers:
                     self.embedding_layers[feature].weight.data = view
                 else:
@@ -454,8 +593,10 @@ class FeatureEmbeddingDict(nn.Module):
                 if grp.table is not None:
                     grp.table.normal_(0.0, 1.0)
                     for _, (base, V, pidx) in grp.tables.items():
-                        if pidx is not None:
-                            grp.table[base + pidx].zero_()
+                        if pidx is not None and grp.local_row(base + pidx) is not None:
+                            grp.table[grp.local_row(base + pidx)].zero_()
+                    if grp.n_shards > 1:
+                        grp.table[grp.rows_per_shard].zero_()   # the all-to-all pad row
                 if grp.num_w is not None:
                     grp.num_w.uniform_(-1.0, 1.0)
 
@@ -475,7 +616,16 @@ class FeatureEmbeddingDict(nn.Module):
                 if "share_embedding" in self._feature_map.features[k]:
                     continue
                 if isinstance(v, _TableView):
-                    if v.padding_idx is not None:
+                    grp = self._groups[self._feat_group[k]]
+                    if grp.n_shards > 1:
+                        # a shard holds every n-th row: initialise the local rows, then restore
+                        # the zero padding row if this rank owns it
+                        if v.weight.numel():
+                            self.embedding_initializer(v.weight)
+                        base, _, pidx = grp.table_of(k)
+                        if pidx is not None and grp.local_row(base + pidx) is not None:
+                            grp.table[grp.local_row(base + pidx)].zero_()
+                    elif v.padding_idx is not None:
                         self.embedding_initializer(v.weight[1:, :])
                     else:
                         self.embedding_initializer(v.weight)
@@ -515,9 +665,9 @@ class FeatureEmbeddingDict(nn.Module):
             plan = grp.plan_for(feats)
             ids, dense = grp.pack_inputs(plan, inputs)
             track = torch.is_grad_enabled() and self.training
-            dd = grp.prepare_train(plan, ids, inputs) if track else None
+            dd = grp.prepare_train(plan, ids, inputs) if (track and grp.n_shards == 1) else None
             anchor = self._anchor(grp)
-            out = _EmbGatherFn.apply(anchor, grp, plan, ids, dense, dd, inputs)
+            out = _EmbGatherFn.apply(anchor, grp, plan, ids, dense, dd, inputs, track)
             rec = out.view(out.shape[0], plan.n_slots, D)
             for f in feats:
                 s, w = plan.slot[f]
@@ -589,6 +739,42 @@ class FeatureEmbeddingDict(nn.Module):
             return rec
         return rec[:, lo:nxt, :]
 
+    # -- sharded checkpoints ------------------------------------------------------------------
+    def load_full_tables(self, full_state, prefix=""):
+        """Copy this rank's rows out of a FULL (unsharded, reference-layout) state dict."""
+        with torch.no_grad():
+            for grp in self._groups.values():
+                for feature, (base, V, _) in grp.tables.items():
+                    w = full_state[prefix + "embedding_layers." + feature + ".weight"]
+                    lo, hi = grp.local_range(feature)
+                    if hi > lo:
+                        first = lo * grp.n_shards + grp.rank - base      # row inside the feature
+                        grp.table[lo:hi] = w[first::grp.n_shards].to(grp.device)
+                for j, feature in enumerate(grp.numeric):
+                    w = full_state[prefix + "embedding_layers." + feature + ".weight"]
+                    grp.num_w[j] = w.reshape(-1).to(grp.device)
+
+    def gather_full_tables(self, prefix=""):
+        """All ranks -> a FULL state dict (reference layout) on every rank (tests, small tables)."""
+        out = {}
+        for grp in self._groups.values():
+            for feature, (base, V, _) in grp.tables.items():
+                full = torch.zeros(V, grp.D, dtype=torch.float32, device=grp.device)
+                lo, hi = grp.local_range(feature)
+                if hi > lo:
+                    first = lo * grp.n_shards + grp.rank - base
+                    full[first::grp.n_shards] = grp.table[lo:hi]
+                if grp.dist is not None:
+                    grp.dist.all_reduce_sum(full)
+                out[prefix + "embedding_layers." + feature + ".weight"] = full
+                for f2, owner in grp.alias.items():
+                    if owner == feature:
+                        out[prefix + "embedding_layers." + f2 + ".weight"] = full
+            for j, feature in enumerate(grp.numeric):
+                out[prefix + "embedding_layers." + feature + ".weight"] = \
+                    grp.num_w[j].view(grp.D, 1).clone()
+        return out
+
     # -- optimizer hooks --------------------------------------------------------------------
     def table_groups(self):
         return list(self._groups.values())
@@ -646,13 +832,20 @@ class _LRFn(torch.autograd.Function):
     """out[b] = sum of the D=1 rows + numeric terms + bias, one launch (logistic_regression.py:55-58)."""
 
     @staticmethod
-    def forward(ctx, anchor, bias, group, plan, ids, dense, dd, inputs):
+    def forward(ctx, anchor, bias, group, plan, ids, dense, dd, inputs, track):
         B = (ids if ids is not None else dense).shape[0]
         out = torch.empty(B, 1, dtype=torch.float32, device=group.device)
         num_w1 = group.select_num_w(plan)
-        ops.lr_fwd(group.table, ids, plan.col_row_base, plan.col_vocab, dense, num_w1, bias, out,
-                   group.ensure_scal())
-        ctx.group, ctx.plan, ctx.ids, ctx.dense, ctx.dd = group, plan, ids, dense, dd
+        sx = None
+        if group.n_shards > 1 and plan.C:
+            sx = group.shard_exchange_ids(plan, ids, inputs)
+            rows = group.shard_fetch_rows(sx, track)
+            ops.lr_fwd(rows, sx.lookup_slot, sx.slot_base, sx.slot_vocab, dense, num_w1, bias,
+                       out, group.ensure_scal())
+        else:
+            ops.lr_fwd(group.table, ids, plan.col_row_base, plan.col_vocab, dense, num_w1, bias,
+                       out, group.ensure_scal())
+        ctx.group, ctx.plan, ctx.ids, ctx.dense, ctx.dd, ctx.sx = group, plan, ids, dense, dd, sx
         ctx.inputs = inputs if hasattr(inputs, "cache") else None
         ctx.has_bias = bias is not None
         return out
@@ -662,9 +855,9 @@ class _LRFn(torch.autograd.Function):
         dout = dout.contiguous()
         # every column of a sample receives the same upstream value: ld = 1, offsets = 0
         ctx.group.backward(ctx.plan, ctx.ids, ctx.dense, dout, 1, ctx.plan.col_zero_off,
-                           ctx.plan.num_zero_off, ctx.dd, ctx.inputs)
+                           ctx.plan.num_zero_off, ctx.dd, ctx.inputs, sx=ctx.sx)
         dbias = dout.sum().reshape(1) if ctx.has_bias else None
-        return None, dbias, None, None, None, None, None, None
+        return None, dbias, None, None, None, None, None, None, None
 
 
 class LogisticRegression(nn.Module):
@@ -694,8 +887,8 @@ class LogisticRegression(nn.Module):
         plan = grp.plan_for(feats)
         ids, dense = grp.pack_inputs(plan, X)
         track = torch.is_grad_enabled() and self.training
-        dd = grp.prepare_train(plan, ids, X) if track else None
-        return _LRFn.apply(layer._anchor(grp), self.bias, grp, plan, ids, dense, dd, X)
+        dd = grp.prepare_train(plan, ids, X) if (track and grp.n_shards == 1) else None
+        return _LRFn.apply(layer._anchor(grp), self.bias, grp, plan, ids, dense, dd, X, track)
 
 
 class _FMFn(torch.autograd.Function):

@@ -129,9 +129,11 @@ def dedup_workspace_bytes(n):
 
 class DedupResult(object):
     """Unique rows of a batch's lookups (device resident; count stays on the device)."""
-    __slots__ = ("sorted_key", "sorted_pos", "uniq_row", "seg_start", "n_unique", "n_max", "C")
+    __slots__ = ("sorted_key", "sorted_pos", "uniq_row", "seg_start", "n_unique", "n_max", "C",
+                 "sorted_uid")
 
-    def __init__(self, n, C_, device):
+    def __init__(self, n, C_, device, want_uid=False):
+        self.sorted_uid = torch.empty(n, dtype=torch.int32, device=device) if want_uid else None
         self.sorted_key = torch.empty(n, dtype=torch.int32, device=device)
         self.sorted_pos = torch.empty(n, dtype=torch.int32, device=device)
         self.uniq_row = torch.empty(n, dtype=torch.int32, device=device)
@@ -141,17 +143,36 @@ class DedupResult(object):
         self.C = C_
 
 
-def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None):
+def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None,
+          n_shards=1, want_uid=False):
     lib = _lib.load()
     B, C_ = ids.shape
     if result is None:
-        result = DedupResult(B * C_, C_, ids.device)
+        result = DedupResult(B * C_, C_, ids.device, want_uid=want_uid)
     check(lib.fx_dedup(ptr(ids), ids.stride(0), B, C_, ptr(col_row_base), ptr(col_vocab),
                        ptr(col_pad), total_rows, ptr(workspace), workspace.numel(),
                        ptr(result.sorted_key), ptr(result.sorted_pos), ptr(result.uniq_row),
-                       ptr(result.seg_start), ptr(result.n_unique), stream_ptr(ids.device)),
+                       ptr(result.seg_start), ptr(result.n_unique), ptr(result.sorted_uid),
+                       n_shards, stream_ptr(ids.device)),
           "fx_dedup")
     return result
+
+
+def shard_plan(dd, n_shards, total_rows, cap, send_idx, uniq_slot, lookup_slot, scal):
+    check(_lib.load().fx_shard_plan(ptr(dd.uniq_row), ptr(dd.n_unique), ptr(dd.sorted_pos),
+                                    ptr(dd.sorted_uid), dd.n_max, n_shards, total_rows, cap,
+                                    ptr(send_idx), ptr(uniq_slot), ptr(lookup_slot), ptr(scal),
+                                    stream_ptr(send_idx.device)), "fx_shard_plan")
+
+
+def scatter_rows(src, row_map, n_rows, n_max, D, dst):
+    check(_lib.load().fx_scatter_rows(ptr(src), ptr(row_map), ptr(n_rows), n_max, D, ptr(dst),
+                                      stream_ptr(dst.device)), "fx_scatter_rows")
+
+
+def sum_parts(parts, out):
+    check(_lib.load().fx_sum_parts(_lib.ptr_array(parts), _lib.i64_array([p.numel() for p in parts]),
+                                   len(parts), ptr(out), stream_ptr(out.device)), "fx_sum_parts")
 
 
 def emb_grad_reduce_partials(n_max, D):

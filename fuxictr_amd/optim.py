@@ -21,6 +21,7 @@ from .layers import FeatureEmbeddingDict
 
 class _NativeOptimizer(torch.optim.Optimizer):
     kind = None
+    _require_cuda = True     # tests of the host logic lift this together with emulated kernels
 
     def __init__(self, params, lr, model=None, sparse_update="exact", betas=(0.9, 0.999),
                  eps=1e-8):
@@ -44,14 +45,25 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 self.device = p.device
                 break
         if self.device is None:
-            raise _lib.FxError("native optimizer needs parameters on the GPU (no CPU fallback)")
+            if self._require_cuda:
+                raise _lib.FxError("native optimizer needs parameters on the GPU (no CPU fallback)")
+            self.device = params[0].device
         self.scal = ops.new_scalars(self.device, lr=lr, beta1=betas[0], beta2=betas[1], eps=eps)
         self._lr_dev = float(lr)
         self._max_norm = 0.0
         self._state_dense = {}   # id(tensor) -> (m, v)
         self._sq_dense = None
+        self.dist = None
         for grp in self._groups:
             self._attach(grp)
+            if grp.dist is not None:
+                self.dist = grp.dist
+        if self.dist is not None:
+            # data-parallel dense side: every rank starts from rank 0's tower / numeric weights
+            with torch.no_grad():
+                for p in params:
+                    if id(p) not in self._table_param_ids:
+                        self.dist.broadcast(p.data, 0)
 
     # -- setup --------------------------------------------------------------------------------
     def _attach(self, grp):
@@ -61,7 +73,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
         if self.kind == "adam" and grp.table is not None:
             grp.m = torch.zeros_like(grp.table)
             grp.v = torch.zeros_like(grp.table)
-            grp.last_step = torch.zeros(grp.total_rows, dtype=torch.int32, device=grp.device)
+            grp.last_step = torch.zeros(grp.table.shape[0], dtype=torch.int32, device=grp.device)
 
     def set_max_norm(self, max_norm):
         max_norm = float(max_norm) if max_norm else 0.0
@@ -92,6 +104,9 @@ class _NativeOptimizer(torch.optim.Optimizer):
         flag = int(self.scal.view(torch.int32)[_lib.SC_ERR].item())
         if flag & _lib.FX_FLAG_BAD_ID:
             raise IndexError("embedding id out of range (native gather flagged FX_FLAG_BAD_ID)")
+        if flag & _lib.FX_FLAG_A2A_OVERFLOW:
+            raise RuntimeError("row-sharded exchange overflowed its per-peer capacity: raise "
+                               "`a2a_capacity_factor` (>= world size can never overflow)")
 
     # -- step ---------------------------------------------------------------------------------
     def _dense_lists(self):
@@ -131,6 +146,15 @@ class _NativeOptimizer(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError("closure is not supported by the native optimizer")
         ps, gs = self._dense_lists()
+        if self.dist is not None and ps:
+            # one flat all-reduce for every dense gradient (losses were pre-scaled by 1/world)
+            flat = torch.cat([g.reshape(-1) for g in gs])
+            self.dist.all_reduce_sum(flat)
+            out, off = [], 0
+            for g in gs:
+                out.append(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+            gs = out
         parts = []
         if ps:
             need = len(ps) * _lib.FX_MT_BLOCKS
@@ -145,6 +169,15 @@ class _NativeOptimizer(torch.optim.Optimizer):
                     "sparse gradients per step is not implemented" % len(grp.pending))
             for rec in grp.pending:
                 parts.append(rec.sq)
+        if self.dist is not None:
+            # table rows are disjoint across ranks: global norm^2 = dense part (identical on every
+            # rank after the all-reduce) + sum over ranks of the local table parts
+            tparts = parts[1:] if ps else parts
+            tsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+            if tparts:
+                ops.sum_parts(tparts, tsq)
+            self.dist.all_reduce_sum(tsq)
+            parts = (parts[:1] if ps else []) + [tsq]
         ops.clip_coef(parts, self.scal)
         if ps:
             self._dense_update(ps, gs)

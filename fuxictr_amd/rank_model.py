@@ -224,6 +224,16 @@ class BaseModel(nn.Module):
         self.device = get_device(gpu)
         torch.cuda.set_device(self.device)
         layers.set_default_device(self.device)  # native layers allocate their tables here
+        shard = kwargs.get("shard", None)
+        self._dist = None
+        if shard in ("row", True):
+            from .dist import DistContext
+            self._dist = DistContext()
+            if self._dist.world == 1:
+                self._dist = None
+        elif shard not in (None, False, "none"):
+            raise ValueError("shard={} is not supported.".format(shard))
+        layers.set_dist_context(self._dist)      # tables built below are row-sharded over ranks
         self._monitor = Monitor(kv=monitor)
         self._monitor_mode = monitor_mode
         self._early_stop_patience = early_stop_patience
@@ -234,7 +244,7 @@ class BaseModel(nn.Module):
         self._reduce_lr_on_plateau = reduce_lr_on_plateau
         self._verbose = kwargs["verbose"]
         self._sparse_update = kwargs.get("sparse_update", "exact")
-        self._use_graph = bool(kwargs.get("hip_graph", False))
+        self._use_graph = bool(kwargs.get("hip_graph", False)) and self._dist is None
         self._graph_state = None
         self._graph_warm = 0
         self._max_gradient_norm = 10.
@@ -395,9 +405,34 @@ class BaseModel(nn.Module):
         return_dict = self.forward(batch_data)
         y_true = self.get_labels(batch_data)
         loss = self.compute_loss(return_dict, y_true)
-        loss.backward()
+        if self._dist is not None:
+            # global-batch mean = mean of the ranks' local means: scale, then SUM-reduce grads
+            (loss / self._dist.world).backward()
+        else:
+            loss.backward()
         opt.step()  # global-norm clip (rank_model.py:321) is fused into the update kernels
         return loss
+
+    def load_full_state_dict(self, full_state):
+        """Load a FULL (reference-layout) state dict into a row-sharded model: every rank keeps
+        its rows of each table; dense parameters are copied as they are."""
+        own = self.state_dict()
+        dense = {k: v for k, v in full_state.items() if k in own and own[k].shape == v.shape
+                 and ".embedding_layers." not in k}
+        self.load_state_dict(dense, strict=False)
+        for name, mod in self.named_modules():
+            if isinstance(mod, FeatureEmbeddingDict):
+                mod.load_full_tables(full_state, prefix=name + ".")
+
+    def full_state_dict(self):
+        """FULL (reference-layout) state dict of a row-sharded model (tables are all-gathered)."""
+        if hasattr(self.optimizer, "flush"):
+            self.optimizer.flush()
+        out = {k: v for k, v in self.state_dict().items() if ".embedding_layers." not in k}
+        for name, mod in self.named_modules():
+            if isinstance(mod, FeatureEmbeddingDict):
+                out.update(mod.gather_full_tables(prefix=name + "."))
+        return out
 
     def train_step(self, batch_data):
         """rank_model.py:307-323 on the native path.  With `hip_graph: true` the whole step

@@ -35,7 +35,7 @@ enum { FX_OK = 0, FX_ERR_INVALID = 1, FX_ERR_HIP = 2, FX_ERR_UNSUPPORTED = 3 };
 enum { FX_F32 = 0, FX_F64 = 1, FX_I32 = 2, FX_I64 = 3 };
 
 /* bits of fx_scalars.err_flag (sticky, set by kernels, read by the host at its own sync points) */
-enum { FX_FLAG_BAD_ID = 1 };
+enum { FX_FLAG_BAD_ID = 1, FX_FLAG_A2A_OVERFLOW = 2 };
 
 /* Device-resident per-step scalars (64 bytes; the shim allocates it as 16 x 4-byte words).
  * Mirrors the python-side scalars of torch.optim.Adam._single_tensor_adam and
@@ -96,6 +96,8 @@ int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* ids, int64_t
  *     sorted_key/sorted_pos = stable radix sort of (key, pos=b*C+c) by key
  *     uniq_row[u], seg_start[u]..seg_start[u+1] = the u-th distinct key and its run in sorted_*
  *     *n_unique = number of distinct non-sentinel keys
+ *     sorted_uid[i] (optional, may be NULL) = u of sorted lookup i, 0xFFFFFFFF for sentinels
+ * n_shards = 1 for an unsharded table (see fx_shard_plan for n_shards > 1).
  * This replaces the zero-filled dense [V,D] gradient + index_add of aten::embedding_dense_backward
  * (triggered at rank_model.py:320) — no dense gradient ever exists.  Deterministic.
  * Packed tables are limited to < 2^32 - 1 rows.
@@ -105,7 +107,32 @@ int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
              const int64_t* col_row_base, const int32_t* col_vocab, const int32_t* col_pad,
              int64_t total_rows, void* workspace, size_t workspace_bytes, uint32_t* sorted_key,
              uint32_t* sorted_pos, uint32_t* uniq_row, uint32_t* seg_start, int32_t* n_unique,
-             fx_stream_t stream);
+             uint32_t* sorted_uid, int32_t n_shards, fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-sharded tables (new functionality: the reference has no multi-GPU path).
+ * With the packed table sharded row-wise over n_shards ranks (owner = row % n_shards, local row =
+ * row / n_shards, rows_per_shard = ceil(total_rows / n_shards)) fx_dedup(n_shards > 1) keys the
+ * lookups owner-major, so the unique keys of a batch are already grouped by owning rank.
+ * fx_shard_plan turns them into fixed-capacity all-to-all buffers (no host-side counts):
+ *     send_idx[o*cap + j]   local row (at owner o) of this rank's j-th unique key owned by o,
+ *                           rows_per_shard (the owner's all-zero pad row) past the bucket end
+ *     uniq_slot[u]          slot o*cap + j of unique key u in the padded buffers
+ *     lookup_slot[b*C + c]  slot of lookup (b,c): the id matrix to gather from the received rows
+ *                           (n_shards*cap = pad slot for padding_idx lookups)
+ * A bucket larger than cap sets FX_FLAG_A2A_OVERFLOW.  sorted_uid is fx_dedup's optional output
+ * (unique index of every sorted lookup).  fx_scatter_rows moves reduced gradient rows into their
+ * all-to-all slots; fx_sum_parts reduces partial squared norms to one device scalar (the
+ * rank-local table term of the global clip norm, summed across ranks by the host's all-reduce).
+ * ------------------------------------------------------------------------------------------ */
+int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique, const uint32_t* sorted_pos,
+                  const uint32_t* sorted_uid, int64_t n_lookups, int32_t n_shards,
+                  int64_t total_rows, int32_t cap, int32_t* send_idx, int32_t* uniq_slot,
+                  int32_t* lookup_slot, fx_scalars* scal, fx_stream_t stream);
+int fx_scatter_rows(const float* src, const int32_t* row_map, const int32_t* n_rows, int64_t n_max,
+                    int32_t D, float* dst, fx_stream_t stream);
+int fx_sum_parts(const float* const* parts_host, const int64_t* counts_host, int32_t n_parts,
+                 float* out, fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Embedding backward, sparse side: G[u,:] = sum over the run of unique row u of

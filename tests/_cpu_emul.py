@@ -54,11 +54,17 @@ class DedupResult(object):
     pass
 
 
-def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None):
+def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None,
+          n_shards=1, want_uid=False):
     B, C = ids.shape
     keys = ids.long() + col_row_base.view(1, -1)
     valid = (ids != col_pad.view(1, -1)) & (ids >= 0) & (ids < col_vocab.view(1, -1))
-    keys = torch.where(valid, keys, torch.full_like(keys, total_rows)).reshape(-1)
+    sentinel = total_rows
+    if n_shards > 1:
+        rps = -(-total_rows // n_shards)
+        keys = (keys % n_shards) * rps + keys // n_shards
+        sentinel = rps * n_shards
+    keys = torch.where(valid, keys, torch.full_like(keys, sentinel)).reshape(-1)
     skey, spos = torch.sort(keys, stable=True)
     nvalid = int(valid.sum())
     uniq, counts = torch.unique_consecutive(skey[:nvalid], return_counts=True)
@@ -71,7 +77,42 @@ def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=N
     dd.seg_start[1:len(uniq) + 1] = torch.cumsum(counts, 0).int()
     dd.n_unique = torch.tensor([len(uniq)], dtype=torch.int32)
     dd.n_max, dd.C = n, C
+    dd.sorted_uid = None
+    if want_uid:
+        uid = torch.full((n,), -1, dtype=torch.int32)
+        if nvalid:
+            uid[:nvalid] = (torch.repeat_interleave(torch.arange(len(uniq)), counts)).int()
+        dd.sorted_uid = uid
     return dd
+
+
+def shard_plan(dd, n_shards, total_rows, cap, send_idx, uniq_slot, lookup_slot, scal):
+    rps = -(-total_rows // n_shards)
+    nu = int(dd.n_unique)
+    keys = dd.uniq_row[:nu].long()
+    send_idx.fill_(rps)
+    uniq_slot.fill_(n_shards * cap)
+    for o in range(n_shards):
+        sel = ((keys >= o * rps) & (keys < (o + 1) * rps)).nonzero().reshape(-1)
+        if len(sel) > cap:
+            scal.view(torch.int32)[SC.SC_ERR] |= _lib.FX_FLAG_A2A_OVERFLOW
+            sel = sel[:cap]
+        send_idx[o * cap:o * cap + len(sel)] = (keys[sel] - o * rps).int()
+        uniq_slot[sel] = (o * cap + torch.arange(len(sel))).int()
+    flat = lookup_slot.view(-1)
+    uid = dd.sorted_uid.long()
+    slots = torch.where(uid >= 0, uniq_slot[uid.clamp(min=0)].long(),
+                        torch.full_like(uid, n_shards * cap))
+    flat[dd.sorted_pos.long()] = slots.int()
+
+
+def scatter_rows(src, row_map, n_rows, n_max, D, dst):
+    n = int(n_rows)
+    dst[row_map[:n].long()] = src[:n]
+
+
+def sum_parts(parts, out):
+    out[0] = sum(float(p.double().sum()) for p in parts)
 
 
 def emb_grad_reduce_partials(n_max, D):
@@ -255,11 +296,37 @@ class KernelTimer(object):
     enabled = False
 
 
+NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes", "dedup",
+         "emb_grad_reduce_partials", "emb_grad_reduce_scratch_ints", "emb_grad_reduce",
+         "emb_numeric_grad", "opt_begin_step", "clip_coef", "sparse_adam", "adam_catchup",
+         "sparse_sgd", "mt_sqnorm", "mt_adam", "mt_sgd", "fm_fwd", "fm_bwd", "lr_fwd", "gemm",
+         "colsum", "mask_mul", "cross_bwd_prep", "sigmoid_bce", "shard_plan", "scatter_rows",
+         "sum_parts"]
+
+
+def install_plain():
+    """Same as install() without pytest's monkeypatch (for spawned worker processes)."""
+    import fuxictr_amd.ops as real
+    import fuxictr_amd.optim as optim
+    import fuxictr_amd.rank_model as rm
+    me = globals()
+    for name in NAMES:
+        setattr(real, name, me[name])
+    rm.get_device = lambda gpu=-1: torch.device("cpu")
+    torch.cuda.set_device = lambda d: None
+    optim._NativeOptimizer._require_cuda = False
+
+
 def install(monkeypatch):
     """Route fuxictr_amd.ops.* to this module and let BaseModel live on the CPU."""
     import fuxictr_amd.ops as real
     import fuxictr_amd.rank_model as rm
     me = globals()
+    for name in NAMES:
+        monkeypatch.setattr(real, name, me[name])
+    monkeypatch.setattr(rm, "get_device", lambda gpu=-1: torch.device("cpu"))
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    return
     for name in ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes", "dedup",
                  "emb_grad_reduce_partials", "emb_grad_reduce_scratch_ints", "emb_grad_reduce",
                  "emb_numeric_grad",
