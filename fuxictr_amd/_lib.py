@@ -13,7 +13,7 @@ FX_OK = 0
 FX_F32, FX_F64, FX_I32, FX_I64 = 0, 1, 2, 3
 FX_FLAG_BAD_ID = 1
 FX_FLAG_A2A_OVERFLOW = 2
-FX_MT_BLOCKS = 32
+FX_MT_BLOCKS = 96
 FX_MT_MAX = 64
 FX_COLSUM_CHUNKS = 64
 FX_PACK_MAX_COLS = 64
@@ -33,7 +33,7 @@ class GemmEpilogue(C.Structure):
     """struct fx_gemm_epilogue"""
     _fields_ = [("bias", vp), ("zout", vp), ("ldz", i64), ("act", i32),
                 ("mul", vp), ("ldmul", i64), ("mask", vp), ("ldmask", i64),
-                ("add", vp), ("ldadd", i64)]
+                ("add", vp), ("ldadd", i64), ("rowsum", vp)]
 
 
 # name -> (restype, argtypes).  This table is also what tests/test_abi.py checks against the header.

@@ -147,6 +147,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
+    // optional fused row sums of op(A) (bias gradient when op(A) = dZ^T): blocks of the first
+    // tile column add up their A tiles straight from LDS
+    const bool do_rowsum = (a.epi.rowsum != nullptr) && (n0 == 0);
+    float rsum = 0.f;
+
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -173,6 +178,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
         }
         const float* as = As[cur] + half * LDA + wm * (BM / 2) + l31;
         const float* bs = Bs[cur] + half * LDB + wn * (BN / 2) + l31;
+        if (do_rowsum && threadIdx.x < BM) {
+            const float* col = As[cur] + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < FX_BK; ++k) rsum += col[k * LDA];
+        }
         // Software-pipelined fragment reads, two k-pairs deep: the LDS reads of k-pair s+2 are
         // issued right after the MFMAs of k-pair s (same register set), so an LDS latency is
         // always covered by MFMAs.  Pinned with sched_group_barrier — left alone, hipcc sinks
@@ -211,6 +221,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
         __syncthreads();
     }
 
+    if (do_rowsum && threadIdx.x < BM && m0 + threadIdx.x < a.M) {
+        if (a.split_k > 1) a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + m0 + threadIdx.x] = rsum;
+        else a.epi.rowsum[m0 + threadIdx.x] = rsum;
+    }
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -240,6 +254,15 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a) {
         for (int z = 0; z < a.split_k; ++z) s += a.ws[(int64_t)z * total + i];
         const int64_t m = i / a.N, n = i - m * a.N;
         a.C[m * a.ldc + n] = fx_epilogue(a.epi, s, m, n);
+    }
+    if (a.epi.rowsum) {
+        const float* rs = a.ws + (int64_t)a.split_k * total;
+        for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < a.M;
+             m += (int64_t)gridDim.x * 256) {
+            float s = 0.f;
+            for (int z = 0; z < a.split_k; ++z) s += rs[(int64_t)z * a.M + m];
+            a.epi.rowsum[m] = s;
+        }
     }
 }
 
@@ -295,6 +318,11 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs a) {
     const int z = blockIdx.y;
     const int64_t kbeg = (int64_t)z * a.k_chunk;
     const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
+    if (a.epi.rowsum && blockIdx.x == 0 && (int64_t)threadIdx.x < a.M) {
+        float r = 0.f;
+        for (int64_t k = kbeg; k < kend; ++k) r += a.A[k * a.lda + threadIdx.x];
+        a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + threadIdx.x] = r;
+    }
     if (n >= a.N) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t k = kbeg; k < kend; ++k) {
@@ -376,6 +404,9 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     a.tiles_m = (int32_t)fx_ceil_div(M, bm);
     a.tiles_n = (int32_t)fx_ceil_div(N, bn);
     hipStream_t s = fx_hip_stream(stream);
+    const bool want_rowsum = a.epi.rowsum != nullptr;
+    FX_CHECK_ARG(!want_rowsum || (K > 8 && !(N <= 4 && !transa)),
+                 "fx_gemm_f32: epilogue.rowsum is not available on the K<=8 / N<=4 skinny paths");
     if (K <= 8) {
         a.split_k = 1;
         int64_t blocks = fx_ceil_div(M * N, 256);

@@ -210,6 +210,30 @@ __device__ __forceinline__ void fx_accum_lookup(const ReduceArgs& a, uint32_t i,
     for (int k = 0; k < VEC; ++k) acc[k] += v[k];
 }
 
+// four lookups in flight per lane (positions first, then the four independent row loads), summed
+// in ascending order: same result as the one-at-a-time loop, ~4x fewer dependent latencies
+template <int VEC>
+__device__ __forceinline__ void fx_accum_run(const ReduceArgs& a, uint32_t beg, uint32_t end,
+                                             uint32_t stride, int d0, float (&acc)[VEC]) {
+    uint32_t i = beg;
+    for (; i + 3 * stride < end; i += 4 * stride) {
+        uint32_t p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = a.sorted_pos[i + j * stride];
+        float v[4][VEC];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t b = p[j] / (uint32_t)a.C, c = p[j] - b * (uint32_t)a.C;
+            fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += v[j][k];
+    }
+    for (; i < end; i += stride) fx_accum_lookup<VEC>(a, i, d0, acc);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void k_emb_grad_reduce_short(ReduceArgs a) {
     const int lanes = 1 << a.lanes_log2;
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(256) void k_emb_grad_reduce_short(ReduceArgs a) {
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-    for (uint32_t i = beg; i < end; ++i) fx_accum_lookup<VEC>(a, i, d0, acc);
+    fx_accum_run<VEC>(a, beg, end, 1u, d0, acc);
     fx_store<VEC>(a.G + u * a.D + d0, acc);
 }
 
@@ -248,8 +272,7 @@ __global__ __launch_bounds__(256) void k_emb_grad_reduce_long(ReduceArgs a) {
         float part[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) part[k] = 0.f;
-        if (lane_on)
-            for (uint32_t i = beg + grp; i < end; i += rpb) fx_accum_lookup<VEC>(a, i, d0, part);
+        if (lane_on) fx_accum_run<VEC>(a, beg + grp, end, (uint32_t)rpb, d0, part);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) red[k * 256 + threadIdx.x] = part[k];
         __syncthreads();

@@ -994,12 +994,10 @@ def linear_weight_grads(dz, x, W_shape, need_bias):
     K_in = x.shape[1]
     dW = torch.empty(N_out, K_in, dtype=torch.float32, device=dz.device)
     sk = _split_k_for(N_out, K_in, Bsz)
-    ws = _Workspace.get(dz.device, max(sk * N_out * K_in, _lib.FX_COLSUM_CHUNKS * N_out))
-    ops.gemm(dz, x, dW, transa=True, transb=False, split_k=sk, workspace=ws)
-    db = None
-    if need_bias:
-        db = torch.empty(N_out, dtype=torch.float32, device=dz.device)
-        ops.colsum(dz, db, ws)
+    ws = _Workspace.get(dz.device, sk * N_out * (K_in + 1))
+    db = torch.empty(N_out, dtype=torch.float32, device=dz.device) if need_bias else None
+    # the bias gradient (column sums of dz) rides along in the dW GEMM: its A tiles ARE dz
+    ops.gemm(dz, x, dW, transa=True, transb=False, split_k=sk, workspace=ws, rowsum=db)
     return dW, db
 
 

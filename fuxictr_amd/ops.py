@@ -301,7 +301,7 @@ def lr_fwd(table1, ids, col_row_base, col_vocab, dense, num_w1, bias, out, scal)
 
 
 def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul=None, mask=None,
-         add=None, split_k=1, workspace=None):
+         add=None, split_k=1, workspace=None, rowsum=None):
     """C = epilogue(op(A) . op(B)).  A, B, C: 2-D fp32 with unit inner stride."""
     lib = _lib.load()
     M, N = C_.shape
@@ -317,6 +317,8 @@ def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul
         epi.mask, epi.ldmask = mask.data_ptr(), mask.stride(0)
     if add is not None:
         epi.add, epi.ldadd = add.data_ptr(), add.stride(0)
+    if rowsum is not None:
+        epi.rowsum = rowsum.data_ptr()
     ev = KernelTimer.start()
     check(lib.fx_gemm_f32(1 if transa else 0, 1 if transb else 0, M, N, K, ptr(A), A.stride(0),
                           ptr(B_), B_.stride(0), ptr(C_), C_.stride(0), C.byref(epi), split_k,

@@ -196,7 +196,7 @@ int fx_sparse_sgd(float* table, int32_t D, const uint32_t* uniq_row, const int32
  *  fx_mt_adam   : torch.optim.Adam single-tensor formulas with g * clip_coef
  *  fx_mt_sgd    : p -= lr * clip_coef * g
  * ------------------------------------------------------------------------------------------ */
-#define FX_MT_BLOCKS 32
+#define FX_MT_BLOCKS 96
 int fx_mt_sqnorm(const float* const* grads_host, const int64_t* sizes_host, int32_t n,
                  float* sq_partials, fx_stream_t stream);
 int fx_mt_adam(float* const* params_host, const float* const* grads_host, float* const* m_host,
@@ -249,6 +249,9 @@ typedef struct fx_gemm_epilogue {
     int64_t ldmask;
     const float* add;
     int64_t ldadd;
+    float* rowsum; /* optional extra output [M]: rowsum[m] = sum_k op(A)[m,k] — the bias gradient
+                      when op(A) = dZ^T (fuses the column-sum pass into the dW GEMM); with
+                      split_k > 1 the workspace needs split_k*M extra floats */
 } fx_gemm_epilogue;
 
 int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K, const float* A,

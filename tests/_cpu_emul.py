@@ -244,9 +244,11 @@ def lr_fwd(table1, ids, col_row_base, col_vocab, dense, num_w1, bias, out, scal)
 
 
 def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul=None, mask=None,
-         add=None, split_k=1, workspace=None):
+         add=None, split_k=1, workspace=None, rowsum=None):
     a = A.t() if transa else A
     b = B_.t() if transb else B_
+    if rowsum is not None:
+        rowsum.copy_(a.sum(1))
     z = a @ b
     if bias is not None:
         z = z + bias

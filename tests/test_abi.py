@@ -52,7 +52,7 @@ def test_argument_validation_without_gpu():
 
 
 def test_struct_layout_matches_header():
-    assert ctypes.sizeof(_lib.GemmEpilogue) == 80
+    assert ctypes.sizeof(_lib.GemmEpilogue) == 88
     assert _lib.SC_WORDS * 4 == 64
 
 

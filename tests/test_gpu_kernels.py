@@ -376,6 +376,22 @@ def test_gemm_epilogues_and_split_k():
         assert (C.cpu().double() - ref).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(1024, 624, 4096, 6), (1024, 1024, 4096, 1), (1, 1024, 4096, 64),
+                                      (100, 70, 515, 3), (32, 1648, 4096, 16)])
+def test_gemm_fused_rowsum_is_the_bias_gradient(M, N, K, sk):
+    g = torch.Generator().manual_seed(M + K)
+    dz = torch.randn(K, M, generator=g)          # [batch, N_out]
+    x = torch.randn(K, N, generator=g)           # [batch, K_in]
+    dW = torch.empty(M, N, device=DEV)
+    db = torch.full((M,), float("nan"), device=DEV)
+    ws = torch.empty(sk * M * (N + 1) + 64, device=DEV)
+    ops.gemm(_dev(dz), _dev(x), dW, transa=True, split_k=sk, workspace=ws, rowsum=db)
+    ref = dz.double().t() @ x.double()
+    assert (dW.cpu().double() - ref).abs().max().item() <= 3e-6 * (dz.abs().double().t() @ x.abs().double()).max().item()
+    refb = dz.double().sum(0)
+    assert (db.cpu().double() - refb).abs().max().item() <= 2e-4
+
+
 def test_colsum_mask_cross_prep_bce():
     g = torch.Generator().manual_seed(8)
     M, N = 4096, 1000
