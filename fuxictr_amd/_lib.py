@@ -16,6 +16,7 @@ FX_FLAG_A2A_OVERFLOW = 2
 FX_MT_BLOCKS = 96
 FX_MT_MAX = 64
 FX_COLSUM_CHUNKS = 64
+FX_NUMGRAD_CHUNKS = 16
 FX_PACK_MAX_COLS = 64
 FX_CLIP_MAX_PARTS = 16
 
@@ -46,14 +47,14 @@ SIGNATURES = {
                                 i64, vp, vp]),
     "fx_dedup_workspace_bytes": (C.c_size_t, [i64]),
     "fx_dedup": (i32, [vp, i64, i64, i32, vp, vp, vp, i64, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
-                       i32, vp]),
+                       i32, i32, vp]),
     "fx_shard_plan": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, vp, vp, vp, vp, vp]),
     "fx_scatter_rows": (i32, [vp, vp, vp, i64, i32, vp, vp]),
     "fx_sum_parts": (i32, [C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
     "fx_emb_grad_reduce_partials": (i64, [i64, i32]),
     "fx_emb_grad_reduce_scratch_ints": (i64, [i64]),
     "fx_emb_grad_reduce": (i32, [vp, i64, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
-    "fx_emb_numeric_grad": (i32, [vp, i64, vp, vp, i64, i32, i32, i64, vp, vp]),
+    "fx_emb_numeric_grad": (i32, [vp, i64, vp, vp, i64, i32, i32, i64, vp, vp, vp]),
     "fx_opt_begin_step": (i32, [vp, vp]),
     "fx_clip_coef": (i32, [C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
     "fx_sparse_adam": (i32, [vp, vp, vp, vp, i32, vp, vp, i64, vp, vp, vp]),

@@ -194,20 +194,24 @@ extern "C" int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* i
 // fx_emb_numeric_grad: one 1024-thread block per numeric feature j; thread (grp, d) sums rows
 // b = grp, grp + ngrp, ... then a fixed-order LDS reduction over the groups.
 // ---------------------------------------------------------------------------------------------
+#define FX_NUMGRAD_CHUNKS 16
 __global__ __launch_bounds__(1024) void k_emb_numeric_grad(const float* dout, int64_t dout_ld,
                                                            const int64_t* num_out_off,
                                                            const float* dense, int64_t dense_ld,
                                                            int D, int Dp, int64_t B,
-                                                           float* dnum_w) {
+                                                           float* partial) {
     __shared__ float red[1024];
     const int j = blockIdx.x;
     const int d = threadIdx.x % Dp;
     const int grp = threadIdx.x / Dp;
     const int ngrp = 1024 / Dp;
     const int64_t off = num_out_off[j];
+    const int64_t rows = (B + gridDim.y - 1) / gridDim.y;
+    const int64_t b0 = (int64_t)blockIdx.y * rows;
+    const int64_t b1 = (b0 + rows < B) ? b0 + rows : B;
     float acc = 0.f;
     if (d < D) {
-        for (int64_t b = grp; b < B; b += ngrp)
+        for (int64_t b = b0 + grp; b < b1; b += ngrp)
             acc = fmaf(dense[b * dense_ld + j], dout[b * dout_ld + off + d], acc);
     }
     red[threadIdx.x] = acc;
@@ -216,20 +220,39 @@ __global__ __launch_bounds__(1024) void k_emb_numeric_grad(const float* dout, in
         if (grp < s) red[threadIdx.x] += red[threadIdx.x + s * Dp];
         __syncthreads();
     }
-    if (grp == 0 && d < D) dnum_w[(int64_t)j * D + d] = red[d];
+    if (grp == 0 && d < D)
+        partial[((int64_t)blockIdx.y * gridDim.x + j) * D + d] = red[d];
+}
+
+__global__ __launch_bounds__(256) void k_emb_numeric_grad_final(const float* partial, int64_t n,
+                                                                int chunks, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * n + i];
+    out[i] = s;
 }
 
 extern "C" int fx_emb_numeric_grad(const float* dout, int64_t dout_ld,
                                    const int64_t* num_out_off, const float* dense,
                                    int64_t dense_ld, int32_t Fd, int32_t D, int64_t B,
-                                   float* dnum_w, fx_stream_t stream) {
+                                   float* dnum_w, float* workspace, fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256, "fx_emb_numeric_grad: D=%d not in [1,256]", D);
     if (Fd <= 0) return FX_OK;
     FX_CHECK_ARG(dout && num_out_off && dense && dnum_w, "fx_emb_numeric_grad: null pointer");
     int Dp = 1;
     while (Dp < D) Dp <<= 1;
-    hipLaunchKernelGGL(k_emb_numeric_grad, dim3(Fd), dim3(1024), 0, fx_hip_stream(stream), dout,
-                       dout_ld, num_out_off, dense, dense_ld, (int)D, Dp, B, dnum_w);
+    if (workspace) {   // two deterministic stages: FX_NUMGRAD_CHUNKS row chunks, then their sum
+        hipLaunchKernelGGL(k_emb_numeric_grad, dim3(Fd, FX_NUMGRAD_CHUNKS), dim3(1024), 0,
+                           fx_hip_stream(stream), dout, dout_ld, num_out_off, dense, dense_ld,
+                           (int)D, Dp, B, workspace);
+        const int64_t n = (int64_t)Fd * D;
+        hipLaunchKernelGGL(k_emb_numeric_grad_final, dim3((unsigned)fx_ceil_div(n, 256)), dim3(256),
+                           0, fx_hip_stream(stream), workspace, n, (int)FX_NUMGRAD_CHUNKS, dnum_w);
+    } else {
+        hipLaunchKernelGGL(k_emb_numeric_grad, dim3(Fd, 1), dim3(1024), 0, fx_hip_stream(stream),
+                           dout, dout_ld, num_out_off, dense, dense_ld, (int)D, Dp, B, dnum_w);
+    }
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

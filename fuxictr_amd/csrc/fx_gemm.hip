@@ -334,6 +334,55 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs a) {
     for (int m = 0; m < a.M; ++m) a.ws[((int64_t)z * a.M + m) * a.N + n] = acc[m];
 }
 
+// vectorised M <= 4 variant (N % 4 == 0, 16-B aligned B rows): 64 float4 column groups x 4 row
+// lanes per workgroup, LDS combine of the row lanes
+__global__ __launch_bounds__(256) void k_gemm_small_m_v4(GemmArgs a) {
+    __shared__ float4 red[4][256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t n = ((int64_t)blockIdx.x * 64 + tx) * 4;
+    const int z = blockIdx.y;
+    const int64_t kbeg = (int64_t)z * a.k_chunk;
+    const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
+    if (a.epi.rowsum && blockIdx.x == 0 && (int64_t)threadIdx.x < a.M) {
+        float r = 0.f;
+        for (int64_t k = kbeg; k < kend; ++k) r += a.A[k * a.lda + threadIdx.x];
+        a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + threadIdx.x] = r;
+    }
+    float4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < a.N) {
+        for (int64_t k = kbeg + ty; k < kend; k += 4) {
+            const float4 b = *reinterpret_cast<const float4*>(a.B + k * a.ldb + n);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m < a.M) {
+                    const float w = a.A[k * a.lda + m];
+                    acc[m].x = fmaf(w, b.x, acc[m].x);
+                    acc[m].y = fmaf(w, b.y, acc[m].y);
+                    acc[m].z = fmaf(w, b.z, acc[m].z);
+                    acc[m].w = fmaf(w, b.w, acc[m].w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) red[m][threadIdx.x] = acc[m];
+    __syncthreads();
+    if (ty == 0 && n < a.N) {
+        for (int m = 0; m < a.M; ++m) {
+            const float4 a0 = red[m][tx], a1 = red[m][tx + 64], a2 = red[m][tx + 128],
+                         a3 = red[m][tx + 192];
+            float4 r;
+            r.x = (a0.x + a1.x) + (a2.x + a3.x);
+            r.y = (a0.y + a1.y) + (a2.y + a3.y);
+            r.z = (a0.z + a1.z) + (a2.z + a3.z);
+            r.w = (a0.w + a1.w) + (a2.w + a3.w);
+            *reinterpret_cast<float4*>(a.ws + ((int64_t)z * a.M + m) * a.N + n) = r;
+        }
+    }
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC>
 static void fx_gemm_dispatch_vec(bool av, bool bv, dim3 grid, hipStream_t s, const GemmArgs& a) {
     if (av && bv)
@@ -432,8 +481,17 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
         if (kc2 < 1) kc2 = 1;
         a.k_chunk = kc2;
         a.split_k = (int32_t)fx_ceil_div(K, kc2);
-        hipLaunchKernelGGL(k_gemm_small_m, dim3((unsigned)fx_ceil_div(N, 256), (unsigned)a.split_k),
-                           dim3(256), 0, s, a);
+        const bool v4 = (N % 4 == 0) && (ldb % 4 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(B) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
+        if (v4)
+            hipLaunchKernelGGL(k_gemm_small_m_v4,
+                               dim3((unsigned)fx_ceil_div(N, 256), (unsigned)a.split_k), dim3(256),
+                               0, s, a);
+        else
+            hipLaunchKernelGGL(k_gemm_small_m,
+                               dim3((unsigned)fx_ceil_div(N, 256), (unsigned)a.split_k), dim3(256),
+                               0, s, a);
         FX_CHECK_LAUNCH();
         int64_t blocks = fx_ceil_div(M * N, 256);
         if (blocks > 2048) blocks = 2048;

@@ -41,6 +41,35 @@ __global__ __launch_bounds__(256) void k_build_keys(const int32_t* ids, int64_t 
     }
 }
 
+// Fast path when every id column owns a distinct table and the tables are laid out in column
+// order: keys of column c all lie in [base_c, base_c + V_c), so sorting each column on its own (one
+// segmented sort, a workgroup per column) yields the globally sorted array.  Keys are written
+// column-major (segment c = [c*B, (c+1)*B)).  Padding / bad-id lookups keep a key inside their
+// column (so the array stays sorted) but carry pos = 0xFFFFFFFF = "contributes nothing".
+__global__ __launch_bounds__(256) void k_build_keys_colmajor(const int32_t* ids, int64_t ids_ld,
+                                                             int64_t B, int C,
+                                                             const int64_t* col_row_base,
+                                                             const int32_t* col_vocab,
+                                                             const int32_t* col_pad,
+                                                             uint32_t* keys, uint32_t* pos) {
+    const int64_t n = B * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / B);
+        const int64_t b = i - (int64_t)c * B;
+        const int32_t id = ids[b * ids_ld + c];
+        const bool ok = id >= 0 && id < col_vocab[c] && id != col_pad[c];
+        const int32_t row = (id >= 0 && id < col_vocab[c]) ? id : 0;
+        keys[i] = (uint32_t)(col_row_base[c] + row);
+        pos[i] = ok ? (uint32_t)(b * C + c) : 0xFFFFFFFFu;
+    }
+}
+
+struct SegOffset {
+    uint32_t B;
+    __host__ __device__ uint32_t operator()(uint32_t c) const { return c * B; }
+};
+
 struct HeadFlag {
     const uint32_t* key;
     uint32_t sentinel;
@@ -80,6 +109,23 @@ __global__ __launch_bounds__(256) void k_scatter_unique(const uint32_t* key, con
 
 static inline size_t fx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+static int fx_key_bits(int64_t total_rows) {
+    int bits = 1;
+    while (((int64_t)1 << bits) <= total_rows) ++bits;
+    return bits;
+}
+
+static hipError_t fx_segsort(void* temp, size_t& bytes, uint32_t* kin, uint32_t* kout,
+                             uint32_t* vin, uint32_t* vout, int64_t B, int C, int bits,
+                             hipStream_t s) {
+    SegOffset so{(uint32_t)B};
+    auto begin = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), so);
+    auto end = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(1), so);
+    return rocprim::segmented_radix_sort_pairs(temp, bytes, kin, kout, vin, vout,
+                                               (unsigned)(B * C), (unsigned)C, begin, end, 0u,
+                                               (unsigned)bits, s);
+}
+
 static hipError_t fx_dedup_temp_bytes(int64_t n, size_t* sort_bytes, size_t* scan_bytes) {
     // size queries are host-only but not free; a training loop asks for the same n every step
     static thread_local int64_t c_n = -1;
@@ -98,6 +144,12 @@ static hipError_t fx_dedup_temp_bytes(int64_t n, size_t* sort_bytes, size_t* sca
     e = rocprim::inclusive_scan(nullptr, *scan_bytes, in, nul, (size_t)n,
                                 rocprim::plus<uint32_t>(), (hipStream_t)0);
     if (e == hipSuccess) {
+        // the column-segmented fast path shares the same temp area: its need is bounded by a
+        // query with the worst case of one segment holding everything
+        size_t seg_bytes = 0;
+        uint32_t* nul2 = nullptr;
+        hipError_t e2 = fx_segsort(nullptr, seg_bytes, nul2, nul2, nul2, nul2, n, 1, 32, (hipStream_t)0);
+        if (e2 == hipSuccess && seg_bytes > *sort_bytes) *sort_bytes = seg_bytes;
         c_n = n;
         c_sort = *sort_bytes;
         c_scan = *scan_bytes;
@@ -122,7 +174,8 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
                         const int32_t* col_pad, int64_t total_rows, void* workspace,
                         size_t workspace_bytes, uint32_t* sorted_key, uint32_t* sorted_pos,
                         uint32_t* uniq_row, uint32_t* seg_start, int32_t* n_unique,
-                        uint32_t* sorted_uid, int32_t n_shards, fx_stream_t stream) {
+                        uint32_t* sorted_uid, int32_t n_shards, int32_t columns_sorted,
+                        fx_stream_t stream) {
     FX_CHECK_ARG(B >= 0 && C >= 0, "fx_dedup: negative size");
     FX_CHECK_ARG(total_rows > 0 && total_rows < (int64_t)0xFFFFFFFFLL,
                  "fx_dedup: total_rows=%lld must be in (0, 2^32-1)", (long long)total_rows);
@@ -157,13 +210,26 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
 
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_build_keys, dim3((unsigned)blocks), dim3(256), 0, s, ids, ids_ld, n,
-                       (int)C, col_row_base, col_vocab, col_pad, sentinel, (uint32_t)n_shards,
-                       (uint32_t)rows_per_shard, keys_in, pos_in);
-    FX_CHECK_LAUNCH();
     size_t tb = tmp;
-    FX_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, sorted_key, pos_in, sorted_pos,
-                                           (size_t)n, 0u, 32u, s));
+    if (columns_sorted && n_shards == 1) {
+        hipLaunchKernelGGL(k_build_keys_colmajor, dim3((unsigned)blocks), dim3(256), 0, s, ids,
+                           ids_ld, B, (int)C, col_row_base, col_vocab, col_pad, keys_in, pos_in);
+        FX_CHECK_LAUNCH();
+        size_t need = 0;
+        FX_CHECK_HIP(fx_segsort(nullptr, need, keys_in, sorted_key, pos_in, sorted_pos, B, (int)C,
+                                fx_key_bits(total_rows), s));
+        FX_CHECK_ARG(need <= tmp, "fx_dedup: segmented-sort temp (%zu) exceeds workspace (%zu)",
+                     need, tmp);
+        FX_CHECK_HIP(fx_segsort(temp, tb, keys_in, sorted_key, pos_in, sorted_pos, B, (int)C,
+                                fx_key_bits(total_rows), s));
+    } else {
+        hipLaunchKernelGGL(k_build_keys, dim3((unsigned)blocks), dim3(256), 0, s, ids, ids_ld, n,
+                           (int)C, col_row_base, col_vocab, col_pad, sentinel, (uint32_t)n_shards,
+                           (uint32_t)rows_per_shard, keys_in, pos_in);
+        FX_CHECK_LAUNCH();
+        FX_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, sorted_key, pos_in, sorted_pos,
+                                               (size_t)n, 0u, 32u, s));
+    }
     HeadFlag hf{sorted_key, sentinel};
     auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), hf);
     tb = tmp;
@@ -203,6 +269,7 @@ template <int VEC>
 __device__ __forceinline__ void fx_accum_lookup(const ReduceArgs& a, uint32_t i, int d0,
                                                 float (&acc)[VEC]) {
     const uint32_t p = a.sorted_pos[i];
+    if (p == 0xFFFFFFFFu) return;   // padding_idx / bad-id lookup: contributes nothing
     const uint32_t b = p / (uint32_t)a.C, c = p - b * (uint32_t)a.C;
     float v[VEC];
     fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v);
@@ -223,6 +290,11 @@ __device__ __forceinline__ void fx_accum_run(const ReduceArgs& a, uint32_t beg, 
         float v[4][VEC];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (p[j] == 0xFFFFFFFFu) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[j][k] = 0.f;
+                continue;
+            }
             const uint32_t b = p[j] / (uint32_t)a.C, c = p[j] - b * (uint32_t)a.C;
             fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v[j]);
         }

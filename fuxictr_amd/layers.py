@@ -262,6 +262,8 @@ class _TableGroup(object):
         p.num_zero_off = torch.zeros(max(p.Fd, 1), dtype=torch.int64, device=dev)
         p.num_rows = [self.numeric.index(f) for f in p.num_feats]
         p.num_full = p.num_rows == list(range(len(self.numeric)))
+        p.columns_sorted = all(w == 1 for _, w in p.id_feats) and \
+            all(row_base[i] < row_base[i + 1] for i in range(len(row_base) - 1))
         p.sig = (tuple(p.id_feats), tuple(row_base), tuple(pad))
         p.pack_sig = (tuple(p.id_feats), tuple(p.num_feats))
         self.plans[key] = p
@@ -297,7 +299,7 @@ class _TableGroup(object):
             self.dedup_ws = (n, torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8,
                                             device=self.device))
         dd = ops.dedup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad, self.total_rows,
-                       self.dedup_ws[1])
+                       self.dedup_ws[1], columns_sorted=plan.columns_sorted)
         if cache is not None:
             cache[ckey] = dd
         return dd
@@ -965,13 +967,14 @@ class FactorizationMachine(nn.Module):
 # dense tower
 # ------------------------------------------------------------------------------------------------
 def _split_k_for(M, N, K):
-    """Split the contraction when the output grid alone cannot fill 256 CUs (weight gradients)."""
+    """Split the contraction when the output grid alone cannot fill 256 CUs (weight gradients):
+    aim for ~512 workgroups of 64x64 (2 per CU); every extra split costs a partial-slab round trip."""
     if M <= 4:                      # skinny weight gradient: column-parallel reduction kernel
         return max(1, min(64, K // 64))
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 192:
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if tiles >= 448:
         return 1
-    s = max(1, min(256 // tiles, K // 256))
+    s = max(1, min(-(-512 // tiles), K // 256))
     return min(s, 16)
 
 

@@ -144,7 +144,7 @@ class DedupResult(object):
 
 
 def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None,
-          n_shards=1, want_uid=False):
+          n_shards=1, want_uid=False, columns_sorted=False):
     lib = _lib.load()
     B, C_ = ids.shape
     if result is None:
@@ -153,7 +153,8 @@ def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=N
                        ptr(col_pad), total_rows, ptr(workspace), workspace.numel(),
                        ptr(result.sorted_key), ptr(result.sorted_pos), ptr(result.uniq_row),
                        ptr(result.seg_start), ptr(result.n_unique), ptr(result.sorted_uid),
-                       n_shards, stream_ptr(ids.device)),
+                       n_shards, 1 if (columns_sorted and n_shards == 1) else 0,
+                       stream_ptr(ids.device)),
           "fx_dedup")
     return result
 
@@ -194,8 +195,9 @@ def emb_grad_reduce(dout, dout_ld, col_out_off, C_, D, dd, G, sq_partials, scrat
 def emb_numeric_grad(dout, dout_ld, num_out_off, dense, D, dnum_w):
     lib = _lib.load()
     B, Fd = dense.shape
+    ws = torch.empty(_lib.FX_NUMGRAD_CHUNKS * Fd * D, dtype=torch.float32, device=dout.device)
     check(lib.fx_emb_numeric_grad(ptr(dout), dout_ld, ptr(num_out_off), ptr(dense),
-                                  dense.stride(0), Fd, D, B, ptr(dnum_w),
+                                  dense.stride(0), Fd, D, B, ptr(dnum_w), ptr(ws),
                                   stream_ptr(dout.device)), "fx_emb_numeric_grad")
 
 

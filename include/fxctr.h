@@ -98,6 +98,11 @@ int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* ids, int64_t
  *     *n_unique = number of distinct non-sentinel keys
  *     sorted_uid[i] (optional, may be NULL) = u of sorted lookup i, 0xFFFFFFFF for sentinels
  * n_shards = 1 for an unsharded table (see fx_shard_plan for n_shards > 1).
+ * columns_sorted != 0 (hint; needs n_shards = 1): every id column owns its own table and
+ * col_row_base is strictly increasing — the sort is then one segmented sort (a workgroup per
+ * column).  In that mode padding_idx / bad-id lookups stay inside their column's key range with
+ * sorted_pos = 0xFFFFFFFF ("contributes nothing"): the padding row may appear as a unique row
+ * whose reduced gradient is exactly zero.
  * This replaces the zero-filled dense [V,D] gradient + index_add of aten::embedding_dense_backward
  * (triggered at rank_model.py:320) — no dense gradient ever exists.  Deterministic.
  * Packed tables are limited to < 2^32 - 1 rows.
@@ -107,7 +112,7 @@ int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
              const int64_t* col_row_base, const int32_t* col_vocab, const int32_t* col_pad,
              int64_t total_rows, void* workspace, size_t workspace_bytes, uint32_t* sorted_key,
              uint32_t* sorted_pos, uint32_t* uniq_row, uint32_t* seg_start, int32_t* n_unique,
-             uint32_t* sorted_uid, int32_t n_shards, fx_stream_t stream);
+             uint32_t* sorted_uid, int32_t n_shards, int32_t columns_sorted, fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row-sharded tables (new functionality: the reference has no multi-GPU path).
@@ -151,9 +156,11 @@ int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int64_t* col_ou
 
 /* Numeric-feature weight gradient: dnum_w[j,d] = sum_b dense[b,j] * dout[b*dout_ld + num_out_off[j] + d]
  * (autograd of the nn.Linear(1,D) at feature_embedding.py:280-282).  Deterministic tree sum. */
+#define FX_NUMGRAD_CHUNKS 16
 int fx_emb_numeric_grad(const float* dout, int64_t dout_ld, const int64_t* num_out_off,
                         const float* dense, int64_t dense_ld, int32_t Fd, int32_t D, int64_t B,
-                        float* dnum_w, fx_stream_t stream);
+                        float* dnum_w, float* workspace /* FX_NUMGRAD_CHUNKS*Fd*D floats or NULL */,
+                        fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer scalars.  fx_opt_begin_step: step += 1 and the bias corrections of

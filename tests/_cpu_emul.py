@@ -55,7 +55,7 @@ class DedupResult(object):
 
 
 def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None,
-          n_shards=1, want_uid=False):
+          n_shards=1, want_uid=False, columns_sorted=False):
     B, C = ids.shape
     keys = ids.long() + col_row_base.view(1, -1)
     valid = (ids != col_pad.view(1, -1)) & (ids >= 0) & (ids < col_vocab.view(1, -1))

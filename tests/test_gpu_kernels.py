@@ -119,6 +119,42 @@ def test_dedup_matches_numpy_unique(B):
         assert np.all(flat_keys[run] == uniq[u])
 
 
+@pytest.mark.parametrize("B", [1, 777, 4096])
+def test_dedup_column_segmented_fast_path(B):
+    """columns_sorted=1: same unique rows / runs as the generic path, except that padding rows may
+    appear as unique rows whose lookups carry pos = 0xFFFFFFFF (no contribution)."""
+    rng = np.random.default_rng(B + 1)
+    vocabs = [4, 100, 50000, 9, 3000000]
+    pads = [0, 0, -1, 3, 0]
+    ids = np.stack([rng.integers(0, v, B) for v in vocabs], axis=1)
+    bases = np.concatenate([[0], np.cumsum(vocabs)[:-1]]).astype(np.int64)
+    R = int(sum(vocabs))
+    C = len(vocabs)
+    ws = torch.empty(ops.dedup_workspace_bytes(B * C), dtype=torch.uint8, device=DEV)
+    dd = ops.dedup(_dev(ids, torch.int32), _dev(bases, torch.int64), _dev(vocabs, torch.int32),
+                   _dev(pads, torch.int32), R, ws, columns_sorted=True)
+    nu = int(dd.n_unique.item())
+    keys = (ids + bases[None, :]).reshape(-1)
+    uniq_all = np.unique(keys)
+    got = dd.uniq_row[:nu].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert np.array_equal(got, uniq_all)
+    seg = dd.seg_start[:nu + 1].cpu().numpy().astype(np.int64)
+    pos = dd.sorted_pos.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    valid = np.ones_like(ids, dtype=bool)
+    for c, p in enumerate(pads):
+        if p >= 0:
+            valid[:, c] = ids[:, c] != p
+    flat_valid = valid.reshape(-1)
+    for u in range(0, nu, max(1, nu // 50)):
+        run = pos[seg[u]:seg[u + 1]]
+        live = run[run != 0xFFFFFFFF]
+        assert np.all(np.diff(live) > 0)
+        assert np.all(keys[live] == uniq_all[u]) and np.all(flat_valid[live])
+        expect = int(((keys == uniq_all[u]) & flat_valid).sum())
+        assert len(live) == expect
+    assert seg[nu] == B * C
+
+
 def test_dedup_all_padding_and_all_same():
     ids = np.zeros((128, 2), dtype=np.int64)
     dd, _, _ = _dedup(ids, [5, 5], [0, 0])
@@ -389,7 +425,7 @@ def test_gemm_fused_rowsum_is_the_bias_gradient(M, N, K, sk):
     ref = dz.double().t() @ x.double()
     assert (dW.cpu().double() - ref).abs().max().item() <= 3e-6 * (dz.abs().double().t() @ x.abs().double()).max().item()
     refb = dz.double().sum(0)
-    assert (db.cpu().double() - refb).abs().max().item() <= 2e-4
+    assert (db.cpu().double() - refb).abs().max().item() <= 1e-6 * dz.abs().double().sum(0).max().item()
 
 
 def test_colsum_mask_cross_prep_bce():
