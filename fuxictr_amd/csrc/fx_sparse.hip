@@ -42,33 +42,50 @@ __global__ __launch_bounds__(256) void k_build_keys(const int32_t* ids, int64_t 
 }
 
 // Fast path when every id column owns a distinct table and the tables are laid out in column
-// order: keys of column c all lie in [base_c, base_c + V_c), so sorting each column on its own (one
-// segmented sort, a workgroup per column) yields the globally sorted array.  Keys are written
-// column-major (segment c = [c*B, (c+1)*B)).  Padding / bad-id lookups keep a key inside their
-// column (so the array stays sorted) but carry pos = 0xFFFFFFFF = "contributes nothing".
-__global__ __launch_bounds__(256) void k_build_keys_colmajor(const int32_t* ids, int64_t ids_ld,
-                                                             int64_t B, int C,
-                                                             const int64_t* col_row_base,
-                                                             const int32_t* col_vocab,
-                                                             const int32_t* col_pad,
-                                                             uint32_t* keys, uint32_t* pos) {
-    const int64_t n = B * C;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i / B);
-        const int64_t b = i - (int64_t)c * B;
-        const int32_t id = ids[b * ids_ld + c];
-        const bool ok = id >= 0 && id < col_vocab[c] && id != col_pad[c];
-        const int32_t row = (id >= 0 && id < col_vocab[c]) ? id : 0;
-        keys[i] = (uint32_t)(col_row_base[c] + row);
-        pos[i] = ok ? (uint32_t)(b * C + c) : 0xFFFFFFFFu;
+// order: keys of column c all lie in [base_c, base_c + V_c), so sorting each column on its own
+// yields the globally sorted array (segment c = [c*B, (c+1)*B)).  Padding / bad-id lookups keep a
+// key inside their column (so the array stays sorted) but carry pos = 0xFFFFFFFF = "contributes
+// nothing".
+// One workgroup sorts one id column entirely in LDS (rocprim::block_radix_sort as the in-block
+// primitive) over only the bits its vocabulary needs: a 3-row table takes one 2-bit pass, the
+// 10 M-row table three passes.  Output is the globally sorted (key, pos) array, column after column.
+template <int IPT>
+__global__ __launch_bounds__(1024) void k_sort_columns(const int32_t* ids, int64_t ids_ld,
+                                                       int64_t B, const int64_t* col_row_base,
+                                                       const int32_t* col_vocab,
+                                                       const int32_t* col_pad, int C,
+                                                       uint32_t* sorted_key, uint32_t* sorted_pos) {
+    using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t>;
+    __shared__ typename Sort::storage_type storage;
+    const int c = blockIdx.x;
+    const int32_t V = col_vocab[c], pad = col_pad[c];
+    int bits = 1;
+    while ((1u << bits) < (uint32_t)V && bits < 31) ++bits;
+    const uint32_t fill = (1u << bits) - 1u;   // >= every real id; ties keep real items first
+    uint32_t k[IPT], v[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const int64_t b = (int64_t)threadIdx.x * IPT + j;
+        k[j] = fill;
+        v[j] = 0xFFFFFFFFu;
+        if (b < B) {
+            const int32_t id = ids[b * ids_ld + c];
+            const bool in_range = id >= 0 && id < V;
+            k[j] = in_range ? (uint32_t)id : 0u;
+            if (in_range && id != pad) v[j] = (uint32_t)(b * C + c);
+        }
+    }
+    Sort().sort(k, v, storage, 0, bits);
+    const uint32_t base = (uint32_t)col_row_base[c];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const int64_t i = (int64_t)threadIdx.x * IPT + j;
+        if (i < B) {
+            sorted_key[(int64_t)c * B + i] = base + k[j];
+            sorted_pos[(int64_t)c * B + i] = v[j];
+        }
     }
 }
-
-struct SegOffset {
-    uint32_t B;
-    __host__ __device__ uint32_t operator()(uint32_t c) const { return c * B; }
-};
 
 struct HeadFlag {
     const uint32_t* key;
@@ -109,23 +126,6 @@ __global__ __launch_bounds__(256) void k_scatter_unique(const uint32_t* key, con
 
 static inline size_t fx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static int fx_key_bits(int64_t total_rows) {
-    int bits = 1;
-    while (((int64_t)1 << bits) <= total_rows) ++bits;
-    return bits;
-}
-
-static hipError_t fx_segsort(void* temp, size_t& bytes, uint32_t* kin, uint32_t* kout,
-                             uint32_t* vin, uint32_t* vout, int64_t B, int C, int bits,
-                             hipStream_t s) {
-    SegOffset so{(uint32_t)B};
-    auto begin = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), so);
-    auto end = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(1), so);
-    return rocprim::segmented_radix_sort_pairs(temp, bytes, kin, kout, vin, vout,
-                                               (unsigned)(B * C), (unsigned)C, begin, end, 0u,
-                                               (unsigned)bits, s);
-}
-
 static hipError_t fx_dedup_temp_bytes(int64_t n, size_t* sort_bytes, size_t* scan_bytes) {
     // size queries are host-only but not free; a training loop asks for the same n every step
     static thread_local int64_t c_n = -1;
@@ -144,12 +144,6 @@ static hipError_t fx_dedup_temp_bytes(int64_t n, size_t* sort_bytes, size_t* sca
     e = rocprim::inclusive_scan(nullptr, *scan_bytes, in, nul, (size_t)n,
                                 rocprim::plus<uint32_t>(), (hipStream_t)0);
     if (e == hipSuccess) {
-        // the column-segmented fast path shares the same temp area: its need is bounded by a
-        // query with the worst case of one segment holding everything
-        size_t seg_bytes = 0;
-        uint32_t* nul2 = nullptr;
-        hipError_t e2 = fx_segsort(nullptr, seg_bytes, nul2, nul2, nul2, nul2, n, 1, 32, (hipStream_t)0);
-        if (e2 == hipSuccess && seg_bytes > *sort_bytes) *sort_bytes = seg_bytes;
         c_n = n;
         c_sort = *sort_bytes;
         c_scan = *scan_bytes;
@@ -211,17 +205,22 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 4096) blocks = 4096;
     size_t tb = tmp;
-    if (columns_sorted && n_shards == 1) {
-        hipLaunchKernelGGL(k_build_keys_colmajor, dim3((unsigned)blocks), dim3(256), 0, s, ids,
-                           ids_ld, B, (int)C, col_row_base, col_vocab, col_pad, keys_in, pos_in);
+    if (columns_sorted && n_shards == 1 && B <= 8192) {
+        // (measured: rocprim's segmented_radix_sort takes 81 us for 26 x 4096, its device merge
+        // sort 57 us; one in-LDS workgroup sort per column over only the needed bits is the path)
+        if (B <= 1024)
+            hipLaunchKernelGGL(k_sort_columns<1>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,
+                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos);
+        else if (B <= 2048)
+            hipLaunchKernelGGL(k_sort_columns<2>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,
+                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos);
+        else if (B <= 4096)
+            hipLaunchKernelGGL(k_sort_columns<4>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,
+                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos);
+        else
+            hipLaunchKernelGGL(k_sort_columns<8>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,
+                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos);
         FX_CHECK_LAUNCH();
-        size_t need = 0;
-        FX_CHECK_HIP(fx_segsort(nullptr, need, keys_in, sorted_key, pos_in, sorted_pos, B, (int)C,
-                                fx_key_bits(total_rows), s));
-        FX_CHECK_ARG(need <= tmp, "fx_dedup: segmented-sort temp (%zu) exceeds workspace (%zu)",
-                     need, tmp);
-        FX_CHECK_HIP(fx_segsort(temp, tb, keys_in, sorted_key, pos_in, sorted_pos, B, (int)C,
-                                fx_key_bits(total_rows), s));
     } else {
         hipLaunchKernelGGL(k_build_keys, dim3((unsigned)blocks), dim3(256), 0, s, ids, ids_ld, n,
                            (int)C, col_row_base, col_vocab, col_pad, sentinel, (uint32_t)n_shards,

@@ -99,8 +99,8 @@ int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* ids, int64_t
  *     sorted_uid[i] (optional, may be NULL) = u of sorted lookup i, 0xFFFFFFFF for sentinels
  * n_shards = 1 for an unsharded table (see fx_shard_plan for n_shards > 1).
  * columns_sorted != 0 (hint; needs n_shards = 1): every id column owns its own table and
- * col_row_base is strictly increasing — the sort is then one segmented sort (a workgroup per
- * column).  In that mode padding_idx / bad-id lookups stay inside their column's key range with
+ * col_row_base is strictly increasing — each column is then sorted by one workgroup entirely in
+ * LDS over only the bits its vocabulary needs (B <= 8192; larger batches use the generic path).  In that mode padding_idx / bad-id lookups stay inside their column's key range with
  * sorted_pos = 0xFFFFFFFF ("contributes nothing"): the padding row may appear as a unique row
  * whose reduced gradient is exactly zero.
  * This replaces the zero-filled dense [V,D] gradient + index_add of aten::embedding_dense_backward
