@@ -53,88 +53,62 @@ __device__ __forceinline__ float fx_epilogue(const fx_gemm_epilogue& e, float z,
 // (conflict-free), R+4 when filled by 16-byte writes (keeps 16-B alignment).
 template <int R, bool KC, bool VEC>
 struct TileLoader {
-    static constexpr int NST = R / 32;            // float4 staging registers per thread and set
+    static constexpr int NST = R / 32;            // float4 staging registers per thread
     static constexpr int LD = KC ? R + 1 : R + 4;
-    float4 st2[2][NST];                           // two sets: k-tiles t+1 and t+2 in flight
-    const float* fbk[NST];                        // always-valid address for predicated-off loads
-    uint32_t okm[2];                              // bit p of okm[set]: st2[set][p] is real data
+    float4 st[NST];
 
-    // Vector loads are branch-free (select the address, apply the predicate when the chunk is
-    // written to LDS): with exec-masked branches around them hipcc falls back to vmcnt(0) and
-    // would wait for the loads it has only just issued.
-    __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int64_t r0,
-                                         int64_t Rext, int64_t kbeg, int64_t kend) {
-        okm[0] = okm[1] = 0;
-#pragma unroll
-        for (int p = 0; p < NST; ++p) {
-            const int q = threadIdx.x + 256 * p;
-            int64_t r, k;
-            if constexpr (KC) { r = r0 + (q >> 3); k = kbeg + ((q & 7) << 2); }
-            else { k = kbeg + q / (R / 4); r = r0 + ((q % (R / 4)) << 2); }
-            const bool ok = (r < Rext) && (k < kend);
-            fbk[p] = ok ? (KC ? P + r * ld + k : P + k * ld + r) : P;
-        }
-    }
-
-    template <int SET>
     __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int64_t r0,
                                          int64_t Rext, int64_t k0, int64_t kend) {
-        float4(&st)[NST] = st2[SET];
 #pragma unroll
         for (int p = 0; p < NST; ++p) {
             const int q = threadIdx.x + 256 * p;
-            int64_t r, k;
-            if constexpr (KC) { r = r0 + (q >> 3); k = k0 + ((q & 7) << 2); }
-            else { k = k0 + q / (R / 4); r = r0 + ((q % (R / 4)) << 2); }
-            const float* src = KC ? P + r * ld + k : P + k * ld + r;
-            if constexpr (VEC) {
-                const bool ok = (r < Rext) && (k < kend);
-                st[p] = *reinterpret_cast<const float4*>(ok ? src : fbk[p]);
-                okm[SET] = ok ? (okm[SET] | (1u << p)) : (okm[SET] & ~(1u << p));
-            } else {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (KC) {
-                    if (r < Rext) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (KC) {
+                const int64_t r = r0 + (q >> 3);
+                const int64_t k = k0 + ((q & 7) << 2);
+                if (r < Rext) {
+                    const float* src = P + r * ld + k;
+                    if constexpr (VEC) {
+                        if (k < kend) v = *reinterpret_cast<const float4*>(src);
+                    } else {
                         if (k + 0 < kend) v.x = src[0];
                         if (k + 1 < kend) v.y = src[1];
                         if (k + 2 < kend) v.z = src[2];
                         if (k + 3 < kend) v.w = src[3];
                     }
-                } else {
-                    if (k < kend) {
+                }
+            } else {
+                const int64_t k = k0 + q / (R / 4);
+                const int64_t r = r0 + ((q % (R / 4)) << 2);
+                if (k < kend) {
+                    const float* src = P + k * ld + r;
+                    if constexpr (VEC) {
+                        if (r < Rext) v = *reinterpret_cast<const float4*>(src);
+                    } else {
                         if (r + 0 < Rext) v.x = src[0];
                         if (r + 1 < Rext) v.y = src[1];
                         if (r + 2 < Rext) v.z = src[2];
                         if (r + 3 < Rext) v.w = src[3];
                     }
                 }
-                st[p] = v;
-                okm[SET] |= (1u << p);
             }
+            st[p] = v;
         }
     }
 
-    template <int SET>
     __device__ __forceinline__ void store(float* __restrict__ T) const {
-        const float4(&st)[NST] = st2[SET];
 #pragma unroll
         for (int p = 0; p < NST; ++p) {
             const int q = threadIdx.x + 256 * p;
-            const bool ok = (okm[SET] >> p) & 1u;
-            float4 v;
-            v.x = ok ? st[p].x : 0.f;
-            v.y = ok ? st[p].y : 0.f;
-            v.z = ok ? st[p].z : 0.f;
-            v.w = ok ? st[p].w : 0.f;
             if constexpr (KC) {
                 const int r = q >> 3, kq = (q & 7) << 2;
-                T[(kq + 0) * LD + r] = v.x;
-                T[(kq + 1) * LD + r] = v.y;
-                T[(kq + 2) * LD + r] = v.z;
-                T[(kq + 3) * LD + r] = v.w;
+                T[(kq + 0) * LD + r] = st[p].x;
+                T[(kq + 1) * LD + r] = st[p].y;
+                T[(kq + 2) * LD + r] = st[p].z;
+                T[(kq + 3) * LD + r] = st[p].w;
             } else {
                 const int k = q / (R / 4), r = (q % (R / 4)) << 2;
-                *reinterpret_cast<float4*>(T + k * LD + r) = v;
+                *reinterpret_cast<float4*>(T + k * LD + r) = st[p];
             }
         }
     }
@@ -189,11 +163,19 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     LoaderA la;
     LoaderB lb;
     const int64_t nk = (kend > kbeg) ? (kend - kbeg + FX_BK - 1) / FX_BK : 0;
-
-    // MFMAs of one k-tile held in LDS stage `cur`.  Fragment reads are software-pipelined two
-    // k-pairs deep and pinned with sched_group_barrier — left alone, hipcc sinks every read next
-    // to its use and pays a full LDS latency per MFMA group.
-    auto compute = [&](int cur) __attribute__((always_inline)) {
+    if (nk > 0) {
+        la.load(a.A, a.lda, m0, a.M, kbeg, kend);
+        lb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
+        la.store(As[0]);
+        lb.store(Bs[0]);
+    }
+    __syncthreads();
+    for (int64_t t = 0; t < nk; ++t) {
+        const int cur = (int)(t & 1);
+        if (t + 1 < nk) {
+            la.load(a.A, a.lda, m0, a.M, kbeg + (t + 1) * FX_BK, kend);
+            lb.load(a.B, a.ldb, n0, a.N, kbeg + (t + 1) * FX_BK, kend);
+        }
         const float* as = As[cur] + half * LDA + wm * (BM / 2) + l31;
         const float* bs = Bs[cur] + half * LDB + wn * (BN / 2) + l31;
         if (do_rowsum && threadIdx.x < BM) {
@@ -201,6 +183,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
 #pragma unroll
             for (int k = 0; k < FX_BK; ++k) rsum += col[k * LDA];
         }
+        // Software-pipelined fragment reads, two k-pairs deep: the LDS reads of k-pair s+2 are
+        // issued right after the MFMAs of k-pair s (same register set), so an LDS latency is
+        // always covered by MFMAs.  Pinned with sched_group_barrier — left alone, hipcc sinks
+        // every read next to its use and pays a full LDS latency per MFMA group.
         float fa[2][MI], fb[2][NJ];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -228,38 +214,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
         }
-    };
-
-    // Global -> register prefetch runs TWO k-tiles ahead (two staging register sets): the loads of
-    // tile t+2 are issued at the top of iteration t and are only needed at the bottom of
-    // iteration t+1, so an L2-miss latency of a few microseconds (what the tower shapes see with
-    // 4 workgroups per CU sharing the MFMA pipes) no longer drains the pipe.
-    la.init(a.A, a.lda, m0, a.M, kbeg, kend);
-    lb.init(a.B, a.ldb, n0, a.N, kbeg, kend);
-    if (nk > 0) {
-        la.template load<0>(a.A, a.lda, m0, a.M, kbeg, kend);
-        lb.template load<0>(a.B, a.ldb, n0, a.N, kbeg, kend);
-        la.template store<0>(As[0]);
-        lb.template store<0>(Bs[0]);
-        la.template load<1>(a.A, a.lda, m0, a.M, kbeg + FX_BK, kend);   // zeros past the K range
-        lb.template load<1>(a.B, a.ldb, n0, a.N, kbeg + FX_BK, kend);
-    }
-    __syncthreads();
-    for (int64_t t = 0; t < nk; t += 2) {
-        // even half: tile t in stage 0, set 1 carries tile t+1, fetch tile t+2 into set 0
-        la.template load<0>(a.A, a.lda, m0, a.M, kbeg + (t + 2) * FX_BK, kend);
-        lb.template load<0>(a.B, a.ldb, n0, a.N, kbeg + (t + 2) * FX_BK, kend);
-        compute(0);
-        la.template store<1>(As[1]);
-        lb.template store<1>(Bs[1]);
-        __syncthreads();
-        if (t + 1 >= nk) break;
-        // odd half: tile t+1 in stage 1, set 0 carries tile t+2, fetch tile t+3 into set 1
-        la.template load<1>(a.A, a.lda, m0, a.M, kbeg + (t + 3) * FX_BK, kend);
-        lb.template load<1>(a.B, a.ldb, n0, a.N, kbeg + (t + 3) * FX_BK, kend);
-        compute(1);
-        la.template store<0>(As[0]);
-        lb.template store<0>(Bs[0]);
+        if (t + 1 < nk) {
+            la.store(As[cur ^ 1]);
+            lb.store(Bs[cur ^ 1]);
+        }
         __syncthreads();
     }
 
