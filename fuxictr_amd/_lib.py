@@ -73,6 +73,13 @@ SIGNATURES = {
     "fx_mask_mul": (i32, [vp, vp, vp, i64, vp]),
     "fx_cross_bwd_prep": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "fx_sigmoid_bce": (i32, [vp, vp, i64, vp, vp, vp, vp]),
+    "fx_din_concat_fwd": (i32, [vp, i64, vp, i64, i64, i64, i32, i32, vp, vp]),
+    "fx_din_concat_bwd": (i32, [vp, vp, i64, vp, i64, i64, i64, i32, i32, vp, vp, i64, i64, i32, vp]),
+    "fx_din_pool_fwd": (i32, [vp, vp, i64, vp, i64, i64, i64, i32, i32, vp, vp]),
+    "fx_din_pool_bwd": (i32, [vp, vp, i64, vp, i64, i64, vp, i64, i32, i32, vp, vp, i64, i64, vp]),
+    "fx_dice_workspace_floats": (i64, [i32]),
+    "fx_dice_fwd": (i32, [vp, i64, i32, vp, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp, vp]),
+    "fx_dice_bwd": (i32, [vp, vp, i64, i32, vp, C.c_float, i32, vp, vp, vp, vp, vp]),
 }
 
 _lib = None

@@ -689,6 +689,7 @@ class FeatureEmbeddingDict(nn.Module):
                 feature_emb_dict._encoded.add(f)
             feature_emb_dict[f] = e
         feature_emb_dict._records = [v for k, v in emb.items() if isinstance(k, tuple)]
+        feature_emb_dict._orig = {f: id(t) for f, t in feature_emb_dict.items()}
         return feature_emb_dict
 
     def _anchor(self, grp):
@@ -729,6 +730,8 @@ class FeatureEmbeddingDict(nn.Module):
         for f in names:
             if f not in plan.slot or f in embedding_dict._encoded:
                 return None
+            if embedding_dict._orig.get(f) != id(embedding_dict[f]):
+                return None          # the caller replaced this entry (e.g. DIN's pooled sequence)
             s, w = plan.slot[f]
             if w != 1:
                 return None
@@ -801,6 +804,7 @@ class _EmbDict(OrderedDict):
         super().__init__(*a, **kw)
         self._records = []
         self._encoded = set()
+        self._orig = {}
 
 
 class FeatureEmbedding(nn.Module):
@@ -975,7 +979,7 @@ def _split_k_for(M, N, K):
     if tiles >= 448:
         return 1
     s = max(1, min(-(-512 // tiles), K // 256))
-    return min(s, 16)
+    return min(s, 256 if tiles <= 4 else 16)
 
 
 class _Workspace(object):
@@ -1061,6 +1065,51 @@ class FxLinear(nn.Linear):
         return y.reshape(*lead, self.out_features)
 
 
+class _DiceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, alpha, mod):
+        z = z.contiguous()
+        N, H = z.shape
+        stats = torch.empty(2 * H, dtype=torch.float32, device=z.device)
+        y = torch.empty_like(z)
+        ws = torch.empty(ops.dice_workspace_floats(H), dtype=torch.float32, device=z.device)
+        ops.dice_fwd(z, alpha, mod.bn.eps, mod.bn.momentum, mod.training, mod.bn.running_mean,
+                     mod.bn.running_var, stats, y, ws)
+        ctx.save_for_backward(z, alpha, stats)
+        ctx.training, ctx.eps = mod.training, mod.bn.eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, alpha, stats = ctx.saved_tensors
+        N, H = z.shape
+        dz = torch.empty_like(z)
+        dalpha = torch.empty(H, dtype=torch.float32, device=z.device)
+        ws = torch.empty(ops.dice_workspace_floats(H), dtype=torch.float32, device=z.device)
+        ops.dice_bwd(z, dy.contiguous(), alpha, ctx.eps, ctx.training, stats, dz, dalpha, ws)
+        return dz, dalpha, None
+
+
+class Dice(nn.Module):
+    """fuxictr/pytorch/layers/activations.py:24-51 — same submodule / parameter names
+    (`bn.running_mean`, `bn.running_var`, `bn.num_batches_tracked`, `alpha`); the BatchNorm module
+    only holds the running statistics, the arithmetic is fx_dice_fwd / fx_dice_bwd."""
+
+    def __init__(self, input_dim, eps=1e-9):
+        super(Dice, self).__init__()
+        dev = _alloc_device()
+        self.bn = nn.BatchNorm1d(input_dim, affine=False, eps=eps, momentum=0.01, device=dev)
+        self.alpha = nn.Parameter(torch.zeros(input_dim, device=dev))
+
+    def forward(self, X):
+        if X.dim() != 2:
+            lead = X.shape[:-1]
+            return self.forward(X.reshape(-1, X.shape[-1])).reshape(*lead, X.shape[-1])
+        if self.training:
+            self.bn.num_batches_tracked += 1
+        return _DiceFn.apply(X, self.alpha, self)
+
+
 def get_activation(activation, hidden_units=None):
     """fuxictr/pytorch/torch_utils.py:137-173."""
     if isinstance(activation, str):
@@ -1077,7 +1126,7 @@ def get_activation(activation, hidden_units=None):
         elif activation.lower() == "prelu":
             return nn.PReLU(hidden_units, init=0.1)
         elif activation.lower() == "dice":
-            raise NotImplementedError("activation=dice: DIN path is not built yet (SURVEY §8 a10)")
+            return Dice(hidden_units)
         else:
             return getattr(nn, activation)()
     elif isinstance(activation, list):
@@ -1130,26 +1179,112 @@ class MLP_Block(nn.Module):
         self._fused = self._fusable()
 
     def _fusable(self):
-        """(list of (FxLinear, relu?)) if the stack is Linear[/ReLU] only, else None."""
+        """(prefix of (FxLinear, relu?) pairs, remaining modules): the Linear[/ReLU] prefix of the
+        stack runs as one fused node, whatever follows (Dice, Sigmoid, ...) module by module."""
         mods = list(self.mlp)
         stack = []
         i = 0
-        while i < len(mods):
-            if not isinstance(mods[i], FxLinear):
-                return None
+        while i < len(mods) and isinstance(mods[i], FxLinear):
             relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
             stack.append((mods[i], relu))
             i += 2 if relu else 1
-        return stack or None
+        if not stack:
+            return None
+        return stack, mods[i:]
 
     def forward(self, inputs):
         if self._fused is None or inputs.dim() != 2:
             return self.mlp(inputs)
-        acts = tuple(r for _, r in self._fused)
+        stack, tail = self._fused
+        acts = tuple(r for _, r in stack)
         wb = []
-        for lin, _ in self._fused:
+        for lin, _ in stack:
             wb += [lin.weight, lin.bias]
-        return _MLPFn.apply(inputs, acts, *wb)
+        out = _MLPFn.apply(inputs, acts, *wb)
+        for mod in tail:
+            out = mod(out)
+        return out
+
+
+class _DinConcatFn(torch.autograd.Function):
+    """[q, k, q-k, q*k] for every (sample, position): target_attention.py:80-82."""
+
+    @staticmethod
+    def forward(ctx, q, K):
+        q = q.contiguous()
+        B, L, E = K.shape
+        x = torch.empty(B * L, 4 * E, dtype=torch.float32, device=q.device)
+        ops.din_concat_fwd(q, K, x)
+        ctx.save_for_backward(q, K)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        q, K = ctx.saved_tensors
+        B, L, E = K.shape
+        dq = torch.empty(B, E, dtype=torch.float32, device=q.device)
+        dK = torch.empty(B, L, E, dtype=torch.float32, device=q.device)
+        ops.din_concat_bwd(dx.contiguous(), q, K, dq, dK)
+        return dq, dK
+
+
+class _DinPoolFn(torch.autograd.Function):
+    """out[b] = sum_l w[b,l] mask[b,l] k[b,l]: target_attention.py:85-91 without softmax."""
+
+    @staticmethod
+    def forward(ctx, w, K, mask_i32):
+        w = w.contiguous()
+        B, L, E = K.shape
+        out = torch.empty(B, E, dtype=torch.float32, device=w.device)
+        ops.din_pool_fwd(w, mask_i32, K, out)
+        ctx.save_for_backward(w, K, mask_i32)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w, K, mask_i32 = ctx.saved_tensors
+        B, L, E = K.shape
+        dw = torch.empty(B, L, dtype=torch.float32, device=w.device)
+        dK = torch.empty(B, L, E, dtype=torch.float32, device=w.device)
+        ops.din_pool_bwd(w, mask_i32, K, dout.contiguous(), dw, dK)
+        return dw, dK, None
+
+
+class DIN_Attention(nn.Module):
+    """fuxictr/pytorch/layers/attentions/target_attention.py:26-92."""
+
+    def __init__(self, embedding_dim=64, attention_units=[32], hidden_activations="ReLU",
+                 output_activation=None, dropout_rate=0, batch_norm=False, use_softmax=False):
+        super(DIN_Attention, self).__init__()
+        self.embedding_dim = embedding_dim
+        self.use_softmax = use_softmax
+        if isinstance(hidden_activations, str) and hidden_activations.lower() == "dice":
+            hidden_activations = [Dice(units) for units in attention_units]
+        self.attention_layer = MLP_Block(input_dim=4 * embedding_dim, output_dim=1,
+                                         hidden_units=attention_units,
+                                         hidden_activations=hidden_activations,
+                                         output_activation=output_activation,
+                                         dropout_rates=dropout_rate, batch_norm=batch_norm)
+
+    def forward(self, target_item, history_sequence, mask=None):
+        seq_len = history_sequence.size(1)
+        attention_input = _DinConcatFn.apply(target_item, history_sequence)   # [B*L, 4E]
+        attention_weight = self.attention_layer(attention_input).view(-1, seq_len)
+        if self.use_softmax or history_sequence.size(2) > 64:
+            # softmax variant: the reference's torch formulas (not in the BASELINE configs)
+            if mask is not None:
+                attention_weight = attention_weight * mask.float()
+            if self.use_softmax:
+                if mask is not None:
+                    attention_weight = attention_weight + -1.e9 * (1 - mask.float())
+                attention_weight = attention_weight.softmax(dim=-1)
+            return (attention_weight.unsqueeze(-1) * history_sequence).sum(dim=1)
+        if mask is None:
+            m = torch.ones(attention_weight.shape, dtype=torch.int32,
+                           device=attention_weight.device)
+        else:
+            m = mask.to(torch.int32).contiguous()
+        return _DinPoolFn.apply(attention_weight, history_sequence, m)
 
 
 class _CrossNetV2Fn(torch.autograd.Function):

@@ -351,3 +351,62 @@ def cross_bwd_prep(dxn, x0, z, t, dx0, init, add_dxn):
 def sigmoid_bce(logit, y, prob=None, loss=None, dlogit=None):
     check(_lib.load().fx_sigmoid_bce(ptr(logit), ptr(y), logit.numel(), ptr(prob), ptr(loss),
                                      ptr(dlogit), stream_ptr(logit.device)), "fx_sigmoid_bce")
+
+
+# ---- DIN attention / Dice ---------------------------------------------------------------------
+def _k_strides(K):
+    """K: [B, L, E] with unit stride in E (a strided view of the gather record is fine)."""
+    if K.stride(2) != 1:
+        K = K.contiguous()
+    return K, K.stride(0), K.stride(1)
+
+
+def din_concat_fwd(q, K, out):
+    K, sb, sl = _k_strides(K)
+    B, L, E = K.shape
+    check(_lib.load().fx_din_concat_fwd(ptr(q), q.stride(0), ptr(K), sb, sl, B, L, E, ptr(out),
+                                        stream_ptr(out.device)), "fx_din_concat_fwd")
+    return out
+
+
+def din_concat_bwd(dx, q, K, dq, dK):
+    K, sb, sl = _k_strides(K)
+    B, L, E = K.shape
+    check(_lib.load().fx_din_concat_bwd(ptr(dx), ptr(q), q.stride(0), ptr(K), sb, sl, B, L, E,
+                                        ptr(dq), ptr(dK), dK.stride(0), dK.stride(1), 0,
+                                        stream_ptr(dx.device)), "fx_din_concat_bwd")
+
+
+def din_pool_fwd(w, ids, K, out):
+    K, sb, sl = _k_strides(K)
+    B, L, E = K.shape
+    check(_lib.load().fx_din_pool_fwd(ptr(w), ptr(ids), ids.stride(0), ptr(K), sb, sl, B, L, E,
+                                      ptr(out), stream_ptr(out.device)), "fx_din_pool_fwd")
+    return out
+
+
+def din_pool_bwd(w, ids, K, dout, dw, dK):
+    K, sb, sl = _k_strides(K)
+    B, L, E = K.shape
+    check(_lib.load().fx_din_pool_bwd(ptr(w), ptr(ids), ids.stride(0), ptr(K), sb, sl, ptr(dout),
+                                      B, L, E, ptr(dw), ptr(dK), dK.stride(0), dK.stride(1),
+                                      stream_ptr(dout.device)), "fx_din_pool_bwd")
+
+
+def dice_workspace_floats(H):
+    return int(_lib.load().fx_dice_workspace_floats(H))
+
+
+def dice_fwd(Z, alpha, eps, momentum, training, running_mean, running_var, stats, Y, workspace):
+    N, H = Z.shape
+    check(_lib.load().fx_dice_fwd(ptr(Z), N, H, ptr(alpha), eps, momentum, 1 if training else 0,
+                                  ptr(running_mean), ptr(running_var), ptr(stats), ptr(Y),
+                                  ptr(workspace), stream_ptr(Z.device)), "fx_dice_fwd")
+    return Y
+
+
+def dice_bwd(Z, dY, alpha, eps, training, stats, dZ, dalpha, workspace):
+    N, H = Z.shape
+    check(_lib.load().fx_dice_bwd(ptr(Z), ptr(dY), N, H, ptr(alpha), eps, 1 if training else 0,
+                                  ptr(stats), ptr(dZ), ptr(dalpha), ptr(workspace),
+                                  stream_ptr(Z.device)), "fx_dice_bwd")

@@ -8,7 +8,8 @@ layers through `fuxictr_amd.patch.install()`.
 import torch
 from torch import nn
 
-from .layers import (CrossNetV2, FactorizationMachine, FeatureEmbedding, FxLinear, MLP_Block)
+from .layers import (CrossNetV2, DIN_Attention, Dice, FactorizationMachine, FeatureEmbedding,
+                     FeatureEmbeddingDict, FxLinear, MLP_Block)
 from .rank_model import BaseModel
 
 
@@ -96,3 +97,78 @@ class DCNv2(BaseModel):
         y_pred = self.fc(final_out)
         y_pred = self.output_activation(y_pred)
         return {"y_pred": y_pred}
+
+
+def _flatten(items):
+    for x in items:
+        if isinstance(x, (list, tuple)):
+            for y in _flatten(x):
+                yield y
+        else:
+            yield x
+
+
+class DIN(BaseModel):
+    """model_zoo/DIN/src/DIN.py:50-150."""
+
+    def __init__(self, feature_map, model_id="DIN", gpu=-1, dnn_hidden_units=[512, 128, 64],
+                 dnn_activations="ReLU", attention_hidden_units=[64],
+                 attention_hidden_activations="Dice", attention_output_activation=None,
+                 attention_dropout=0, learning_rate=1e-3, embedding_dim=10, net_dropout=0,
+                 batch_norm=False, din_target_field=[("item_id", "cate_id")],
+                 din_sequence_field=[("click_history", "cate_history")], din_use_softmax=False,
+                 embedding_regularizer=None, net_regularizer=None, **kwargs):
+        super(DIN, self).__init__(feature_map, model_id=model_id, gpu=gpu,
+                                  embedding_regularizer=embedding_regularizer,
+                                  net_regularizer=net_regularizer, **kwargs)
+        if not isinstance(din_target_field, list):
+            din_target_field = [din_target_field]
+        self.din_target_field = [tuple(f) if isinstance(f, list) else f for f in din_target_field]
+        if not isinstance(din_sequence_field, list):
+            din_sequence_field = [din_sequence_field]
+        self.din_sequence_field = [tuple(f) if isinstance(f, list) else f
+                                   for f in din_sequence_field]
+        assert len(self.din_target_field) == len(self.din_sequence_field), \
+            "len(din_target_field) != len(din_sequence_field)"
+        if isinstance(dnn_activations, str) and dnn_activations.lower() == "dice":
+            dnn_activations = [Dice(units) for units in dnn_hidden_units]
+        self.feature_map = feature_map
+        self.embedding_dim = embedding_dim
+        self.embedding_layer = FeatureEmbeddingDict(feature_map, embedding_dim)
+        self.attention_layers = nn.ModuleList(
+            [DIN_Attention(embedding_dim * len(target_field) if type(target_field) == tuple
+                           else embedding_dim,
+                           attention_units=attention_hidden_units,
+                           hidden_activations=attention_hidden_activations,
+                           output_activation=attention_output_activation,
+                           dropout_rate=attention_dropout, use_softmax=din_use_softmax)
+             for target_field in self.din_target_field])
+        self.dnn = MLP_Block(input_dim=feature_map.sum_emb_out_dim(), output_dim=1,
+                             hidden_units=dnn_hidden_units, hidden_activations=dnn_activations,
+                             output_activation=self.output_activation, dropout_rates=net_dropout,
+                             batch_norm=batch_norm)
+        self.compile(kwargs["optimizer"], kwargs["loss"], learning_rate)
+        self.reset_parameters()
+        self.model_to_device()
+
+    def forward(self, inputs):
+        X = self.get_inputs(inputs)
+        feature_emb_dict = self.embedding_layer(X)
+        for idx, (target_field, sequence_field) in enumerate(zip(self.din_target_field,
+                                                                 self.din_sequence_field)):
+            target_emb = self.get_embedding(target_field, feature_emb_dict)
+            sequence_emb = self.get_embedding(sequence_field, feature_emb_dict)
+            seq_field = list(_flatten([sequence_field]))[0]
+            mask = X[seq_field].long() != 0   # padding_idx = 0 required
+            pooling_emb = self.attention_layers[idx](target_emb, sequence_emb, mask)
+            for field, field_emb in zip(list(_flatten([sequence_field])),
+                                        pooling_emb.split(self.embedding_dim, dim=-1)):
+                feature_emb_dict[field] = field_emb
+        feature_emb = self.embedding_layer.dict2tensor(feature_emb_dict, flatten_emb=True)
+        y_pred = self.dnn(feature_emb)
+        return {"y_pred": y_pred}
+
+    def get_embedding(self, field, feature_emb_dict):
+        if type(field) == tuple:
+            return torch.cat([feature_emb_dict[f] for f in field], dim=-1)
+        return feature_emb_dict[field]

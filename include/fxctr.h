@@ -294,6 +294,43 @@ int fx_cross_bwd_prep(const float* dxn, const float* x0, const float* z, float* 
 int fx_sigmoid_bce(const float* logit, const float* y, int64_t B, float* prob, float* loss,
                    float* dlogit, fx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * DIN target attention (fuxictr/pytorch/layers/attentions/target_attention.py:66-92) and Dice
+ * (fuxictr/pytorch/layers/activations.py:24-51).  The attention MLP itself runs on fx_gemm_f32;
+ * these are the pieces around it.  q: [B,E] (row stride q_ld); K: [B,L,E] addressed as
+ * K[b*k_ldb + l*k_ldl + e] (so a strided view of the gather record works); ids: the raw id
+ * columns of the sequence (mask = id != 0, DIN.py:125).
+ *   fx_din_concat_fwd : X[b*L+l, :] = [q_b, k_bl, q_b - k_bl, q_b * k_bl]            ([B*L, 4E])
+ *   fx_din_concat_bwd : dq[b,:], dK[b,l,:] from dX
+ *   fx_din_pool_fwd   : out[b,:] = sum_l w[b,l] * (ids[b,l] != 0) * k_bl
+ *   fx_din_pool_bwd   : dw[b,l], dK[b,l,:] from dout
+ *   fx_dice_fwd       : y = p z + alpha (1-p) z, p = sigmoid(BN(z)); training != 0 uses (and
+ *                       stores in stats[2H]) the batch mean / biased variance over ALL N rows and
+ *                       updates the running statistics with `momentum` (unbiased variance), like
+ *                       nn.BatchNorm1d(affine=False); training == 0 uses the running statistics
+ *   fx_dice_bwd       : dz (through the batch statistics in training mode) and dalpha[H]
+ * workspace: fx_dice_workspace_floats(H) floats.
+ * ------------------------------------------------------------------------------------------ */
+int fx_din_concat_fwd(const float* q, int64_t q_ld, const float* K, int64_t k_ldb, int64_t k_ldl,
+                      int64_t B, int32_t L, int32_t E, float* out, fx_stream_t stream);
+int fx_din_concat_bwd(const float* dx, const float* q, int64_t q_ld, const float* K, int64_t k_ldb,
+                      int64_t k_ldl, int64_t B, int32_t L, int32_t E, float* dq, float* dK,
+                      int64_t dk_ldb, int64_t dk_ldl, int32_t accumulate_dk, fx_stream_t stream);
+int fx_din_pool_fwd(const float* w, const int32_t* ids, int64_t ids_ld, const float* K,
+                    int64_t k_ldb, int64_t k_ldl, int64_t B, int32_t L, int32_t E, float* out,
+                    fx_stream_t stream);
+int fx_din_pool_bwd(const float* w, const int32_t* ids, int64_t ids_ld, const float* K,
+                    int64_t k_ldb, int64_t k_ldl, const float* dout, int64_t B, int32_t L,
+                    int32_t E, float* dw, float* dK, int64_t dk_ldb, int64_t dk_ldl,
+                    fx_stream_t stream);
+int64_t fx_dice_workspace_floats(int32_t H);
+int fx_dice_fwd(const float* Z, int64_t N, int32_t H, const float* alpha, float eps, float momentum,
+                int32_t training, float* running_mean, float* running_var, float* stats, float* Y,
+                float* workspace, fx_stream_t stream);
+int fx_dice_bwd(const float* Z, const float* dY, int64_t N, int32_t H, const float* alpha, float eps,
+                int32_t training, const float* stats, float* dZ, float* dalpha, float* workspace,
+                fx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

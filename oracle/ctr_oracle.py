@@ -113,7 +113,51 @@ def dcnv2_logit(state, features, X, n_cross, n_hidden):
     return F.linear(torch.cat([cross, dnn], dim=-1), state["fc.weight"], state["fc.bias"])
 
 
-def model_logit(cfg, state, features, X):
+def dice(state, prefix, x, training):
+    """Dice, fuxictr/pytorch/layers/activations.py:40-51: BatchNorm1d(affine=False, eps=1e-9,
+    momentum=0.01) over ALL rows (training: batch statistics, running statistics updated in place),
+    then p = sigmoid(.), y = p x + alpha (1-p) x."""
+    bn = F.batch_norm(x, state[prefix + "bn.running_mean"], state[prefix + "bn.running_var"],
+                      None, None, training, 0.01, 1e-9)
+    if training:
+        state[prefix + "bn.num_batches_tracked"] += 1
+    p = torch.sigmoid(bn)
+    return p * x + state[prefix + "alpha"] * (1 - p) * x
+
+
+def din_attention(state, prefix, target, seq, mask, training):
+    """DIN_Attention.forward (use_softmax=False), target_attention.py:66-92; the attention MLP is
+    Linear(4E,H) -> Dice(H) -> Linear(H,1) (mlp.0 / mlp.1 / mlp.2)."""
+    L = seq.size(1)
+    E = target.size(-1)
+    t = target.unsqueeze(1).expand(-1, L, -1)
+    x = torch.cat([t, seq, t - seq, t * seq], dim=-1).view(-1, 4 * E)
+    h = F.linear(x, state[prefix + "attention_layer.mlp.0.weight"],
+                 state[prefix + "attention_layer.mlp.0.bias"])
+    h = dice(state, prefix + "attention_layer.mlp.1.", h, training)
+    w = F.linear(h, state[prefix + "attention_layer.mlp.2.weight"],
+                 state[prefix + "attention_layer.mlp.2.bias"]).view(-1, L)
+    w = w * mask.float()
+    return (w.unsqueeze(-1) * seq).sum(dim=1)
+
+
+DIN_EMB = "embedding_layer.embedding_layers."
+
+
+def din_logit(state, features, X, cfg, training):
+    """DIN.forward, model_zoo/DIN/src/DIN.py:109-133 (single-name target / sequence fields)."""
+    emb = feature_embedding(state, DIN_EMB, features, X)
+    for idx, (tf, sf) in enumerate(zip(cfg["din_target_field"], cfg["din_sequence_field"])):
+        mask = X[sf].long() != 0
+        emb[sf] = din_attention(state, "attention_layers.%d." % idx, emb[tf], emb[sf], mask,
+                                training)
+    x = dict2tensor(features, emb, flatten_emb=True)
+    return mlp_block(state, "dnn.", x, cfg["n_hidden"], True)
+
+
+def model_logit(cfg, state, features, X, training=False):
+    if cfg["model"] == "DIN":
+        return din_logit(state, features, X, cfg, training)
     if cfg["model"] == "DeepFM":
         return deepfm_logit(state, features, X, cfg["n_hidden"])
     if cfg["model"] == "DCNv2":
@@ -167,18 +211,23 @@ class OracleTrainer(object):
         self.state = OrderedDict()
         # share_embedding (feature_embedding.py:149-151): in the main table dict the sharing
         # feature's key is the SAME Parameter as its target's key
-        alias = {EMB + f + ".weight": EMB + spec["share_embedding"] + ".weight"
-                 for f, spec in features.items() if spec.get("share_embedding")}
+        alias = {}
+        for pre in (EMB, DIN_EMB):
+            alias.update({pre + f + ".weight": pre + spec["share_embedding"] + ".weight"
+                          for f, spec in features.items() if spec.get("share_embedding")})
         for k, t in state.items():
             if k in alias and alias[k] in self.state:
                 self.state[k] = self.state[alias[k]]
                 continue
             t = torch.as_tensor(t)
+            if "running_" in k or "num_batches_tracked" in k:      # BatchNorm buffers
+                self.state[k] = t.detach().clone()
+                continue
             self.state[k] = t.detach().clone().float().requires_grad_(True)
         self.params = []
         seen = set()
         for t in self.state.values():
-            if id(t) not in seen:
+            if id(t) not in seen and t.requires_grad:
                 seen.add(id(t))
                 self.params.append(t)
         self.m = [torch.zeros_like(p) for p in self.params]
@@ -188,7 +237,7 @@ class OracleTrainer(object):
     def train_step(self, X, y):
         for p in self.params:
             p.grad = None                                   # optimizer.zero_grad()
-        prob = torch.sigmoid(model_logit(self.cfg, self.state, self.features, X))
+        prob = torch.sigmoid(model_logit(self.cfg, self.state, self.features, X, training=True))
         loss = bce_mean(prob, y.float().view(-1, 1))
         loss.backward()                                     # dense [V, D] embedding grads
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]

@@ -294,6 +294,72 @@ def sigmoid_bce(logit, y, prob=None, loss=None, dlogit=None):
         dlogit.copy_((p - y) / torch.clamp((1 - p) * p, min=1e-12) / logit.numel() * (p * (1 - p)))
 
 
+def din_concat_fwd(q, K, out):
+    B, L, E = K.shape
+    t = q.unsqueeze(1).expand(-1, L, -1)
+    out.copy_(torch.cat([t, K, t - K, t * K], dim=-1).reshape(B * L, 4 * E))
+    return out
+
+
+def din_concat_bwd(dx, q, K, dq, dK):
+    B, L, E = K.shape
+    d = dx.view(B, L, 4, E)
+    dq.copy_((d[:, :, 0] + d[:, :, 2] + d[:, :, 3] * K).sum(1))
+    dK.copy_(d[:, :, 1] - d[:, :, 2] + d[:, :, 3] * q.unsqueeze(1))
+
+
+def din_pool_fwd(w, ids, K, out):
+    out.copy_(((w * (ids != 0).float()).unsqueeze(-1) * K).sum(1))
+    return out
+
+
+def din_pool_bwd(w, ids, K, dout, dw, dK):
+    m = (ids != 0).float()
+    dw.copy_(m * (dout.unsqueeze(1) * K).sum(-1))
+    dK.copy_((w * m).unsqueeze(-1) * dout.unsqueeze(1))
+
+
+def dice_workspace_floats(H):
+    return 64 * 3 * H
+
+
+def _dice_stats(Z, training, running_mean, running_var, momentum, stats, update):
+    H = Z.shape[1]
+    if training:
+        mean = Z.double().mean(0)
+        var = Z.double().var(0, unbiased=False)
+        if update:
+            N = Z.shape[0]
+            running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+            running_var.mul_(1 - momentum).add_(momentum * (var * N / max(N - 1, 1)).float())
+        stats[:H] = mean.float()
+        stats[H:] = var.float()
+    else:
+        stats[:H] = running_mean
+        stats[H:] = running_var
+
+
+def dice_fwd(Z, alpha, eps, momentum, training, running_mean, running_var, stats, Y, workspace):
+    H = Z.shape[1]
+    _dice_stats(Z, training, running_mean, running_var, momentum, stats, True)
+    zh = (Z - stats[:H]) / torch.sqrt(stats[H:] + eps)
+    p = torch.sigmoid(zh)
+    Y.copy_(p * Z + alpha * (1 - p) * Z)
+    return Y
+
+
+def dice_bwd(Z, dY, alpha, eps, training, stats, dZ, dalpha, workspace):
+    N, H = Z.shape
+    rstd = 1.0 / torch.sqrt(stats[H:] + eps)
+    zh = (Z - stats[:H]) * rstd
+    p = torch.sigmoid(zh)
+    dalpha.copy_((dY * (1 - p) * Z).sum(0))
+    dzh = dY * Z * (1 - alpha) * p * (1 - p)
+    if training:
+        dzh = dzh - dzh.mean(0) - zh * (dzh * zh).mean(0)
+    dZ.copy_(dY * (p + alpha * (1 - p)) + dzh * rstd)
+
+
 class KernelTimer(object):
     enabled = False
 
@@ -303,7 +369,8 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "emb_numeric_grad", "opt_begin_step", "clip_coef", "sparse_adam", "adam_catchup",
          "sparse_sgd", "mt_sqnorm", "mt_adam", "mt_sgd", "fm_fwd", "fm_bwd", "lr_fwd", "gemm",
          "colsum", "mask_mul", "cross_bwd_prep", "sigmoid_bce", "shard_plan", "scatter_rows",
-         "sum_parts"]
+         "sum_parts", "din_concat_fwd", "din_concat_bwd", "din_pool_fwd", "din_pool_bwd",
+         "dice_workspace_floats", "dice_fwd", "dice_bwd"]
 
 
 def install_plain():

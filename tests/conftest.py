@@ -44,7 +44,8 @@ class Golden(object):
 
     def cfg(self):
         m = self.meta
-        return {"model": m["model"], "n_hidden": len(m["hidden"]), "n_cross": m.get("n_cross", 0)}
+        return {"model": m["model"], "n_hidden": len(m["hidden"]), "n_cross": m.get("n_cross", 0),
+                "din_target_field": ["adgroup_id"], "din_sequence_field": ["click_sequence"]}
 
 
 def assert_weights_close(got, ref, lr, steps, name, tol=2e-5):
@@ -59,7 +60,8 @@ def assert_weights_close(got, ref, lr, steps, name, tol=2e-5):
     assert float(err.max()) <= lr * steps + tol, (name, float(err.max()))
 
 
-GOLDEN_CASES = ["deepfm_adam", "deepfm_adam_clip", "deepfm_sgd", "deepfm_d10", "dcnv2_adam"]
+GOLDEN_CASES = ["deepfm_adam", "deepfm_adam_clip", "deepfm_sgd", "deepfm_d10", "dcnv2_adam",
+                "din_adam"]
 
 
 @pytest.fixture(params=GOLDEN_CASES)

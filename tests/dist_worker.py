@@ -34,6 +34,11 @@ def run(rank, world, case, port, out_path, use_gpu):
                   model_root="/tmp/fx_dist_%d" % rank, shard="row")
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=case, hidden_units=m["hidden"], **common)
+    elif m["model"] == "DIN":
+        model = zoo.DIN(fmap, model_id=case, dnn_hidden_units=m["hidden"],
+                        dnn_activations="relu", attention_hidden_units=m["att_hidden"],
+                        attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
+                        din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
     else:
         model = zoo.DCNv2(fmap, model_id=case, model_structure="parallel",
                           num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"],

@@ -38,6 +38,22 @@ def small_criteo_spec(dataset_id, n_dense, cards):
             "input_length": len(feats), "labels": ["label"], "features": feats}
 
 
+def small_seq_spec(dataset_id, L=6):
+    """tiny_seq-like schema: a sequence feature sharing the item table, padding_idx 0."""
+    feats = [
+        {"price": {"source": "item", "type": "numeric"}},
+        {"userid": {"source": "user", "type": "categorical", "padding_idx": 0, "vocab_size": 301}},
+        {"adgroup_id": {"source": "item", "type": "categorical", "padding_idx": 0, "vocab_size": 97}},
+        {"cate_id": {"source": "item", "type": "categorical", "padding_idx": 0, "vocab_size": 23}},
+        {"pid": {"source": "context", "type": "categorical", "padding_idx": 0, "vocab_size": 4}},
+        {"click_sequence": {"source": "user", "type": "sequence", "feature_encoder": None,
+                            "share_embedding": "adgroup_id", "padding_idx": 0, "vocab_size": 97,
+                            "max_len": L}},
+    ]
+    return {"dataset_id": dataset_id, "num_fields": len(feats), "total_features": 0,
+            "input_length": 0, "labels": ["label"], "features": feats}
+
+
 def make_batches(rng, spec, B, n, pad_frac=0.02):
     import numpy as np
     batches = []
@@ -47,6 +63,12 @@ def make_batches(rng, spec, B, n, pad_frac=0.02):
             (name, fs), = item.items()
             if fs["type"] == "numeric":
                 b[name] = rng.random(B, dtype=np.float32)
+            elif fs["type"] == "sequence":
+                card, L = fs["vocab_size"] - 1, fs["max_len"]
+                ids = rng.integers(1, card + 1, size=(B, L)).astype(np.int64)
+                lens = rng.integers(0, L + 1, size=B)          # post-padded with 0, some empty
+                ids[np.arange(L)[None, :] >= lens[:, None]] = 0
+                b[name] = ids
             else:
                 card = fs["vocab_size"] - 1
                 ids = np.floor(card * rng.random(B) ** 3).astype(np.int64) + 1
@@ -64,7 +86,10 @@ def run_case(case):
     from fuxictr.features import FeatureMap
     from fuxictr.pytorch.torch_utils import seed_everything
     name = case["name"]
-    spec = small_criteo_spec(name, case["n_dense"], case["cards"])
+    if case["model"] == "DIN":
+        spec = small_seq_spec(name)
+    else:
+        spec = small_criteo_spec(name, case["n_dense"], case["cards"])
     os.makedirs(os.path.join(TMP, name), exist_ok=True)
     fm_path = os.path.join(TMP, name, "feature_map.json")
     with open(fm_path, "w") as f:
@@ -80,6 +105,12 @@ def run_case(case):
     if case["model"] == "DeepFM":
         from model_zoo.DeepFM.DeepFM_torch.src import DeepFM
         model = DeepFM(fmap, model_id=name, hidden_units=case["hidden"], **common)
+    elif case["model"] == "DIN":
+        from model_zoo import DIN
+        model = DIN(fmap, model_id=name, dnn_hidden_units=case["hidden"], dnn_activations="relu",
+                    attention_hidden_units=case["att_hidden"],
+                    attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
+                    din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
     else:
         from model_zoo import DCNv2
         model = DCNv2(fmap, model_id=name, model_structure="parallel",
@@ -96,6 +127,11 @@ def run_case(case):
     model._max_gradient_norm = case["max_norm"]          # what fit() would set (rank_model.py:251)
     logits = []
     model.output_activation.register_forward_pre_hook(lambda m, inp: logits.append(inp[0].detach().clone()))
+    if case["model"] == "DIN":       # make the Dice gate and its alpha non-trivial
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if k.endswith(".alpha"):
+                    p.uniform_(-0.5, 0.5)
     rng = np.random.default_rng(case["seed"])
     batches = make_batches(rng, spec, case["B"], case["steps"] + 1)
     out = {}
@@ -150,6 +186,8 @@ CASES = [
     dict(name="deepfm_d10", model="DeepFM", n_dense=3, cards=CARDS[:9], embedding_dim=10,
          hidden=[48], B=100, steps=3, lr=1e-2, optimizer="adam", max_norm=10.0, seed=3,
          emb_scale=1000.0, lr_scale=1000.0),
+    dict(name="din_adam", model="DIN", embedding_dim=8, hidden=[32, 16], att_hidden=[16], B=160,
+         steps=5, lr=1e-2, optimizer="adam", max_norm=10.0, seed=5, emb_scale=1000.0),
     dict(name="dcnv2_adam", model="DCNv2", n_dense=5, cards=CARDS, embedding_dim=8,
          hidden=[64, 32], n_cross=3, B=192, steps=5, lr=1e-2, optimizer="adam", max_norm=10.0,
          seed=2019, emb_scale=1000.0),

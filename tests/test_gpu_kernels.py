@@ -467,3 +467,78 @@ def test_colsum_mask_cross_prep_bce():
     assert (dl.cpu() - logit.grad).abs().max().item() <= 1e-9 + 2e-6 * logit.grad.abs().max().item()
     ops.sigmoid_bce(_dev(logit.detach()), None, prob=prob)
     assert (prob.cpu() - p_ref.detach()).abs().max().item() <= 2e-7
+
+
+# ---- DIN attention pieces and Dice -----------------------------------------------------------
+def _seq_inputs(B=333, L=7, E=16, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, E, generator=g)
+    rec = torch.randn(B, L + 3, E, generator=g)        # K is a strided view of a wider record
+    K = rec[:, 2:2 + L, :]
+    ids = torch.randint(0, 4, (B, L), generator=g).int()
+    return q, rec, K, ids
+
+
+def test_din_concat_and_pool_match_autograd():
+    q, rec, K, ids = _seq_inputs()
+    B, L, E = K.shape
+    dq_, drec = _dev(q), _dev(rec)
+    dK_ = drec[:, 2:2 + L, :]
+    x = torch.empty(B * L, 4 * E, device=DEV)
+    ops.din_concat_fwd(dq_, dK_, x)
+    qr, Kr = q.clone().requires_grad_(True), K.clone().requires_grad_(True)
+    t = qr.unsqueeze(1).expand(-1, L, -1)
+    ref = torch.cat([t, Kr, t - Kr, t * Kr], dim=-1).view(B * L, 4 * E)
+    assert torch.equal(x.cpu(), ref.detach())
+    gx = torch.randn(B * L, 4 * E, generator=torch.Generator().manual_seed(1))
+    ref.backward(gx)
+    dq = torch.empty(B, E, device=DEV)
+    dK = torch.empty(B, L, E, device=DEV)
+    ops.din_concat_bwd(_dev(gx), dq_, dK_, dq, dK)
+    assert (dq.cpu() - qr.grad).abs().max().item() <= 1e-5
+    assert (dK.cpu() - Kr.grad).abs().max().item() <= 1e-5
+    # pooling
+    w = torch.randn(B, L, generator=torch.Generator().manual_seed(2))
+    out = torch.empty(B, E, device=DEV)
+    ops.din_pool_fwd(_dev(w), _dev(ids), dK_, out)
+    wr, Kr2 = w.clone().requires_grad_(True), K.clone().requires_grad_(True)
+    refo = ((wr * (ids != 0).float()).unsqueeze(-1) * Kr2).sum(1)
+    assert (out.cpu() - refo.detach()).abs().max().item() <= 1e-5
+    go = torch.randn(B, E, generator=torch.Generator().manual_seed(3))
+    refo.backward(go)
+    dw = torch.empty(B, L, device=DEV)
+    dK2 = torch.empty(B, L, E, device=DEV)
+    ops.din_pool_bwd(_dev(w), _dev(ids), dK_, _dev(go), dw, dK2)
+    assert (dw.cpu() - wr.grad).abs().max().item() <= 1e-5
+    assert (dK2.cpu() - Kr2.grad).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("N,H", [(20480, 64), (777, 16), (5, 100)])
+def test_dice_matches_reference_batchnorm_gate(training, N, H):
+    g = torch.Generator().manual_seed(N + H)
+    z = (torch.randn(N, H, generator=g) * 1.5 + 0.3)
+    alpha = torch.rand(H, generator=g) - 0.5
+    rm0 = torch.randn(H, generator=g) * 0.1
+    rv0 = torch.rand(H, generator=g) + 0.5
+    state = {"p.bn.running_mean": rm0.clone(), "p.bn.running_var": rv0.clone(),
+             "p.bn.num_batches_tracked": torch.zeros((), dtype=torch.long),
+             "p.alpha": alpha.clone().requires_grad_(True)}
+    zr = z.clone().requires_grad_(True)
+    ref = O.dice(state, "p.", zr, training)
+    gy = torch.randn(N, H, generator=g)
+    ref.backward(gy)
+    rm, rv = _dev(rm0), _dev(rv0)
+    stats = torch.empty(2 * H, device=DEV)
+    y = torch.empty(N, H, device=DEV)
+    ws = torch.empty(ops.dice_workspace_floats(H), device=DEV)
+    ops.dice_fwd(_dev(z), _dev(alpha), 1e-9, 0.01, training, rm, rv, stats, y, ws)
+    assert (y.cpu() - ref.detach()).abs().max().item() <= 2e-5
+    assert (rm.cpu() - state["p.bn.running_mean"]).abs().max().item() <= 1e-6
+    assert (rv.cpu() - state["p.bn.running_var"]).abs().max().item() <= 1e-5
+    dz = torch.empty(N, H, device=DEV)
+    da = torch.empty(H, device=DEV)
+    ops.dice_bwd(_dev(z), _dev(gy), _dev(alpha), 1e-9, training, stats, dz, da, ws)
+    scale = max(1.0, zr.grad.abs().max().item())
+    assert (dz.cpu() - zr.grad).abs().max().item() <= 5e-5 * scale
+    assert (da.cpu() - state["p.alpha"].grad).abs().max().item() <= 2e-4 * max(1.0, state["p.alpha"].grad.abs().max().item())

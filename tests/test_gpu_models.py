@@ -32,6 +32,11 @@ def build_native(g, tmp_path, sparse_update="exact", optimizer=None, hip_graph=F
                   sparse_update=sparse_update, hip_graph=hip_graph)
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"], **common)
+    elif m["model"] == "DIN":
+        model = zoo.DIN(fmap, model_id=m["name"], dnn_hidden_units=m["hidden"],
+                        dnn_activations="relu", attention_hidden_units=m["att_hidden"],
+                        attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
+                        din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
     else:
         model = zoo.DCNv2(fmap, model_id=m["name"], model_structure="parallel",
                           num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"],

@@ -26,6 +26,11 @@ def _build(g, tmp_path, monkeypatch, sparse_update="exact"):
                   model_root=str(tmp_path), sparse_update=sparse_update)
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"], **common)
+    elif m["model"] == "DIN":
+        model = zoo.DIN(fmap, model_id=m["name"], dnn_hidden_units=m["hidden"],
+                        dnn_activations="relu", attention_hidden_units=m["att_hidden"],
+                        attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
+                        din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
     else:
         model = zoo.DCNv2(fmap, model_id=m["name"], model_structure="parallel",
                           num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"],
