@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
-    ap.add_argument("--model", default="DeepFM", choices=["DeepFM", "DCNv2"])
+    ap.add_argument("--model", default="DeepFM", choices=["DeepFM", "DCNv2", "DIN"])
     ap.add_argument("--dist", default="powerlaw", choices=["powerlaw", "uniform"])
     ap.add_argument("--sparse-update", default="exact", choices=["exact", "lazy"])
     ap.add_argument("--vocab-scale", type=float, default=1.0, help="debug: shrink the tables")
@@ -51,7 +51,10 @@ def parse():
 
 def build_model(args, device_index, cards, shard=None):
     from fuxictr_amd import synthetic, zoo
-    fmap, spec = synthetic.criteo_feature_map(cards=cards, embedding_dim=16)
+    if args.model == "DIN":
+        fmap, spec = synthetic.taobao_feature_map(embedding_dim=16, scale=args.vocab_scale)
+    else:
+        fmap, spec = synthetic.criteo_feature_map(cards=cards, embedding_dim=16)
     common = dict(gpu=device_index, embedding_dim=16, learning_rate=1e-3, optimizer="adam",
                   loss="binary_crossentropy", task="binary_classification",
                   metrics=["logloss", "AUC"], verbose=0, model_root="/tmp/fx_bench",
@@ -59,6 +62,11 @@ def build_model(args, device_index, cards, shard=None):
     torch.manual_seed(2019)
     if args.model == "DeepFM":
         model = zoo.DeepFM(fmap, model_id="bench", hidden_units=[1024] * 4, **common)
+    elif args.model == "DIN":
+        model = zoo.DIN(fmap, model_id="bench", dnn_hidden_units=[512, 128, 64],
+                        dnn_activations="relu", attention_hidden_units=[64],
+                        attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
+                        din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
     else:
         model = zoo.DCNv2(fmap, model_id="bench", model_structure="parallel", num_cross_layers=3,
                           parallel_dnn_hidden_units=[1024] * 4, **common)
@@ -194,7 +202,10 @@ def main():
     n_pool = 8
     pool = []
     for _ in range(n_pool):
-        b = synthetic.criteo_batch(rng, args.batch, cards=cards, dist=args.dist)
+        if args.model == "DIN":
+            b = synthetic.taobao_batch(rng, args.batch, spec, dist=args.dist)
+        else:
+            b = synthetic.criteo_batch(rng, args.batch, cards=cards, dist=args.dist)
         pool.append({k: torch.from_numpy(v).to(dev) for k, v in b.items()})
 
     def sync():
@@ -249,9 +260,15 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %s on synthetic Criteo (26 sparse + 13 dense, "
-                                   "%d rows, emb_dim 16, MLP 4x1024), Adam, full training step"
-                                   % (args.model, sum(cards) + len(cards)),
+            "config": {"workload": ("configs[3]: DIN on synthetic Taobao-shape sequences (14 "
+                                    "categorical + click_sequence len 50 sharing adgroup_id, "
+                                    "emb_dim 16, attention [64] Dice, dnn [512,128,64]), Adam, "
+                                    "full training step") if args.model == "DIN" else
+                                   "configs[%d]: %s on synthetic Criteo (26 sparse + 13 dense, "
+                                   "%d rows, emb_dim 16, MLP 4x1024%s), Adam, full training step"
+                                   % (1 if args.model == "DeepFM" else 2, args.model,
+                                      sum(cards) + len(cards),
+                                      ", 3 cross layers" if args.model == "DCNv2" else ""),
                        "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "id_distribution": args.dist, "sparse_update": args.sparse_update,
                        "launch": "hipGraph replay" if model._use_graph else "eager",
@@ -265,8 +282,7 @@ def main():
                                "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                                "traffic": None, "launches": g["launches"],
                                "avg_launch_us": g["avg_us"], "timing": timing_mode,
-                               "gemm_us_per_step": 1e3 * g["total_ms"] * 15.0 / g["launches"]
-                               if args.model == "DeepFM" else None}
+                               "gemm_share_of_instrumented_step": None}
         e = ktimes.get("k_emb_gather_fwd")
         if e and e["total_ms"] > 0:
             ach = e["work"] / (e["total_ms"] * 1e-3) / 1e9
@@ -274,7 +290,7 @@ def main():
                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": ach / PEAK_HBM_GBS, "traffic": None,
                                       "launches": e["launches"], "avg_launch_us": e["avg_us"]}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model != "DIN":
             del pool
             out["cpu_baseline"] = cpu_baseline(args, cards, args.cpu_baseline_steps)
         print(json.dumps(out), flush=True)

@@ -44,3 +44,48 @@ def criteo_batch(rng, B, cards=None, n_dense=13, dist="powerlaw", label_rate=0.2
         out["C%d" % (c + 1)] = np.minimum(ids, card)
     out["label"] = (rng.random(B) < label_rate).astype(np.float32)
     return out
+
+
+# Taobao-ad-shaped sequence data for DIN (BASELINE config c4)
+TAOBAO_CARDS = [("userid", 1141729), ("adgroup_id", 846811), ("pid", 2), ("cate_id", 6769),
+                ("campaign_id", 423436), ("customer", 255875), ("brand", 99815),
+                ("cms_segid", 97), ("cms_group_id", 13), ("final_gender_code", 2),
+                ("age_level", 7), ("pvalue_level", 4), ("shopping_level", 3), ("occupation", 2)]
+
+
+def taobao_feature_map(max_len=50, embedding_dim=16, dataset_id="synthetic_taobao", scale=1.0):
+    feats = []
+    for name, card in TAOBAO_CARDS:
+        card = max(2, int(card * scale))
+        feats.append({name: {"source": "", "type": "categorical", "padding_idx": 0,
+                             "vocab_size": card + 1}})
+    item_card = max(2, int(dict(TAOBAO_CARDS)["adgroup_id"] * scale))
+    feats.append({"click_sequence": {"source": "", "type": "sequence", "feature_encoder": None,
+                                     "share_embedding": "adgroup_id", "padding_idx": 0,
+                                     "vocab_size": item_card + 1, "max_len": max_len}})
+    spec = {"dataset_id": dataset_id, "num_fields": len(feats), "total_features": 0,
+            "input_length": 0, "labels": ["label"], "features": feats}
+    fmap = FeatureMap(dataset_id, data_dir="")
+    fmap.load_dict(spec, {"embedding_dim": embedding_dim})
+    return fmap, spec
+
+
+def taobao_batch(rng, B, spec, dist="powerlaw", label_rate=0.05):
+    out = {}
+    for item in spec["features"]:
+        (name, fs), = item.items()
+        card = fs["vocab_size"] - 1
+        if fs["type"] == "sequence":
+            L = fs["max_len"]
+            u = rng.random((B, L))
+            ids = (np.floor(card * u ** 3) if dist == "powerlaw" else np.floor(card * u))
+            ids = np.minimum(ids.astype(np.int64) + 1, card)
+            lens = rng.integers(1, L + 1, size=B)
+            ids[np.arange(L)[None, :] >= lens[:, None]] = 0      # post-padded with 0
+            out[name] = ids
+        else:
+            u = rng.random(B)
+            ids = (np.floor(card * u ** 3) if dist == "powerlaw" else np.floor(card * u))
+            out[name] = np.minimum(ids.astype(np.int64) + 1, card)
+    out["label"] = (rng.random(B) < label_rate).astype(np.float32)
+    return out
