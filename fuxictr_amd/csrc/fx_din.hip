@@ -12,7 +12,7 @@
 // All reductions are two-stage with a fixed order (deterministic).
 #include "fx_common.h"
 
-#define FX_STAT_CHUNKS 64
+#define FX_STAT_CHUNKS 512
 
 // ---------------------------------------------------------------------------------------------
 // attention input [B*L, 4E] and its backward

@@ -311,10 +311,16 @@ __global__ __launch_bounds__(256) void k_gemm_small_n(GemmArgs a, int tb) {
     }
 }
 
-// M <= 4, A stored [K,M], B stored [K,N]: thread per column n, K split over blockIdx.y into
-// workspace slabs (reduced, with the epilogue, by k_splitk_reduce)
-__global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs a) {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// M <= 4, A stored [K,M], B stored [K,N]: Np = min(256, pow2 >= N) column lanes x 256/Np row lanes
+// per workgroup, K split over blockIdx.y into workspace slabs (reduced, with the epilogue, by
+// k_splitk_reduce).  Narrow outputs (the 64 -> 1 head of the DIN attention MLP has N = 64 and
+// K = B*L = 204800) keep all 256 lanes busy through the row lanes.
+__global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs a, int np_log2) {
+    __shared__ float red[4][256];
+    const int Np = 1 << np_log2;
+    const int tx = threadIdx.x & (Np - 1), ty = threadIdx.x >> np_log2;
+    const int lanes = 256 >> np_log2;
+    const int64_t n = (int64_t)blockIdx.x * Np + tx;
     const int z = blockIdx.y;
     const int64_t kbeg = (int64_t)z * a.k_chunk;
     const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
@@ -323,15 +329,27 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs a) {
         for (int64_t k = kbeg; k < kend; ++k) r += a.A[k * a.lda + threadIdx.x];
         a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + threadIdx.x] = r;
     }
-    if (n >= a.N) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t k = kbeg; k < kend; ++k) {
-        const float b = a.B[k * a.ldb + n];
+    if (n < a.N) {
+        for (int64_t k = kbeg + ty; k < kend; k += lanes) {
+            const float b = a.B[k * a.ldb + n];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if (m < a.M) acc[m] = fmaf(a.A[k * a.lda + m], b, acc[m]);
+            for (int m = 0; m < 4; ++m)
+                if (m < a.M) acc[m] = fmaf(a.A[k * a.lda + m], b, acc[m]);
+        }
     }
-    for (int m = 0; m < a.M; ++m) a.ws[((int64_t)z * a.M + m) * a.N + n] = acc[m];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) red[m][threadIdx.x] = acc[m];
+    __syncthreads();
+    for (int s2 = lanes >> 1; s2 > 0; s2 >>= 1) {
+        if (ty < s2) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) red[m][threadIdx.x] += red[m][threadIdx.x + (s2 << np_log2)];
+        }
+        __syncthreads();
+    }
+    if (ty == 0 && n < a.N)
+        for (int m = 0; m < a.M; ++m) a.ws[((int64_t)z * a.M + m) * a.N + n] = red[m][tx];
 }
 
 // vectorised M <= 4 variant (N % 4 == 0, 16-B aligned B rows): 64 float4 column groups x 4 row
@@ -448,6 +466,8 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
         else if (forced == 0 && fx_ceil_div(M, 128) * fx_ceil_div(N, 128) * split_k < want) {
             bm = 64;
             bn = 64;
+        } else if (forced == 0 && N <= 64) {
+            bn = 64;   // e.g. the DIN attention MLP: 204800 x 64 x 64 — do not pad N to 128
         }
     }
     a.tiles_m = (int32_t)fx_ceil_div(M, bm);
@@ -481,17 +501,19 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
         if (kc2 < 1) kc2 = 1;
         a.k_chunk = kc2;
         a.split_k = (int32_t)fx_ceil_div(K, kc2);
-        const bool v4 = (N % 4 == 0) && (ldb % 4 == 0) &&
+        const bool v4 = (N >= 256) && (N % 4 == 0) && (ldb % 4 == 0) &&
                         ((reinterpret_cast<uintptr_t>(B) & 15) == 0) &&
                         ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
+        int np_log2 = 0;
+        while ((1 << np_log2) < N && np_log2 < 8) ++np_log2;
         if (v4)
             hipLaunchKernelGGL(k_gemm_small_m_v4,
                                dim3((unsigned)fx_ceil_div(N, 256), (unsigned)a.split_k), dim3(256),
                                0, s, a);
         else
             hipLaunchKernelGGL(k_gemm_small_m,
-                               dim3((unsigned)fx_ceil_div(N, 256), (unsigned)a.split_k), dim3(256),
-                               0, s, a);
+                               dim3((unsigned)fx_ceil_div(N, 1 << np_log2), (unsigned)a.split_k),
+                               dim3(256), 0, s, a, np_log2);
         FX_CHECK_LAUNCH();
         int64_t blocks = fx_ceil_div(M * N, 256);
         if (blocks > 2048) blocks = 2048;

@@ -714,10 +714,39 @@ class FeatureEmbeddingDict(nn.Module):
         fast = self._record_slice(embedding_dict, names)
         if fast is not None:
             return fast.flatten(start_dim=1) if flatten_emb else fast
-        tensors = [embedding_dict[f] for f in names]
         if flatten_emb:
-            return torch.cat(tensors, dim=-1)
-        return torch.stack(tensors, dim=1)
+            return torch.cat(self._merged_runs(embedding_dict, names), dim=-1)
+        return torch.stack([embedding_dict[f] for f in names], dim=1)
+
+    @staticmethod
+    def _merged_runs(embedding_dict, names):
+        """Pieces to concatenate for flatten_emb: consecutive untouched [B,D] views of the gather
+        record are taken as ONE slice of it (one view-backward instead of one per feature — DIN
+        replaces only its sequence entries, the other 14 fields stay one run)."""
+        records = getattr(embedding_dict, "_records", None)
+        if not records or len(records) != 1:
+            return [embedding_dict[f] for f in names]
+        rec, plan = records[0]
+        pieces, run = [], None          # run = [lo, hi)
+        def flush():
+            if run is not None:
+                pieces.append(rec[:, run[0]:run[1], :].flatten(start_dim=1))
+        for f in names:
+            ok = (f in plan.slot and plan.slot[f][1] == 1 and f not in embedding_dict._encoded
+                  and embedding_dict._orig.get(f) == id(embedding_dict[f]))
+            if ok:
+                s0 = plan.slot[f][0]
+                if run is not None and run[1] == s0:
+                    run[1] = s0 + 1
+                else:
+                    flush()
+                    run = [s0, s0 + 1]
+            else:
+                flush()
+                run = None
+                pieces.append(embedding_dict[f])
+        flush()
+        return pieces
 
     @staticmethod
     def _record_slice(embedding_dict, names):
@@ -974,7 +1003,7 @@ def _split_k_for(M, N, K):
     """Split the contraction when the output grid alone cannot fill 256 CUs (weight gradients):
     aim for ~512 workgroups of 64x64 (2 per CU); every extra split costs a partial-slab round trip."""
     if M <= 4:                      # skinny weight gradient: column-parallel reduction kernel
-        return max(1, min(64, K // 64))
+        return max(1, min(512 if N <= 256 else 64, K // 128))
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     if tiles >= 448:
         return 1
