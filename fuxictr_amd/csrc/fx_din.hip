@@ -12,7 +12,7 @@
 // All reductions are two-stage with a fixed order (deterministic).
 #include "fx_common.h"
 
-#define FX_STAT_CHUNKS 512
+#define FX_STAT_CHUNKS 256
 
 // ---------------------------------------------------------------------------------------------
 // attention input [B*L, 4E] and its backward
@@ -235,19 +235,31 @@ __global__ __launch_bounds__(256) void k_dice_reduce(const float* Z, const float
     }
 }
 
+// fixed-order sum over the chunks of one term: 64 columns x 4 chunk lanes per workgroup
+__device__ __forceinline__ float fx_chunk_sum(const float* partial, int nt, int k, int chunks,
+                                              int H, int h, int ty, float* red /*[256]*/) {
+    float s = 0.f;
+    if (h < H)
+        for (int c = ty; c < chunks; c += 4) s += partial[((int64_t)c * nt + k) * H + h];
+    const int tx = threadIdx.x & 63;
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    return (red[tx] + red[tx + 64]) + (red[tx + 128] + red[tx + 192]);
+}
+
 // stage 2 of the forward statistics: mean / biased var -> stats; running stats updated like
 // nn.BatchNorm1d(momentum) (unbiased variance N/(N-1) into running_var)
 __global__ __launch_bounds__(256) void k_dice_stats_final(const float* partial, int chunks, int H,
                                                           int64_t N, float momentum, float* stats,
                                                           float* running_mean,
                                                           float* running_var) {
-    const int h = blockIdx.x * 256 + threadIdx.x;
-    if (h >= H) return;
-    double s = 0.0, ss = 0.0;
-    for (int c = 0; c < chunks; ++c) {
-        s += (double)partial[((int64_t)c * 2 + 0) * H + h];
-        ss += (double)partial[((int64_t)c * 2 + 1) * H + h];
-    }
+    __shared__ float red[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int h = blockIdx.x * 64 + tx;
+    const double s = (double)fx_chunk_sum(partial, 2, 0, chunks, H, h, ty, red);
+    const double ss = (double)fx_chunk_sum(partial, 2, 1, chunks, H, h, ty, red);
+    if (ty != 0 || h >= H) return;
     const double mean = s / (double)N;
     double var = ss / (double)N - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -262,12 +274,12 @@ __global__ __launch_bounds__(256) void k_dice_stats_final(const float* partial, 
 
 __global__ __launch_bounds__(256) void k_dice_bwd_final(const float* partial, int chunks, int H,
                                                         float* sums) {
-    const int h = blockIdx.x * 256 + threadIdx.x;
-    if (h >= H) return;
+    __shared__ float red[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int h = blockIdx.x * 64 + tx;
     for (int k = 0; k < 3; ++k) {
-        float s = 0.f;
-        for (int c = 0; c < chunks; ++c) s += partial[((int64_t)c * 3 + k) * H + h];
-        sums[k * H + h] = s;
+        const float s = fx_chunk_sum(partial, 3, k, chunks, H, h, ty, red);
+        if (ty == 0 && h < H) sums[k * H + h] = s;
     }
 }
 
@@ -321,7 +333,7 @@ extern "C" int fx_dice_fwd(const float* Z, int64_t N, int32_t H, const float* al
         hipLaunchKernelGGL(k_dice_reduce<0>, dim3((unsigned)fx_ceil_div(H, 64), FX_STAT_CHUNKS),
                            dim3(256), 0, s, Z, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, eps, N, (int)H, rows, workspace);
-        hipLaunchKernelGGL(k_dice_stats_final, dim3((unsigned)fx_ceil_div(H, 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL(k_dice_stats_final, dim3((unsigned)fx_ceil_div(H, 64)), dim3(256), 0, s,
                            workspace, (int)FX_STAT_CHUNKS, (int)H, N, momentum, stats, running_mean,
                            running_var);
     } else {
@@ -355,7 +367,7 @@ extern "C" int fx_dice_bwd(const float* Z, const float* dY, int64_t N, int32_t H
     (void)rows;
     hipLaunchKernelGGL(k_dice_reduce<1>, dim3((unsigned)fx_ceil_div(H, 64), chunks), dim3(256), 0, s,
                        Z, dY, stats, alpha, eps, N, (int)H, rows2, workspace);
-    hipLaunchKernelGGL(k_dice_bwd_final, dim3((unsigned)fx_ceil_div(H, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_dice_bwd_final, dim3((unsigned)fx_ceil_div(H, 64)), dim3(256), 0, s,
                        workspace, chunks, (int)H, sums);
     FX_CHECK_HIP(hipMemcpyAsync(dalpha, sums, sizeof(float) * H, hipMemcpyDeviceToDevice, s));
     const int64_t n = N * H;

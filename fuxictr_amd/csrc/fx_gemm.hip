@@ -267,6 +267,47 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a) {
 }
 
 
+// many slabs over a small output (skinny weight gradients with K = B*L): 32 elements x 8 slab
+// lanes per workgroup, fixed LDS tree over the slab lanes
+__global__ __launch_bounds__(256) void k_splitk_reduce_wide(GemmArgs a) {
+    __shared__ float red[256];
+    const int ii = threadIdx.x & 31, zi = threadIdx.x >> 5;
+    const int64_t total = a.M * a.N;
+    const int64_t i = (int64_t)blockIdx.x * 32 + ii;
+    float s = 0.f;
+    if (i < total)
+        for (int z = zi; z < a.split_k; z += 8) s += a.ws[(int64_t)z * total + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (zi == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + ii];
+        const int64_t m = i / a.N, n = i - m * a.N;
+        a.C[m * a.ldc + n] = fx_epilogue(a.epi, t, m, n);
+    }
+    if (a.epi.rowsum && blockIdx.x == 0) {
+        const float* rs = a.ws + (int64_t)a.split_k * total;
+        for (int64_t m = threadIdx.x; m < a.M; m += 256) {
+            float r = 0.f;
+            for (int z = 0; z < a.split_k; ++z) r += rs[(int64_t)z * a.M + m];
+            a.epi.rowsum[m] = r;
+        }
+    }
+}
+
+static void fx_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
+    const int64_t total = a.M * a.N;
+    if (a.split_k >= 32 && total <= 65536 && a.M <= 256) {
+        hipLaunchKernelGGL(k_splitk_reduce_wide, dim3((unsigned)fx_ceil_div(total, 32)), dim3(256), 0,
+                           s, a);
+    } else {
+        int64_t blocks = fx_ceil_div(total, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Skinny shapes.  Every CTR tower ends in Linear(hidden -> 1): its forward (N = 1), weight
 // gradient (M = 1) and input gradient (K = 1) would each occupy a full 128-wide MFMA tile per
@@ -515,9 +556,7 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
                                dim3((unsigned)fx_ceil_div(N, 1 << np_log2), (unsigned)a.split_k),
                                dim3(256), 0, s, a, np_log2);
         FX_CHECK_LAUNCH();
-        int64_t blocks = fx_ceil_div(M * N, 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        fx_launch_splitk_reduce(a, s);
         FX_CHECK_LAUNCH();
         return FX_OK;
     }
@@ -532,9 +571,7 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     else fx_gemm_dispatch_layout<64, 64>(a_kc, b_kc, av, bv, grid, s, a);
     FX_CHECK_LAUNCH();
     if (split_k > 1) {
-        int64_t blocks = fx_ceil_div(M * N, 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        fx_launch_splitk_reduce(a, s);
         FX_CHECK_LAUNCH();
     }
     return FX_OK;

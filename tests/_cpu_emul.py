@@ -320,7 +320,7 @@ def din_pool_bwd(w, ids, K, dout, dw, dK):
 
 
 def dice_workspace_floats(H):
-    return 512 * 3 * H
+    return 256 * 3 * H
 
 
 def _dice_stats(Z, training, running_mean, running_var, momentum, stats, update):
