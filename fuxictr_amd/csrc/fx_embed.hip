@@ -437,3 +437,87 @@ extern "C" int fx_lr_fwd(const float* table1, const int32_t* ids, int64_t ids_ld
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Pairwise dot interaction (DLRM "dot"): out[b, p(i,j)] = <e[b,i,:], e[b,j,:]> for i < j, pairs in
+// row-major upper-triangle order — InnerProductInteraction "inner_product",
+// fuxictr/pytorch/layers/interactions/inner_product.py:63-66 (bmm + triu masked_select).
+// One workgroup stages a sample's F x D embeddings in LDS; backward:
+// de[b,i,:] = sum_{j != i} g[b, p(min,max)] e[b,j,:].
+// ---------------------------------------------------------------------------------------------
+#define FX_DOT_MAX_FD 4096
+
+__device__ __forceinline__ int fx_pair_index(int i, int j, int F) {  // i < j
+    return i * F - (i * (i + 1)) / 2 + (j - i - 1);
+}
+
+__global__ __launch_bounds__(256) void k_dot_interact_fwd(const float* emb, int64_t emb_ld, int F,
+                                                          int D, int64_t B, float* out) {
+    __shared__ float e[FX_DOT_MAX_FD];
+    const int P = F * (F - 1) / 2;
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        for (int t = threadIdx.x; t < F * D; t += 256) e[t] = emb[b * emb_ld + t];
+        __syncthreads();
+        for (int p = threadIdx.x; p < P; p += 256) {
+            // invert p -> (i, j): rows of the upper triangle have F-1, F-2, ... entries
+            int i = 0, rem = p;
+            while (rem >= F - 1 - i) { rem -= F - 1 - i; ++i; }
+            const int j = i + 1 + rem;
+            float acc = 0.f;
+            for (int d = 0; d < D; ++d) acc = fmaf(e[i * D + d], e[j * D + d], acc);
+            out[b * P + p] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dot_interact_bwd(const float* emb, int64_t emb_ld,
+                                                          const float* g, int F, int D, int64_t B,
+                                                          float* demb, int64_t demb_ld) {
+    __shared__ float e[FX_DOT_MAX_FD];
+    __shared__ float gs[FX_DOT_MAX_FD];
+    const int P = F * (F - 1) / 2;
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        for (int t = threadIdx.x; t < F * D; t += 256) e[t] = emb[b * emb_ld + t];
+        for (int t = threadIdx.x; t < P; t += 256) gs[t] = g[b * P + t];
+        __syncthreads();
+        for (int t = threadIdx.x; t < F * D; t += 256) {
+            const int i = t / D, d = t - i * D;
+            float acc = 0.f;
+            for (int j = 0; j < F; ++j) {
+                if (j == i) continue;
+                const int p = j > i ? fx_pair_index(i, j, F) : fx_pair_index(j, i, F);
+                acc = fmaf(gs[p], e[j * D + d], acc);
+            }
+            demb[b * demb_ld + t] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int fx_dot_interact_fwd(const float* emb, int64_t emb_ld, int32_t F, int32_t D,
+                                   int64_t B, float* out, fx_stream_t stream) {
+    FX_CHECK_ARG(F >= 2 && D >= 1 && F * D <= FX_DOT_MAX_FD && F * (F - 1) / 2 <= FX_DOT_MAX_FD,
+                 "fx_dot_interact_fwd: F=%d D=%d outside the supported range", F, D);
+    if (B <= 0) return FX_OK;
+    FX_CHECK_ARG(emb && out, "fx_dot_interact_fwd: null pointer");
+    int64_t blocks = B < 8192 ? B : 8192;
+    hipLaunchKernelGGL(k_dot_interact_fwd, dim3((unsigned)blocks), dim3(256), 0,
+                       fx_hip_stream(stream), emb, emb_ld, (int)F, (int)D, B, out);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+extern "C" int fx_dot_interact_bwd(const float* emb, int64_t emb_ld, const float* g, int32_t F,
+                                   int32_t D, int64_t B, float* demb, int64_t demb_ld,
+                                   fx_stream_t stream) {
+    FX_CHECK_ARG(F >= 2 && D >= 1 && F * D <= FX_DOT_MAX_FD && F * (F - 1) / 2 <= FX_DOT_MAX_FD,
+                 "fx_dot_interact_bwd: F=%d D=%d outside the supported range", F, D);
+    if (B <= 0) return FX_OK;
+    FX_CHECK_ARG(emb && g && demb, "fx_dot_interact_bwd: null pointer");
+    int64_t blocks = B < 8192 ? B : 8192;
+    hipLaunchKernelGGL(k_dot_interact_bwd, dim3((unsigned)blocks), dim3(256), 0,
+                       fx_hip_stream(stream), emb, emb_ld, g, (int)F, (int)D, B, demb, demb_ld);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}

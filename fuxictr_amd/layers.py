@@ -8,8 +8,9 @@ into libfxctr.so (include/fxctr.h):
       one packed [sum(V_f), D] table per embedding dim, ONE gather launch for all fields that
       writes the final [B, F, D] record (dict entries are views of it; dict2tensor returns the
       record itself), sparse backward to unique rows, sparse-row Adam/SGD.
-  LogisticRegression / FactorizationMachine / InnerProductInteraction
+  LogisticRegression / FactorizationMachine / InnerProductInteraction (product_sum, inner_product)
       logistic_regression.py:24-59, factorization_machine.py:25-59, inner_product.py:23-70
+  DIN_Attention / Dice                      target_attention.py:26-92, activations.py:24-51
   MLP_Block                                 mlp_block.py:24-96  (one autograd node, fp32 MFMA GEMMs)
   CrossNetV2                                cross_net.py:95-129 (one autograd node, fused epilogue)
 
@@ -949,6 +950,27 @@ class _FMFn(torch.autograd.Function):
         return demb, (g if ctx.has_add else None)
 
 
+class _DotInteractFn(torch.autograd.Function):
+    """All pairwise field dots (DLRM "dot"), inner_product.py:63-66."""
+
+    @staticmethod
+    def forward(ctx, emb):
+        emb = emb.contiguous()
+        B, F, D = emb.shape
+        out = torch.empty(B, F * (F - 1) // 2, dtype=torch.float32, device=emb.device)
+        ops.dot_interact_fwd(emb.view(B, F * D), F, D, out)
+        ctx.save_for_backward(emb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (emb,) = ctx.saved_tensors
+        B, F, D = emb.shape
+        demb = torch.empty_like(emb)
+        ops.dot_interact_bwd(emb.view(B, F * D), g.contiguous(), F, D, demb.view(B, F * D))
+        return demb
+
+
 class InnerProductInteraction(nn.Module):
     """inner_product.py:23-70.  `product_sum` is native; the other outputs run the reference's
     torch formulas (not on the BASELINE path)."""
@@ -976,6 +998,9 @@ class InnerProductInteraction(nn.Module):
             square_of_sum = torch.sum(feature_emb ** 2, dim=1)
             return (sum_of_square - square_of_sum) * 0.5
         if self._output_type == "inner_product":
+            F_, D_ = feature_emb.shape[1], feature_emb.shape[2]
+            if F_ * D_ <= 4096 and F_ * (F_ - 1) // 2 <= 4096:
+                return _DotInteractFn.apply(feature_emb)
             ipm = torch.bmm(feature_emb, feature_emb.transpose(1, 2))
             return torch.masked_select(ipm, self.triu_mask).view(-1, self.interaction_units)
         emb1 = torch.index_select(feature_emb, 1, self.triu_index[0])

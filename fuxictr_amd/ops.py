@@ -410,3 +410,18 @@ def dice_bwd(Z, dY, alpha, eps, training, stats, dZ, dalpha, workspace):
     check(_lib.load().fx_dice_bwd(ptr(Z), ptr(dY), N, H, ptr(alpha), eps, 1 if training else 0,
                                   ptr(stats), ptr(dZ), ptr(dalpha), ptr(workspace),
                                   stream_ptr(Z.device)), "fx_dice_bwd")
+
+
+def dot_interact_fwd(emb, F, D, out):
+    B = emb.shape[0]
+    check(_lib.load().fx_dot_interact_fwd(ptr(emb), emb.stride(0), F, D, B, ptr(out),
+                                          stream_ptr(emb.device)), "fx_dot_interact_fwd")
+    return out
+
+
+def dot_interact_bwd(emb, g, F, D, demb):
+    B = emb.shape[0]
+    check(_lib.load().fx_dot_interact_bwd(ptr(emb), emb.stride(0), ptr(g), F, D, B, ptr(demb),
+                                          demb.stride(0), stream_ptr(emb.device)),
+          "fx_dot_interact_bwd")
+    return demb

@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from .layers import (CrossNetV2, DIN_Attention, Dice, FactorizationMachine, FeatureEmbedding,
-                     FeatureEmbeddingDict, FxLinear, MLP_Block)
+                     FeatureEmbeddingDict, FxLinear, InnerProductInteraction, MLP_Block)
 from .rank_model import BaseModel
 
 
@@ -172,3 +172,59 @@ class DIN(BaseModel):
         if type(field) == tuple:
             return torch.cat([feature_emb_dict[f] for f in field], dim=-1)
         return feature_emb_dict[field]
+
+
+class DLRM(BaseModel):
+    """model_zoo/DLRM/src/DLRM.py:44-124."""
+
+    def __init__(self, feature_map, model_id="DLRM", gpu=-1, learning_rate=1e-3, embedding_dim=10,
+                 top_mlp_units=[64, 64, 64], bottom_mlp_units=[64, 64, 64],
+                 top_mlp_activations="ReLU", bottom_mlp_activations="ReLU", top_mlp_dropout=0,
+                 bottom_mlp_dropout=0, interaction_op="dot", batch_norm=False,
+                 embedding_regularizer=None, net_regularizer=None, **kwargs):
+        super(DLRM, self).__init__(feature_map, model_id=model_id, gpu=gpu,
+                                   embedding_regularizer=embedding_regularizer,
+                                   net_regularizer=net_regularizer, **kwargs)
+        self.dense_feats = [feat for feat, spec in feature_map.features.items()
+                            if spec["type"] == "numeric"]
+        self.embedding_layer = FeatureEmbedding(feature_map, embedding_dim,
+                                                not_required_feature_columns=self.dense_feats)
+        if len(self.dense_feats) > 0:
+            n_fields = feature_map.num_fields - len(self.dense_feats) + 1
+            self.bottom_mlp = MLP_Block(input_dim=len(self.dense_feats), output_dim=embedding_dim,
+                                        hidden_units=bottom_mlp_units,
+                                        hidden_activations=bottom_mlp_activations,
+                                        output_activation=bottom_mlp_activations,
+                                        dropout_rates=bottom_mlp_dropout, batch_norm=batch_norm)
+        else:
+            n_fields = feature_map.num_fields
+        self.interaction_op = interaction_op
+        if self.interaction_op == "dot":
+            self.interact = InnerProductInteraction(num_fields=n_fields, output="inner_product")
+            top_input_dim = (n_fields * (n_fields - 1)) // 2 + \
+                embedding_dim * int(len(self.dense_feats) > 0)
+        elif self.interaction_op == "cat":
+            self.interact = nn.Flatten(start_dim=1)
+            top_input_dim = n_fields * embedding_dim
+        else:
+            raise ValueError("interaction_op={} not supported.".format(self.interaction_op))
+        self.top_mlp = MLP_Block(input_dim=top_input_dim, output_dim=1, hidden_units=top_mlp_units,
+                                 hidden_activations=top_mlp_activations,
+                                 output_activation=self.output_activation,
+                                 dropout_rates=top_mlp_dropout, batch_norm=batch_norm)
+        self.compile(kwargs["optimizer"], kwargs["loss"], learning_rate)
+        self.reset_parameters()
+        self.model_to_device()
+
+    def forward(self, inputs):
+        X = self.get_inputs(inputs)
+        feat_emb = self.embedding_layer(X)
+        if len(self.dense_feats) > 0:
+            dense_x = torch.cat([X[k].float().view(-1, 1) for k in self.dense_feats], dim=-1)
+            dense_emb = self.bottom_mlp(dense_x)
+            feat_emb = torch.cat([feat_emb, dense_emb.unsqueeze(1)], dim=1)
+        interact_out = self.interact(feat_emb)
+        if self.interaction_op == "dot" and len(self.dense_feats) > 0:
+            interact_out = torch.cat([interact_out, dense_emb], dim=-1)
+        y_pred = self.top_mlp(interact_out)
+        return {"y_pred": y_pred}

@@ -155,7 +155,37 @@ def din_logit(state, features, X, cfg, training):
     return mlp_block(state, "dnn.", x, cfg["n_hidden"], True)
 
 
+def dot_interaction(feature_emb):
+    """InnerProductInteraction 'inner_product', inner_product.py:63-66."""
+    F_ = feature_emb.shape[1]
+    ipm = torch.bmm(feature_emb, feature_emb.transpose(1, 2))
+    mask = torch.triu(torch.ones(F_, F_), 1).bool()
+    return torch.masked_select(ipm, mask).view(-1, F_ * (F_ - 1) // 2)
+
+
+def dlrm_logit(state, features, X, cfg):
+    """DLRM.forward (interaction_op='dot'), model_zoo/DLRM/src/DLRM.py:103-123: sparse-only
+    FeatureEmbedding, bottom MLP (ReLU after its last layer too) on the numeric columns appended as
+    an extra field, pairwise dots ++ dense embedding -> top MLP."""
+    sparse = OrderedDict((f, s) for f, s in features.items() if s["type"] != "numeric")
+    dense_feats = [f for f, s in features.items() if s["type"] == "numeric"]
+    emb = dict2tensor(sparse, feature_embedding(state, EMB, sparse, X))
+    if dense_feats:
+        dense_x = torch.cat([X[k].float().view(-1, 1) for k in dense_feats], dim=-1)
+        h = dense_x
+        for i in range(cfg["n_bottom"] + 1):
+            h = F.relu(F.linear(h, state["bottom_mlp.mlp.%d.weight" % (2 * i)],
+                                state["bottom_mlp.mlp.%d.bias" % (2 * i)]))
+        emb = torch.cat([emb, h.unsqueeze(1)], dim=1)
+        inter = torch.cat([dot_interaction(emb), h], dim=-1)
+    else:
+        inter = dot_interaction(emb)
+    return mlp_block(state, "top_mlp.", inter, cfg["n_hidden"], True)
+
+
 def model_logit(cfg, state, features, X, training=False):
+    if cfg["model"] == "DLRM":
+        return dlrm_logit(state, features, X, cfg)
     if cfg["model"] == "DIN":
         return din_logit(state, features, X, cfg, training)
     if cfg["model"] == "DeepFM":

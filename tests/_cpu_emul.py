@@ -360,6 +360,24 @@ def dice_bwd(Z, dY, alpha, eps, training, stats, dZ, dalpha, workspace):
     dZ.copy_(dY * (p + alpha * (1 - p)) + dzh * rstd)
 
 
+def dot_interact_fwd(emb, F, D, out):
+    e = emb.view(-1, F, D)
+    ipm = torch.bmm(e, e.transpose(1, 2))
+    mask = torch.triu(torch.ones(F, F), 1).bool()
+    out.copy_(torch.masked_select(ipm, mask).view(-1, F * (F - 1) // 2))
+    return out
+
+
+def dot_interact_bwd(emb, g, F, D, demb):
+    e = emb.view(-1, F, D)
+    G = torch.zeros(e.shape[0], F, F)
+    iu = torch.triu_indices(F, F, 1)
+    G[:, iu[0], iu[1]] = g
+    G = G + G.transpose(1, 2)
+    demb.copy_(torch.bmm(G, e).reshape(demb.shape))
+    return demb
+
+
 class KernelTimer(object):
     enabled = False
 
@@ -370,7 +388,7 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "sparse_sgd", "mt_sqnorm", "mt_adam", "mt_sgd", "fm_fwd", "fm_bwd", "lr_fwd", "gemm",
          "colsum", "mask_mul", "cross_bwd_prep", "sigmoid_bce", "shard_plan", "scatter_rows",
          "sum_parts", "din_concat_fwd", "din_concat_bwd", "din_pool_fwd", "din_pool_bwd",
-         "dice_workspace_floats", "dice_fwd", "dice_bwd"]
+         "dice_workspace_floats", "dice_fwd", "dice_bwd", "dot_interact_fwd", "dot_interact_bwd"]
 
 
 def install_plain():

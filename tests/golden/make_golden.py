@@ -105,6 +105,10 @@ def run_case(case):
     if case["model"] == "DeepFM":
         from model_zoo.DeepFM.DeepFM_torch.src import DeepFM
         model = DeepFM(fmap, model_id=name, hidden_units=case["hidden"], **common)
+    elif case["model"] == "DLRM":
+        from model_zoo import DLRM
+        model = DLRM(fmap, model_id=name, top_mlp_units=case["hidden"],
+                     bottom_mlp_units=case["bottom"], interaction_op="dot", **common)
     elif case["model"] == "DIN":
         from model_zoo import DIN
         model = DIN(fmap, model_id=name, dnn_hidden_units=case["hidden"], dnn_activations="relu",
@@ -138,7 +142,13 @@ def run_case(case):
     for k, v in model.state_dict().items():
         out["state0/" + k] = v.detach().cpu().numpy().copy()
     def to_torch(b):
-        return {k: torch.from_numpy(v) for k, v in b.items()}
+        out_b = {k: torch.from_numpy(v) for k, v in b.items()}
+        if case["model"] == "DLRM":      # DLRM.py:114 concatenates X[k] on dim -1: needs [B,1]
+            for item in spec["features"]:
+                (fname, fs), = item.items()
+                if fs["type"] == "numeric":
+                    out_b[fname] = out_b[fname].view(-1, 1)
+        return out_b
     model.eval()
     with torch.no_grad():
         p0 = model.forward(to_torch(batches[-1]))["y_pred"]
@@ -186,6 +196,9 @@ CASES = [
     dict(name="deepfm_d10", model="DeepFM", n_dense=3, cards=CARDS[:9], embedding_dim=10,
          hidden=[48], B=100, steps=3, lr=1e-2, optimizer="adam", max_norm=10.0, seed=3,
          emb_scale=1000.0, lr_scale=1000.0),
+    dict(name="dlrm_adam", model="DLRM", n_dense=5, cards=CARDS, embedding_dim=8,
+         hidden=[64, 32], bottom=[32, 16], B=192, steps=5, lr=1e-2, optimizer="adam",
+         max_norm=10.0, seed=13, emb_scale=1000.0),
     dict(name="din_adam", model="DIN", embedding_dim=8, hidden=[32, 16], att_hidden=[16], B=160,
          steps=5, lr=1e-2, optimizer="adam", max_norm=10.0, seed=5, emb_scale=1000.0),
     dict(name="dcnv2_adam", model="DCNv2", n_dense=5, cards=CARDS, embedding_dim=8,

@@ -542,3 +542,20 @@ def test_dice_matches_reference_batchnorm_gate(training, N, H):
     scale = max(1.0, zr.grad.abs().max().item())
     assert (dz.cpu() - zr.grad).abs().max().item() <= 5e-5 * scale
     assert (da.cpu() - state["p.alpha"].grad).abs().max().item() <= 2e-4 * max(1.0, state["p.alpha"].grad.abs().max().item())
+
+
+@pytest.mark.parametrize("F,D", [(27, 16), (15, 8), (2, 3), (40, 40)])
+def test_dot_interaction_matches_bmm_triu(F, D):
+    g = torch.Generator().manual_seed(F * D)
+    B = 300
+    emb = torch.randn(B, F, D, generator=g)
+    out = torch.empty(B, F * (F - 1) // 2, device=DEV)
+    ops.dot_interact_fwd(_dev(emb).view(B, F * D), F, D, out)
+    e = emb.clone().requires_grad_(True)
+    ref = O.dot_interaction(e)
+    assert (out.cpu() - ref.detach()).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    demb = torch.empty(B, F * D, device=DEV)
+    ops.dot_interact_bwd(_dev(emb).view(B, F * D), _dev(gy), F, D, demb)
+    assert (demb.cpu().view(B, F, D) - e.grad).abs().max().item() <= 2e-5 * max(1.0, e.grad.abs().max().item())
