@@ -79,6 +79,10 @@ SIGNATURES = {
     "fx_din_concat_bwd": (i32, [vp, vp, i64, vp, i64, i64, i64, i32, i32, vp, vp, i64, i64, i32, vp]),
     "fx_din_pool_fwd": (i32, [vp, vp, i64, vp, i64, i64, i64, i32, i32, vp, vp]),
     "fx_din_pool_bwd": (i32, [vp, vp, i64, vp, i64, i64, vp, i64, i32, i32, vp, vp, i64, i64, vp]),
+    "fx_cin_workgroups": (i64, []),
+    "fx_cin_fwd": (i32, [vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, vp, vp, i64, i64, vp]),
+    "fx_cin_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, vp, i32, vp, vp, i64, vp, i64, i32, vp,
+                         i64, vp, i64, vp]),
     "fx_dice_workspace_floats": (i64, [i32]),
     "fx_dice_fwd": (i32, [vp, i64, i32, vp, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp, vp]),
     "fx_dice_bwd": (i32, [vp, vp, i64, i32, vp, C.c_float, i32, vp, vp, vp, vp, vp]),

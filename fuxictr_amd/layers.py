@@ -1341,6 +1341,88 @@ class DIN_Attention(nn.Module):
         return _DinPoolFn.apply(attention_weight, history_sequence, m)
 
 
+class _CINFn(torch.autograd.Function):
+    """Whole CIN stack as one autograd node (compressed_interaction_net.py:54-76); returns the
+    concatenated pooled outputs [B, sum(O_i)].  args = (X0, W1, b1, W2, b2, ...), W_i = Conv1d
+    weights [O_i, F0*M_i, 1]."""
+
+    @staticmethod
+    def forward(ctx, x0, *wb):
+        x0 = x0.contiguous()
+        B, F0, D = x0.shape
+        n = len(wb) // 2
+        total = sum(wb[2 * i].shape[0] for i in range(n))
+        pooled = torch.empty(B, total, dtype=torch.float32, device=x0.device)
+        xs = [x0]
+        xi, off = x0, 0
+        for i in range(n):
+            W, b = wb[2 * i], wb[2 * i + 1]
+            O = W.shape[0]
+            xn = torch.empty(B, O, D, dtype=torch.float32, device=x0.device)
+            ops.cin_fwd(x0, xi, W.view(O, -1), b, xn, pooled[:, off:off + O])
+            xs.append(xn)
+            xi = xn
+            off += O
+        ctx.wb, ctx.xs = wb, xs
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        wb, xs = ctx.wb, ctx.xs
+        x0 = xs[0]
+        B, F0, D = x0.shape
+        n = len(wb) // 2
+        dpooled = dpooled.contiguous()
+        G = ops.cin_workgroups()
+        dx0 = torch.empty_like(x0)
+        grads = [None] * (2 * n)
+        offs = [0]
+        for i in range(n):
+            offs.append(offs[-1] + wb[2 * i].shape[0])
+        dxn = None
+        for i in range(n - 1, -1, -1):
+            W = wb[2 * i]
+            O = W.shape[0]
+            xi = xs[i]
+            C = W.shape[1]
+            partial = torch.empty(G, O * C + O, dtype=torch.float32, device=x0.device)
+            dxi = torch.empty_like(xi)
+            ops.cin_bwd(x0, xi, W.view(O, -1), dxn, dpooled[:, offs[i]:offs[i + 1]], dx0,
+                        accumulate_dx0=(i != n - 1), dXi=dxi, partial=partial)
+            red = torch.empty(O * C + O, dtype=torch.float32, device=x0.device)
+            ws = _Workspace.get(x0.device, _lib.FX_COLSUM_CHUNKS * (O * C + O))
+            ops.colsum(partial, red, ws)
+            grads[2 * i] = red[:O * C].view(W.shape)
+            grads[2 * i + 1] = red[O * C:]
+            dxn = dxi
+        dx0 = dx0 + dxn        # layer 1 reads X0 on both sides of the outer product
+        return (dx0,) + tuple(grads)
+
+
+class CompressedInteractionNet(nn.Module):
+    """fuxictr/pytorch/layers/interactions/compressed_interaction_net.py:23-76 — same parameter
+    containers (`cin_layer.layer_i` Conv1d, `fc` Linear) and keys; the arithmetic is fx_cin_*."""
+
+    def __init__(self, num_fields, cin_hidden_units, output_dim=1):
+        super(CompressedInteractionNet, self).__init__()
+        dev = _alloc_device()
+        self.cin_hidden_units = cin_hidden_units
+        self.fc = FxLinear(sum(cin_hidden_units), output_dim, device=dev)
+        self.cin_layer = nn.ModuleDict()
+        for i, unit in enumerate(self.cin_hidden_units):
+            in_channels = num_fields * self.cin_hidden_units[i - 1] if i > 0 else num_fields ** 2
+            self.cin_layer["layer_" + str(i + 1)] = nn.Conv1d(in_channels, unit, kernel_size=1,
+                                                              device=dev)
+
+    def forward(self, feature_emb):
+        wb = []
+        for i in range(len(self.cin_hidden_units)):
+            conv = self.cin_layer["layer_" + str(i + 1)]
+            wb += [conv.weight, conv.bias]
+        pooled = _CINFn.apply(feature_emb, *wb)
+        return self.fc(pooled)
+
+
 class _CrossNetV2Fn(torch.autograd.Function):
     """X_{i+1} = X_i + X_0 * (W_i X_i + b_i), cross_net.py:126-129; one GEMM per layer with the
     bias / Hadamard / residual in its epilogue.  args = (x0, W0, b0, W1, b1, ...)."""

@@ -425,3 +425,28 @@ def dot_interact_bwd(emb, g, F, D, demb):
                                           demb.stride(0), stream_ptr(emb.device)),
           "fx_dot_interact_bwd")
     return demb
+
+
+# ---- CIN ------------------------------------------------------------------------------------------
+def cin_workgroups():
+    return int(_lib.load().fx_cin_workgroups())
+
+
+def cin_fwd(X0, Xi, W, bias, Xn, pool):
+    """X0 [B,F0,D], Xi [B,Mi,D] contiguous; W [O, F0*Mi]; Xn [B,O,D]; pool: [B,O] view (stride ok)."""
+    B, F0, D = X0.shape
+    Mi, O = Xi.shape[1], W.shape[0]
+    check(_lib.load().fx_cin_fwd(ptr(X0), X0.stride(0), F0, ptr(Xi), Xi.stride(0), Mi, D, ptr(W),
+                                 ptr(bias), O, ptr(Xn), ptr(pool),
+                                 0 if pool is None else pool.stride(0), B,
+                                 stream_ptr(X0.device)), "fx_cin_fwd")
+
+
+def cin_bwd(X0, Xi, W, dXn, dpool, dX0, accumulate_dx0, dXi, partial):
+    B, F0, D = X0.shape
+    Mi, O = Xi.shape[1], W.shape[0]
+    check(_lib.load().fx_cin_bwd(ptr(X0), X0.stride(0), F0, ptr(Xi), Xi.stride(0), Mi, D, ptr(W), O,
+                                 ptr(dXn), ptr(dpool), 0 if dpool is None else dpool.stride(0),
+                                 ptr(dX0), dX0.stride(0), 1 if accumulate_dx0 else 0, ptr(dXi),
+                                 dXi.stride(0), ptr(partial), B, stream_ptr(X0.device)),
+          "fx_cin_bwd")

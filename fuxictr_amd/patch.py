@@ -16,7 +16,7 @@ import sys
 
 LAYER_NAMES = ["FeatureEmbedding", "FeatureEmbeddingDict", "LogisticRegression",
                "FactorizationMachine", "InnerProductInteraction", "MLP_Block", "CrossNetV2",
-               "MaskedAveragePooling", "MaskedSumPooling", "DIN_Attention", "Dice"]
+               "MaskedAveragePooling", "MaskedSumPooling", "DIN_Attention", "Dice", "CompressedInteractionNet"]
 
 
 def install():

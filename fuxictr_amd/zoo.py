@@ -8,8 +8,9 @@ layers through `fuxictr_amd.patch.install()`.
 import torch
 from torch import nn
 
-from .layers import (CrossNetV2, DIN_Attention, Dice, FactorizationMachine, FeatureEmbedding,
-                     FeatureEmbeddingDict, FxLinear, InnerProductInteraction, MLP_Block)
+from .layers import (CompressedInteractionNet, CrossNetV2, DIN_Attention, Dice,
+                     FactorizationMachine, FeatureEmbedding, FeatureEmbeddingDict, FxLinear,
+                     InnerProductInteraction, LogisticRegression, MLP_Block)
 from .rank_model import BaseModel
 
 
@@ -227,4 +228,37 @@ class DLRM(BaseModel):
         if self.interaction_op == "dot" and len(self.dense_feats) > 0:
             interact_out = torch.cat([interact_out, dense_emb], dim=-1)
         y_pred = self.top_mlp(interact_out)
+        return {"y_pred": y_pred}
+
+
+class xDeepFM(BaseModel):
+    """model_zoo/xDeepFM/src/xDeepFM.py:41-97."""
+
+    def __init__(self, feature_map, model_id="xDeepFM", gpu=-1, learning_rate=1e-3,
+                 embedding_dim=10, dnn_hidden_units=[64, 64, 64], dnn_activations="ReLU",
+                 cin_hidden_units=[16, 16, 16], net_dropout=0, batch_norm=False,
+                 embedding_regularizer=None, net_regularizer=None, **kwargs):
+        super(xDeepFM, self).__init__(feature_map, model_id=model_id, gpu=gpu,
+                                      embedding_regularizer=embedding_regularizer,
+                                      net_regularizer=net_regularizer, **kwargs)
+        self.embedding_layer = FeatureEmbedding(feature_map, embedding_dim)
+        self.dnn = MLP_Block(input_dim=feature_map.sum_emb_out_dim(), output_dim=1,
+                             hidden_units=dnn_hidden_units, hidden_activations=dnn_activations,
+                             output_activation=None, dropout_rates=net_dropout,
+                             batch_norm=batch_norm) if dnn_hidden_units else None
+        self.lr_layer = LogisticRegression(feature_map, use_bias=False)
+        self.cin = CompressedInteractionNet(feature_map.num_fields, cin_hidden_units, output_dim=1)
+        self.compile(kwargs["optimizer"], kwargs["loss"], learning_rate)
+        self.reset_parameters()
+        self.model_to_device()
+
+    def forward(self, inputs):
+        X = self.get_inputs(inputs)
+        feature_emb = self.embedding_layer(X)
+        lr_logit = self.lr_layer(X)
+        cin_logit = self.cin(feature_emb)
+        y_pred = lr_logit + cin_logit
+        if self.dnn is not None:
+            y_pred = y_pred + self.dnn(feature_emb.flatten(start_dim=1))
+        y_pred = self.output_activation(y_pred)
         return {"y_pred": y_pred}

@@ -337,6 +337,27 @@ int fx_dice_bwd(const float* Z, const float* dY, int64_t N, int32_t H, const flo
                 int32_t training, const float* stats, float* dZ, float* dalpha, float* workspace,
                 fx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * xDeepFM Compressed Interaction Network layer, fused (compressed_interaction_net.py:54-76):
+ *     Xn[b,o,d] = sum_{h,m} W[o, h*Mi+m] X0[b,h,d] Xi[b,m,d] + bias[o];  pool[b,o] = sum_d Xn[b,o,d]
+ * X0: [B,F0,D] (sample stride x0_ld), Xi: [B,Mi,D] (xi_ld), W: [O, F0*Mi] (the Conv1d(k=1) weight),
+ * Xn: [B,O,D] contiguous; pool (nullable) is written at pool[b*pool_ld + o], i.e. straight into its
+ * slot of the concatenated pooling vector.  The einsum tensor [B, F0*Mi, D] is never materialised.
+ * fx_cin_bwd: with g = dXn (nullable) + dpool (nullable, broadcast over d):
+ *     dX0 (+)= ..., dXi = ..., partial[G][O*F0*Mi + O] = per-workgroup sums of dW and dbias
+ *     (G = fx_cin_workgroups(); finish with fx_colsum over G).
+ * Limits: O*F0*Mi + O <= 30720 floats per call (LDS-resident weights), D <= 256.
+ * ------------------------------------------------------------------------------------------ */
+int64_t fx_cin_workgroups(void);
+int fx_cin_fwd(const float* X0, int64_t x0_ld, int32_t F0, const float* Xi, int64_t xi_ld,
+               int32_t Mi, int32_t D, const float* W, const float* bias, int32_t O, float* Xn,
+               float* pool, int64_t pool_ld, int64_t B, fx_stream_t stream);
+int fx_cin_bwd(const float* X0, int64_t x0_ld, int32_t F0, const float* Xi, int64_t xi_ld,
+               int32_t Mi, int32_t D, const float* W, int32_t O, const float* dXn,
+               const float* dpool, int64_t dpool_ld, float* dX0, int64_t dx0_ld,
+               int32_t accumulate_dx0, float* dXi, int64_t dxi_ld, float* partial, int64_t B,
+               fx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

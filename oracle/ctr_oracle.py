@@ -183,7 +183,33 @@ def dlrm_logit(state, features, X, cfg):
     return mlp_block(state, "top_mlp.", inter, cfg["n_hidden"], True)
 
 
+def cin(state, prefix, feature_emb, n_layers):
+    """CompressedInteractionNet.forward, compressed_interaction_net.py:54-76."""
+    X_0 = feature_emb
+    B, _, D = X_0.shape
+    X_i = X_0
+    pooled = []
+    for i in range(n_layers):
+        had = torch.einsum("bhd,bmd->bhmd", X_0, X_i).view(B, -1, D)
+        X_i = F.conv1d(had, state[prefix + "cin_layer.layer_%d.weight" % (i + 1)],
+                       state[prefix + "cin_layer.layer_%d.bias" % (i + 1)]).view(B, -1, D)
+        pooled.append(X_i.sum(dim=-1))
+    return F.linear(torch.cat(pooled, dim=-1), state[prefix + "fc.weight"], state[prefix + "fc.bias"])
+
+
+def xdeepfm_logit(state, features, X, cfg):
+    """xDeepFM.forward, model_zoo/xDeepFM/src/xDeepFM.py:78-97 (LR without bias + CIN + DNN)."""
+    emb = dict2tensor(features, feature_embedding(state, EMB, features, X))
+    lr = logistic_regression(state, features, X,
+                             emb_prefix="lr_layer.embedding_layer.embedding_layer.embedding_layers.",
+                             bias_key="lr_layer.bias")
+    y = lr + cin(state, "cin.", emb, cfg["n_cin"])
+    return y + mlp_block(state, "dnn.", emb.flatten(start_dim=1), cfg["n_hidden"], True)
+
+
 def model_logit(cfg, state, features, X, training=False):
+    if cfg["model"] == "xDeepFM":
+        return xdeepfm_logit(state, features, X, cfg)
     if cfg["model"] == "DLRM":
         return dlrm_logit(state, features, X, cfg)
     if cfg["model"] == "DIN":

@@ -378,6 +378,36 @@ def dot_interact_bwd(emb, g, F, D, demb):
     return demb
 
 
+def cin_workgroups():
+    return 4
+
+
+def cin_fwd(X0, Xi, W, bias, Xn, pool):
+    had = torch.einsum("bhd,bmd->bhmd", X0, Xi).reshape(X0.shape[0], -1, X0.shape[2])
+    out = torch.einsum("oc,bcd->bod", W, had) + bias.view(1, -1, 1)
+    Xn.copy_(out)
+    if pool is not None:
+        pool.copy_(out.sum(-1))
+
+
+def cin_bwd(X0, Xi, W, dXn, dpool, dX0, accumulate_dx0, dXi, partial):
+    B, F0, D = X0.shape
+    Mi, O = Xi.shape[1], W.shape[0]
+    g = torch.zeros(B, O, D)
+    if dXn is not None:
+        g = g + dXn
+    if dpool is not None:
+        g = g + dpool.unsqueeze(-1)
+    T = torch.einsum("bod,oc->bcd", g, W).view(B, F0, Mi, D)
+    d0 = (T * Xi.unsqueeze(1)).sum(2)
+    dX0.copy_(dX0 + d0 if accumulate_dx0 else d0)
+    dXi.copy_((T * X0.unsqueeze(2)).sum(1))
+    had = torch.einsum("bhd,bmd->bhmd", X0, Xi).reshape(B, -1, D)
+    partial.zero_()
+    partial[0, :O * F0 * Mi] = torch.einsum("bod,bcd->oc", g, had).reshape(-1)
+    partial[0, O * F0 * Mi:] = g.sum((0, 2))
+
+
 class KernelTimer(object):
     enabled = False
 
@@ -388,7 +418,8 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "sparse_sgd", "mt_sqnorm", "mt_adam", "mt_sgd", "fm_fwd", "fm_bwd", "lr_fwd", "gemm",
          "colsum", "mask_mul", "cross_bwd_prep", "sigmoid_bce", "shard_plan", "scatter_rows",
          "sum_parts", "din_concat_fwd", "din_concat_bwd", "din_pool_fwd", "din_pool_bwd",
-         "dice_workspace_floats", "dice_fwd", "dice_bwd", "dot_interact_fwd", "dot_interact_bwd"]
+         "dice_workspace_floats", "dice_fwd", "dice_bwd", "dot_interact_fwd", "dot_interact_bwd",
+         "cin_workgroups", "cin_fwd", "cin_bwd"]
 
 
 def install_plain():

@@ -45,7 +45,7 @@ class Golden(object):
     def cfg(self):
         m = self.meta
         return {"model": m["model"], "n_hidden": len(m["hidden"]), "n_cross": m.get("n_cross", 0),
-                "n_bottom": len(m.get("bottom", [])),
+                "n_bottom": len(m.get("bottom", [])), "n_cin": len(m.get("cin", [])),
                 "din_target_field": ["adgroup_id"], "din_sequence_field": ["click_sequence"]}
 
 
@@ -62,7 +62,7 @@ def assert_weights_close(got, ref, lr, steps, name, tol=2e-5):
 
 
 GOLDEN_CASES = ["deepfm_adam", "deepfm_adam_clip", "deepfm_sgd", "deepfm_d10", "dcnv2_adam",
-                "din_adam", "dlrm_adam"]
+                "din_adam", "dlrm_adam", "xdeepfm_adam"]
 
 
 @pytest.fixture(params=GOLDEN_CASES)

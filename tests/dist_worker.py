@@ -34,6 +34,9 @@ def run(rank, world, case, port, out_path, use_gpu):
                   model_root="/tmp/fx_dist_%d" % rank, shard="row")
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=case, hidden_units=m["hidden"], **common)
+    elif m["model"] == "xDeepFM":
+        model = zoo.xDeepFM(fmap, model_id=case, dnn_hidden_units=m["hidden"],
+                            cin_hidden_units=m["cin"], **common)
     elif m["model"] == "DLRM":
         model = zoo.DLRM(fmap, model_id=case, top_mlp_units=m["hidden"],
                          bottom_mlp_units=m["bottom"], interaction_op="dot", **common)

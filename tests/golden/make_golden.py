@@ -105,6 +105,10 @@ def run_case(case):
     if case["model"] == "DeepFM":
         from model_zoo.DeepFM.DeepFM_torch.src import DeepFM
         model = DeepFM(fmap, model_id=name, hidden_units=case["hidden"], **common)
+    elif case["model"] == "xDeepFM":
+        from model_zoo import xDeepFM
+        model = xDeepFM(fmap, model_id=name, dnn_hidden_units=case["hidden"],
+                        cin_hidden_units=case["cin"], **common)
     elif case["model"] == "DLRM":
         from model_zoo import DLRM
         model = DLRM(fmap, model_id=name, top_mlp_units=case["hidden"],
@@ -196,6 +200,9 @@ CASES = [
     dict(name="deepfm_d10", model="DeepFM", n_dense=3, cards=CARDS[:9], embedding_dim=10,
          hidden=[48], B=100, steps=3, lr=1e-2, optimizer="adam", max_norm=10.0, seed=3,
          emb_scale=1000.0, lr_scale=1000.0),
+    dict(name="xdeepfm_adam", model="xDeepFM", n_dense=3, cards=CARDS[:9], embedding_dim=8,
+         hidden=[32, 16], cin=[12, 6, 5], B=128, steps=4, lr=1e-2, optimizer="adam", max_norm=10.0,
+         seed=17, emb_scale=1000.0, lr_scale=1000.0),
     dict(name="dlrm_adam", model="DLRM", n_dense=5, cards=CARDS, embedding_dim=8,
          hidden=[64, 32], bottom=[32, 16], B=192, steps=5, lr=1e-2, optimizer="adam",
          max_norm=10.0, seed=13, emb_scale=1000.0),

@@ -559,3 +559,41 @@ def test_dot_interaction_matches_bmm_triu(F, D):
     demb = torch.empty(B, F * D, device=DEV)
     ops.dot_interact_bwd(_dev(emb).view(B, F * D), _dev(gy), F, D, demb)
     assert (demb.cpu().view(B, F, D) - e.grad).abs().max().item() <= 2e-5 * max(1.0, e.grad.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F0,D,units,B", [(39, 16, [16, 16, 16], 700), (9, 8, [12, 6, 5], 130),
+                                          (5, 10, [7], 3), (26, 40, [8, 4], 260)])
+def test_cin_stack_matches_einsum_conv1d(F0, D, units, B):
+    """fx_cin_fwd/bwd through the autograd node vs the oracle's einsum + conv1d (fp32: sums of up
+    to F0*Mi products, tolerance relative to the output scale)."""
+    from fuxictr_amd import layers as L
+    g = torch.Generator().manual_seed(F0 * D + B)
+    x0 = torch.randn(B, F0, D, generator=g) * 0.5
+    state, wb, prev = {}, [], F0
+    for i, u in enumerate(units):
+        W = torch.randn(u, F0 * prev, 1, generator=g) * (1.0 / (F0 * prev) ** 0.5)
+        b = torch.randn(u, generator=g) * 0.1
+        state["cin.cin_layer.layer_%d.weight" % (i + 1)] = W
+        state["cin.cin_layer.layer_%d.bias" % (i + 1)] = b
+        wb += [W, b]
+        prev = u
+    state["cin.fc.weight"] = torch.randn(1, sum(units), generator=g)
+    state["cin.fc.bias"] = torch.zeros(1)
+    leaves = [x0.clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in wb]
+    st = dict(state)
+    for i in range(len(units)):
+        st["cin.cin_layer.layer_%d.weight" % (i + 1)] = leaves[1 + 2 * i]
+        st["cin.cin_layer.layer_%d.bias" % (i + 1)] = leaves[2 + 2 * i]
+    ref = O.cin(st, "cin.", leaves[0], len(units))
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+
+    dl = [_dev(t).requires_grad_(True) for t in [x0] + wb]
+    pooled = L._CINFn.apply(*dl)
+    out = torch.nn.functional.linear(pooled, _dev(state["cin.fc.weight"]), _dev(state["cin.fc.bias"]))
+    out.backward(_dev(gy))
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    for a, r in zip(dl, leaves):
+        scale = max(1.0, r.grad.abs().max().item())
+        assert (a.grad.cpu() - r.grad).abs().max().item() <= 5e-5 * scale, (tuple(r.shape), scale)

@@ -32,6 +32,9 @@ def build_native(g, tmp_path, sparse_update="exact", optimizer=None, hip_graph=F
                   sparse_update=sparse_update, hip_graph=hip_graph)
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"], **common)
+    elif m["model"] == "xDeepFM":
+        model = zoo.xDeepFM(fmap, model_id=m["name"], dnn_hidden_units=m["hidden"],
+                            cin_hidden_units=m["cin"], **common)
     elif m["model"] == "DLRM":
         model = zoo.DLRM(fmap, model_id=m["name"], top_mlp_units=m["hidden"],
                          bottom_mlp_units=m["bottom"], interaction_op="dot", **common)

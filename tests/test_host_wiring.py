@@ -26,6 +26,9 @@ def _build(g, tmp_path, monkeypatch, sparse_update="exact"):
                   model_root=str(tmp_path), sparse_update=sparse_update)
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"], **common)
+    elif m["model"] == "xDeepFM":
+        model = zoo.xDeepFM(fmap, model_id=m["name"], dnn_hidden_units=m["hidden"],
+                            cin_hidden_units=m["cin"], **common)
     elif m["model"] == "DLRM":
         model = zoo.DLRM(fmap, model_id=m["name"], top_mlp_units=m["hidden"],
                          bottom_mlp_units=m["bottom"], interaction_op="dot", **common)
