@@ -17,12 +17,15 @@ FX_MT_BLOCKS = 96
 FX_MT_MAX = 64
 FX_COLSUM_CHUNKS = 64
 FX_NUMGRAD_CHUNKS = 16
+FX_REG_BLOCKS = 1024
+FX_REG_CROSS_BLOCKS = 256
 FX_PACK_MAX_COLS = 64
 FX_CLIP_MAX_PARTS = 16
 
 # indices of the 4-byte words of struct fx_scalars (include/fxctr.h)
 SC_STEP, SC_ERR, SC_LR, SC_BETA1, SC_BETA2, SC_EPS = 0, 1, 2, 3, 4, 5
 SC_BC1, SC_BC2S, SC_STEP_SIZE, SC_CLIP, SC_TOTAL_NORM, SC_MAX_NORM, SC_LOSS = 6, 7, 8, 9, 10, 11, 12
+SC_REG_L1, SC_REG_L2 = 13, 14
 SC_WORDS = 16
 
 vp = C.c_void_p
@@ -59,7 +62,10 @@ SIGNATURES = {
     "fx_clip_coef": (i32, [C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
     "fx_sparse_adam": (i32, [vp, vp, vp, vp, i32, vp, vp, i64, vp, vp, vp]),
     "fx_adam_catchup": (i32, [vp, vp, vp, vp, i32, vp, vp, i64, i64, i32, vp, vp]),
-    "fx_sparse_sgd": (i32, [vp, i32, vp, vp, i64, vp, vp, vp]),
+    "fx_sparse_sgd": (i32, [vp, vp, i32, vp, vp, i64, vp, vp, vp]),
+    "fx_reg_stats": (i32, [vp, i64, vp, vp, vp]),
+    "fx_reg_cross": (i32, [vp, i32, vp, vp, i64, vp, vp, vp, vp]),
+    "fx_reg_dense_update": (i32, [vp, vp, vp, vp, i64, i32, i32, vp, vp]),
     "fx_mt_sqnorm": (i32, [C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
     "fx_mt_adam": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                          C.POINTER(i64), i32, vp, vp]),

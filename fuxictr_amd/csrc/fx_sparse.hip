@@ -698,6 +698,13 @@ __device__ __forceinline__ void fx_adam_elem(float& p, float& m, float& v, float
     p = p - step_size * (m / denom);       // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+// d/dp of (l1 * |p| + l2/2 * p^2): the embedding regularizer of rank_model.py:106-112
+__device__ __forceinline__ float fx_reg_grad(float p, float l1, float l2) {
+    float r = l2 * p;
+    if (l1 != 0.f) r += p > 0.f ? l1 : (p < 0.f ? -l1 : 0.f);
+    return r;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void k_sparse_adam(RowOptArgs a) {
     const int lanes = 1 << a.lanes_log2;
@@ -717,6 +724,10 @@ __global__ __launch_bounds__(256) void k_sparse_adam(RowOptArgs a) {
             fx_load<VEC>(a.m + o, m);
             fx_load<VEC>(a.v + o, v);
             fx_load<VEC>(a.G + u * a.D + d0, g);
+            if (sc.reg_l1 != 0.f || sc.reg_l2 != 0.f) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) g[k] += fx_reg_grad(p[k], sc.reg_l1, sc.reg_l2);
+            }
 #pragma unroll
             for (int k = 0; k < VEC; ++k)
                 fx_adam_elem(p[k], m[k], v[k], g[k] * sc.clip_coef, w1, sc.beta2, w2, sc.bc2_sqrt,
@@ -804,6 +815,8 @@ __global__ __launch_bounds__(256) void k_sparse_sgd(RowOptArgs a) {
     const int nu = *a.n_unique;
     const int64_t rpb = 256 >> a.lanes_log2;
     const float scale = a.scal->lr * a.scal->clip_coef;
+    const float l1 = a.scal->reg_l1, l2 = a.scal->reg_l2;
+    const int step = a.scal->step;
     for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2); u < nu;
          u += (int64_t)gridDim.x * rpb) {
         if (d0 >= a.D) continue;
@@ -812,9 +825,174 @@ __global__ __launch_bounds__(256) void k_sparse_sgd(RowOptArgs a) {
         fx_load<VEC>(a.table + row * a.D + d0, p);
         fx_load<VEC>(a.G + u * a.D + d0, g);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) p[k] = p[k] - scale * g[k];
+        for (int k = 0; k < VEC; ++k) p[k] = p[k] - scale * (g[k] + fx_reg_grad(p[k], l1, l2));
         fx_store<VEC>(a.table + row * a.D + d0, p);
+        if (sub == 0 && a.last_step) a.last_step[row] = step;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding regularizer (rank_model.py:95-112): a dense term over EVERY table row.  Three kernels:
+//   k_reg_stats   sum p^2, sum |p|, sum r^2 (r = l1 sign(p) + l2 p) over the whole packed table
+//   k_reg_cross   sum 2 G.r over the rows the batch touched: with it
+//                 |G + r|^2 summed over all rows = sum r^2 + sum G^2 + sum 2 G.r
+//   k_reg_dense   the optimizer step with g = r for the rows the batch did NOT touch
+//                 (touched rows: k_sparse_adam / k_sparse_sgd add r themselves and mark last_step)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reg_stats(const float* __restrict__ x, int64_t n,
+                                                   const fx_scalars* scal, float* partials) {
+    __shared__ float red4[4];
+    const float l1 = scal->reg_l1, l2 = scal->reg_l2;
+    float s2 = 0.f, s1 = 0.f, sr = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? (n >> 2) : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 q = x4[i];
+        const float e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float r = fx_reg_grad(e[k], l1, l2);
+            s2 = fmaf(e[k], e[k], s2);
+            s1 += fabsf(e[k]);
+            sr = fmaf(r, r, sr);
+        }
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float e = x[i], r = fx_reg_grad(e, l1, l2);
+        s2 = fmaf(e, e, s2);
+        s1 += fabsf(e);
+        sr = fmaf(r, r, sr);
+    }
+    const float t2 = fx_block_sum_256(s2, red4);
+    __syncthreads();
+    const float t1 = fx_block_sum_256(s1, red4);
+    __syncthreads();
+    const float tr = fx_block_sum_256(sr, red4);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = t2;
+        partials[FX_REG_BLOCKS + blockIdx.x] = t1;
+        partials[2 * FX_REG_BLOCKS + blockIdx.x] = tr;
+    }
+}
+
+extern "C" int fx_reg_stats(const float* x, int64_t n, const fx_scalars* scal, float* partials,
+                            fx_stream_t stream) {
+    FX_CHECK_ARG(n >= 0, "fx_reg_stats: n=%lld", (long long)n);
+    FX_CHECK_ARG((x || n == 0) && scal && partials, "fx_reg_stats: null pointer");
+    hipLaunchKernelGGL(k_reg_stats, dim3(FX_REG_BLOCKS), dim3(256), 0, fx_hip_stream(stream), x, n,
+                       scal, partials);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_reg_cross(RowOptArgs a, float* partials) {
+    __shared__ float red4[4];
+    const int lanes = 1 << a.lanes_log2;
+    const int sub = threadIdx.x & (lanes - 1);
+    const int d0 = sub * VEC;
+    const int nu = *a.n_unique;
+    const int64_t rpb = 256 >> a.lanes_log2;
+    const float l1 = a.scal->reg_l1, l2 = a.scal->reg_l2;
+    float acc = 0.f;
+    for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2); u < nu;
+         u += (int64_t)gridDim.x * rpb) {
+        if (d0 >= a.D) continue;
+        const int64_t row = a.uniq_row[u];
+        float p[VEC], g[VEC];
+        fx_load<VEC>(a.table + row * a.D + d0, p);
+        fx_load<VEC>(a.G + u * a.D + d0, g);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc = fmaf(2.f * g[k], fx_reg_grad(p[k], l1, l2), acc);
+    }
+    const float tot = fx_block_sum_256(acc, red4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+extern "C" int fx_reg_cross(const float* table, int32_t D, const uint32_t* uniq_row,
+                            const int32_t* n_unique, int64_t n_max, const float* G,
+                            const fx_scalars* scal, float* partials, fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256, "fx_reg_cross: D=%d not in [1,256]", D);
+    FX_CHECK_ARG(table && uniq_row && n_unique && G && scal && partials,
+                 "fx_reg_cross: null pointer");
+    RowOptArgs a{const_cast<float*>(table), nullptr, nullptr, nullptr, uniq_row, n_unique, G, scal,
+                 0, D, 0, 0};
+    const FxRowGeom g = fx_row_geom(D);
+    int ll = 0;
+    while ((1 << ll) < g.lanes) ++ll;
+    a.lanes_log2 = ll;
+    hipStream_t s = fx_hip_stream(stream);
+    dim3 grid(FX_REG_CROSS_BLOCKS);       // fixed: every block writes its (possibly zero) partial
+    if (g.vec == 4) hipLaunchKernelGGL(k_reg_cross<4>, grid, dim3(256), 0, s, a, partials);
+    else if (g.vec == 2) hipLaunchKernelGGL(k_reg_cross<2>, grid, dim3(256), 0, s, a, partials);
+    else hipLaunchKernelGGL(k_reg_cross<1>, grid, dim3(256), 0, s, a, partials);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+template <int VEC, bool ADAM>
+__global__ __launch_bounds__(256) void k_reg_dense(RowOptArgs a) {
+    const int lanes = 1 << a.lanes_log2;
+    const int sub = threadIdx.x & (lanes - 1);
+    const int d0 = sub * VEC;
+    const int64_t rpb = 256 >> a.lanes_log2;
+    const fx_scalars sc = *a.scal;
+    const float w1 = 1.f - sc.beta1, w2 = 1.f - sc.beta2;
+    const float scale = sc.lr * sc.clip_coef;
+    for (int64_t row = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2); row < a.total_rows;
+         row += (int64_t)gridDim.x * rpb) {
+        if (d0 >= a.D) continue;
+        if (a.last_step[row] == sc.step) continue;       // updated by the sparse kernel this step
+        const int64_t o = row * a.D + d0;
+        float p[VEC];
+        fx_load<VEC>(a.table + o, p);
+        if constexpr (ADAM) {
+            float m[VEC], v[VEC];
+            fx_load<VEC>(a.m + o, m);
+            fx_load<VEC>(a.v + o, v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                fx_adam_elem(p[k], m[k], v[k], fx_reg_grad(p[k], sc.reg_l1, sc.reg_l2) * sc.clip_coef,
+                             w1, sc.beta2, w2, sc.bc2_sqrt, sc.eps, sc.step_size);
+            fx_store<VEC>(a.m + o, m);
+            fx_store<VEC>(a.v + o, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) p[k] = p[k] - scale * fx_reg_grad(p[k], sc.reg_l1, sc.reg_l2);
+        }
+        fx_store<VEC>(a.table + o, p);
+    }
+}
+
+extern "C" int fx_reg_dense_update(float* table, float* m, float* v, const int32_t* last_step,
+                                   int64_t total_rows, int32_t D, int32_t adam,
+                                   const fx_scalars* scal, fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256, "fx_reg_dense_update: D=%d not in [1,256]", D);
+    if (total_rows <= 0) return FX_OK;
+    FX_CHECK_ARG(table && last_step && scal && (!adam || (m && v)),
+                 "fx_reg_dense_update: null pointer");
+    RowOptArgs a{table, m, v, const_cast<int32_t*>(last_step), nullptr, nullptr, nullptr, scal,
+                 total_rows, D, 0, 0};
+    const FxRowGeom g = fx_row_geom(D);
+    int ll = 0;
+    while ((1 << ll) < g.lanes) ++ll;
+    a.lanes_log2 = ll;
+    int64_t blocks = fx_ceil_div(total_rows, 256 / g.lanes);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    dim3 grid((unsigned)blocks);
+    hipStream_t s = fx_hip_stream(stream);
+#define FX_REG_DENSE(V)                                                                      \
+    do {                                                                                     \
+        if (adam) hipLaunchKernelGGL((k_reg_dense<V, true>), grid, dim3(256), 0, s, a);      \
+        else hipLaunchKernelGGL((k_reg_dense<V, false>), grid, dim3(256), 0, s, a);          \
+    } while (0)
+    if (g.vec == 4) FX_REG_DENSE(4);
+    else if (g.vec == 2) FX_REG_DENSE(2);
+    else FX_REG_DENSE(1);
+#undef FX_REG_DENSE
+    FX_CHECK_LAUNCH();
+    return FX_OK;
 }
 
 #define FX_LAUNCH_ROWOPT(KERNEL, n_rows_max)                                             \
@@ -862,13 +1040,13 @@ extern "C" int fx_adam_catchup(float* table, float* m, float* v, int32_t* last_s
     return FX_OK;
 }
 
-extern "C" int fx_sparse_sgd(float* table, int32_t D, const uint32_t* uniq_row,
+extern "C" int fx_sparse_sgd(float* table, int32_t* last_step, int32_t D, const uint32_t* uniq_row,
                              const int32_t* n_unique, int64_t n_max, const float* G,
                              const fx_scalars* scal, fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256, "fx_sparse_sgd: D=%d not in [1,256]", D);
     if (n_max <= 0) return FX_OK;
     FX_CHECK_ARG(table && uniq_row && n_unique && G && scal, "fx_sparse_sgd: null pointer");
-    RowOptArgs a{table, nullptr, nullptr, nullptr, uniq_row, n_unique, G, scal, 0, D, 0, 0};
+    RowOptArgs a{table, nullptr, nullptr, last_step, uniq_row, n_unique, G, scal, 0, D, 0, 0};
     FX_LAUNCH_ROWOPT(k_sparse_sgd, n_max);
     return FX_OK;
 }

@@ -234,10 +234,28 @@ def adam_catchup(table, m, v, last_step, D, dd, total_rows, upto_offset, scal):
               "fx_adam_catchup")
 
 
-def sparse_sgd(table, D, dd, G, scal):
-    check(_lib.load().fx_sparse_sgd(ptr(table), D, ptr(dd.uniq_row), ptr(dd.n_unique), dd.n_max,
-                                    ptr(G), ptr(scal), stream_ptr(table.device)),
-          "fx_sparse_sgd")
+def sparse_sgd(table, D, dd, G, scal, last_step=None):
+    check(_lib.load().fx_sparse_sgd(ptr(table), ptr(last_step), D, ptr(dd.uniq_row),
+                                    ptr(dd.n_unique), dd.n_max, ptr(G), ptr(scal),
+                                    stream_ptr(table.device)), "fx_sparse_sgd")
+
+
+def reg_stats(x, scal, partials):
+    """partials [3 * FX_REG_BLOCKS]: sum p^2 | sum |p| | sum r(p)^2 over the flat tensor x."""
+    check(_lib.load().fx_reg_stats(ptr(x), x.numel(), ptr(scal), ptr(partials),
+                                   stream_ptr(x.device)), "fx_reg_stats")
+
+
+def reg_cross(table, D, dd, G, scal, partials):
+    check(_lib.load().fx_reg_cross(ptr(table), D, ptr(dd.uniq_row), ptr(dd.n_unique), dd.n_max,
+                                   ptr(G), ptr(scal), ptr(partials), stream_ptr(table.device)),
+          "fx_reg_cross")
+
+
+def reg_dense_update(table, m, v, last_step, D, adam, scal):
+    check(_lib.load().fx_reg_dense_update(ptr(table), ptr(m), ptr(v), ptr(last_step),
+                                          table.shape[0], D, 1 if adam else 0, ptr(scal),
+                                          stream_ptr(table.device)), "fx_reg_dense_update")
 
 
 def _chunks(n):

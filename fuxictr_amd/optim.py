@@ -24,7 +24,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
     _require_cuda = True     # tests of the host logic lift this together with emulated kernels
 
     def __init__(self, params, lr, model=None, sparse_update="exact", betas=(0.9, 0.999),
-                 eps=1e-8):
+                 eps=1e-8, emb_reg=None):
         if sparse_update not in ("exact", "lazy"):
             raise ValueError("sparse_update={} is not supported.".format(sparse_update))
         params = list(params)
@@ -54,10 +54,21 @@ class _NativeOptimizer(torch.optim.Optimizer):
         self._state_dense = {}   # id(tensor) -> (m, v)
         self._sq_dense = None
         self.dist = None
+        # embedding_regularizer: [(p_norm, weight)] -> (l1, l2); non-zero switches the tables to the
+        # dense-regularized step (every row has a gradient every step, rank_model.py:106-112)
+        self.reg_l1 = float(sum(w for p, w in (emb_reg or []) if p == 1))
+        self.reg_l2 = float(sum(w for p, w in (emb_reg or []) if p == 2))
+        self.dense_reg = (self.reg_l1 != 0.0 or self.reg_l2 != 0.0) and bool(self._groups)
+        if self.dense_reg:
+            self.scal[_lib.SC_REG_L1:_lib.SC_REG_L1 + 1].fill_(self.reg_l1)
+            self.scal[_lib.SC_REG_L2:_lib.SC_REG_L2 + 1].fill_(self.reg_l2)
         for grp in self._groups:
             self._attach(grp)
             if grp.dist is not None:
                 self.dist = grp.dist
+        if self.dense_reg and self.dist is not None:
+            raise NotImplementedError("embedding_regularizer with row-sharded tables is not "
+                                      "implemented")
         if self.dist is not None:
             # data-parallel dense side: every rank starts from rank 0's tower / numeric weights
             with torch.no_grad():
@@ -69,11 +80,20 @@ class _NativeOptimizer(torch.optim.Optimizer):
     def _attach(self, grp):
         grp.scal = self.scal
         grp.opt_kind = self.kind
-        grp.exact = self.kind == "adam" and self.sparse_update == "exact"
+        # dense_reg: every row is stepped every step, so there is nothing to catch up
+        grp.exact = self.kind == "adam" and self.sparse_update == "exact" and not self.dense_reg
+        grp.dense_reg = self.dense_reg
         if self.kind == "adam" and grp.table is not None:
             grp.m = torch.zeros_like(grp.table)
             grp.v = torch.zeros_like(grp.table)
+        if (self.kind == "adam" or self.dense_reg) and grp.table is not None:
             grp.last_step = torch.zeros(grp.table.shape[0], dtype=torch.int32, device=grp.device)
+        if self.dense_reg and grp.table is not None:
+            grp.reg_partials = torch.zeros(3 * _lib.FX_REG_BLOCKS, dtype=torch.float32,
+                                           device=grp.device)
+            grp.reg_cross = torch.zeros(_lib.FX_REG_CROSS_BLOCKS, dtype=torch.float32,
+                                        device=grp.device)
+            grp.reg_fresh = False
 
     def set_max_norm(self, max_norm):
         max_norm = float(max_norm) if max_norm else 0.0
@@ -108,6 +128,38 @@ class _NativeOptimizer(torch.optim.Optimizer):
             raise RuntimeError("row-sharded exchange overflowed its per-peer capacity: raise "
                                "`a2a_capacity_factor` (>= world size can never overflow)")
 
+    # -- embedding regularizer ----------------------------------------------------------------
+    def _reg_grad(self, w):
+        r = self.reg_l2 * w
+        if self.reg_l1:
+            r = r + self.reg_l1 * torch.sign(w)
+        return r
+
+    @torch.no_grad()
+    def emb_reg_loss(self):
+        """sum over the FeatureEmbeddingDict parameters of l1 |p|_1 + l2/2 |p|_2^2 (device scalar,
+        no autograd: its gradient is applied inside the update kernels)."""
+        if not self.dense_reg:
+            return 0
+        nb = _lib.FX_REG_BLOCKS
+        sq = torch.empty(1, dtype=torch.float32, device=self.device)
+        ab = torch.empty(1, dtype=torch.float32, device=self.device)
+        sqs, abs_ = [], []
+        for grp in self._groups:
+            if grp.table is not None:
+                ops.reg_stats(grp.table, self.scal, grp.reg_partials)
+                grp.reg_fresh = True
+                sqs.append(grp.reg_partials[:nb])
+                abs_.append(grp.reg_partials[nb:2 * nb])
+        ops.sum_parts(sqs, sq)
+        ops.sum_parts(abs_, ab)
+        term = (0.5 * self.reg_l2) * sq[0] + self.reg_l1 * ab[0]
+        for grp in self._groups:
+            if grp.num_w is not None:
+                term = term + (0.5 * self.reg_l2) * (grp.num_w * grp.num_w).sum() \
+                    + self.reg_l1 * grp.num_w.abs().sum()
+        return term
+
     # -- step ---------------------------------------------------------------------------------
     def _dense_lists(self):
         ps, gs = [], []
@@ -125,7 +177,13 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 ps.append(p.data)
                 gs.append(g)
         for grp in self._groups:
-            if grp.num_w is not None and grp.num_grad is not None:
+            if grp.num_w is None:
+                continue
+            if self.dense_reg:
+                g = self._reg_grad(grp.num_w)
+                ps.append(grp.num_w)
+                gs.append(g if grp.num_grad is None else g + grp.num_grad)
+            elif grp.num_grad is not None:
                 ps.append(grp.num_w)
                 gs.append(grp.num_grad)
         return ps, gs
@@ -169,6 +227,14 @@ class _NativeOptimizer(torch.optim.Optimizer):
                     "sparse gradients per step is not implemented" % len(grp.pending))
             for rec in grp.pending:
                 parts.append(rec.sq)
+            if self.dense_reg and grp.table is not None:
+                if not grp.reg_fresh:
+                    ops.reg_stats(grp.table, self.scal, grp.reg_partials)
+                grp.reg_fresh = False
+                parts.append(grp.reg_partials[2 * _lib.FX_REG_BLOCKS:])
+                for rec in grp.pending:
+                    ops.reg_cross(grp.table, grp.D, rec.dd, rec.G, self.scal, grp.reg_cross)
+                    parts.append(grp.reg_cross)
         if self.dist is not None:
             # table rows are disjoint across ranks: global norm^2 = dense part (identical on every
             # rank after the all-reduce) + sum over ranks of the local table parts
@@ -184,6 +250,9 @@ class _NativeOptimizer(torch.optim.Optimizer):
         for grp in self._groups:
             for rec in grp.pending:
                 self._sparse_update(grp, rec)
+            if self.dense_reg and grp.table is not None:
+                ops.reg_dense_update(grp.table, grp.m, grp.v, grp.last_step, grp.D,
+                                     self.kind == "adam", self.scal)
             grp.pending = []
             grp.num_grad = None
         return None
@@ -215,15 +284,15 @@ class NativeSGD(_NativeOptimizer):
         ops.mt_sgd(ps, gs, self.scal)
 
     def _sparse_update(self, grp, rec):
-        ops.sparse_sgd(grp.table, grp.D, rec.dd, rec.G, self.scal)
+        ops.sparse_sgd(grp.table, grp.D, rec.dd, rec.G, self.scal, last_step=grp.last_step)
 
 
-def get_optimizer(optimizer, params, lr, model=None, sparse_update="exact"):
+def get_optimizer(optimizer, params, lr, model=None, sparse_update="exact", emb_reg=None):
     """fuxictr/pytorch/torch_utils.py:58-79 — string -> optimizer; Adam and SGD are native."""
     if isinstance(optimizer, str):
         name = optimizer.lower()
         if name == "adam":
-            return NativeAdam(params, lr, model=model, sparse_update=sparse_update)
+            return NativeAdam(params, lr, model=model, sparse_update=sparse_update, emb_reg=emb_reg)
         if name == "sgd":
-            return NativeSGD(params, lr, model=model, sparse_update=sparse_update)
+            return NativeSGD(params, lr, model=model, sparse_update=sparse_update, emb_reg=emb_reg)
     raise NotImplementedError("optimizer={} is not supported.".format(optimizer))

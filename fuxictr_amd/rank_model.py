@@ -254,20 +254,21 @@ class BaseModel(nn.Module):
         self.model_dir = os.path.join(kwargs["model_root"], feature_map.dataset_id)
         self.checkpoint = os.path.abspath(os.path.join(self.model_dir, self.model_id + ".model"))
         self.validation_metrics = kwargs["metrics"]
-        if self._embedding_regularizer:
-            raise NotImplementedError(
-                "embedding_regularizer={} needs a dense pass over every table row each step "
-                "(rank_model.py:106-112); the sparse-row path supports 0/None only for now"
-                .format(embedding_regularizer))
 
     def compile(self, optimizer, loss, lr):
         self.optimizer = get_optimizer(optimizer, self.parameters(), lr, model=self,
-                                       sparse_update=self._sparse_update)
+                                       sparse_update=self._sparse_update,
+                                       emb_reg=get_regularizer(self._embedding_regularizer)
+                                       if self._embedding_regularizer else None)
         self.loss_fn = get_loss(loss)
 
     def regularization_loss(self):
-        """rank_model.py:95-118 for the non-embedding parameters."""
+        """rank_model.py:95-118.  The embedding part is computed by fx_reg_stats and carries no
+        autograd graph: its gradient (every table row, every step) is applied inside the native
+        update kernels; the net part is plain torch on the dense parameters."""
         reg_term = 0
+        if self._embedding_regularizer and hasattr(self.optimizer, "emb_reg_loss"):
+            reg_term = reg_term + self.optimizer.emb_reg_loss()
         if self._net_regularizer:
             net_reg = get_regularizer(self._net_regularizer)
             emb_params = set()

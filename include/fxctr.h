@@ -54,7 +54,9 @@ typedef struct fx_scalars {
     float total_norm;  /* 10 */
     float max_norm;    /* 11: <= 0 disables clipping (coef = 1) */
     float loss;        /* 12: scratch for the fused loss kernel */
-    float pad[3];
+    float reg_l1;      /* 13: embedding regularizer, l1 weight (0 = off)   rank_model.py:106-112 */
+    float reg_l2;      /* 14: embedding regularizer, l2 weight: loss += l1 |p|_1 + l2/2 |p|_2^2 */
+    float pad[1];
 } fx_scalars;
 
 int fx_abi_version(void);
@@ -184,7 +186,9 @@ int fx_clip_coef(const float* const* parts_host, const int64_t* counts_host, int
  *                     all rows [0,total_rows) (uniq_row == NULL, flush before evaluate/save), so
  *                     the table equals the reference's dense-Adam table.  upto_offset is added
  *                     to scal->step (-1: bring rows to t-1 before the forward of step t; 0: flush).
- *  fx_sparse_sgd    : p -= lr * clip * g (exactly the dense SGD result).
+ *  fx_sparse_sgd    : p -= lr * clip * g (exactly the dense SGD result); last_step (nullable) is
+ *                     marked like fx_sparse_adam's.
+ * With scal->reg_l1/reg_l2 set, both add the regularizer gradient r(p) = l1 sign(p) + l2 p to g.
  * ------------------------------------------------------------------------------------------ */
 int fx_sparse_adam(float* table, float* m, float* v, int32_t* last_step, int32_t D,
                    const uint32_t* uniq_row, const int32_t* n_unique, int64_t n_max,
@@ -193,8 +197,33 @@ int fx_adam_catchup(float* table, float* m, float* v, int32_t* last_step, int32_
                     const uint32_t* uniq_row, const int32_t* n_unique, int64_t n_max,
                     int64_t total_rows, int32_t upto_offset, const fx_scalars* scal,
                     fx_stream_t stream);
-int fx_sparse_sgd(float* table, int32_t D, const uint32_t* uniq_row, const int32_t* n_unique,
-                  int64_t n_max, const float* G, const fx_scalars* scal, fx_stream_t stream);
+int fx_sparse_sgd(float* table, int32_t* last_step, int32_t D, const uint32_t* uniq_row,
+                  const int32_t* n_unique, int64_t n_max, const float* G, const fx_scalars* scal,
+                  fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * embedding_regularizer != 0 (BaseModel.regularization_loss, rank_model.py:95-112): the loss gets
+ * sum over every FeatureEmbeddingDict parameter of (l1 |p|_1 + l2/2 |p|_2^2), so EVERY table row
+ * has a gradient each step — the reference's dense pass, kept dense here (but fused: 2 reads +
+ * 1 read-modify-write of the table per step instead of autograd's zero-fill + norm + clip + Adam).
+ *  fx_reg_stats        : partials[0..NB) = sum p^2, [NB..2NB) = sum |p|, [2NB..3NB) = sum r(p)^2
+ *                        over x[0..n)  (NB = FX_REG_BLOCKS; fixed order -> deterministic)
+ *  fx_reg_cross        : partials[0..FX_REG_CROSS_BLOCKS) = sum 2 G.r(p) over the touched rows;
+ *                        |G + r|^2 over all rows = sum r^2 + sum G^2 + this  (for the global clip)
+ *  fx_reg_dense_update : Adam (adam=1) / SGD (adam=0) step with g = r(p) * clip for every row
+ *                        whose last_step != scal->step (touched rows were stepped, with G + r, by
+ *                        fx_sparse_adam / fx_sparse_sgd, which mark last_step).
+ * ------------------------------------------------------------------------------------------ */
+#define FX_REG_BLOCKS 1024
+#define FX_REG_CROSS_BLOCKS 256
+int fx_reg_stats(const float* x, int64_t n, const fx_scalars* scal, float* partials,
+                 fx_stream_t stream);
+int fx_reg_cross(const float* table, int32_t D, const uint32_t* uniq_row, const int32_t* n_unique,
+                 int64_t n_max, const float* G, const fx_scalars* scal, float* partials,
+                 fx_stream_t stream);
+int fx_reg_dense_update(float* table, float* m, float* v, const int32_t* last_step,
+                        int64_t total_rows, int32_t D, int32_t adam, const fx_scalars* scal,
+                        fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense (multi-tensor) side of clip + Adam/SGD for the MLP / CrossNet / bias parameters.

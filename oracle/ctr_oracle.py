@@ -258,11 +258,28 @@ def adam_dense(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     p.addcdiv_(m, denom, value=-step_size)
 
 
+def parse_regularizer(reg):
+    """get_regularizer, torch_utils.py:106-135: float -> L2; "l1(x)", "l2(x)", "l1_l2(x,y)"."""
+    if isinstance(reg, float):
+        return [(2, reg)]
+    if isinstance(reg, str):
+        val = reg.rstrip(")").split("(")[-1]
+        if reg.startswith("l1(") or reg.startswith("l2("):
+            return [(int(reg[1]), float(val))]
+        if reg.startswith("l1_l2"):
+            a, b = val.split(",")
+            return [(1, float(a)), (2, float(b))]
+        raise NotImplementedError("regularizer={} is not supported.".format(reg))
+    return []
+
+
 class OracleTrainer(object):
     """State + dense Adam, one `train_step` == BaseModel.train_step (rank_model.py:307-323)."""
 
-    def __init__(self, cfg, state, features, lr=1e-3, max_norm=10.0, optimizer="adam"):
+    def __init__(self, cfg, state, features, lr=1e-3, max_norm=10.0, optimizer="adam",
+                 emb_reg=None, net_reg=None):
         self.cfg, self.features = cfg, features
+        self.emb_reg, self.net_reg = emb_reg or [], net_reg or []   # [(p_norm, weight)]
         self.lr, self.max_norm, self.kind = lr, max_norm, optimizer
         self.state = OrderedDict()
         # share_embedding (feature_embedding.py:149-151): in the main table dict the sharing
@@ -280,12 +297,14 @@ class OracleTrainer(object):
                 self.state[k] = t.detach().clone()
                 continue
             self.state[k] = t.detach().clone().float().requires_grad_(True)
-        self.params = []
+        self.params, self.is_emb = [], []
         seen = set()
-        for t in self.state.values():
+        for k, t in self.state.items():
             if id(t) not in seen and t.requires_grad:
                 seen.add(id(t))
                 self.params.append(t)
+                # parameters of a FeatureEmbeddingDict module (rank_model.py:106-109)
+                self.is_emb.append(".embedding_layers." in k or ".feature_encoders." in k)
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
         self.step = 0
@@ -294,7 +313,7 @@ class OracleTrainer(object):
         for p in self.params:
             p.grad = None                                   # optimizer.zero_grad()
         prob = torch.sigmoid(model_logit(self.cfg, self.state, self.features, X, training=True))
-        loss = bce_mean(prob, y.float().view(-1, 1))
+        loss = bce_mean(prob, y.float().view(-1, 1)) + self.regularization_loss()
         loss.backward()                                     # dense [V, D] embedding grads
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         total = clip_grad_norm(grads, self.max_norm)
@@ -306,6 +325,14 @@ class OracleTrainer(object):
                 else:
                     p.add_(g, alpha=-self.lr)               # torch.optim.SGD defaults
         return float(loss.detach()), total
+
+    def regularization_loss(self):
+        """BaseModel.regularization_loss, rank_model.py:95-118."""
+        reg_term = 0
+        for p, emb in zip(self.params, self.is_emb):
+            for norm_p, lam in (self.emb_reg if emb else self.net_reg):
+                reg_term = reg_term + (lam / norm_p) * torch.norm(p, norm_p) ** norm_p
+        return reg_term
 
     def predict(self, X):
         return predict(self.cfg, self.state, self.features, X)

@@ -171,11 +171,43 @@ def _adam(p, m, v, g, scal):
     p -= scal[SC.SC_STEP_SIZE] * (m / (v.sqrt() / scal[SC.SC_BC2S] + eps))
 
 
+def _reg(p, scal):
+    return scal[SC.SC_REG_L1] * torch.sign(p) + scal[SC.SC_REG_L2] * p
+
+
+def reg_stats(x, scal, partials):
+    nb = _lib.FX_REG_BLOCKS
+    partials.zero_()
+    partials[0] = float((x.double() ** 2).sum())
+    partials[nb] = float(x.double().abs().sum())
+    partials[2 * nb] = float((_reg(x, scal).double() ** 2).sum())
+
+
+def reg_cross(table, D, dd, G, scal, partials):
+    nu = int(dd.n_unique)
+    rows = dd.uniq_row[:nu].long()
+    partials.zero_()
+    partials[0] = float((2.0 * G[:nu].double() * _reg(table[rows], scal).double()).sum())
+
+
+def reg_dense_update(table, m, v, last_step, D, adam, scal):
+    rows = (last_step != _step(scal)).nonzero().view(-1)
+    p = table[rows]
+    g = _reg(p, scal) * scal[SC.SC_CLIP]
+    if adam:
+        mm, vv = m[rows], v[rows]
+        _adam(p, mm, vv, g, scal)
+        m[rows], v[rows] = mm, vv
+    else:
+        p -= scal[SC.SC_LR] * g
+    table[rows] = p
+
+
 def sparse_adam(table, m, v, last_step, D, dd, G, scal):
     nu = int(dd.n_unique)
     rows = dd.uniq_row[:nu].long()
     p, mm, vv = table[rows], m[rows], v[rows]
-    _adam(p, mm, vv, G[:nu] * scal[SC.SC_CLIP], scal)
+    _adam(p, mm, vv, (G[:nu] + _reg(p, scal)) * scal[SC.SC_CLIP], scal)
     table[rows], m[rows], v[rows] = p, mm, vv
     last_step[rows] = _step(scal)
 
@@ -195,10 +227,12 @@ def adam_catchup(table, m, v, last_step, D, dd, total_rows, upto_offset, scal):
             last_step[r] = upto
 
 
-def sparse_sgd(table, D, dd, G, scal):
+def sparse_sgd(table, D, dd, G, scal, last_step=None):
     nu = int(dd.n_unique)
     rows = dd.uniq_row[:nu].long()
-    table[rows] -= scal[SC.SC_LR] * scal[SC.SC_CLIP] * G[:nu]
+    table[rows] -= scal[SC.SC_LR] * scal[SC.SC_CLIP] * (G[:nu] + _reg(table[rows], scal))
+    if last_step is not None:
+        last_step[rows] = _step(scal)
 
 
 def mt_sqnorm(grads, sq_partials):
@@ -419,7 +453,7 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "colsum", "mask_mul", "cross_bwd_prep", "sigmoid_bce", "shard_plan", "scatter_rows",
          "sum_parts", "din_concat_fwd", "din_concat_bwd", "din_pool_fwd", "din_pool_bwd",
          "dice_workspace_floats", "dice_fwd", "dice_bwd", "dot_interact_fwd", "dot_interact_bwd",
-         "cin_workgroups", "cin_fwd", "cin_bwd"]
+         "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update"]
 
 
 def install_plain():

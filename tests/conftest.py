@@ -62,7 +62,8 @@ def assert_weights_close(got, ref, lr, steps, name, tol=2e-5):
 
 
 GOLDEN_CASES = ["deepfm_adam", "deepfm_adam_clip", "deepfm_sgd", "deepfm_d10", "dcnv2_adam",
-                "din_adam", "dlrm_adam", "xdeepfm_adam"]
+                "din_adam", "dlrm_adam", "xdeepfm_adam", "deepfm_reg",
+                "deepfm_reg_sgd"]
 
 
 @pytest.fixture(params=GOLDEN_CASES)

@@ -101,7 +101,8 @@ def run_case(case):
     common = dict(gpu=-1, embedding_dim=case["embedding_dim"], learning_rate=case["lr"],
                   optimizer=case["optimizer"], loss="binary_crossentropy",
                   task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
-                  model_root=TMP, embedding_regularizer=0, net_regularizer=0)
+                  model_root=TMP, embedding_regularizer=case.get("emb_reg", 0),
+                  net_regularizer=case.get("net_reg", 0))
     if case["model"] == "DeepFM":
         from model_zoo.DeepFM.DeepFM_torch.src import DeepFM
         model = DeepFM(fmap, model_id=name, hidden_units=case["hidden"], **common)
@@ -200,6 +201,12 @@ CASES = [
     dict(name="deepfm_d10", model="DeepFM", n_dense=3, cards=CARDS[:9], embedding_dim=10,
          hidden=[48], B=100, steps=3, lr=1e-2, optimizer="adam", max_norm=10.0, seed=3,
          emb_scale=1000.0, lr_scale=1000.0),
+    dict(name="deepfm_reg", model="DeepFM", n_dense=3, cards=CARDS[:8], embedding_dim=8,
+         hidden=[32, 16], B=128, steps=5, lr=1e-2, optimizer="adam", max_norm=10.0, seed=23,
+         emb_scale=1000.0, lr_scale=1000.0, emb_reg=1e-3, net_reg="l1_l2(1e-5,1e-4)"),
+    dict(name="deepfm_reg_sgd", model="DeepFM", n_dense=3, cards=CARDS[:8], embedding_dim=8,
+         hidden=[32, 16], B=128, steps=5, lr=5e-2, optimizer="SGD", max_norm=0.05, seed=29,
+         emb_scale=1000.0, lr_scale=1000.0, emb_reg="l1_l2(1e-4,1e-2)", net_reg=0),
     dict(name="xdeepfm_adam", model="xDeepFM", n_dense=3, cards=CARDS[:9], embedding_dim=8,
          hidden=[32, 16], cin=[12, 6, 5], B=128, steps=4, lr=1e-2, optimizer="adam", max_norm=10.0,
          seed=17, emb_scale=1000.0, lr_scale=1000.0),

@@ -597,3 +597,60 @@ def test_cin_stack_matches_einsum_conv1d(F0, D, units, B):
     for a, r in zip(dl, leaves):
         scale = max(1.0, r.grad.abs().max().item())
         assert (a.grad.cpu() - r.grad).abs().max().item() <= 5e-5 * scale, (tuple(r.shape), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,adam", [(16, True), (1, True), (10, False), (16, False)])
+def test_embedding_regularizer_dense_step_equals_dense_optimizer(D, adam):
+    """fx_reg_stats / fx_reg_cross / sparse update with r(p) / fx_reg_dense_update together ==
+    one dense Adam|SGD step on grad = scatter(G) + l1 sign(p) + l2 p with the global-norm clip."""
+    R, l1, l2, lr = 3001, 3e-3, 2e-2, 0.05
+    g = torch.Generator().manual_seed(D + 7 * adam)
+    table0 = torch.randn(R, D, generator=g)
+    table0[0].zero_()                                   # a padding row stays exactly zero
+    table = _dev(table0)
+    m = torch.zeros(R, D, device=DEV)
+    v = torch.zeros(R, D, device=DEV)
+    last = torch.zeros(R, dtype=torch.int32, device=DEV)
+    scal = ops.new_scalars(DEV, lr=lr, max_norm=0.5)
+    scal[_lib.SC_REG_L1:_lib.SC_REG_L1 + 1].fill_(l1)
+    scal[_lib.SC_REG_L2:_lib.SC_REG_L2 + 1].fill_(l2)
+    p_ref, m_ref, v_ref = table0.clone(), torch.zeros(R, D), torch.zeros(R, D)
+    ws = torch.empty(ops.dedup_workspace_bytes(64), dtype=torch.uint8, device=DEV)
+    parts = torch.zeros(3 * _lib.FX_REG_BLOCKS, device=DEV)
+    cross = torch.zeros(_lib.FX_REG_CROSS_BLOCKS, device=DEV)
+    for step in range(1, 4):
+        ops.opt_begin_step(scal)
+        ids = torch.randint(1, R, (64, 1), generator=g).numpy()
+        dd = ops.dedup(_dev(ids, torch.int32), _dev([0], torch.int64), _dev([R], torch.int32),
+                       _dev([-1], torch.int32), R, ws)
+        nu = int(dd.n_unique.item())
+        rows = dd.uniq_row[:nu].long().cpu()
+        G = torch.zeros(64, D)
+        G[:nu] = torch.randn(nu, D, generator=g) * 0.01
+        ops.reg_stats(table, scal, parts)
+        ops.reg_cross(table, D, dd, _dev(G), scal, cross)
+        nb = _lib.FX_REG_BLOCKS
+        r = l1 * torch.sign(p_ref) + l2 * p_ref
+        np.testing.assert_allclose(parts[:nb].sum().item(), (p_ref.double() ** 2).sum().item(), rtol=1e-5)
+        np.testing.assert_allclose(parts[nb:2 * nb].sum().item(), p_ref.double().abs().sum().item(), rtol=1e-5)
+        np.testing.assert_allclose(parts[2 * nb:].sum().item(), (r.double() ** 2).sum().item(), rtol=1e-5)
+        grad = r.clone()
+        grad[rows] += G[:nu]
+        sq = _dev([(G.double() ** 2).sum().item()], torch.float32)
+        ops.clip_coef([sq, parts[2 * nb:], cross], scal)
+        total = grad.double().norm().item()
+        np.testing.assert_allclose(float(scal[_lib.SC_TOTAL_NORM]), total, rtol=2e-5)
+        coef = min(1.0, 0.5 / (total + 1e-6))
+        if adam:
+            ops.sparse_adam(table, m, v, last, D, dd, _dev(G), scal)
+            O.adam_dense(p_ref, grad * coef, m_ref, v_ref, step, lr)
+        else:
+            ops.sparse_sgd(table, D, dd, _dev(G), scal, last_step=last)
+            p_ref -= lr * coef * grad
+        ops.reg_dense_update(table, m if adam else None, v if adam else None, last, D, adam, scal)
+        assert (table.cpu() - p_ref).abs().max().item() <= 2e-6
+        assert table[0].abs().max().item() == 0.0
+    if adam:
+        assert (m.cpu() - m_ref).abs().max().item() <= 1e-6
+        assert (v.cpu() - v_ref).abs().max().item() <= 1e-6

@@ -28,7 +28,8 @@ def build_native(g, tmp_path, sparse_update="exact", optimizer=None, hip_graph=F
     common = dict(gpu=0, embedding_dim=m["embedding_dim"], learning_rate=m["lr"],
                   optimizer=optimizer or m["optimizer"], loss="binary_crossentropy",
                   task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
-                  model_root=str(tmp_path), embedding_regularizer=0, net_regularizer=0,
+                  model_root=str(tmp_path), embedding_regularizer=m.get("emb_reg", 0),
+                  net_regularizer=m.get("net_reg", 0),
                   sparse_update=sparse_update, hip_graph=hip_graph)
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"], **common)

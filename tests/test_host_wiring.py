@@ -23,7 +23,8 @@ def _build(g, tmp_path, monkeypatch, sparse_update="exact"):
     common = dict(gpu=-1, embedding_dim=m["embedding_dim"], learning_rate=m["lr"],
                   optimizer=m["optimizer"], loss="binary_crossentropy",
                   task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
-                  model_root=str(tmp_path), sparse_update=sparse_update)
+                  model_root=str(tmp_path), sparse_update=sparse_update,
+                  embedding_regularizer=m.get("emb_reg", 0), net_regularizer=m.get("net_reg", 0))
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"], **common)
     elif m["model"] == "xDeepFM":

@@ -23,7 +23,9 @@ def test_oracle_forward_matches_reference(golden):
 def test_oracle_training_trajectory_matches_reference(golden):
     m = golden.meta
     tr = O.OracleTrainer(golden.cfg(), golden.state0, golden.features, lr=m["lr"],
-                         max_norm=m["max_norm"], optimizer=m["optimizer"].lower())
+                         max_norm=m["max_norm"], optimizer=m["optimizer"].lower(),
+                         emb_reg=O.parse_regularizer(m.get("emb_reg", 0)),
+                         net_reg=O.parse_regularizer(m.get("net_reg", 0)))
     losses = []
     for i in range(m["steps"]):
         b = _torch_batch(golden.batches[i])
