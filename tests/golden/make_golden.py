@@ -187,6 +187,81 @@ def run_case(case):
           out["expect/pred1"][:3], "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_c1():
+    """BASELINE.json configs[0]: the reference's own demo (demo/example3_DeepFM_with_npz_input.py,
+    config demo/config/example3_config `DeepFM_test_npz`, data/tiny_npz) run through its own
+    RankDataLoader + BaseModel.fit + evaluate.  Stored: the batches fit() actually saw (in shuffled
+    order), the validation set, initial/final weights and the reference's logloss/AUC."""
+    import numpy as np
+    import torch
+    from fuxictr.features import FeatureMap
+    from fuxictr.pytorch.dataloaders import RankDataLoader
+    from fuxictr.pytorch.torch_utils import seed_everything
+    from fuxictr.utils import load_config
+    from model_zoo.DeepFM.DeepFM_torch.src import DeepFM
+    name = "c1_tiny_npz"
+    params = load_config(os.path.join(REF, "demo/config/example3_config"), "DeepFM_test_npz")
+    params["gpu"] = -1
+    params["model_root"] = os.path.join(TMP, name)
+    os.makedirs(os.path.join(TMP, name, params["dataset_id"]), exist_ok=True)
+    params["num_workers"] = 0
+    params["verbose"] = 0
+    for k in ("train_data", "valid_data", "test_data"):
+        params[k] = os.path.join(REF, "data/tiny_npz", os.path.basename(params[k]))
+    data_dir = os.path.join(REF, "data", params["dataset_id"])
+    fmap = FeatureMap(params["dataset_id"], data_dir)
+    fmap.load(os.path.join(data_dir, "feature_map.json"), params)
+    with open(os.path.join(data_dir, "feature_map.json")) as f:
+        spec = json.load(f)
+    seed_everything(params["seed"])
+    model = DeepFM(fmap, **params)
+    out = {}
+    for k, v in model.state_dict().items():
+        out["state0/" + k] = v.detach().cpu().numpy().copy()
+    train_gen, valid_gen = RankDataLoader(fmap, stage="train", **params).make_iterator()
+    seen, losses = [], []
+    inner = model.train_step
+
+    def recording_step(batch_data):
+        seen.append({k: v.detach().clone() for k, v in batch_data.items()})
+        loss = inner(batch_data)
+        losses.append(float(loss.item()))
+        return loss
+    model.train_step = recording_step
+    model.fit(train_gen, validation_data=valid_gen, **params)
+    model.train_step = inner
+    res = model.evaluate(valid_gen)
+    valid = {}
+    for b in valid_gen:
+        for k, v in b.items():
+            valid.setdefault(k, []).append(v)
+    valid = {k: torch.cat(v) for k, v in valid.items()}
+    model.eval()
+    with torch.no_grad():
+        p1 = model.forward(valid)["y_pred"]
+    out["expect/pred1"] = p1.numpy().reshape(-1).copy()
+    out["expect/loss"] = np.asarray(losses, dtype=np.float64)
+    out["expect/valid_logloss"] = np.asarray([res["logloss"]], dtype=np.float64)
+    out["expect/valid_auc"] = np.asarray([res["AUC"]], dtype=np.float64)
+    for k, v in model.state_dict().items():
+        out["state1/" + k] = v.detach().cpu().numpy().copy()
+    for i, b in enumerate(seen + [valid]):
+        for k, v in b.items():
+            out["batch%d/%s" % (i, k)] = v.numpy()
+    meta = dict(name=name, model="DeepFM", hidden=list(params["hidden_units"]),
+                embedding_dim=params["embedding_dim"], lr=params["learning_rate"],
+                optimizer=params["optimizer"], max_norm=10.0, steps=len(seen),
+                B=params["batch_size"], seed=params["seed"],
+                emb_reg=params["embedding_regularizer"], net_reg=params["net_regularizer"])
+    meta["spec"] = spec
+    meta["torch"] = torch.__version__
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "steps", len(seen), "loss", losses, "valid", dict(res), "->", path,
+          os.path.getsize(path) // 1024, "KiB")
+
+
 CARDS = [37, 13, 1500, 900, 11, 5, 211, 19, 3, 401, 97, 1200, 53, 7]
 CASES = [
     dict(name="deepfm_adam", model="DeepFM", n_dense=5, cards=CARDS, embedding_dim=8,
@@ -226,3 +301,5 @@ if __name__ == "__main__":
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
+    if not only or "c1_tiny_npz" in only:
+        run_c1()
