@@ -13,7 +13,47 @@ import torch
 import torch.distributed as dist
 
 
+class GraphSegments(object):
+    """A training step with collectives, as hipGraph segments with the collectives launched eagerly
+    in between: [graph 0] a2a ids [graph 1] a2a rows ... [graph k] all-reduce [graph k+1].
+    Nothing about RCCL is captured; every buffer a collective touches was allocated inside the
+    capture (one memory pool shared by all segments), so its address is fixed across replays."""
+
+    def __init__(self):
+        self.pool = torch.cuda.graph_pool_handle()
+        self.items = []          # CUDAGraph | callable, in program order
+        self._cur = None
+
+    def begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self.pool)
+        self._cur = g
+
+    def cut(self, fn):
+        """End the current segment, run `fn` eagerly (now, and at this point of every replay),
+        start the next segment."""
+        self._cur.capture_end()
+        self.items.append(self._cur)
+        fn()
+        self.items.append(fn)
+        self.begin()
+
+    def finish(self):
+        self._cur.capture_end()
+        self.items.append(self._cur)
+        self._cur = None
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+
 class DistContext(object):
+    recorder = None      # a GraphSegments while a sharded step is being captured
+
     def __init__(self, group=None):
         if not dist.is_initialized():
             raise RuntimeError("shard='row' needs torch.distributed to be initialised "
@@ -28,28 +68,37 @@ class DistContext(object):
 
     def all_to_all(self, send):
         """send: [world * k, ...] -> recv of the same shape (chunk i goes to rank i)."""
-        if self._stage(send):
+        send = send.contiguous()
+        recv = torch.empty_like(send)
+        if self.recorder is not None:
+            self.recorder.cut(lambda: self._a2a_into(recv, send))
+        else:
+            self._a2a_into(recv, send)
+        return recv
+
+    def _a2a_into(self, recv, send):
+        if self._stage(send):      # gloo on GPU tensors: through the host (test / debug only)
             s = send.cpu()
             r = torch.empty_like(s)
             dist.all_to_all_single(r, s, group=self.group)
-            return r.to(send.device)
-        if self.backend == "gloo":
-            # gloo implements all_to_all_single for CPU tensors via send/recv pairs
-            recv = torch.empty_like(send)
-            dist.all_to_all_single(recv, send.contiguous(), group=self.group)
-            return recv
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send.contiguous(), group=self.group)
-        return recv
+            recv.copy_(r)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
 
     def all_reduce_sum(self, t):
+        if self.recorder is not None:
+            self.recorder.cut(lambda: self._all_reduce_into(t))
+        else:
+            self._all_reduce_into(t)
+        return t
+
+    def _all_reduce_into(self, t):
         if self._stage(t):
             c = t.cpu()
             dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(c)
-            return t
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast(self, t, src=0):
         if self._stage(t):

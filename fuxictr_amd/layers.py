@@ -157,6 +157,8 @@ class _TableGroup(object):
         self.m = self.v = self.last_step = None
         self.num_grad = None
         self.pending = []
+        self._shard_consts = {}
+        self._await_exchange = []     # row-gradient buffers waiting for their all-to-all
         self.dedup_ws = None
         # row sharding (owner = row % world, local row = row // world)
         self.dist = _DIST
@@ -383,15 +385,19 @@ class _TableGroup(object):
             self.owner_ws = (N * cap, torch.empty(ops.dedup_workspace_bytes(N * cap),
                                                   dtype=torch.uint8, device=dev))
         rps = self.rows_per_shard
-        sx.own_base = torch.zeros(1, dtype=torch.int64, device=dev)
-        sx.own_vocab = torch.tensor([rps + 1], dtype=torch.int32, device=dev)
-        sx.own_pad = torch.tensor([rps], dtype=torch.int32, device=dev)
+        C = ids.shape[1]
+        consts = self._shard_consts.get((C, cap))
+        if consts is None:      # built once, outside any graph capture (H2D copies)
+            consts = self._shard_consts[(C, cap)] = (
+                torch.zeros(1, dtype=torch.int64, device=dev),
+                torch.tensor([rps + 1], dtype=torch.int32, device=dev),
+                torch.tensor([rps], dtype=torch.int32, device=dev),
+                # lookups gather from the received-rows buffer [N*cap + 1, D] (last row = zeros)
+                torch.zeros(C, dtype=torch.int64, device=dev),
+                torch.full((C,), N * cap + 1, dtype=torch.int32, device=dev))
+        sx.own_base, sx.own_vocab, sx.own_pad, sx.slot_base, sx.slot_vocab = consts
         sx.owner_dd = ops.dedup(sx.recv_idx, sx.own_base, sx.own_vocab, sx.own_pad, rps + 1,
                                 self.owner_ws[1])
-        # lookups gather from the received-rows buffer [N*cap + 1, D] (last row = zeros)
-        C = ids.shape[1]
-        sx.slot_base = torch.zeros(C, dtype=torch.int64, device=dev)
-        sx.slot_vocab = torch.full((C,), N * cap + 1, dtype=torch.int32, device=dev)
         if cache is not None:
             cache[ckey] = sx
         return sx
@@ -422,6 +428,19 @@ class _TableGroup(object):
         ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G_loc, sq, scratch)
         gsend = torch.zeros(N * cap + 1, D, dtype=torch.float32, device=self.device)
         ops.scatter_rows(G_loc, sx.uniq_slot, dd.n_unique, dd.n_max, D, gsend)
+        # the exchange itself runs after autograd returns (finish_backward, called by the
+        # optimizer on the main thread): collectives stay in one fixed program order on every rank
+        self._await_exchange.append((sx, gsend))
+
+    def finish_backward(self):
+        """Owner side of the sharded backward: ship row gradients to their owners, reduce the
+        contributions of all ranks per owned row."""
+        waiting, self._await_exchange = self._await_exchange, []
+        for sx, gsend in waiting:
+            self._finish_one(sx, gsend)
+
+    def _finish_one(self, sx, gsend):
+        N, cap, D = self.n_shards, sx.cap, self.D
         grecv = self.dist.all_to_all(gsend[:N * cap])
         odd = sx.owner_dd
         G_own = torch.empty(odd.n_max, D, dtype=torch.float32, device=self.device)

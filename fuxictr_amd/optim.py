@@ -203,16 +203,30 @@ class _NativeOptimizer(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closure is not supported by the native optimizer")
+        for grp in self._groups:
+            if grp.dist is not None:
+                grp.finish_backward()       # row-gradient all-to-all + owner-side reduction
         ps, gs = self._dense_lists()
-        if self.dist is not None and ps:
-            # one flat all-reduce for every dense gradient (losses were pre-scaled by 1/world)
-            flat = torch.cat([g.reshape(-1) for g in gs])
+        tsq = None
+        if self.dist is not None:
+            for grp in self._groups:
+                if len(grp.pending) > 1:
+                    raise NotImplementedError("several lookups of one table group per step")
+            # ONE all-reduce per step: every dense gradient (losses were pre-scaled by 1/world)
+            # followed by one float — this rank's table part of the squared gradient norm (table
+            # rows are disjoint across ranks, so the SUM is the global table part)
+            tsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+            tparts = [rec.sq for grp in self._groups for rec in grp.pending]
+            if tparts:
+                ops.sum_parts(tparts, tsq)
+            flat = torch.cat([g.reshape(-1) for g in gs] + [tsq])
             self.dist.all_reduce_sum(flat)
             out, off = [], 0
             for g in gs:
                 out.append(flat[off:off + g.numel()].view_as(g))
                 off += g.numel()
             gs = out
+            tsq = flat[off:off + 1]
         parts = []
         if ps:
             need = len(ps) * _lib.FX_MT_BLOCKS
@@ -225,8 +239,9 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 raise NotImplementedError(
                     "a table group was looked up %d times in one training step; merging several "
                     "sparse gradients per step is not implemented" % len(grp.pending))
-            for rec in grp.pending:
-                parts.append(rec.sq)
+            if tsq is None:
+                for rec in grp.pending:
+                    parts.append(rec.sq)
             if self.dense_reg and grp.table is not None:
                 if not grp.reg_fresh:
                     ops.reg_stats(grp.table, self.scal, grp.reg_partials)
@@ -235,15 +250,10 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 for rec in grp.pending:
                     ops.reg_cross(grp.table, grp.D, rec.dd, rec.G, self.scal, grp.reg_cross)
                     parts.append(grp.reg_cross)
-        if self.dist is not None:
-            # table rows are disjoint across ranks: global norm^2 = dense part (identical on every
-            # rank after the all-reduce) + sum over ranks of the local table parts
-            tparts = parts[1:] if ps else parts
-            tsq = torch.zeros(1, dtype=torch.float32, device=self.device)
-            if tparts:
-                ops.sum_parts(tparts, tsq)
-            self.dist.all_reduce_sum(tsq)
-            parts = (parts[:1] if ps else []) + [tsq]
+        if tsq is not None:
+            # global norm^2 = dense part (identical on every rank after the all-reduce) + the
+            # all-reduced table part
+            parts.append(tsq)
         ops.clip_coef(parts, self.scal)
         if ps:
             self._dense_update(ps, gs)

@@ -189,9 +189,29 @@ class _GraphStep(object):
         self._pack_keys = {k for k, *_ in self.packs}
         self.fill(batch)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=model._graph_stream):
-            self.loss = model._step_body(static)
+        if model._dist is None:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=model._graph_stream):
+                self.loss = model._step_body(static)
+        else:
+            # row-sharded: hipGraph segments with the collectives launched eagerly in between
+            import gc
+            from .dist import GraphSegments
+            self.graph = GraphSegments()
+            gc.collect()
+            torch.cuda.empty_cache()
+            cur = torch.cuda.current_stream(dev)
+            model._graph_stream.wait_stream(cur)
+            with torch.cuda.stream(model._graph_stream):
+                model._dist.recorder = self.graph
+                try:
+                    self.graph.begin()
+                    self.loss = model._step_body(static)
+                    self.graph.finish()
+                finally:
+                    model._dist.recorder = None
+            cur.wait_stream(model._graph_stream)
+            torch.cuda.synchronize(dev)
         # the capture only recorded the step; drop per-batch caches created while recording
         static.cache = {k: v for k, v in static.cache.items() if k in self._pack_keys}
 
@@ -250,7 +270,7 @@ class BaseModel(nn.Module):
         self._reduce_lr_on_plateau = reduce_lr_on_plateau
         self._verbose = kwargs["verbose"]
         self._sparse_update = kwargs.get("sparse_update", "exact")
-        self._use_graph = bool(kwargs.get("hip_graph", False)) and self._dist is None
+        self._use_graph = bool(kwargs.get("hip_graph", False))
         self._graph_state = None
         self._graph_warm = 0
         self._max_gradient_norm = 10.

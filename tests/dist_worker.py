@@ -31,7 +31,8 @@ def run(rank, world, case, port, out_path, use_gpu):
     common = dict(gpu=0 if use_gpu else -1, embedding_dim=m["embedding_dim"],
                   learning_rate=m["lr"], optimizer=m["optimizer"], loss="binary_crossentropy",
                   task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
-                  model_root="/tmp/fx_dist_%d" % rank, shard="row")
+                  model_root="/tmp/fx_dist_%d" % rank, shard="row",
+                  hip_graph=os.environ.get("FX_HIP_GRAPH", "0") == "1")
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=case, hidden_units=m["hidden"], **common)
     elif m["model"] == "xDeepFM":
