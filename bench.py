@@ -241,6 +241,9 @@ def main():
     model.optimizer.check_errors()
     timing_mode = "hip events inside the timed region (eager launches)"
     if model._use_graph and not args.no_kernel_timing:
+        # the eager pass runs on the default stream; the parameters' AccumulateGrad nodes were
+        # created on the capture stream — harmless here, silence the per-parameter warning
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         model._use_graph = False
         ops.KernelTimer.enabled = True
         for _ in range(min(args.steps, 20)):

@@ -20,6 +20,10 @@
 // key = global packed row g, or — with the table row-sharded over n_shards ranks — the
 // owner-major pair (g % n_shards) * rows_per_shard + g / n_shards, so that a sort groups the
 // lookups by owning rank and the key itself carries (owner, local row).
+__global__ void k_zero_words(int32_t* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void k_build_keys(const int32_t* ids, int64_t ids_ld, int64_t n,
                                                     int C, const int64_t* col_row_base,
                                                     const int32_t* col_vocab,
@@ -181,8 +185,9 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
     hipStream_t s = fx_hip_stream(stream);
     const int64_t n = B * (int64_t)C;
     if (n == 0) {
-        FX_CHECK_HIP(hipMemsetAsync(n_unique, 0, sizeof(int32_t), s));
-        FX_CHECK_HIP(hipMemsetAsync(seg_start, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, n_unique, 1);
+        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, reinterpret_cast<int32_t*>(seg_start), 1);
+        FX_CHECK_LAUNCH();
         return FX_OK;
     }
     FX_CHECK_ARG(n < (int64_t)0x7FFFFFFF, "fx_dedup: too many lookups (%lld)", (long long)n);
@@ -402,7 +407,8 @@ extern "C" int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int6
     hipStream_t s = fx_hip_stream(stream);
     FX_CHECK_ARG(sq_partials && scratch, "fx_emb_grad_reduce: null sq_partials / scratch");
     if (n_max <= 0) {
-        FX_CHECK_HIP(hipMemsetAsync(sq_partials, 0, sizeof(float), s));
+        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, reinterpret_cast<int32_t*>(sq_partials), 1);
+        FX_CHECK_LAUNCH();
         return FX_OK;
     }
     FX_CHECK_ARG(dout && col_out_off && sorted_pos && seg_start && n_unique && G,
@@ -414,7 +420,9 @@ extern "C" int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int6
     while ((1 << ll) < g.lanes) ++ll;
     ReduceArgs a{dout, dout_ld, col_out_off, sorted_pos, seg_start, n_unique, G, sq_partials,
                  scratch, C, D, ll};
-    FX_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(int32_t), s));
+    // the long-run counter is zeroed by a kernel, not hipMemsetAsync: as the root node of a captured
+    // hipGraph segment the 4-byte memset node was observed not to be ordered before the kernels
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, scratch, 1);
     const int64_t blocks = fx_ceil_div(n_max, 256 / g.lanes);
     dim3 grid((unsigned)blocks), grid_long(512);
 #define FX_REDUCE_LAUNCH(V)                                                              \

@@ -9,6 +9,8 @@ One process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI on RO
 The gloo path (CPU tensors, or GPU tensors staged through the host) exists so that the routing logic
 is testable with 2 processes in a GPU-less container and on a 1-GPU box.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -44,6 +46,12 @@ class GraphSegments(object):
         self._cur = None
 
     def replay(self):
+        if os.environ.get("FX_SEG_DEBUG"):
+            for i, it in enumerate(self.items):
+                print("[seg %d] %s" % (i, type(it).__name__), flush=True)
+                it.replay() if isinstance(it, torch.cuda.CUDAGraph) else it()
+                torch.cuda.synchronize()
+            return
         for it in self.items:
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
