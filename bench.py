@@ -187,11 +187,12 @@ def main():
     cards = [max(3, int(c * args.vocab_scale)) for c in synthetic.CRITEO_CARDS]
     parallelism = "single GPU"
     if world > 1 and not args.replicas:
-        # row-sharded tables (row % world) + all-to-all exchange + dense all-reduce, eager launches
+        # row-sharded tables (row % world) + all-to-all exchange + dense all-reduce
         model, fmap, spec = build_model(args, local_rank, cards, shard="row")
-        parallelism = ("tables row-sharded over %d ranks (RCCL all-to-all ids/rows/row-grads), "
-                       "towers data-parallel (one flat all-reduce), global clip; eager launches"
-                       % world)
+        parallelism = ("tables row-sharded over %d ranks (RCCL all-to-all of ids / rows / row "
+                       "gradients), towers data-parallel (one flat all-reduce carrying the clip "
+                       "norm); %s" % (world, "eager launches" if args.no_graph else
+                                      "hipGraph segments with the collectives launched between them"))
     else:
         model, fmap, spec = build_model(args, local_rank, cards)
         if world > 1:
