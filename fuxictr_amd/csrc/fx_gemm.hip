@@ -17,6 +17,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FX_BK 32
@@ -244,6 +246,378 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined variant for 16-byte-aligned operands (every tower GEMM of the B=4096 step).
+// The kernel above stops its MFMA stream at every k-tile boundary (wait for the prefetched
+// registers, 8-32 ds_writes, barrier, fragment-read latency) — ~15-20 % of a tile when only one
+// workgroup fits a CU.  Here the boundary work is spread over the MFMA stream instead:
+//   * two register staging sets: the global loads of tile t+2 are issued at the top of tile t,
+//     the registers of tile t+1 (loaded a whole tile earlier) go to the other LDS stage during
+//     MFMA groups 2..12, one ds_write after each MFMA;
+//   * ONE barrier per tile after group 13; groups 14/15 already read the first fragments of tile
+//     t+1 from the other stage, so the next tile starts with its MFMAs;
+//   * MFMA operands in VGPR form (amdgpu_waves_per_eu(2,2)): with AGPR accumulators the compiler
+//     copied all 64 of them in and out around the loop's branches.
+// Out-of-range rows / the K tail are clamped addresses + zero selects (no exec-mask branches).
+// ---------------------------------------------------------------------------------------------
+template <int R, bool KC>
+struct PipeLoader {
+    static constexpr int NST = R / 32;
+    static constexpr int LD = KC ? R + 1 : R + 4;
+    const float* P;
+    int32_t ld;
+    int32_t rc[NST];       // KC: clamped row * ld ; else: clamped first row of the float4
+    int32_t kl[NST];       // k of this thread's float4 inside a tile
+    uint32_t rok;          // bit p: the row(s) of float4 p exist
+    uint32_t voff[NST];    // byte offset of float4 p in tile 0 (valid when the rows exist)
+    int32_t kbeg, kend;
+
+    __device__ __forceinline__ void init(const float* P_, int64_t ld_, int64_t r0, int64_t Rext,
+                                         int64_t kbeg_, int64_t kend_) {
+        P = P_;
+        ld = (int32_t)ld_;
+        kbeg = (int32_t)kbeg_;
+        kend = (int32_t)kend_;
+        rok = 0;
+#pragma unroll
+        for (int p = 0; p < NST; ++p) {
+            const int q = threadIdx.x + 256 * p;
+            if constexpr (KC) {
+                const int32_t r = (int32_t)r0 + (q >> 3);
+                kl[p] = (q & 7) << 2;
+                if (r < (int32_t)Rext) rok |= 1u << p;
+                rc[p] = (r < (int32_t)Rext ? r : (int32_t)Rext - 1) * ld;
+                voff[p] = (uint32_t)(rc[p] + kbeg + kl[p]) * 4u;
+            } else {
+                const int32_t r = (int32_t)r0 + ((q % (R / 4)) << 2);
+                kl[p] = q / (R / 4);
+                if (r < (int32_t)Rext) rok |= 1u << p;
+                rc[p] = r < (int32_t)Rext ? r : (int32_t)Rext - 4;
+                voff[p] = (uint32_t)((kbeg + kl[p]) * ld + rc[p]) * 4u;
+            }
+        }
+    }
+
+    // Issues the loads only; the zero select of out-of-range elements happens in store_one, so no
+    // instruction between here and the LDS write (a tile later) has to wait for the data.
+    // Returns the validity bits of the NST float4s.
+    __device__ __forceinline__ uint32_t load(int64_t t, float4 (&st)[NST]) const {
+        uint32_t okm = 0;
+#pragma unroll
+        for (int p = 0; p < NST; ++p) {
+            const int32_t k = kbeg + (int32_t)t * FX_BK + kl[p];
+            if ((k < kend) && ((rok >> p) & 1u)) okm |= 1u << p;
+            if constexpr (KC) {
+                const int32_t kc = k < kend ? k : kend - 4;
+                st[p] = *reinterpret_cast<const float4*>(P + (rc[p] + kc));
+            } else {
+                const int32_t kc = k < kend ? k : kend - 1;
+                st[p] = *reinterpret_cast<const float4*>(P + (kc * ld + rc[p]));
+            }
+        }
+        return okm;
+    }
+
+    // tile fully inside the matrix: uniform tile base + constant 32-bit per-lane byte offset (the
+    // global_load saddr form: no per-lane address arithmetic in the loop)
+    template <int p>
+    __device__ __forceinline__ void load_plain(int64_t t, float4 (&st)[NST], uint32_t& okm) const {
+        const int64_t tile_off = KC ? t * (FX_BK * 4) : t * (FX_BK * 4) * (int64_t)ld;
+        const char* base = reinterpret_cast<const char*>(P) + tile_off;
+        st[p] = *reinterpret_cast<const float4*>(base + voff[p]);
+        okm = (1u << NST) - 1u;
+    }
+
+    template <int p>
+    __device__ __forceinline__ void load_one(int64_t t, float4 (&st)[NST], uint32_t& okm) const {
+        const int32_t k = kbeg + (int32_t)t * FX_BK + kl[p];
+        if ((k < kend) && ((rok >> p) & 1u)) okm |= 1u << p;
+        else okm &= ~(1u << p);
+        if constexpr (KC) {
+            const int32_t kc = k < kend ? k : kend - 4;
+            st[p] = *reinterpret_cast<const float4*>(P + (rc[p] + kc));
+        } else {
+            const int32_t kc = k < kend ? k : kend - 1;
+            st[p] = *reinterpret_cast<const float4*>(P + (kc * ld + rc[p]));
+        }
+    }
+
+    // one LDS write instruction: component `comp` of float4 p (KC, transposing) or the whole float4
+    template <int p, int comp, bool MASK>
+    __device__ __forceinline__ void store_piece(float* __restrict__ T, const float4 (&st)[NST],
+                                                uint32_t okm) const {
+        const int q = threadIdx.x + 256 * p;
+        const bool ok = MASK ? ((okm >> p) & 1u) : true;
+        if constexpr (KC) {
+            const int r = q >> 3, kq = (q & 7) << 2;
+            const float x = comp == 0 ? st[p].x : comp == 1 ? st[p].y : comp == 2 ? st[p].z : st[p].w;
+            T[(kq + comp) * LD + r] = ok ? x : 0.f;
+        } else {
+            const int k = q / (R / 4), r = (q % (R / 4)) << 2;
+            float4 v;
+            v.x = ok ? st[p].x : 0.f;
+            v.y = ok ? st[p].y : 0.f;
+            v.z = ok ? st[p].z : 0.f;
+            v.w = ok ? st[p].w : 0.f;
+            *reinterpret_cast<float4*>(T + k * LD + r) = v;
+        }
+    }
+
+    template <int p>
+    __device__ __forceinline__ void store_one(float* __restrict__ T, const float4 (&st)[NST],
+                                              uint32_t okm) const {
+        const int q = threadIdx.x + 256 * p;
+        const bool ok = (okm >> p) & 1u;
+        float4 v;
+        v.x = ok ? st[p].x : 0.f;
+        v.y = ok ? st[p].y : 0.f;
+        v.z = ok ? st[p].z : 0.f;
+        v.w = ok ? st[p].w : 0.f;
+        if constexpr (KC) {
+            const int r = q >> 3, kq = (q & 7) << 2;
+            T[(kq + 0) * LD + r] = v.x;
+            T[(kq + 1) * LD + r] = v.y;
+            T[(kq + 2) * LD + r] = v.z;
+            T[(kq + 3) * LD + r] = v.w;
+        } else {
+            const int k = q / (R / 4), r = (q % (R / 4)) << 2;
+            *reinterpret_cast<float4*>(T + k * LD + r) = v;
+        }
+    }
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void fx_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        fx_static_for<I + 1, N>(f);
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_gemm_f32_pipe(GemmArgs a) {
+    using LoaderA = PipeLoader<BM, A_KC>;
+    using LoaderB = PipeLoader<BN, B_KC>;
+    constexpr int LDA = LoaderA::LD, LDB = LoaderB::LD;
+    constexpr int NSA = LoaderA::NST, NSB = LoaderB::NST, NS = NSA + NSB;
+    constexpr int MI = BM / 64, NJ = BN / 64;
+    constexpr int SA = FX_BK * LDA, SB = FX_BK * LDB;
+    constexpr int NG = FX_BK / 2;                      // MFMA groups (k-pairs) per tile
+    extern __shared__ __attribute__((aligned(16))) float fx_gemm_smem[];
+    float* const As0 = fx_gemm_smem;
+    float* const Bs0 = fx_gemm_smem + 2 * SA;
+
+    const int64_t nwg = (int64_t)a.tiles_m * a.tiles_n;
+    const int64_t L = blockIdx.x;
+    int64_t T = L;
+    if (nwg >= 8) {
+        const int64_t q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+        T = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    }
+    const int64_t m0 = (T / a.tiles_n) * BM;
+    const int64_t n0 = (T % a.tiles_n) * BN;
+    const int z = blockIdx.y;
+    const int64_t kbeg = (int64_t)z * a.k_chunk;
+    const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const bool do_rowsum = (a.epi.rowsum != nullptr) && (n0 == 0);
+    float rsum = 0.f;
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int64_t nk = (kend > kbeg) ? (kend - kbeg + FX_BK - 1) / FX_BK : 0;
+    if (nk > 0) {
+        LoaderA la;
+        LoaderB lb;
+        la.init(a.A, a.lda, m0, a.M, kbeg, kend);
+        lb.init(a.B, a.ldb, n0, a.N, kbeg, kend);
+        float4 ra[2][NSA], rb[2][NSB];
+        uint32_t oka[2], okb[2];
+        oka[0] = la.load(0, ra[0]);
+        okb[0] = lb.load(0, rb[0]);
+        oka[1] = la.load(1, ra[1]);      // past the last tile: clamped addresses, all bits clear
+        okb[1] = lb.load(1, rb[1]);
+        fx_static_for<0, NSA>([&](auto p) { la.template store_one<p.value>(As0, ra[0], oka[0]); });
+        fx_static_for<0, NSB>([&](auto p) { lb.template store_one<p.value>(Bs0, rb[0], okb[0]); });
+        __syncthreads();
+        const int foff_a = half * LDA + wm * (BM / 2) + l31;
+        const int foff_b = half * LDB + wn * (BN / 2) + l31;
+        float fa[2][MI], fb[2][NJ];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[c][i] = As0[foff_a + (2 * c) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[c][j] = Bs0[foff_b + (2 * c) * LDB + 32 * j];
+        }
+        int s = 0;                                      // LDS stage of tile t
+        // MASK = false: the tile being written to LDS (t+1) lies fully inside the matrix, its
+        // registers go to LDS as they are (1 instruction per write instead of and/cmp/cndmask/write)
+        auto body = [&](int64_t t, auto par, auto msk) {
+            constexpr int P = decltype(par)::value;
+            constexpr bool MASK = decltype(msk)::value;
+            const int sn = s ^ 1;
+            // (tile t+1 sits in register set P^1; past the last tile the loads are clamped)
+            const uint32_t oka_n = oka[P ^ 1], okb_n = okb[P ^ 1];
+            const int64_t tl = t + 2;
+            const float* as = As0 + s * SA + foff_a;
+            const float* bs = Bs0 + s * SB + foff_b;
+            const float* asn = As0 + sn * SA + foff_a;
+            const float* bsn = Bs0 + sn * SB + foff_b;
+            float* wa = As0 + sn * SA;
+            float* wb = Bs0 + sn * SB;
+            if (do_rowsum && threadIdx.x < BM) {
+                const float* col = As0 + s * SA + threadIdx.x;
+#pragma unroll
+                for (int k = 0; k < FX_BK; ++k) rsum += col[k * LDA];
+            }
+            // One k-pair group = MI*NJ MFMAs.  Its LDS work — MI+NJ fragment reads for group g+2
+            // and this group's share of the refill writes — is issued ONE instruction after each
+            // MFMA (measured, scripts/ubench/mfma_stream*.hip: a clump of 8 LDS instructions between
+            // two groups costs the MFMA pipe ~10 %, spread out it is free with two waves per SIMD).
+            fx_static_for<0, NG>([&](auto gg) {
+                constexpr int g = decltype(gg)::value;
+                constexpr int c = g & 1;
+                constexpr int S = MI * NJ;
+                constexpr int PA = A_KC ? 4 : 1, PB = B_KC ? 4 : 1;        // LDS writes per float4
+                constexpr int NP = NSA * PA + NSB * PB;                     // write pieces per tile
+                // groups [0, GL): the NS global loads of tile t+2 (with their address arithmetic);
+                // groups [G0, G0+GW): the LDS writes of tile t+1; barrier after group NG-3
+                constexpr int GL = 4, G0 = GL, GW = NG - 3 - G0;
+                constexpr int llo = g < GL ? (g * NS + GL - 1) / GL : 0;
+                constexpr int lhi = g < GL ? ((g + 1) * NS + GL - 1) / GL : 0;
+                constexpr int lo = (g >= G0 && g < G0 + GW) ? ((g - G0) * NP + GW - 1) / GW : 0;
+                constexpr int hi = (g >= G0 && g < G0 + GW) ? ((g - G0 + 1) * NP + GW - 1) / GW : 0;
+                constexpr int NOPS = MI + NJ + (hi - lo) + (lhi - llo);
+                float nfa[MI], nfb[NJ];
+                fx_static_for<0, S>([&](auto mm) {
+                    constexpr int m = decltype(mm)::value;
+                    constexpr int i = m / NJ, j = m % NJ;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j],
+                                                                     0, 0, 0);
+                    fx_static_for<0, NOPS>([&](auto oo) {
+                        constexpr int o = decltype(oo)::value;
+                        if constexpr (o % S == m) {
+                            if constexpr (o < MI) {
+                                if constexpr (g + 2 < NG) nfa[o] = as[(2 * g + 4) * LDA + 32 * o];
+                                else nfa[o] = asn[(2 * (g + 2 - NG)) * LDA + 32 * o];
+                            } else if constexpr (o < MI + NJ) {
+                                constexpr int jj = o - MI;
+                                if constexpr (g + 2 < NG) nfb[jj] = bs[(2 * g + 4) * LDB + 32 * jj];
+                                else nfb[jj] = bsn[(2 * (g + 2 - NG)) * LDB + 32 * jj];
+                            } else if constexpr (g < GL) {
+                                constexpr int idx = llo + (o - MI - NJ);
+                                if constexpr (MASK) {
+                                    if constexpr (idx < NSA) la.template load_one<idx>(tl, ra[P], oka[P]);
+                                    else lb.template load_one<idx - NSA>(tl, rb[P], okb[P]);
+                                } else {
+                                    if constexpr (idx < NSA) la.template load_plain<idx>(tl, ra[P], oka[P]);
+                                    else lb.template load_plain<idx - NSA>(tl, rb[P], okb[P]);
+                                }
+                            } else {
+                                constexpr int pp = lo + (o - MI - NJ);
+                                if constexpr (pp < NSA * PA)
+                                    la.template store_piece<pp / PA, pp % PA, MASK>(wa, ra[P ^ 1], oka_n);
+                                else
+                                    lb.template store_piece<(pp - NSA * PA) / PB, (pp - NSA * PA) % PB,
+                                                            MASK>(wb, rb[P ^ 1], okb_n);
+                            }
+                        }
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[c][i] = nfa[i];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[c][j] = nfb[j];
+                // Barrier once per tile, after group NG-3: every read of stage s has been issued (the
+                // fragments of the last two groups were fetched in groups NG-4/NG-3) and is complete
+                // (lgkmcnt(0)), every wave's writes of stage sn are complete; groups NG-2/NG-1 then
+                // prefetch from sn.  Two stages are enough: nobody reads s after this barrier, and
+                // the next writes into s (tile t+2's data) come after it in program order.
+                if constexpr (g == NG - 3) {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            s = sn;
+        };
+        // pairs in the loop, odd tail outside: a skip path inside the loop would join two different
+        // "loads in flight" states at the back edge and the compiler then waits vmcnt(0) there
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        const bool rows_full = (m0 + BM <= a.M) && (n0 + BN <= a.N);
+        const int64_t nk_full = (kend - kbeg) / FX_BK;           // tiles with all 32 k inside
+        // plain bodies: tile t+1 (written to LDS) and tile t+2 (loaded) are full tiles
+        const int64_t n_plain = rows_full ? nk_full - 2 : 0;
+        int64_t t = 0;
+        for (; t + 1 < n_plain; t += 2) {
+            body(t, P0{}, std::false_type{});
+            body(t + 1, P1{}, std::false_type{});
+        }
+        for (; t + 1 < nk; t += 2) {
+            body(t, P0{}, std::true_type{});
+            body(t + 1, P1{}, std::true_type{});
+        }
+        if (t < nk) body(t, P0{}, std::true_type{});
+    }
+
+    if (do_rowsum && threadIdx.x < BM && m0 + threadIdx.x < a.M) {
+        if (a.split_k > 1) a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + m0 + threadIdx.x] = rsum;
+        else a.epi.rowsum[m0 + threadIdx.x] = rsum;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int64_t n = n0 + wn * (BN / 2) + j * 32 + l31;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= a.M) continue;
+                if (a.split_k > 1) {
+                    a.ws[((int64_t)z * a.M + m) * a.N + n] = acc[i][j][r];
+                } else {
+                    a.C[m * a.ldc + n] = fx_epilogue(a.epi, acc[i][j][r], m, n);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+static int fx_gemm_launch_pipe(dim3 grid, hipStream_t s, const GemmArgs& a) {
+    constexpr size_t lds = 2 * FX_BK * (size_t)(PipeLoader<BM, A_KC>::LD + PipeLoader<BN, B_KC>::LD) *
+                           sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FX_CHECK_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&k_gemm_f32_pipe<BM, BN, A_KC, B_KC>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC>), grid, dim3(256), lds, s, a);
+    return FX_OK;
+}
+
+template <int BM, int BN>
+static int fx_gemm_dispatch_pipe(bool a_kc, bool b_kc, dim3 grid, hipStream_t s, const GemmArgs& a) {
+    if (a_kc && b_kc) return fx_gemm_launch_pipe<BM, BN, true, true>(grid, s, a);
+    if (a_kc) return fx_gemm_launch_pipe<BM, BN, true, false>(grid, s, a);
+    if (b_kc) return fx_gemm_launch_pipe<BM, BN, false, true>(grid, s, a);
+    return fx_gemm_launch_pipe<BM, BN, false, false>(grid, s, a);
 }
 
 __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a) {
@@ -498,17 +872,19 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
             if (!strcmp(e, "64x64")) return 3;
             return 0;
         }();
-        // Measured on MI355X (profiles/r01_gemm_tiles.txt): when 128x128 tiles cannot give ~2
-        // workgroups per CU, 64x64 (4 workgroups per CU, 33 KB LDS each) beats 128x64 on every
-        // tower shape of the B=4096 step (e.g. 4096x1024x624: 85.9 vs 79.1 TFLOP/s).
-        const int64_t want = 448;
+        // Measured on MI355X (profiles/r01_gemm_pipe.txt), pipelined kernel: 128x128 whenever its
+        // grid covers the 256 CUs (4096x1024 towers: exactly 256 tiles), 128x64 when that one does
+        // twice, else 64x64 (three co-resident workgroups per CU hide the ragged last wave, e.g.
+        // N = 624: 640 tiles).
+        const int64_t t128 = fx_ceil_div(M, 128) * fx_ceil_div(N, 128) * split_k;
+        const int64_t t12864 = fx_ceil_div(M, 128) * fx_ceil_div(N, 64) * split_k;
         if (forced == 2) { bn = 64; }
         else if (forced == 3) { bm = 64; bn = 64; }
-        else if (forced == 0 && fx_ceil_div(M, 128) * fx_ceil_div(N, 128) * split_k < want) {
-            bm = 64;
-            bn = 64;
-        } else if (forced == 0 && N <= 64) {
+        else if (forced == 0 && N <= 64) {
             bn = 64;   // e.g. the DIN attention MLP: 204800 x 64 x 64 — do not pad N to 128
+        } else if (forced == 0 && t128 < 230) {
+            if (t12864 >= 460) bn = 64;
+            else { bm = 64; bn = 64; }
         }
     }
     a.tiles_m = (int32_t)fx_ceil_div(M, bm);
@@ -566,7 +942,19 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     const bool av = a_al && (a_kc ? (K % 4 == 0) : (M % 4 == 0));
     const bool bv = b_al && (b_kc ? (K % 4 == 0) : (N % 4 == 0));
     dim3 grid((unsigned)((int64_t)a.tiles_m * a.tiles_n), (unsigned)split_k);
-    if (bm == 128 && bn == 128) fx_gemm_dispatch_layout<128, 128>(a_kc, b_kc, av, bv, grid, s, a);
+    static const int pipe_mode = []() {   // FX_GEMM_PIPE=0 falls back to the unpipelined kernel
+        const char* e = getenv("FX_GEMM_PIPE");
+        return e ? atoi(e) : 1;
+    }();
+    const bool small_offsets = (transa ? K * lda : M * lda) < (int64_t)0x3FFFFFF0 &&
+                               (transb ? N * ldb : K * ldb) < (int64_t)0x3FFFFFF0;   // 32-bit byte offsets
+    if (pipe_mode && av && bv && small_offsets && kc >= 4) {
+        int rc;
+        if (bm == 128 && bn == 128) rc = fx_gemm_dispatch_pipe<128, 128>(a_kc, b_kc, grid, s, a);
+        else if (bm == 128) rc = fx_gemm_dispatch_pipe<128, 64>(a_kc, b_kc, grid, s, a);
+        else rc = fx_gemm_dispatch_pipe<64, 64>(a_kc, b_kc, grid, s, a);
+        if (rc != FX_OK) return rc;
+    } else if (bm == 128 && bn == 128) fx_gemm_dispatch_layout<128, 128>(a_kc, b_kc, av, bv, grid, s, a);
     else if (bm == 128) fx_gemm_dispatch_layout<128, 64>(a_kc, b_kc, av, bv, grid, s, a);
     else fx_gemm_dispatch_layout<64, 64>(a_kc, b_kc, av, bv, grid, s, a);
     FX_CHECK_LAUNCH();
