@@ -406,7 +406,7 @@ void k_gemm_f32_pipe(GemmArgs a) {
     constexpr int MI = BM / 64, NJ = BN / 64;
     constexpr int SA = FX_BK * LDA, SB = FX_BK * LDB;
     constexpr int NG = FX_BK / 2;                      // MFMA groups (k-pairs) per tile
-    extern __shared__ __attribute__((aligned(16))) float fx_gemm_smem[];
+    __shared__ __attribute__((aligned(16))) float fx_gemm_smem[2 * SA + 2 * SB];
     float* const As0 = fx_gemm_smem;
     float* const Bs0 = fx_gemm_smem + 2 * SA;
 
@@ -599,16 +599,7 @@ void k_gemm_f32_pipe(GemmArgs a) {
 
 template <int BM, int BN, bool A_KC, bool B_KC>
 static int fx_gemm_launch_pipe(dim3 grid, hipStream_t s, const GemmArgs& a) {
-    constexpr size_t lds = 2 * FX_BK * (size_t)(PipeLoader<BM, A_KC>::LD + PipeLoader<BN, B_KC>::LD) *
-                           sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        FX_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&k_gemm_f32_pipe<BM, BN, A_KC, B_KC>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC>), grid, dim3(256), 0, s, a);
     return FX_OK;
 }
 
@@ -837,6 +828,14 @@ static void fx_gemm_dispatch_layout(bool a_kc, bool b_kc, bool av, bool bv, dim3
     else fx_gemm_dispatch_vec<BM, BN, false, false>(av, bv, grid, s, a);
 }
 
+static int fx_gemm_pipe_mode() {   // FX_GEMM_PIPE=0 falls back to the unpipelined kernel (A/B runs)
+    static const int mode = []() {
+        const char* e = getenv("FX_GEMM_PIPE");
+        return e ? atoi(e) : 1;
+    }();
+    return mode;
+}
+
 extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
                            const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                            int64_t ldc, const fx_gemm_epilogue* epi_host, int32_t split_k,
@@ -882,6 +881,8 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
         else if (forced == 3) { bm = 64; bn = 64; }
         else if (forced == 0 && N <= 64) {
             bn = 64;   // e.g. the DIN attention MLP: 204800 x 64 x 64 — do not pad N to 128
+        } else if (forced == 0 && !fx_gemm_pipe_mode()) {
+            if (t128 < 448) { bm = 64; bn = 64; }      // the unpipelined kernel's rule
         } else if (forced == 0 && t128 < 230) {
             if (t12864 >= 460) bn = 64;
             else { bm = 64; bn = 64; }
@@ -942,10 +943,7 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     const bool av = a_al && (a_kc ? (K % 4 == 0) : (M % 4 == 0));
     const bool bv = b_al && (b_kc ? (K % 4 == 0) : (N % 4 == 0));
     dim3 grid((unsigned)((int64_t)a.tiles_m * a.tiles_n), (unsigned)split_k);
-    static const int pipe_mode = []() {   // FX_GEMM_PIPE=0 falls back to the unpipelined kernel
-        const char* e = getenv("FX_GEMM_PIPE");
-        return e ? atoi(e) : 1;
-    }();
+    const int pipe_mode = fx_gemm_pipe_mode();
     const bool small_offsets = (transa ? K * lda : M * lda) < (int64_t)0x3FFFFFF0 &&
                                (transb ? N * ldb : K * ldb) < (int64_t)0x3FFFFFF0;   // 32-bit byte offsets
     if (pipe_mode && av && bv && small_offsets && kc >= 4) {
