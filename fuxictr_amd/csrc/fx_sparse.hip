@@ -58,9 +58,13 @@ __global__ __launch_bounds__(1024) void k_sort_columns(const int32_t* ids, int64
                                                        int64_t B, const int64_t* col_row_base,
                                                        const int32_t* col_vocab,
                                                        const int32_t* col_pad, int C,
-                                                       uint32_t* sorted_key, uint32_t* sorted_pos) {
+                                                       uint32_t* sorted_key, uint32_t* sorted_pos,
+                                                       uint32_t* col_scan, uint32_t* col_cnt) {
     using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t>;
+    using Scan = rocprim::block_scan<uint32_t, 1024>;
     __shared__ typename Sort::storage_type storage;
+    __shared__ typename Scan::storage_type scan_storage;
+    __shared__ uint32_t lastk[1024];
     const int c = blockIdx.x;
     const int32_t V = col_vocab[c], pad = col_pad[c];
     int bits = 1;
@@ -80,13 +84,65 @@ __global__ __launch_bounds__(1024) void k_sort_columns(const int32_t* ids, int64
         }
     }
     Sort().sort(k, v, storage, 0, bits);
+    // heads of runs inside this column (the first item of a column is always a head: columns own
+    // disjoint row ranges), their inclusive count per item and the column's number of unique rows —
+    // the device-wide scan over all lookups is then a 26-term prefix in k_finish_columns
+    lastk[threadIdx.x] = k[IPT - 1];
+    __syncthreads();
+    uint32_t flag[IPT], h = 0;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const int64_t i = (int64_t)threadIdx.x * IPT + j;
+        const uint32_t prev = j > 0 ? k[j - 1] : (threadIdx.x > 0 ? lastk[threadIdx.x - 1] : 0u);
+        flag[j] = (i < B && (i == 0 || k[j] != prev)) ? 1u : 0u;
+        h += flag[j];
+    }
+    uint32_t before = 0, total = 0;
+    Scan().exclusive_scan(h, before, 0u, total, scan_storage);
+    if (threadIdx.x == 0) col_cnt[c] = total;
     const uint32_t base = (uint32_t)col_row_base[c];
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const int64_t i = (int64_t)threadIdx.x * IPT + j;
+        before += flag[j];
         if (i < B) {
             sorted_key[(int64_t)c * B + i] = base + k[j];
             sorted_pos[(int64_t)c * B + i] = v[j];
+            col_scan[(int64_t)c * B + i] = before;
+        }
+    }
+}
+
+// fast path, second launch: global inclusive head count = column offset + count inside the column,
+// then exactly what k_scatter_unique does (every key of this path is valid)
+__global__ __launch_bounds__(256) void k_finish_columns(const uint32_t* key, const uint32_t* col_scan,
+                                                        const uint32_t* col_cnt, int C, int64_t B,
+                                                        uint32_t* uniq_row, uint32_t* seg_start,
+                                                        int32_t* n_unique, uint32_t* sorted_uid) {
+    __shared__ uint32_t off[257];
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int c = 0; c < C; ++c) {
+            off[c] = acc;
+            acc += col_cnt[c];
+        }
+        off[C] = acc;
+    }
+    __syncthreads();
+    const int64_t n = B * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / B);
+        const uint32_t k = key[i];
+        const uint32_t u = off[c] + col_scan[i];
+        if (sorted_uid) sorted_uid[i] = u - 1;
+        if (i == 0 || key[i - 1] != k) {
+            uniq_row[u - 1] = k;
+            seg_start[u - 1] = (uint32_t)i;
+        }
+        if (i == n - 1) {
+            seg_start[u] = (uint32_t)(i + 1);
+            *n_unique = (int32_t)u;
         }
     }
 }
@@ -210,22 +266,30 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 4096) blocks = 4096;
     size_t tb = tmp;
-    if (columns_sorted && n_shards == 1 && B <= 8192) {
+    if (columns_sorted && n_shards == 1 && B <= 8192 && C <= 256) {
         // (measured: rocprim's segmented_radix_sort takes 81 us for 26 x 4096, its device merge
         // sort 57 us; one in-LDS workgroup sort per column over only the needed bits is the path)
         if (B <= 1024)
             hipLaunchKernelGGL(k_sort_columns<1>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,
-                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos);
+                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos,
+                               scan, keys_in);
         else if (B <= 2048)
             hipLaunchKernelGGL(k_sort_columns<2>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,
-                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos);
+                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos,
+                               scan, keys_in);
         else if (B <= 4096)
             hipLaunchKernelGGL(k_sort_columns<4>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,
-                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos);
+                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos,
+                               scan, keys_in);
         else
             hipLaunchKernelGGL(k_sort_columns<8>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,
-                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos);
+                               col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos,
+                               scan, keys_in);
         FX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_finish_columns, dim3((unsigned)blocks), dim3(256), 0, s, sorted_key, scan,
+                           keys_in, (int)C, B, uniq_row, seg_start, n_unique, sorted_uid);
+        FX_CHECK_LAUNCH();
+        return FX_OK;
     } else {
         hipLaunchKernelGGL(k_build_keys, dim3((unsigned)blocks), dim3(256), 0, s, ids, ids_ld, n,
                            (int)C, col_row_base, col_vocab, col_pad, sentinel, (uint32_t)n_shards,
@@ -386,7 +450,10 @@ __global__ __launch_bounds__(256) void k_rows_sqnorm(ReduceArgs a) {
         for (int k = 0; k < VEC; ++k) sq = fmaf(g[k], g[k], sq);
     }
     const float tot = fx_block_sum_256(sq, red4);
-    if (threadIdx.x == 0) a.sq_partials[blockIdx.x] = tot;
+    if (threadIdx.x == 0) {
+        a.sq_partials[blockIdx.x] = tot;
+        if (blockIdx.x == 0) a.scratch[0] = 0;   // ready for the next fx_emb_grad_reduce call
+    }
 }
 
 extern "C" int64_t fx_emb_grad_reduce_partials(int64_t n_max, int32_t D) {
@@ -420,9 +487,9 @@ extern "C" int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int6
     while ((1 << ll) < g.lanes) ++ll;
     ReduceArgs a{dout, dout_ld, col_out_off, sorted_pos, seg_start, n_unique, G, sq_partials,
                  scratch, C, D, ll};
-    // the long-run counter is zeroed by a kernel, not hipMemsetAsync: as the root node of a captured
-    // hipGraph segment the 4-byte memset node was observed not to be ordered before the kernels
-    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, scratch, 1);
+    // scratch[0] (the long-run counter) must be 0 on entry and is left 0 on return: the last launch
+    // resets it (no memset node: as the ROOT node of a captured hipGraph segment a 4-byte
+    // hipMemsetAsync was observed not to be ordered before the kernels that follow it)
     const int64_t blocks = fx_ceil_div(n_max, 256 / g.lanes);
     dim3 grid((unsigned)blocks), grid_long(512);
 #define FX_REDUCE_LAUNCH(V)                                                              \

@@ -158,6 +158,7 @@ class _TableGroup(object):
         self.num_grad = None
         self.pending = []
         self._shard_consts = {}
+        self._reduce_scratch = {}
         self._await_exchange = []     # row-gradient buffers waiting for their all-to-all
         self.dedup_ws = None
         # row sharding (owner = row % world, local row = row // world)
@@ -347,10 +348,17 @@ class _TableGroup(object):
             G = torch.empty(dd.n_max, D, dtype=torch.float32, device=self.device)
             sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max, D), dtype=torch.float32,
                              device=self.device)
-            scratch = torch.empty(ops.emb_grad_reduce_scratch_ints(dd.n_max), dtype=torch.int32,
-                                  device=self.device)
-            ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G, sq, scratch)
+            ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G, sq,
+                                self.reduce_scratch(dd.n_max))
             self.pending.append(_PendingGrad(dd, G, sq))
+
+    def reduce_scratch(self, n_max):
+        """Persistent scratch of fx_emb_grad_reduce (word 0 zero on entry, left zero on return)."""
+        buf = self._reduce_scratch.get(n_max)
+        if buf is None:
+            buf = self._reduce_scratch[n_max] = torch.zeros(
+                ops.emb_grad_reduce_scratch_ints(n_max), dtype=torch.int32, device=self.device)
+        return buf
 
     # -- row-sharded exchange --------------------------------------------------------------
     def a2a_cap(self, n_lookups):
@@ -423,9 +431,8 @@ class _TableGroup(object):
         G_loc = torch.empty(dd.n_max, D, dtype=torch.float32, device=self.device)
         sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max, D), dtype=torch.float32,
                          device=self.device)
-        scratch = torch.empty(ops.emb_grad_reduce_scratch_ints(dd.n_max), dtype=torch.int32,
-                              device=self.device)
-        ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G_loc, sq, scratch)
+        ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G_loc, sq,
+                            self.reduce_scratch(dd.n_max))
         gsend = torch.zeros(N * cap + 1, D, dtype=torch.float32, device=self.device)
         ops.scatter_rows(G_loc, sx.uniq_slot, dd.n_unique, dd.n_max, D, gsend)
         # the exchange itself runs after autograd returns (finish_backward, called by the
@@ -446,9 +453,8 @@ class _TableGroup(object):
         G_own = torch.empty(odd.n_max, D, dtype=torch.float32, device=self.device)
         sq_own = torch.empty(ops.emb_grad_reduce_partials(odd.n_max, D), dtype=torch.float32,
                              device=self.device)
-        scratch2 = torch.empty(ops.emb_grad_reduce_scratch_ints(odd.n_max), dtype=torch.int32,
-                               device=self.device)
-        ops.emb_grad_reduce(grecv, D, sx.own_base, 1, D, odd, G_own, sq_own, scratch2)
+        ops.emb_grad_reduce(grecv, D, sx.own_base, 1, D, odd, G_own, sq_own,
+                            self.reduce_scratch(odd.n_max))
         self.pending.append(_PendingGrad(odd, G_own, sq_own))
 
     def flush(self):
@@ -1047,7 +1053,9 @@ def _split_k_for(M, N, K):
     """Split the contraction when the output grid alone cannot fill 256 CUs (weight gradients):
     aim for ~512 workgroups of 64x64 (2 per CU); every extra split costs a partial-slab round trip."""
     if M <= 4:                      # skinny weight gradient: column-parallel reduction kernel
-        return max(1, min(512 if N <= 256 else 64, K // 128))
+        # enough K slabs to put >= 4 workgroups on every CU (N/256 column blocks x slabs); the wide
+        # slab reduce handles hundreds of slabs in one small launch
+        return max(1, min(512 if N <= 256 else 256, K // 16))
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     if tiles >= 448:
         return 1

@@ -138,7 +138,7 @@ class DedupResult(object):
         self.sorted_pos = torch.empty(n, dtype=torch.int32, device=device)
         self.uniq_row = torch.empty(n, dtype=torch.int32, device=device)
         self.seg_start = torch.empty(n + 1, dtype=torch.int32, device=device)
-        self.n_unique = torch.zeros(1, dtype=torch.int32, device=device)
+        self.n_unique = torch.empty(1, dtype=torch.int32, device=device)   # always written by fx_dedup
         self.n_max = n
         self.C = C_
 

@@ -101,12 +101,33 @@ class _SigmoidFn(torch.autograd.Function):
 
 
 class FxSigmoid(nn.Module):
-    """nn.Sigmoid whose input logit is remembered so that the BCE loss can be fused with it."""
+    """nn.Sigmoid whose input logit is remembered so that the BCE loss can be fused with it.
+    `defer` (set by BaseModel around a training step whose loss is the fused BCE): the
+    probabilities are not needed by anyone, skip their kernel — `y_pred` then carries the logits
+    and must only be consumed through `_fx_logit`."""
+    defer = False
 
     def forward(self, x):
+        if self.defer and self.training:
+            p = x.view_as(x)
+            p._fx_logit = x
+            p._fx_deferred = True
+            return p
         p = _SigmoidFn.apply(x)
         p._fx_logit = x
         return p
+
+
+_UNIT_GRADS = {}
+
+
+def _unit_grad(device):
+    """Persistent 1.0 used as the root gradient of loss.backward(): saves autograd's ones_like
+    fill, and lets _SigmoidBCEFn.backward recognise 'multiply by one' without reading the value."""
+    g = _UNIT_GRADS.get(device)
+    if g is None:
+        g = _UNIT_GRADS[device] = torch.ones((), dtype=torch.float32, device=device)
+    return g
 
 
 class _SigmoidBCEFn(torch.autograd.Function):
@@ -125,6 +146,9 @@ class _SigmoidBCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlogit,) = ctx.saved_tensors
+        unit = _UNIT_GRADS.get(g.device)
+        if unit is not None and g.data_ptr() == unit.data_ptr():
+            return dlogit, None
         return dlogit * g, None
 
 
@@ -132,6 +156,8 @@ def _bce_loss(y_pred, y_true, reduction="mean"):
     logit = getattr(y_pred, "_fx_logit", None)
     if logit is not None and reduction == "mean":
         return _SigmoidBCEFn.apply(logit, y_true)
+    if getattr(y_pred, "_fx_deferred", False):
+        y_pred = torch.sigmoid(logit)
     return torch.nn.functional.binary_cross_entropy(y_pred, y_true, reduction=reduction)
 
 
@@ -480,14 +506,23 @@ class BaseModel(nn.Module):
         opt = self.optimizer
         ops.opt_begin_step(opt.scal)     # t += 1, Adam bias corrections (device side)
         opt.zero_grad()
-        return_dict = self.forward(batch_data)
+        act = self.output_activation
+        fused = (isinstance(act, FxSigmoid) and self.loss_fn is _bce_loss
+                 and type(self).add_loss is BaseModel.add_loss)
+        if fused:
+            act.defer = True        # nobody reads the probabilities of a training step
+        try:
+            return_dict = self.forward(batch_data)
+        finally:
+            if fused:
+                act.defer = False
         y_true = self.get_labels(batch_data)
         loss = self.compute_loss(return_dict, y_true)
         if self._dist is not None:
             # global-batch mean = mean of the ranks' local means: scale, then SUM-reduce grads
             (loss / self._dist.world).backward()
         else:
-            loss.backward()
+            loss.backward(gradient=_unit_grad(loss.device))
         opt.step()  # global-norm clip (rank_model.py:321) is fused into the update kernels
         return loss
 

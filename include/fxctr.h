@@ -147,7 +147,8 @@ int fx_sum_parts(const float* const* parts_host, const int64_t* counts_host, int
  * 32 lookups — hot rows of tiny tables — are reduced by a whole workgroup each).
  * Also writes per-block partial sums of ||G||^2 into sq_partials[0..n_partials), n_partials =
  * fx_emb_grad_reduce_partials(n_max, D); rows >= *n_unique are not touched.
- * scratch: fx_emb_grad_reduce_scratch_ints(n_max) int32 words of device scratch.
+ * scratch: fx_emb_grad_reduce_scratch_ints(n_max) int32 words of device scratch; word 0 must be 0
+ * on entry (allocate zeroed once) and is 0 again on return, so the buffer can be reused as is.
  * ------------------------------------------------------------------------------------------ */
 int64_t fx_emb_grad_reduce_partials(int64_t n_max, int32_t D);
 int64_t fx_emb_grad_reduce_scratch_ints(int64_t n_max);

@@ -178,8 +178,9 @@ def test_grad_reduce_matches_index_add(D, vocabs):
     offs = [(c + 1) * D for c in range(C)]
     G = torch.zeros(dd.n_max, D, device=DEV)
     sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max, D), device=DEV)
-    scr = torch.empty(ops.emb_grad_reduce_scratch_ints(dd.n_max), dtype=torch.int32, device=DEV)
+    scr = torch.zeros(ops.emb_grad_reduce_scratch_ints(dd.n_max), dtype=torch.int32, device=DEV)
     ops.emb_grad_reduce(_dev(dout), n_slots * D, _dev(offs, torch.int64), C, D, dd, G, sq, scr)
+    assert int(scr[0]) == 0       # the counter is left reset for the next call
     ref = torch.zeros(R, D, dtype=torch.float64)
     d3 = dout.view(B, n_slots, D).double()
     for c in range(C):
