@@ -871,10 +871,13 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
             if (!strcmp(e, "64x64")) return 3;
             return 0;
         }();
-        // Measured on MI355X (profiles/r01_gemm_pipe.txt), pipelined kernel: 128x128 whenever its
-        // grid covers the 256 CUs (4096x1024 towers: exactly 256 tiles), 128x64 when that one does
-        // twice, else 64x64 (three co-resident workgroups per CU hide the ragged last wave, e.g.
-        // N = 624: 640 tiles).
+        // Measured on MI355X (profiles/r01_gemm_pipe.txt).  Bare GEMMs favour the big tile (4096^3:
+        // 134 TFLOP/s at 128x128 vs 116 at 64x64), but inside the training step every GEMM has an
+        // epilogue that touches 16-32 MB (bias+ReLU, ReLU mask, split-K slabs): with one 128x128
+        // workgroup per CU all epilogues run at the same time and nothing covers them; with 64x64
+        // tiles three workgroups share a CU and one's epilogue hides under the others' MFMAs.
+        // Whole DeepFM step: 1.20 ms (64x64) vs 1.22 (128x64) vs 1.24 (128x128 where it fits).
+        // So: big tiles only when there are >= 4 waves of them (epilogues then overlap anyway).
         const int64_t t128 = fx_ceil_div(M, 128) * fx_ceil_div(N, 128) * split_k;
         const int64_t t12864 = fx_ceil_div(M, 128) * fx_ceil_div(N, 64) * split_k;
         if (forced == 2) { bn = 64; }
@@ -883,8 +886,8 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
             bn = 64;   // e.g. the DIN attention MLP: 204800 x 64 x 64 — do not pad N to 128
         } else if (forced == 0 && !fx_gemm_pipe_mode()) {
             if (t128 < 448) { bm = 64; bn = 64; }      // the unpipelined kernel's rule
-        } else if (forced == 0 && t128 < 230) {
-            if (t12864 >= 460) bn = 64;
+        } else if (forced == 0 && t128 < 1024) {
+            if (t12864 >= 2048) bn = 64;
             else { bm = 64; bn = 64; }
         }
     }

@@ -28,7 +28,10 @@ class GraphSegments(object):
 
     def begin(self):
         g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self.pool)
+        # thread_local: API calls of OTHER threads (the ProcessGroup watchdog polling its events)
+        # must not invalidate the capture; the autograd thread's launches still land in it because
+        # capture is a property of the stream
+        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
         self._cur = g
 
     def cut(self, fn):
