@@ -632,24 +632,27 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a) {
 }
 
 
-// many slabs over a small output (skinny weight gradients with K = B*L): 32 elements x 8 slab
-// lanes per workgroup, fixed LDS tree over the slab lanes
+// many slabs over a small output (skinny weight gradients with K = B*L): EL elements x 256/EL slab
+// lanes per workgroup, fixed LDS tree over the slab lanes (deterministic)
+template <int EL>
 __global__ __launch_bounds__(256) void k_splitk_reduce_wide(GemmArgs a) {
+    constexpr int ZL = 256 / EL;
     __shared__ float red[256];
-    const int ii = threadIdx.x & 31, zi = threadIdx.x >> 5;
+    const int ii = threadIdx.x % EL, zi = threadIdx.x / EL;
     const int64_t total = a.M * a.N;
-    const int64_t i = (int64_t)blockIdx.x * 32 + ii;
+    const int64_t i = (int64_t)blockIdx.x * EL + ii;
     float s = 0.f;
     if (i < total)
-        for (int z = zi; z < a.split_k; z += 8) s += a.ws[(int64_t)z * total + i];
+        for (int z = zi; z < a.split_k; z += ZL) s += a.ws[(int64_t)z * total + i];
     red[threadIdx.x] = s;
     __syncthreads();
+    for (int h = ZL >> 1; h > 0; h >>= 1) {
+        if (zi < h) red[threadIdx.x] += red[threadIdx.x + h * EL];
+        __syncthreads();
+    }
     if (zi == 0 && i < total) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k * 32 + ii];
         const int64_t m = i / a.N, n = i - m * a.N;
-        a.C[m * a.ldc + n] = fx_epilogue(a.epi, t, m, n);
+        a.C[m * a.ldc + n] = fx_epilogue(a.epi, red[ii], m, n);
     }
     if (a.epi.rowsum && blockIdx.x == 0) {
         const float* rs = a.ws + (int64_t)a.split_k * total;
@@ -664,8 +667,12 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_wide(GemmArgs a) {
 static void fx_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
     const int64_t total = a.M * a.N;
     if (a.split_k >= 32 && total <= 65536 && a.M <= 256) {
-        hipLaunchKernelGGL(k_splitk_reduce_wide, dim3((unsigned)fx_ceil_div(total, 32)), dim3(256), 0,
-                           s, a);
+        if (a.split_k >= 128)   // few outputs, very many slabs: more slab lanes, more workgroups
+            hipLaunchKernelGGL(k_splitk_reduce_wide<8>, dim3((unsigned)fx_ceil_div(total, 8)),
+                               dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_splitk_reduce_wide<32>, dim3((unsigned)fx_ceil_div(total, 32)),
+                               dim3(256), 0, s, a);
     } else {
         int64_t blocks = fx_ceil_div(total, 256);
         if (blocks > 2048) blocks = 2048;
