@@ -12,7 +12,7 @@
 // All reductions are two-stage with a fixed order (deterministic).
 #include "fx_common.h"
 
-#define FX_STAT_CHUNKS 256
+#define FX_STAT_CHUNKS 1024
 
 // ---------------------------------------------------------------------------------------------
 // attention input [B*L, 4E] and its backward
@@ -235,28 +235,126 @@ __global__ __launch_bounds__(256) void k_dice_reduce(const float* Z, const float
     }
 }
 
-// fixed-order sum over the chunks of one term: 64 columns x 4 chunk lanes per workgroup
-__device__ __forceinline__ float fx_chunk_sum(const float* partial, int nt, int k, int chunks,
-                                              int H, int h, int ty, float* red /*[256]*/) {
-    float s = 0.f;
-    if (h < H)
-        for (int c = ty; c < chunks; c += 4) s += partial[((int64_t)c * nt + k) * H + h];
-    const int tx = threadIdx.x & 63;
+// H % 4 == 0: float4 columns, 16 threads per 64-column row segment, 16 row lanes, rows unrolled x2:
+// the statistics pass is a pure HBM stream (52 MB at B*L = 204800, H = 64) and needs many loads in
+// flight per CU to reach the bandwidth the one-float-per-thread version (above) cannot.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dice_reduce_v4(const float* Z, const float* dY,
+                                                        const float* stats, const float* alpha,
+                                                        float eps, int64_t N, int H, int64_t rows,
+                                                        float* partial) {
+    constexpr int NT = MODE == 0 ? 2 : 3;
+    __shared__ float red[NT][16][64];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t h = (int64_t)blockIdx.x * 64 + tx * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * rows;
+    const int64_t r1 = (r0 + rows < N) ? r0 + rows : N;
+    float acc[NT][4];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[k][e] = 0.f;
+    if (h < H) {
+        float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mean[e] = stats[h + e];
+                rstd[e] = rsqrtf(stats[H + h + e] + eps);
+                al[e] = alpha[h + e];
+            }
+        }
+        auto term = [&](const float4& zq, const float4& dq) {
+            const float z[4] = {zq.x, zq.y, zq.z, zq.w};
+            const float d[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (MODE == 0) {
+                    acc[0][e] += z[e];
+                    acc[1][e] = fmaf(z[e], z[e], acc[1][e]);
+                } else {
+                    const float zh = (z[e] - mean[e]) * rstd[e];
+                    const float pr = 1.f / (1.f + expf(-zh));
+                    const float dzh = d[e] * z[e] * (1.f - al[e]) * pr * (1.f - pr);
+                    acc[0][e] = fmaf(d[e] * (1.f - pr), z[e], acc[0][e]);
+                    acc[1][e] += dzh;
+                    acc[2][e] = fmaf(dzh, zh, acc[2][e]);
+                }
+            }
+        };
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t r = r0 + ty;
+        for (; r + 16 < r1; r += 32) {
+            const float4 z0 = *reinterpret_cast<const float4*>(Z + r * H + h);
+            const float4 z1 = *reinterpret_cast<const float4*>(Z + (r + 16) * H + h);
+            float4 d0 = zero, d1 = zero;
+            if (MODE == 1) {
+                d0 = *reinterpret_cast<const float4*>(dY + r * H + h);
+                d1 = *reinterpret_cast<const float4*>(dY + (r + 16) * H + h);
+            }
+            term(z0, d0);
+            term(z1, d1);
+        }
+        for (; r < r1; r += 16) {
+            const float4 z0 = *reinterpret_cast<const float4*>(Z + r * H + h);
+            float4 d0 = zero;
+            if (MODE == 1) d0 = *reinterpret_cast<const float4*>(dY + r * H + h);
+            term(z0, d0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[k][ty][tx * 4 + e] = acc[k][e];
     __syncthreads();
-    red[threadIdx.x] = s;
-    __syncthreads();
-    return (red[tx] + red[tx + 64]) + (red[tx + 128] + red[tx + 192]);
+    if (threadIdx.x < 64) {
+        const int64_t hh = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        if (hh < H) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                float sum = 0.f;
+#pragma unroll
+                for (int y = 0; y < 16; ++y) sum += red[k][y][threadIdx.x];
+                partial[((int64_t)blockIdx.y * NT + k) * H + hh] = sum;
+            }
+        }
+    }
 }
 
-// stage 2 of the forward statistics: mean / biased var -> stats; running stats updated like
-// nn.BatchNorm1d(momentum) (unbiased variance N/(N-1) into running_var)
+// fixed-order sum over the chunks of one term: 64 columns x 4 chunk lanes per workgroup
+// sum over the chunks of term k for 16 columns per workgroup: 16 chunk lanes, 8 independent loads
+// in flight per lane, fixed order -> deterministic.  Returns the column sum to every lane of the
+// column; `red` is [16][16].
+__device__ __forceinline__ float fx_chunk_sum(const float* partial, int nt, int k, int chunks,
+                                              int H, int h, int ty, float (*red)[16]) {
+    float s = 0.f;
+    if (h < H) {
+        int c = ty;
+        for (; c + 7 * 16 < chunks; c += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[((int64_t)(c + u * 16) * nt + k) * H + h];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < chunks; c += 16) s += partial[((int64_t)c * nt + k) * H + h];
+    }
+    const int tx = threadIdx.x & 15;
+    __syncthreads();
+    red[ty][tx] = s;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int y = 0; y < 16; ++y) t += red[y][tx];
+    return t;
+}
 __global__ __launch_bounds__(256) void k_dice_stats_final(const float* partial, int chunks, int H,
                                                           int64_t N, float momentum, float* stats,
                                                           float* running_mean,
                                                           float* running_var) {
-    __shared__ float red[256];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int h = blockIdx.x * 64 + tx;
+    __shared__ float red[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int h = blockIdx.x * 16 + tx;
     const double s = (double)fx_chunk_sum(partial, 2, 0, chunks, H, h, ty, red);
     const double ss = (double)fx_chunk_sum(partial, 2, 1, chunks, H, h, ty, red);
     if (ty != 0 || h >= H) return;
@@ -274,9 +372,9 @@ __global__ __launch_bounds__(256) void k_dice_stats_final(const float* partial, 
 
 __global__ __launch_bounds__(256) void k_dice_bwd_final(const float* partial, int chunks, int H,
                                                         float* sums) {
-    __shared__ float red[256];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int h = blockIdx.x * 64 + tx;
+    __shared__ float red[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int h = blockIdx.x * 16 + tx;
     for (int k = 0; k < 3; ++k) {
         const float s = fx_chunk_sum(partial, 3, k, chunks, H, h, ty, red);
         if (ty == 0 && h < H) sums[k * H + h] = s;
@@ -330,10 +428,15 @@ extern "C" int fx_dice_fwd(const float* Z, int64_t N, int32_t H, const float* al
     if (training) {
         FX_CHECK_ARG(workspace, "fx_dice_fwd: training mode needs a workspace");
         const int64_t rows = fx_ceil_div(N, FX_STAT_CHUNKS);
-        hipLaunchKernelGGL(k_dice_reduce<0>, dim3((unsigned)fx_ceil_div(H, 64), FX_STAT_CHUNKS),
-                           dim3(256), 0, s, Z, (const float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, eps, N, (int)H, rows, workspace);
-        hipLaunchKernelGGL(k_dice_stats_final, dim3((unsigned)fx_ceil_div(H, 64)), dim3(256), 0, s,
+        if (H % 4 == 0 && (reinterpret_cast<uintptr_t>(Z) & 15) == 0)
+            hipLaunchKernelGGL(k_dice_reduce_v4<0>, dim3((unsigned)fx_ceil_div(H, 64), FX_STAT_CHUNKS),
+                               dim3(256), 0, s, Z, (const float*)nullptr, (const float*)nullptr,
+                               (const float*)nullptr, eps, N, (int)H, rows, workspace);
+        else
+            hipLaunchKernelGGL(k_dice_reduce<0>, dim3((unsigned)fx_ceil_div(H, 64), FX_STAT_CHUNKS),
+                               dim3(256), 0, s, Z, (const float*)nullptr, (const float*)nullptr,
+                               (const float*)nullptr, eps, N, (int)H, rows, workspace);
+        hipLaunchKernelGGL(k_dice_stats_final, dim3((unsigned)fx_ceil_div(H, 16)), dim3(256), 0, s,
                            workspace, (int)FX_STAT_CHUNKS, (int)H, N, momentum, stats, running_mean,
                            running_var);
     } else {
@@ -365,9 +468,13 @@ extern "C" int fx_dice_bwd(const float* Z, const float* dY, int64_t N, int32_t H
     const int chunks = FX_STAT_CHUNKS - 1;
     const int64_t rows2 = fx_ceil_div(N, chunks);
     (void)rows;
-    hipLaunchKernelGGL(k_dice_reduce<1>, dim3((unsigned)fx_ceil_div(H, 64), chunks), dim3(256), 0, s,
-                       Z, dY, stats, alpha, eps, N, (int)H, rows2, workspace);
-    hipLaunchKernelGGL(k_dice_bwd_final, dim3((unsigned)fx_ceil_div(H, 64)), dim3(256), 0, s,
+    if (H % 4 == 0 && ((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(dY)) & 15) == 0)
+        hipLaunchKernelGGL(k_dice_reduce_v4<1>, dim3((unsigned)fx_ceil_div(H, 64), chunks), dim3(256),
+                           0, s, Z, dY, stats, alpha, eps, N, (int)H, rows2, workspace);
+    else
+        hipLaunchKernelGGL(k_dice_reduce<1>, dim3((unsigned)fx_ceil_div(H, 64), chunks), dim3(256), 0,
+                           s, Z, dY, stats, alpha, eps, N, (int)H, rows2, workspace);
+    hipLaunchKernelGGL(k_dice_bwd_final, dim3((unsigned)fx_ceil_div(H, 16)), dim3(256), 0, s,
                        workspace, chunks, (int)H, sums);
     FX_CHECK_HIP(hipMemcpyAsync(dalpha, sums, sizeof(float) * H, hipMemcpyDeviceToDevice, s));
     const int64_t n = N * H;

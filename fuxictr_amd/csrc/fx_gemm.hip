@@ -642,8 +642,17 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_wide(GemmArgs a) {
     const int64_t total = a.M * a.N;
     const int64_t i = (int64_t)blockIdx.x * EL + ii;
     float s = 0.f;
-    if (i < total)
-        for (int z = zi; z < a.split_k; z += ZL) s += a.ws[(int64_t)z * total + i];
+    if (i < total) {
+        int z = zi;
+        for (; z + 7 * ZL < a.split_k; z += 8 * ZL) {      // 8 independent loads in flight,
+            float v[8];                                     // summed in slab order
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a.ws[(int64_t)(z + u * ZL) * total + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < a.split_k; z += ZL) s += a.ws[(int64_t)z * total + i];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int h = ZL >> 1; h > 0; h >>= 1) {
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_wide(GemmArgs a) {
 static void fx_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
     const int64_t total = a.M * a.N;
     if (a.split_k >= 32 && total <= 65536 && a.M <= 256) {
-        if (a.split_k >= 128)   // few outputs, very many slabs: more slab lanes, more workgroups
+        if (a.split_k >= 128 && total <= 2048)   // few outputs, very many slabs: more slab lanes
             hipLaunchKernelGGL(k_splitk_reduce_wide<8>, dim3((unsigned)fx_ceil_div(total, 8)),
                                dim3(256), 0, s, a);
         else
@@ -765,12 +774,15 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs a, int np_log2) {
         for (int m = 0; m < a.M; ++m) a.ws[((int64_t)z * a.M + m) * a.N + n] = red[m][tx];
 }
 
-// vectorised M <= 4 variant (N % 4 == 0, 16-B aligned B rows): 64 float4 column groups x 4 row
-// lanes per workgroup, LDS combine of the row lanes
+// vectorised M <= 4 variant (N % 4 == 0, 16-B aligned B rows): CG float4 column groups x 256/CG
+// row lanes per workgroup (CG = 64 for N >= 256, fewer for narrow outputs such as the 64-wide DIN
+// attention layer, K = B*L = 204800), two rows in flight per lane, LDS combine of the row lanes
+template <int CG_LOG2>
 __global__ __launch_bounds__(256) void k_gemm_small_m_v4(GemmArgs a) {
+    constexpr int CG = 1 << CG_LOG2, RL = 256 / CG;
     __shared__ float4 red[4][256];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int64_t n = ((int64_t)blockIdx.x * 64 + tx) * 4;
+    const int tx = threadIdx.x & (CG - 1), ty = threadIdx.x >> CG_LOG2;
+    const int64_t n = ((int64_t)blockIdx.x * CG + tx) * 4;
     const int z = blockIdx.y;
     const int64_t kbeg = (int64_t)z * a.k_chunk;
     const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
@@ -782,19 +794,29 @@ __global__ __launch_bounds__(256) void k_gemm_small_m_v4(GemmArgs a) {
     float4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < a.N) {
-        for (int64_t k = kbeg + ty; k < kend; k += 4) {
-            const float4 b = *reinterpret_cast<const float4*>(a.B + k * a.ldb + n);
+    auto fma_row = [&](const float4& b, int64_t k) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (m < a.M) {
-                    const float w = a.A[k * a.lda + m];
-                    acc[m].x = fmaf(w, b.x, acc[m].x);
-                    acc[m].y = fmaf(w, b.y, acc[m].y);
-                    acc[m].z = fmaf(w, b.z, acc[m].z);
-                    acc[m].w = fmaf(w, b.w, acc[m].w);
-                }
+        for (int m = 0; m < 4; ++m) {
+            if (m < a.M) {
+                const float w = a.A[k * a.lda + m];
+                acc[m].x = fmaf(w, b.x, acc[m].x);
+                acc[m].y = fmaf(w, b.y, acc[m].y);
+                acc[m].z = fmaf(w, b.z, acc[m].z);
+                acc[m].w = fmaf(w, b.w, acc[m].w);
             }
+        }
+    };
+    if (n < a.N) {
+        int64_t k = kbeg + ty;
+        for (; k + RL < kend; k += 2 * RL) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.B + k * a.ldb + n);
+            const float4 b1 = *reinterpret_cast<const float4*>(a.B + (k + RL) * a.ldb + n);
+            fma_row(b0, k);
+            fma_row(b1, k + RL);
+        }
+        for (; k < kend; k += RL) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.B + k * a.ldb + n);
+            fma_row(b0, k);
         }
     }
 #pragma unroll
@@ -802,15 +824,53 @@ __global__ __launch_bounds__(256) void k_gemm_small_m_v4(GemmArgs a) {
     __syncthreads();
     if (ty == 0 && n < a.N) {
         for (int m = 0; m < a.M; ++m) {
-            const float4 a0 = red[m][tx], a1 = red[m][tx + 64], a2 = red[m][tx + 128],
-                         a3 = red[m][tx + 192];
-            float4 r;
-            r.x = (a0.x + a1.x) + (a2.x + a3.x);
-            r.y = (a0.y + a1.y) + (a2.y + a3.y);
-            r.z = (a0.z + a1.z) + (a2.z + a3.z);
-            r.w = (a0.w + a1.w) + (a2.w + a3.w);
+            float4 r = red[m][tx];
+            for (int y = 1; y < RL; ++y) {          // fixed order over the row lanes
+                const float4 q = red[m][tx + y * CG];
+                r.x += q.x;
+                r.y += q.y;
+                r.z += q.z;
+                r.w += q.w;
+            }
             *reinterpret_cast<float4*>(a.ws + ((int64_t)z * a.M + m) * a.N + n) = r;
         }
+    }
+}
+
+// N <= 4, A stored [M,K] with K <= 256, K % 4 == 0, 16-B aligned rows (the 64 -> 1 attention output
+// layer over B*L rows): K/4 lanes read one row as float4s, 64/(K/4) rows per wave instruction
+template <int LPR_LOG2>
+__global__ __launch_bounds__(256) void k_gemm_small_n_v4(GemmArgs a, int tb) {
+    constexpr int LPR = 1 << LPR_LOG2, RPW = 64 / LPR;     // lanes per row, rows per wave
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1), rw = lane >> LPR_LOG2;
+    const int kq = sub * 4;
+    float4 w[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        w[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < a.N && kq < a.K) {
+            w[n].x = fx_b_at(a, tb, kq + 0, n);
+            w[n].y = fx_b_at(a, tb, kq + 1, n);
+            w[n].z = fx_b_at(a, tb, kq + 2, n);
+            w[n].w = fx_b_at(a, tb, kq + 3, n);
+        }
+    }
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    for (int64_t m0 = wave * RPW; m0 < a.M; m0 += waves * RPW) {
+        const int64_t m = m0 + rw;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < a.M && kq < a.K) x = *reinterpret_cast<const float4*>(a.A + m * a.lda + kq);
+        float acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            acc[n] = fmaf(x.w, w[n].w, fmaf(x.z, w[n].z, fmaf(x.y, w[n].y, x.x * w[n].x)));
+#pragma unroll
+            for (int off = LPR >> 1; off > 0; off >>= 1) acc[n] += __shfl_xor(acc[n], off, 64);
+        }
+        if (sub == 0 && m < a.M)
+            for (int n = 0; n < a.N; ++n) a.C[m * a.ldc + n] = fx_epilogue(a.epi, acc[n], m, n);
     }
 }
 
@@ -915,6 +975,28 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     }
     if (N <= 4 && !transa) {
         a.split_k = 1;
+        const bool v4 = K <= 256 && K % 4 == 0 && lda % 4 == 0 &&
+                        ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+        if (v4) {
+            int lpr_log2 = 0;
+            while ((4 << lpr_log2) < K) ++lpr_log2;                 // lanes per row = pow2 >= K/4
+            const int rpw = 64 >> lpr_log2;
+            int64_t blocks = fx_ceil_div(M, 4 * rpw);
+            if (blocks > 16384) blocks = 16384;
+            dim3 g((unsigned)blocks);
+            const int tbi = (int)(transb != 0);
+            switch (lpr_log2) {
+                case 0: hipLaunchKernelGGL(k_gemm_small_n_v4<0>, g, dim3(256), 0, s, a, tbi); break;
+                case 1: hipLaunchKernelGGL(k_gemm_small_n_v4<1>, g, dim3(256), 0, s, a, tbi); break;
+                case 2: hipLaunchKernelGGL(k_gemm_small_n_v4<2>, g, dim3(256), 0, s, a, tbi); break;
+                case 3: hipLaunchKernelGGL(k_gemm_small_n_v4<3>, g, dim3(256), 0, s, a, tbi); break;
+                case 4: hipLaunchKernelGGL(k_gemm_small_n_v4<4>, g, dim3(256), 0, s, a, tbi); break;
+                case 5: hipLaunchKernelGGL(k_gemm_small_n_v4<5>, g, dim3(256), 0, s, a, tbi); break;
+                default: hipLaunchKernelGGL(k_gemm_small_n_v4<6>, g, dim3(256), 0, s, a, tbi); break;
+            }
+            FX_CHECK_LAUNCH();
+            return FX_OK;
+        }
         int64_t blocks = fx_ceil_div(M, 4);
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(k_gemm_small_n, dim3((unsigned)blocks), dim3(256), 0, s, a,
@@ -929,16 +1011,23 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
         if (kc2 < 1) kc2 = 1;
         a.k_chunk = kc2;
         a.split_k = (int32_t)fx_ceil_div(K, kc2);
-        const bool v4 = (N >= 256) && (N % 4 == 0) && (ldb % 4 == 0) &&
+        const bool v4 = (N >= 16) && (N % 4 == 0) && (ldb % 4 == 0) &&
                         ((reinterpret_cast<uintptr_t>(B) & 15) == 0) &&
                         ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
         int np_log2 = 0;
         while ((1 << np_log2) < N && np_log2 < 8) ++np_log2;
-        if (v4)
-            hipLaunchKernelGGL(k_gemm_small_m_v4,
-                               dim3((unsigned)fx_ceil_div(N, 256), (unsigned)a.split_k), dim3(256),
-                               0, s, a);
-        else
+        if (v4) {
+            int cg_log2 = 2;                                        // float4 column groups per block
+            while ((4 << cg_log2) < N && cg_log2 < 6) ++cg_log2;
+            dim3 g((unsigned)fx_ceil_div(N, 4 << cg_log2), (unsigned)a.split_k);
+            switch (cg_log2) {
+                case 2: hipLaunchKernelGGL(k_gemm_small_m_v4<2>, g, dim3(256), 0, s, a); break;
+                case 3: hipLaunchKernelGGL(k_gemm_small_m_v4<3>, g, dim3(256), 0, s, a); break;
+                case 4: hipLaunchKernelGGL(k_gemm_small_m_v4<4>, g, dim3(256), 0, s, a); break;
+                case 5: hipLaunchKernelGGL(k_gemm_small_m_v4<5>, g, dim3(256), 0, s, a); break;
+                default: hipLaunchKernelGGL(k_gemm_small_m_v4<6>, g, dim3(256), 0, s, a); break;
+            }
+        } else
             hipLaunchKernelGGL(k_gemm_small_m,
                                dim3((unsigned)fx_ceil_div(N, 1 << np_log2), (unsigned)a.split_k),
                                dim3(256), 0, s, a, np_log2);
