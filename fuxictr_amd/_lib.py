@@ -89,6 +89,8 @@ SIGNATURES = {
     "fx_cin_fwd": (i32, [vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, vp, vp, i64, i64, vp]),
     "fx_cin_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, vp, i32, vp, vp, i64, vp, i64, i32, vp,
                          i64, vp, i64, vp]),
+    "fx_binary_metrics_workspace_bytes": (C.c_size_t, [i64]),
+    "fx_binary_metrics": (i32, [vp, vp, i64, vp, C.c_size_t, vp, vp, vp]),
     "fx_dice_workspace_floats": (i64, [i32]),
     "fx_dice_fwd": (i32, [vp, i64, i32, vp, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp, vp]),
     "fx_dice_bwd": (i32, [vp, vp, i64, i32, vp, C.c_float, i32, vp, vp, vp, vp, vp]),

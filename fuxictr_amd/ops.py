@@ -468,3 +468,28 @@ def cin_bwd(X0, Xi, W, dXn, dpool, dX0, accumulate_dx0, dXi, partial):
                                  ptr(dX0), dX0.stride(0), 1 if accumulate_dx0 else 0, ptr(dXi),
                                  dXi.stride(0), ptr(partial), B, stream_ptr(X0.device)),
           "fx_cin_bwd")
+
+
+# ---- evaluation metrics ---------------------------------------------------------------------------
+def binary_metrics(y_pred, y_true):
+    """(logloss, AUC) of float32 device vectors, as sklearn's log_loss / roc_auc_score on float64.
+    One host sync (reads three 8-byte words)."""
+    lib = _lib.load()
+    y_pred = y_pred.reshape(-1).contiguous().float()
+    y_true = y_true.reshape(-1).contiguous().float()
+    n = y_pred.numel()
+    nbytes = int(lib.fx_binary_metrics_workspace_bytes(n))
+    if nbytes == 0:
+        check(1, "fx_binary_metrics_workspace_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=y_pred.device)
+    ll = torch.empty(1, dtype=torch.float64, device=y_pred.device)
+    cnt = torch.empty(2, dtype=torch.int64, device=y_pred.device)
+    check(lib.fx_binary_metrics(ptr(y_pred), ptr(y_true), n, ptr(ws), nbytes, ptr(ll), ptr(cnt),
+                                stream_ptr(y_pred.device)), "fx_binary_metrics")
+    s2, n_pos = (int(v) for v in cnt.tolist())
+    n_neg = n - n_pos
+    if n_pos == 0 or n_neg == 0:
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that "
+                         "case.")
+    auc = (s2 - n_pos * (n_pos + 1)) / (2 * n_pos * n_neg)     # exact integers, one rounding
+    return float(ll.item()) / n, auc

@@ -297,6 +297,7 @@ class BaseModel(nn.Module):
         self._verbose = kwargs["verbose"]
         self._sparse_update = kwargs.get("sparse_update", "exact")
         self._use_graph = bool(kwargs.get("hip_graph", False))
+        self._device_metrics = bool(kwargs.get("device_metrics", True))
         self._graph_state = None
         self._graph_warm = 0
         self._max_gradient_norm = 10.
@@ -617,6 +618,23 @@ class BaseModel(nn.Module):
             if self._verbose > 0:
                 from tqdm import tqdm
                 data_generator = tqdm(data_generator, disable=False, file=sys.stdout)
+            want = list(metrics if metrics is not None else self.validation_metrics)
+            on_device = (self._device_metrics and self.device.type == "cuda"
+                         and self.feature_map.group_id is None and len(want) > 0
+                         and all(m in ("logloss", "binary_crossentropy", "AUC") for m in want))
+            if on_device:
+                # predictions and labels stay in HBM; one sort + rank-sum pass at the end
+                # (fx_binary_metrics) instead of a D->H copy and list.extend per batch + sklearn
+                preds, trues = [], []
+                for batch_data in data_generator:
+                    return_dict = self.forward(batch_data)
+                    preds.append(return_dict["y_pred"].detach().reshape(-1).float())
+                    trues.append(self.get_labels(batch_data).reshape(-1))
+                ll, auc = ops.binary_metrics(torch.cat(preds), torch.cat(trues))
+                val_logs = OrderedDict((m, auc if m == "AUC" else ll) for m in want)
+                logging.info('[Metrics] ' + ' - '.join('{}: {:.6f}'.format(k, v)
+                                                       for k, v in val_logs.items()))
+                return val_logs
             for batch_data in data_generator:
                 return_dict = self.forward(batch_data)
                 y_pred.extend(return_dict["y_pred"].data.cpu().numpy().reshape(-1))

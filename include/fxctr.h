@@ -388,6 +388,22 @@ int fx_cin_bwd(const float* X0, int64_t x0_ld, int32_t F0, const float* Xi, int6
                int32_t accumulate_dx0, float* dXi, int64_t dxi_ld, float* partial, int64_t B,
                fx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * On-device evaluation metrics for BaseModel.evaluate (rank_model.py:350-381, metrics.py:49-51):
+ * binary logloss (sklearn.metrics.log_loss on float64: probabilities clipped to
+ * [DBL_EPSILON, 1-DBL_EPSILON]) and AUC (sklearn.metrics.roc_auc_score = Mann-Whitney U with
+ * average ranks for ties) over n predictions resident on the device.
+ *   out_logloss_sum[0] = sum of the per-sample losses (divide by n)
+ *   out_counts[0] = 2 * (rank sum of the positives, ranks 1-based, ties averaged)   (exact integer)
+ *   out_counts[1] = number of positives
+ *   AUC = (out_counts[0]/2 - n_pos (n_pos+1)/2) / (n_pos (n - n_pos))
+ * 1 <= n <= 2^26; y_true in {0,1}; workspace from fx_binary_metrics_workspace_bytes(n).
+ * ------------------------------------------------------------------------------------------ */
+size_t fx_binary_metrics_workspace_bytes(int64_t n);
+int fx_binary_metrics(const float* y_pred, const float* y_true, int64_t n, void* workspace,
+                      size_t workspace_bytes, double* out_logloss_sum, uint64_t* out_counts,
+                      fx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

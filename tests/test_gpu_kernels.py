@@ -655,3 +655,29 @@ def test_embedding_regularizer_dense_step_equals_dense_optimizer(D, adam):
     if adam:
         assert (m.cpu() - m_ref).abs().max().item() <= 1e-6
         assert (v.cpu() - v_ref).abs().max().item() <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ties", [(100, False), (4096, True), (300000, True), (65537, False)])
+def test_binary_metrics_match_sklearn(n, ties):
+    """fx_binary_metrics == sklearn log_loss / roc_auc_score on the float64 view of the same float32
+    predictions (what BaseModel.evaluate feeds them, rank_model.py:369-381), incl. heavy ties and
+    saturated probabilities (exactly 0.0 / 1.0 -> the eps clip)."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    rng = np.random.default_rng(n)
+    p = rng.random(n).astype(np.float32)
+    if ties:
+        p = np.round(p * 50).astype(np.float32) / 50           # ~51 distinct values, 0.0 and 1.0 too
+    y = (rng.random(n) < 0.2 + 0.6 * p).astype(np.float32)
+    ll, auc = ops.binary_metrics(_dev(p), _dev(y))
+    ref_ll = log_loss(y.astype(np.float64), p.astype(np.float64))
+    ref_auc = roc_auc_score(y.astype(np.float64), p.astype(np.float64))
+    assert abs(ll - ref_ll) <= 1e-12 * max(1.0, abs(ref_ll)), (ll, ref_ll)
+    assert abs(auc - ref_auc) <= 1e-12, (auc, ref_auc)
+
+
+@pytest.mark.gpu
+def test_binary_metrics_one_class_raises_like_sklearn():
+    with pytest.raises(ValueError):
+        ops.binary_metrics(_dev(np.linspace(0.1, 0.9, 64).astype(np.float32)),
+                           _dev(np.ones(64, dtype=np.float32)))
