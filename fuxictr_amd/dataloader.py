@@ -11,7 +11,8 @@ copies 40 columns to the device one at a time (rank_model.py:186).  Here the col
 column-major in two host blocks (ids int32, numerics + labels fp32); a batch is one `np.take` per
 column into a pinned staging block and ONE asynchronous H2D copy per block on a copy stream, prepared
 by a background thread while the model trains on the previous batch.  The yielded dict maps column
-names to contiguous device views, so `BaseModel.get_inputs` has nothing left to copy.
+names to contiguous device views, so `BaseModel.get_inputs` has nothing left to copy.  A batch's
+views are valid until the next batch is requested from the iterator (the ring slot is then reused).
 """
 import queue
 import threading

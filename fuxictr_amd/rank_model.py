@@ -629,7 +629,8 @@ class BaseModel(nn.Module):
                 for batch_data in data_generator:
                     return_dict = self.forward(batch_data)
                     preds.append(return_dict["y_pred"].detach().reshape(-1).float())
-                    trues.append(self.get_labels(batch_data).reshape(-1))
+                    # clone: a device loader may hand out views of a buffer it reuses
+                    trues.append(self.get_labels(batch_data).reshape(-1).clone())
                 ll, auc = ops.binary_metrics(torch.cat(preds), torch.cat(trues))
                 val_logs = OrderedDict((m, auc if m == "AUC" else ll) for m in want)
                 logging.info('[Metrics] ' + ' - '.join('{}: {:.6f}'.format(k, v)
