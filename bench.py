@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: run independent replicas instead of the row-sharded model")
+    ap.add_argument("--loader", action="store_true",
+                    help="feed the steps from DeviceNpzDataLoader over a synthetic .npz (end-to-end "
+                         "rate incl. host batch assembly + H2D); not the headline number")
     ap.add_argument("--host-inputs", action="store_true",
                     help="feed host (DataLoader-style) tensors each step: the PCIe-inclusive rate")
     ap.add_argument("--no-graph", action="store_true",
@@ -224,6 +227,28 @@ def main():
         else:
             pool.append({k: torch.from_numpy(v).to(dev) for k, v in b.items()})
 
+    loader_iter = None
+    if args.loader:
+        from fuxictr_amd.dataloader import DeviceNpzDataLoader
+        n_rows = args.batch * 64
+        rng2 = np.random.default_rng(7 + rank)
+        big = synthetic.taobao_batch(rng2, n_rows, spec, dist=args.dist) if args.model == "DIN" \
+            else synthetic.criteo_batch(rng2, n_rows, cards=cards, dist=args.dist)
+        npz_path = "/tmp/fx_bench_loader_%d.npz" % rank
+        np.savez(npz_path, **big)
+        del big
+
+        def _batches():
+            while True:
+                for bt in DeviceNpzDataLoader(fmap, npz_path, batch_size=args.batch, shuffle=True,
+                                              device=dev, seed=rank):
+                    if bt[fmap.labels[0]].shape[0] == args.batch:
+                        yield bt
+        loader_iter = _batches()
+
+    def next_batch(i):
+        return next(loader_iter) if loader_iter is not None else pool[i % n_pool]
+
     def sync():
         torch.cuda.synchronize(dev)
         if dist is not None:
@@ -234,7 +259,7 @@ def main():
     launch_note = None
     try:
         for _ in range(max(args.warmup, 5 if model._use_graph else 0)):   # >= 5: 3 eager + capture
-            model.train_step(pool[step_i % n_pool])
+            model.train_step(next_batch(step_i))
             step_i += 1
         sync()
     except Exception as exc:   # noqa: BLE001 — e.g. a capture problem on a software stack not seen
@@ -255,7 +280,7 @@ def main():
     ops.KernelTimer.enabled = (not model._use_graph) and not args.no_kernel_timing
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.train_step(pool[step_i % n_pool])
+        model.train_step(next_batch(step_i))
         step_i += 1
     sync()
     dt = time.perf_counter() - t0
@@ -310,7 +335,10 @@ def main():
                        "launch": launch_note or ("hipGraph replay" if model._use_graph else "eager"),
                        "inputs": ("host tensors per step (DataLoader-style; one pinned staging "
                                   "copy per dtype) - PCIe-inclusive, NOT the headline number")
-                       if args.host_inputs else "resident in HBM",
+                       if args.host_inputs else
+                       ("DeviceNpzDataLoader over a 64-batch synthetic .npz, shuffled (host column "
+                        "gather + pinned H2D on a copy stream, prefetched) - end-to-end, NOT the "
+                        "headline number") if args.loader else "resident in HBM",
                        "parallelism": parallelism},
         }
         g = ktimes.get("k_gemm_f32")

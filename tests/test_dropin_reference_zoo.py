@@ -75,3 +75,27 @@ def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp
     sd = model.state_dict()
     for k, ref in g.state1.items():
         assert_weights_close(sd[k].numpy(), ref, m["lr"], m["steps"], k)
+
+
+def test_device_loader_through_the_reference_rankdataloader_hook(patched_reference):
+    """`RankDataLoader(..., data_loader=DeviceNpzDataLoader)` (rank_dataloader.py:51-52) on the
+    reference's own data/tiny_npz: same samples as its NpzDataLoader, column by column."""
+    from fuxictr.features import FeatureMap
+    from fuxictr.pytorch.dataloaders import RankDataLoader
+    from fuxictr_amd.dataloader import DeviceNpzDataLoader
+    data_dir = os.path.join(REF, "data", "tiny_npz")
+    fmap = FeatureMap("tiny_npz", data_dir)
+    fmap.load(os.path.join(data_dir, "feature_map.json"), {})
+    paths = dict(train_data=os.path.join(data_dir, "train.npz"),
+                 valid_data=os.path.join(data_dir, "valid.npz"))
+    ours_t, ours_v = RankDataLoader(fmap, stage="train", batch_size=32, shuffle=False,
+                                    data_loader=DeviceNpzDataLoader, device="cpu",
+                                    **paths).make_iterator()
+    ref_t, ref_v = RankDataLoader(fmap, stage="train", batch_size=32, shuffle=False, num_workers=0,
+                                  **paths).make_iterator()
+    for ours, ref in ((ours_t, ref_t), (ours_v, ref_v)):
+        assert len(ours) == len(ref) and ours.num_samples == ref.num_samples
+        for a, b in zip(ours, ref):
+            assert set(a) == set(b)
+            for k in b:
+                np.testing.assert_array_equal(a[k].numpy().astype(np.float64), b[k].numpy())
