@@ -238,10 +238,12 @@ def main():
         np.savez(npz_path, **big)
         del big
 
+        loader = DeviceNpzDataLoader(fmap, npz_path, batch_size=args.batch, shuffle=True,
+                                     device=dev, seed=rank)
+
         def _batches():
-            while True:
-                for bt in DeviceNpzDataLoader(fmap, npz_path, batch_size=args.batch, shuffle=True,
-                                              device=dev, seed=rank):
+            while True:                                   # epochs
+                for bt in loader:
                     if bt[fmap.labels[0]].shape[0] == args.batch:
                         yield bt
         loader_iter = _batches()
