@@ -344,12 +344,24 @@ def main():
                        "parallelism": parallelism},
         }
         g = ktimes.get("k_gemm_f32")
+        traffic = None
+        if args.model == "DeepFM" and args.batch == 4096 and world == 1:
+            # fabric-side bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run
+            # inside this process); only valid for the exact workload it was collected on
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                       "r01_pmc_traffic.json")) as f:
+                    traffic = json.load(f)["traffic_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                traffic = None
         if g and g["total_ms"] > 0:
             ach = g["work"] / (g["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": "k_gemm_f32 (fp32 MFMA GEMM, MLP/CrossNet fwd+bwd)",
                                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                               "traffic": None, "launches": g["launches"],
+                               "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric "
+                               "requests incl. Infinity-Cache hits; profiles/r01_pmc_traffic.txt)",
+                               "launches": g["launches"],
                                "avg_launch_us": g["avg_us"], "timing": timing_mode,
                                "gemm_share_of_instrumented_step": None}
         e = ktimes.get("k_emb_gather_fwd")
