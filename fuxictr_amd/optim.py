@@ -267,6 +267,53 @@ class _NativeOptimizer(torch.optim.Optimizer):
             grp.num_grad = None
         return None
 
+    # -- checkpoint / resume (the reference saves weights only) ------------------
+    def state_dict(self):
+        """Step counter, lr, dense moments (by position in param_groups) and each table group's
+        row moments / last-step stamps — of THIS rank's shard when the tables are row-sharded."""
+        self.flush()                      # exact mode: no pending replays in a checkpoint
+        step = int(self.scal.view(torch.int32)[_lib.SC_STEP].item())
+        dense = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self._state_dense.get(p.data_ptr())
+                dense.append(None if st is None else (st[0].cpu(), st[1].cpu()))
+        groups = []
+        for grp in self._groups:
+            numst = None
+            if grp.num_w is not None:
+                st = self._state_dense.get(grp.num_w.data_ptr())
+                numst = None if st is None else (st[0].cpu(), st[1].cpu())
+            groups.append({"m": None if grp.m is None else grp.m.cpu(),
+                           "v": None if grp.v is None else grp.v.cpu(),
+                           "last_step": None if grp.last_step is None else grp.last_step.cpu(),
+                           "num": numst})
+        return {"fx_step": step, "fx_lr": float(self.param_groups[0]["lr"]), "fx_kind": self.kind,
+                "fx_dense": dense, "fx_groups": groups}
+
+    def load_state_dict(self, state):
+        if state.get("fx_kind") != self.kind:
+            raise ValueError("optimizer state of kind %r loaded into %r" % (state.get("fx_kind"),
+                                                                            self.kind))
+        self.scal.view(torch.int32)[_lib.SC_STEP:_lib.SC_STEP + 1].fill_(int(state["fx_step"]))
+        for group in self.param_groups:
+            group["lr"] = state["fx_lr"]
+        self.scal[_lib.SC_LR:_lib.SC_LR + 1].fill_(state["fx_lr"])
+        self._lr_dev = float(state["fx_lr"])
+        it = iter(state["fx_dense"])
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = next(it)
+                if st is not None:
+                    self._state_dense[p.data_ptr()] = (st[0].to(p.device), st[1].to(p.device))
+        for grp, gs in zip(self._groups, state["fx_groups"]):
+            for name in ("m", "v", "last_step"):
+                if gs[name] is not None and getattr(grp, name) is not None:
+                    getattr(grp, name).copy_(gs[name])
+            if gs["num"] is not None and grp.num_w is not None:
+                self._state_dense[grp.num_w.data_ptr()] = (gs["num"][0].to(grp.device),
+                                                           gs["num"][1].to(grp.device))
+
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none=set_to_none)
         for grp in self._groups:

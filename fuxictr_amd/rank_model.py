@@ -668,16 +668,39 @@ class BaseModel(nn.Module):
     def evaluate_metrics(self, y_true, y_pred, metrics, group_id=None):
         return evaluate_metrics(y_true, y_pred, metrics, group_id)
 
+    def _shard_path(self, checkpoint):
+        """Row-sharded tables: every rank owns a file with ITS rows (+ the replicated dense part)."""
+        if self._dist is None:
+            return checkpoint
+        return "%s.rank%d-of-%d" % (checkpoint, self._dist.rank, self._dist.world)
+
     def save_weights(self, checkpoint):
         if hasattr(self.optimizer, "flush"):
             self.optimizer.flush()
         os.makedirs(os.path.dirname(checkpoint), exist_ok=True)
-        torch.save(self.state_dict(), checkpoint)
+        torch.save(self.state_dict(), self._shard_path(checkpoint))
 
     def load_weights(self, checkpoint):
         self.to(self.device)
-        state_dict = torch.load(checkpoint, map_location="cpu")
+        path = self._shard_path(checkpoint)
+        if self._dist is not None and not os.path.exists(path):
+            # a full (reference-layout) checkpoint: every rank picks its rows out of it
+            self.load_full_state_dict(torch.load(checkpoint, map_location="cpu"))
+            return
+        state_dict = torch.load(path, map_location="cpu")
         self.load_state_dict(state_dict)
+
+    def save_checkpoint(self, checkpoint):
+        """Weights + optimizer state (moments, row stamps, step, lr): a true resume point, which the
+        reference does not have (it saves weights only, rank_model.py:423)."""
+        self.save_weights(checkpoint)
+        torch.save(self.optimizer.state_dict(), self._shard_path(checkpoint) + ".optim")
+
+    def load_checkpoint(self, checkpoint):
+        self.load_weights(checkpoint)
+        self.optimizer.load_state_dict(torch.load(self._shard_path(checkpoint) + ".optim",
+                                                  map_location="cpu", weights_only=False))
+        self._graph_state = None          # a captured step holds the old step's buffers only
 
     def get_output_activation(self, task):
         if task == "binary_classification":

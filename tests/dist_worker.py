@@ -75,6 +75,18 @@ def run(rank, world, case, port, out_path, use_gpu):
     model.eval()
     with torch.no_grad():
         p1 = model.forward(part(g.batches[-1]))["y_pred"].reshape(-1).cpu()
+    if os.environ.get("FX_TEST_CKPT") == "1":
+        # per-shard checkpoint files: every rank writes / reads its own rows
+        ck = os.path.join(os.path.dirname(out_path), "ck", "m.model")
+        model.save_weights(ck)
+        assert os.path.exists("%s.rank%d-of-%d" % (ck, rank, world))
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.add_(1.0)
+        model.load_weights(ck)
+        for k, v in model.state_dict().items():
+            assert torch.equal(v, before[k]), k
     full = {k: v.cpu().numpy() for k, v in model.full_state_dict().items()}
     gp0 = [torch.empty_like(p0) for _ in range(world)]
     gp1 = [torch.empty_like(p1) for _ in range(world)]

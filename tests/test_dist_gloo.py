@@ -55,3 +55,10 @@ def test_three_ranks_uneven_shards(tmp_path):
     g = Golden("deepfm_sgd")
     z = run_workers("deepfm_sgd", tmp_path, use_gpu=False, world=3)
     check_against_golden(z, g)
+
+
+def test_sharded_checkpoint_files_roundtrip(tmp_path):
+    """save_weights / load_weights with row-sharded tables: one file per rank."""
+    g = Golden("deepfm_adam")
+    z = run_workers("deepfm_adam", tmp_path, use_gpu=False, env={"FX_TEST_CKPT": "1"})
+    check_against_golden(z, g)

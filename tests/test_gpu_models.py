@@ -256,3 +256,32 @@ def test_full_criteo_scale_properties(tmp_path, dist):
     losses2 = [float(model2.train_step(b).item()) for b in batches]
     assert losses == losses2
     assert torch.equal(model2.embedding_layer.embedding_layer.table_groups()[0].table, grp.table)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam"])
+def test_checkpoint_resume_is_bit_identical_to_uninterrupted_training(case, tmp_path):
+    """save_checkpoint / load_checkpoint (weights + Adam moments + row stamps + step): training
+    3 steps, saving, loading into a NEW model and training on == training straight through."""
+    g = Golden(case)
+    n = g.meta["steps"]
+    a = build_native(g, tmp_path)
+    a.train()
+    for i in range(n):
+        a.train_step(tb(g.batches[i]))
+    b = build_native(g, tmp_path)
+    b.train()
+    for i in range(3):
+        b.train_step(tb(g.batches[i]))
+    path = str(tmp_path / "ck" / "resume.model")
+    b.save_checkpoint(path)
+    c = build_native(g, tmp_path)
+    c.load_checkpoint(path)
+    c.train()
+    for i in range(3, n):
+        c.train_step(tb(g.batches[i]))
+    a.eval()
+    c.eval()
+    sa, sc = a.state_dict(), c.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sc[k]), k
