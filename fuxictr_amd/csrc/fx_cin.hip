@@ -166,9 +166,13 @@ __global__ __launch_bounds__(256) void k_cin_bwd_dw(CinArgs a) {
 // operands that do not change in the inner loop (a column of Xi, a column of g, the dW / dXi
 // accumulators) live in registers, loops over m are fully unrolled (template MI).
 // =================================================================================================
+// Static LDS (the whole 160 KB a workgroup may have): a launch with > 64 KB of DYNAMIC LDS was
+// measured to cost ~13 us more per launch inside the step graph (profiles/r01_gemm_pipe.txt).
+#define FX_CIN2_LDS_FLOATS 40000
+
 template <int MI>
 __global__ __launch_bounds__(1024) void k_cin_fwd2(CinArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ __attribute__((aligned(16))) float smem[FX_CIN2_LDS_FLOATS];
     const int D = a.D, O = a.O, F0 = a.F0, Mi = a.Mi;
     const int MiP = (Mi + 3) & ~3;
     float* Ws = smem;                                        // [O][F0][MiP]
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(1024) void k_cin_fwd2(CinArgs a) {
 // shuffles + one LDS pass over the 4 waves of the slot.
 template <int MI, int OM>
 __global__ __launch_bounds__(1024) void k_cin_bwd_dx2(CinArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ __attribute__((aligned(16))) float smem[FX_CIN2_LDS_FLOATS];
     const int D = a.D, O = a.O, F0 = a.F0, Mi = a.Mi;
     const int MiP = (Mi + 3) & ~3;
     int Dp = 1;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(1024) void k_cin_bwd_dx2(CinArgs a) {
 // the workgroup; Xi is staged transposed ([d][MiP]) so the m direction is a ds_read_b128 broadcast.
 template <int MI>
 __global__ __launch_bounds__(1024) void k_cin_bwd_dw2(CinArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ __attribute__((aligned(16))) float smem[FX_CIN2_LDS_FLOATS];
     const int D = a.D, O = a.O, F0 = a.F0, Mi = a.Mi, C = F0 * Mi;
     const int MiP = (Mi + 3) & ~3;
     constexpr int SB = 4;                                    // samples staged per round
@@ -430,16 +434,10 @@ extern "C" int fx_cin_fwd(const float* X0, int64_t x0_ld, int32_t F0, const floa
     a.pool = pool; a.pool_ld = pool_ld; a.B = B; a.F0 = F0; a.Mi = Mi; a.D = D; a.O = O;
     const int MiP = (Mi + 3) & ~3;
     const size_t lds2 = sizeof(float) * ((size_t)O * F0 * MiP + 4 * (size_t)(F0 + Mi + O) * D);
-    if (Mi <= 64 && lds2 <= 160 * 1024) {
+    if (Mi <= 64 && lds2 <= sizeof(float) * FX_CIN2_LDS_FLOATS) {
         const int64_t grid2 = fx_ceil_div(B, 4) < 256 ? fx_ceil_div(B, 4) : 256;
 #define FX_CIN_FWD2(MI)                                                                       \
-    do {                                                                                      \
-        FX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cin_fwd2<MI>),       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                                         (int)lds2));                                         \
-        hipLaunchKernelGGL(k_cin_fwd2<MI>, dim3((unsigned)grid2), dim3(1024), lds2,           \
-                           fx_hip_stream(stream), a);                                         \
-    } while (0)
+    hipLaunchKernelGGL(k_cin_fwd2<MI>, dim3((unsigned)grid2), dim3(1024), 0, fx_hip_stream(stream), a)
         if (Mi <= 16) FX_CIN_FWD2(16);
         else if (Mi <= 40) FX_CIN_FWD2(40);
         else FX_CIN_FWD2(64);
@@ -481,16 +479,10 @@ extern "C" int fx_cin_bwd(const float* X0, int64_t x0_ld, int32_t F0, const floa
     const int64_t grid = B < 256 ? B : 256;
     const int MiP = (Mi + 3) & ~3;
     const size_t lds_dx2 = sizeof(float) * ((size_t)O * F0 * MiP + 4 * 4 * (size_t)Mi * D);
-    if (Mi <= 64 && O <= 32 && D <= 64 && lds_dx2 <= 160 * 1024) {
+    if (Mi <= 64 && O <= 32 && D <= 64 && lds_dx2 <= sizeof(float) * FX_CIN2_LDS_FLOATS) {
         const int64_t grid2 = fx_ceil_div(B, 4) < 256 ? fx_ceil_div(B, 4) : 256;
 #define FX_CIN_DX2(MI, OM)                                                                    \
-    do {                                                                                      \
-        FX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cin_bwd_dx2<MI, OM>),\
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                                         (int)lds_dx2));                                      \
-        hipLaunchKernelGGL((k_cin_bwd_dx2<MI, OM>), dim3((unsigned)grid2), dim3(1024), lds_dx2, \
-                           s, a);                                                             \
-    } while (0)
+    hipLaunchKernelGGL((k_cin_bwd_dx2<MI, OM>), dim3((unsigned)grid2), dim3(1024), 0, s, a)
         if (O <= 16) {
             if (Mi <= 16) FX_CIN_DX2(16, 16);
             else if (Mi <= 40) FX_CIN_DX2(40, 16);
@@ -508,14 +500,8 @@ extern "C" int fx_cin_bwd(const float* X0, int64_t x0_ld, int32_t F0, const floa
     }
     // weight-gradient partials always use the full 256 workgroups so `partial` has a fixed shape
     const size_t lds_dw2 = sizeof(float) * 4 * (((size_t)D * MiP + (size_t)(F0 + O) * (D + 1) + 3) & ~(size_t)3);
-    if (Mi <= 64 && (int64_t)O * F0 <= 1024 && lds_dw2 <= 160 * 1024) {
-#define FX_CIN_DW2(MI)                                                                        \
-    do {                                                                                      \
-        FX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cin_bwd_dw2<MI>),    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                                         (int)lds_dw2));                                      \
-        hipLaunchKernelGGL(k_cin_bwd_dw2<MI>, dim3(256), dim3(1024), lds_dw2, s, a);          \
-    } while (0)
+    if (Mi <= 64 && (int64_t)O * F0 <= 1024 && lds_dw2 <= sizeof(float) * FX_CIN2_LDS_FLOATS) {
+#define FX_CIN_DW2(MI) hipLaunchKernelGGL(k_cin_bwd_dw2<MI>, dim3(256), dim3(1024), 0, s, a)
         if (Mi <= 16) FX_CIN_DW2(16);
         else if (Mi <= 40) FX_CIN_DW2(40);
         else FX_CIN_DW2(64);
