@@ -129,6 +129,11 @@ class _ShardExchange(object):
     pass
 
 
+# table groups that route with the same id plan (a model's D=16 tables and its D=1 LR tables):
+# their row / row-gradient exchanges travel in ONE all-to-all per direction
+_SHARD_PEERS = {}
+
+
 class _PendingGrad(object):
     __slots__ = ("dd", "G", "sq")
 
@@ -371,6 +376,9 @@ class _TableGroup(object):
         the same id columns / row bases (the D=16 and the D=1 LR tables)."""
         cache = getattr(inputs, "cache", None)
         ckey = ("shard", plan.sig, self.total_rows, self.n_shards)
+        peers = _SHARD_PEERS.setdefault((plan.sig, self.total_rows, self.n_shards, id(self.dist)), [])
+        if not any(p is self for p in peers):
+            peers.append(self)
         if cache is not None and ckey in cache:
             return cache[ckey]
         dev, N = self.device, self.n_shards
@@ -383,6 +391,8 @@ class _TableGroup(object):
         cap = self.a2a_cap(n)
         sx = _ShardExchange()
         sx.dd, sx.cap = dd, cap
+        sx.key = (plan.sig, self.total_rows, N, id(self.dist))
+        sx.rows = {}                                  # id(group) -> fetched rows of this batch
         sx.send_idx = torch.empty(N * cap, dtype=torch.int32, device=dev)
         sx.uniq_slot = torch.empty(n, dtype=torch.int32, device=dev)
         sx.lookup_slot = torch.empty(ids.shape[0], ids.shape[1], dtype=torch.int32, device=dev)
@@ -413,16 +423,31 @@ class _TableGroup(object):
     def shard_fetch_rows(self, sx, track):
         """Owner side: bring the requested rows up to date (exact mode), gather them, send them
         back.  -> [N*cap + 1, D] rows in the slot order of sx.lookup_slot."""
-        N, cap, D = self.n_shards, sx.cap, self.D
-        if track and self.exact and self.opt_kind == "adam":
-            ops.adam_catchup(self.table, self.m, self.v, self.last_step, D, sx.owner_dd,
-                             self.rows_per_shard + 1, -1, self.scal)
-        rows_send = torch.empty(N * cap, D, dtype=torch.float32, device=self.device)
-        ops.emb_gather_fwd(self.table, D, sx.recv_idx, sx.own_base, sx.own_vocab, sx.own_base,
-                           None, None, None, rows_send, self.ensure_scal())
-        rows = torch.zeros(N * cap + 1, D, dtype=torch.float32, device=self.device)
-        rows[:N * cap] = self.dist.all_to_all(rows_send)
-        return rows
+        N, cap = self.n_shards, sx.cap
+        got = sx.rows.pop(id(self), None)
+        if got is not None:
+            return got                                # fetched together with a peer group
+        peers = [p for p in _SHARD_PEERS.get(sx.key, []) if p.table is not None]
+        if not any(p is self for p in peers):
+            peers = [self]
+        sends = []
+        for p in peers:
+            if track and p.exact and p.opt_kind == "adam":
+                ops.adam_catchup(p.table, p.m, p.v, p.last_step, p.D, sx.owner_dd,
+                                 p.rows_per_shard + 1, -1, p.scal)
+            rs = torch.empty(N * cap, p.D, dtype=torch.float32, device=self.device)
+            ops.emb_gather_fwd(p.table, p.D, sx.recv_idx, sx.own_base, sx.own_vocab, sx.own_base,
+                               None, None, None, rs, p.ensure_scal())
+            sends.append(rs)
+        # one all-to-all for every group routed by this id plan (e.g. [N*cap, 16 + 1])
+        recv = self.dist.all_to_all(sends[0] if len(sends) == 1 else torch.cat(sends, dim=1))
+        off = 0
+        for p in peers:
+            rows = torch.zeros(N * cap + 1, p.D, dtype=torch.float32, device=self.device)
+            rows[:N * cap] = recv[:, off:off + p.D]
+            off += p.D
+            sx.rows[id(p)] = rows
+        return sx.rows.pop(id(self))
 
     def shard_backward(self, plan, sx, dout, dout_ld, col_off):
         """Requester: reduce to local unique keys, ship to owners; owner: reduce across ranks."""
@@ -442,20 +467,19 @@ class _TableGroup(object):
     def finish_backward(self):
         """Owner side of the sharded backward: ship row gradients to their owners, reduce the
         contributions of all ranks per owned row."""
-        waiting, self._await_exchange = self._await_exchange, []
-        for sx, gsend in waiting:
-            self._finish_one(sx, gsend)
+        finish_shard_backward([self])
 
-    def _finish_one(self, sx, gsend):
-        N, cap, D = self.n_shards, sx.cap, self.D
-        grecv = self.dist.all_to_all(gsend[:N * cap])
+    def _finish_one(self, sx, grecv, ld):
+        """grecv: this group's columns of the received gradient block (row stride `ld`)."""
+        D = self.D
         odd = sx.owner_dd
         G_own = torch.empty(odd.n_max, D, dtype=torch.float32, device=self.device)
         sq_own = torch.empty(ops.emb_grad_reduce_partials(odd.n_max, D), dtype=torch.float32,
                              device=self.device)
-        ops.emb_grad_reduce(grecv, D, sx.own_base, 1, D, odd, G_own, sq_own,
+        ops.emb_grad_reduce(grecv, ld, sx.own_base, 1, D, odd, G_own, sq_own,
                             self.reduce_scratch(odd.n_max))
         self.pending.append(_PendingGrad(odd, G_own, sq_own))
+
 
     def flush(self):
         """exact mode: replay pending zero-gradient Adam steps for EVERY row (before eval/save)."""
@@ -463,6 +487,28 @@ class _TableGroup(object):
             rows = self.rows_per_shard + 1 if self.n_shards > 1 else self.total_rows
             ops.adam_catchup(self.table, self.m, self.v, self.last_step, self.D, None,
                              rows, 0, self.scal)
+
+
+def finish_shard_backward(groups):
+    """Row-gradient exchange of every table group that has one waiting: groups that were routed by
+    the same _ShardExchange send their blocks side by side in ONE all-to-all ([N*cap, sum D])."""
+    by_sx = OrderedDict()
+    for grp in groups:
+        waiting, grp._await_exchange = grp._await_exchange, []
+        for sx, gsend in waiting:
+            by_sx.setdefault(id(sx), (sx, []))[1].append((grp, gsend))
+    for sx, items in by_sx.values():
+        n = items[0][0].n_shards * sx.cap
+        if len(items) == 1:
+            grp, gsend = items[0]
+            grp._finish_one(sx, grp.dist.all_to_all(gsend[:n]), grp.D)
+            continue
+        block = torch.cat([gsend[:n] for _, gsend in items], dim=1)
+        recv = items[0][0].dist.all_to_all(block)
+        off = 0
+        for grp, _ in items:
+            grp._finish_one(sx, recv[:, off:off + grp.D], recv.shape[1])
+            off += grp.D
 
 
 class _EmbGatherFn(torch.autograd.Function):

@@ -123,9 +123,15 @@ def emb_grad_reduce_scratch_ints(n_max):
     return n_max // 33 + 2
 
 
+def _flat_from(t):
+    """What a kernel sees: the memory from t's first element on (t may be a strided view)."""
+    n = t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+    return torch.as_strided(t, (n,), (1,), t.storage_offset())
+
+
 def emb_grad_reduce(dout, dout_ld, col_out_off, C, D, dd, G, sq_partials, scratch):
     nu = int(dd.n_unique)
-    flat = dout.reshape(-1)
+    flat = _flat_from(dout)
     sq_partials.zero_()
     for u in range(nu):
         acc = torch.zeros(D)
