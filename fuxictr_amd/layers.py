@@ -503,8 +503,14 @@ def finish_shard_backward(groups):
             grp, gsend = items[0]
             grp._finish_one(sx, grp.dist.all_to_all(gsend[:n]), grp.D)
             continue
-        block = torch.cat([gsend[:n] for _, gsend in items], dim=1)
-        recv = items[0][0].dist.all_to_all(block)
+        # float4-wide groups first so their column offsets stay 16-byte aligned; row stride padded
+        # to a multiple of 4 floats (the reduce kernel reads rows with vector loads)
+        items.sort(key=lambda it: 0 if it[0].D % 4 == 0 else 1)
+        parts = [gsend[:n] for _, gsend in items]
+        width = sum(g.D for g, _ in items)
+        if width % 4:
+            parts.append(torch.zeros(n, 4 - width % 4, dtype=torch.float32, device=parts[0].device))
+        recv = items[0][0].dist.all_to_all(torch.cat(parts, dim=1))
         off = 0
         for grp, _ in items:
             grp._finish_one(sx, recv[:, off:off + grp.D], recv.shape[1])
