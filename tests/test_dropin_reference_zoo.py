@@ -40,7 +40,8 @@ def patched_reference(monkeypatch):
         sys.modules.pop(k, None)
 
 
-@pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam"])
+@pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam", "din_adam", "dlrm_adam",
+                                  "xdeepfm_adam", "deepfm_reg"])
 def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp_path):
     g = Golden(case)
     m = g.meta
@@ -51,25 +52,47 @@ def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp
     common = dict(gpu=-1, embedding_dim=m["embedding_dim"], learning_rate=m["lr"],
                   optimizer=m["optimizer"], loss="binary_crossentropy",
                   task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
-                  model_root=str(tmp_path), embedding_regularizer=0, net_regularizer=0)
+                  model_root=str(tmp_path), embedding_regularizer=m.get("emb_reg", 0),
+                  net_regularizer=m.get("net_reg", 0))
     if m["model"] == "DeepFM":
         from model_zoo.DeepFM.DeepFM_torch.src import DeepFM as RefModel
         model = RefModel(fmap, model_id=case, hidden_units=m["hidden"], **common)
+    elif m["model"] == "DIN":
+        from model_zoo import DIN as RefModel
+        model = RefModel(fmap, model_id=case, dnn_hidden_units=m["hidden"], dnn_activations="relu",
+                         attention_hidden_units=m["att_hidden"],
+                         attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
+                         din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
+    elif m["model"] == "DLRM":
+        from model_zoo import DLRM as RefModel
+        model = RefModel(fmap, model_id=case, top_mlp_units=m["hidden"],
+                         bottom_mlp_units=m["bottom"], interaction_op="dot", **common)
+    elif m["model"] == "xDeepFM":
+        from model_zoo import xDeepFM as RefModel
+        model = RefModel(fmap, model_id=case, dnn_hidden_units=m["hidden"],
+                         cin_hidden_units=m["cin"], **common)
     else:
         from model_zoo import DCNv2 as RefModel
         model = RefModel(fmap, model_id=case, model_structure="parallel",
                          num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"],
                          **common)
     assert RefModel.__module__.startswith("model_zoo")           # the reference's own class ...
-    assert isinstance(model.embedding_layer, nat.FeatureEmbedding)  # ... built from native layers
+    assert isinstance(model.embedding_layer, (nat.FeatureEmbedding, nat.FeatureEmbeddingDict))  # native
     model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state0.items()})
     model._max_gradient_norm = m["max_norm"]
     model.eval()
+    def batch(i):
+        b = tb(g.batches[i])
+        if m["model"] == "DLRM":          # DLRM.py:114 concatenates X[k] on dim -1: needs [B,1]
+            for name, spec in g.features.items():
+                if spec["type"] == "numeric":
+                    b[name] = b[name].view(-1, 1)
+        return b
     with torch.no_grad():
-        p = model.forward(tb(g.batches[-1]))["y_pred"]
+        p = model.forward(batch(-1))["y_pred"]
     np.testing.assert_allclose(p.reshape(-1).numpy(), g.expect["pred0"], atol=2e-6)
     model.train()
-    losses = [float(model.train_step(tb(g.batches[i])).item()) for i in range(m["steps"])]
+    losses = [float(model.train_step(batch(i)).item()) for i in range(m["steps"])]
     np.testing.assert_allclose(losses, g.expect["loss"], atol=5e-6)
     model.eval()
     sd = model.state_dict()
