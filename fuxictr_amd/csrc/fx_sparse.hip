@@ -567,11 +567,112 @@ __global__ __launch_bounds__(256) void k_shard_lookup_slot(const uint32_t* sorte
     }
 }
 
+// ---- plan for ROW-sorted unique keys (global rows g, owner = g % N, local row = g / N) ------------
+// The column fast path of fx_dedup yields unique global rows in ascending order; owner-major order
+// would need a device-wide sort (rocPRIM merge sort, ~60 us at 106 K keys).  Instead: per-owner
+// ranks by counting — per-block owner histograms, a scan over the blocks, ranks inside a block from
+// wave ballots.  Within an owner's bucket the keys stay in ascending row order (deterministic).
+#define FX_PLAN_BLOCK 1024
+#define FX_PLAN_MAX_SHARDS 64
+
+__global__ __launch_bounds__(FX_PLAN_BLOCK) void k_shard_count(const uint32_t* uniq_key,
+                                                               const int32_t* n_unique, int N,
+                                                               int32_t* blk_cnt) {
+    __shared__ int32_t cnt[FX_PLAN_MAX_SHARDS];
+    if ((int)threadIdx.x < N) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * FX_PLAN_BLOCK + threadIdx.x;
+    if (u < *n_unique) atomicAdd(&cnt[uniq_key[u] % (uint32_t)N], 1);
+    __syncthreads();
+    if ((int)threadIdx.x < N) blk_cnt[(int64_t)blockIdx.x * N + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// one thread per owner: exclusive scan of that owner's counts over the blocks (in place), totals
+__global__ void k_shard_scan_blocks(int32_t* blk_cnt, int nblk, int N, int cap, int32_t* total,
+                                    fx_scalars* scal) {
+    const int o = threadIdx.x;
+    if (o >= N) return;
+    int32_t acc = 0;
+    for (int b = 0; b < nblk; ++b) {
+        const int32_t c = blk_cnt[(int64_t)b * N + o];
+        blk_cnt[(int64_t)b * N + o] = acc;
+        acc += c;
+    }
+    total[o] = acc;
+    if (acc > cap) atomicOr(&scal->err_flag, FX_FLAG_A2A_OVERFLOW);
+}
+
+__global__ __launch_bounds__(FX_PLAN_BLOCK) void k_shard_assign(const uint32_t* uniq_key,
+                                                                const int32_t* n_unique, int N,
+                                                                int cap, int64_t n_max,
+                                                                const int32_t* blk_base,
+                                                                int32_t* uniq_slot, int32_t* send_idx) {
+    __shared__ int32_t wave_cnt[FX_PLAN_BLOCK / 64][FX_PLAN_MAX_SHARDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * FX_PLAN_BLOCK + threadIdx.x;
+    const bool on = u < *n_unique;
+    const uint32_t g = on ? uniq_key[u] : 0u;
+    const int my_o = on ? (int)(g % (uint32_t)N) : -1;
+    int my_rank = 0;
+    for (int o = 0; o < N; ++o) {                           // block-uniform loop
+        const unsigned long long m = __ballot(my_o == o);
+        if (my_o == o) my_rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave][o] = __popcll(m);
+    }
+    __syncthreads();
+    if (on) {
+        int base = blk_base[(int64_t)blockIdx.x * N + my_o];
+        for (int w = 0; w < wave; ++w) base += wave_cnt[w][my_o];
+        const int j = base + my_rank;
+        int32_t slot = N * cap;                             // pad slot on overflow
+        if (j < cap) {
+            slot = my_o * cap + j;
+            send_idx[slot] = (int32_t)(g / (uint32_t)N);
+        }
+        uniq_slot[u] = slot;
+    } else if (u < n_max) {
+        uniq_slot[u] = N * cap;
+    }
+}
+
+// bucket tails: slots past an owner's count carry the owner's pad row
+__global__ __launch_bounds__(256) void k_shard_pad_tails(const int32_t* total, int N, int cap,
+                                                         int32_t pad_row, int32_t* send_idx) {
+    const int64_t n = (int64_t)N * cap;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int o = (int)(e / cap), j = (int)(e - (int64_t)o * cap);
+        if (j >= total[o]) send_idx[e] = pad_row;
+    }
+}
+
+// lookups whose id was padding / out of range have no position in the fast path's sorted arrays:
+// every lookup slot starts at the pad slot, valid positions are overwritten
+__global__ __launch_bounds__(256) void k_shard_lookup_slot_g(const uint32_t* sorted_pos,
+                                                             const uint32_t* sorted_uid,
+                                                             const int32_t* uniq_slot, int64_t n,
+                                                             int32_t* lookup_slot) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t p = sorted_pos[i], uid = sorted_uid[i];
+        if (p != 0xFFFFFFFFu && uid != 0xFFFFFFFFu) lookup_slot[p] = uniq_slot[uid];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        p[i] = v;
+}
+
+extern "C" int64_t fx_shard_plan_workspace_ints(int64_t n_lookups, int32_t n_shards) {
+    if (n_lookups < 0 || n_shards < 1) return 0;
+    return (fx_ceil_div(n_lookups > 0 ? n_lookups : 1, FX_PLAN_BLOCK) + 1) * (int64_t)n_shards;
+}
+
 extern "C" int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique,
                              const uint32_t* sorted_pos, const uint32_t* sorted_uid,
                              int64_t n_lookups, int32_t n_shards, int64_t total_rows, int32_t cap,
                              int32_t* send_idx, int32_t* uniq_slot, int32_t* lookup_slot,
-                             fx_scalars* scal, fx_stream_t stream) {
+                             fx_scalars* scal, int32_t global_keys, int32_t* workspace,
+                             fx_stream_t stream) {
     FX_CHECK_ARG(n_shards >= 1 && cap >= 1 && n_lookups >= 0, "fx_shard_plan: bad sizes");
     FX_CHECK_ARG(uniq_key && n_unique && sorted_pos && sorted_uid && send_idx && uniq_slot &&
                      lookup_slot && scal,
@@ -579,6 +680,35 @@ extern "C" int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique,
     const int64_t rps = fx_ceil_div(total_rows, n_shards);
     hipStream_t s = fx_hip_stream(stream);
     const int64_t total = (int64_t)n_shards * cap;
+    if (global_keys) {
+        FX_CHECK_ARG(workspace, "fx_shard_plan: global_keys needs a workspace");
+        FX_CHECK_ARG(n_shards <= FX_PLAN_MAX_SHARDS, "fx_shard_plan: n_shards=%d > %d", n_shards,
+                     FX_PLAN_MAX_SHARDS);
+        const int nblk = (int)fx_ceil_div(n_lookups > 0 ? n_lookups : 1, FX_PLAN_BLOCK);
+        int32_t* blk_cnt = workspace;
+        int32_t* tot = workspace + (int64_t)nblk * n_shards;
+        hipLaunchKernelGGL(k_shard_count, dim3((unsigned)nblk), dim3(FX_PLAN_BLOCK), 0, s, uniq_key,
+                           n_unique, (int)n_shards, blk_cnt);
+        hipLaunchKernelGGL(k_shard_scan_blocks, dim3(1), dim3(64), 0, s, blk_cnt, nblk,
+                           (int)n_shards, (int)cap, tot, scal);
+        hipLaunchKernelGGL(k_shard_assign, dim3((unsigned)nblk), dim3(FX_PLAN_BLOCK), 0, s, uniq_key,
+                           n_unique, (int)n_shards, (int)cap, n_lookups, blk_cnt, uniq_slot,
+                           send_idx);
+        int64_t bp = fx_ceil_div(total, 256);
+        if (bp > 4096) bp = 4096;
+        hipLaunchKernelGGL(k_shard_pad_tails, dim3((unsigned)bp), dim3(256), 0, s, tot, (int)n_shards,
+                           (int)cap, (int32_t)rps, send_idx);
+        if (n_lookups > 0) {
+            int64_t b2 = fx_ceil_div(n_lookups, 256);
+            if (b2 > 4096) b2 = 4096;
+            hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)b2), dim3(256), 0, s, lookup_slot,
+                               n_lookups, (int32_t)total);
+            hipLaunchKernelGGL(k_shard_lookup_slot_g, dim3((unsigned)b2), dim3(256), 0, s,
+                               sorted_pos, sorted_uid, uniq_slot, n_lookups, lookup_slot);
+        }
+        FX_CHECK_LAUNCH();
+        return FX_OK;
+    }
     int64_t b1 = fx_ceil_div(total, 256);
     if (b1 > 4096) b1 = 4096;
     hipLaunchKernelGGL(k_shard_send_idx, dim3((unsigned)b1), dim3(256), 0, s, uniq_key, n_unique,

@@ -386,8 +386,10 @@ class _TableGroup(object):
         if self.dedup_ws is None or self.dedup_ws[0] != n:
             self.dedup_ws = (n, torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8,
                                             device=dev))
+        # unique GLOBAL rows in ascending order (the column fast path applies); owners and slots are
+        # derived by counting in fx_shard_plan(global_keys), no owner-major device sort
         dd = ops.dedup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad, self.total_rows,
-                       self.dedup_ws[1], n_shards=N, want_uid=True)
+                       self.dedup_ws[1], want_uid=True, columns_sorted=plan.columns_sorted)
         cap = self.a2a_cap(n)
         sx = _ShardExchange()
         sx.dd, sx.cap = dd, cap
@@ -396,8 +398,13 @@ class _TableGroup(object):
         sx.send_idx = torch.empty(N * cap, dtype=torch.int32, device=dev)
         sx.uniq_slot = torch.empty(n, dtype=torch.int32, device=dev)
         sx.lookup_slot = torch.empty(ids.shape[0], ids.shape[1], dtype=torch.int32, device=dev)
+        wkey = ("plan_ws", n, N)
+        pws = self._shard_consts.get(wkey)
+        if pws is None:
+            pws = self._shard_consts[wkey] = torch.empty(ops.shard_plan_workspace_ints(n, N),
+                                                         dtype=torch.int32, device=dev)
         ops.shard_plan(dd, N, self.total_rows, cap, sx.send_idx, sx.uniq_slot, sx.lookup_slot,
-                       self.ensure_scal())
+                       self.ensure_scal(), global_keys=True, workspace=pws)
         sx.recv_idx = self.dist.all_to_all(sx.send_idx).view(N * cap, 1)
         if self.owner_ws is None or self.owner_ws[0] != N * cap:
             self.owner_ws = (N * cap, torch.empty(ops.dedup_workspace_bytes(N * cap),

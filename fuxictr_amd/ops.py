@@ -159,10 +159,16 @@ def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=N
     return result
 
 
-def shard_plan(dd, n_shards, total_rows, cap, send_idx, uniq_slot, lookup_slot, scal):
+def shard_plan_workspace_ints(n_lookups, n_shards):
+    return int(_lib.load().fx_shard_plan_workspace_ints(n_lookups, n_shards))
+
+
+def shard_plan(dd, n_shards, total_rows, cap, send_idx, uniq_slot, lookup_slot, scal,
+               global_keys=False, workspace=None):
     check(_lib.load().fx_shard_plan(ptr(dd.uniq_row), ptr(dd.n_unique), ptr(dd.sorted_pos),
                                     ptr(dd.sorted_uid), dd.n_max, n_shards, total_rows, cap,
                                     ptr(send_idx), ptr(uniq_slot), ptr(lookup_slot), ptr(scal),
+                                    1 if global_keys else 0, ptr(workspace),
                                     stream_ptr(send_idx.device)), "fx_shard_plan")
 
 

@@ -132,10 +132,17 @@ int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
  * all-to-all slots; fx_sum_parts reduces partial squared norms to one device scalar (the
  * rank-local table term of the global clip norm, summed across ranks by the host's all-reduce).
  * ------------------------------------------------------------------------------------------ */
+/* global_keys = 0: uniq_key are owner-major keys (fx_dedup with n_shards = N).
+ * global_keys = 1: uniq_key are GLOBAL packed rows in ascending order (fx_dedup with n_shards = 1,
+ *   e.g. its column fast path): owner = g % N, local row = g / N, an owner's bucket keeps ascending
+ *   row order; needs `workspace` of fx_shard_plan_workspace_ints(n_lookups, n_shards) int32 words;
+ *   positions whose id was padding / out of range get the pad slot. */
+int64_t fx_shard_plan_workspace_ints(int64_t n_lookups, int32_t n_shards);
 int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique, const uint32_t* sorted_pos,
                   const uint32_t* sorted_uid, int64_t n_lookups, int32_t n_shards,
                   int64_t total_rows, int32_t cap, int32_t* send_idx, int32_t* uniq_slot,
-                  int32_t* lookup_slot, fx_scalars* scal, fx_stream_t stream);
+                  int32_t* lookup_slot, fx_scalars* scal, int32_t global_keys, int32_t* workspace,
+                  fx_stream_t stream);
 int fx_scatter_rows(const float* src, const int32_t* row_map, const int32_t* n_rows, int64_t n_max,
                     int32_t D, float* dst, fx_stream_t stream);
 int fx_sum_parts(const float* const* parts_host, const int64_t* counts_host, int32_t n_parts,

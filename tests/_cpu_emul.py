@@ -86,18 +86,28 @@ def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=N
     return dd
 
 
-def shard_plan(dd, n_shards, total_rows, cap, send_idx, uniq_slot, lookup_slot, scal):
+def shard_plan_workspace_ints(n_lookups, n_shards):
+    return 8
+
+
+def shard_plan(dd, n_shards, total_rows, cap, send_idx, uniq_slot, lookup_slot, scal,
+               global_keys=False, workspace=None):
     rps = -(-total_rows // n_shards)
     nu = int(dd.n_unique)
     keys = dd.uniq_row[:nu].long()
     send_idx.fill_(rps)
     uniq_slot.fill_(n_shards * cap)
     for o in range(n_shards):
-        sel = ((keys >= o * rps) & (keys < (o + 1) * rps)).nonzero().reshape(-1)
+        if global_keys:      # keys are global rows: owner = g % N, local row = g // N
+            sel = (keys % n_shards == o).nonzero().reshape(-1)
+            local = keys[sel] // n_shards
+        else:
+            sel = ((keys >= o * rps) & (keys < (o + 1) * rps)).nonzero().reshape(-1)
+            local = keys[sel] - o * rps
         if len(sel) > cap:
             scal.view(torch.int32)[SC.SC_ERR] |= _lib.FX_FLAG_A2A_OVERFLOW
-            sel = sel[:cap]
-        send_idx[o * cap:o * cap + len(sel)] = (keys[sel] - o * rps).int()
+            sel, local = sel[:cap], local[:cap]
+        send_idx[o * cap:o * cap + len(sel)] = local.int()
         uniq_slot[sel] = (o * cap + torch.arange(len(sel))).int()
     flat = lookup_slot.view(-1)
     uid = dd.sorted_uid.long()
@@ -459,7 +469,8 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "colsum", "mask_mul", "cross_bwd_prep", "sigmoid_bce", "shard_plan", "scatter_rows",
          "sum_parts", "din_concat_fwd", "din_concat_bwd", "din_pool_fwd", "din_pool_bwd",
          "dice_workspace_floats", "dice_fwd", "dice_bwd", "dot_interact_fwd", "dot_interact_bwd",
-         "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update"]
+         "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update",
+         "shard_plan_workspace_ints"]
 
 
 def install_plain():

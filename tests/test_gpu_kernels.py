@@ -681,3 +681,61 @@ def test_binary_metrics_one_class_raises_like_sklearn():
     with pytest.raises(ValueError):
         ops.binary_metrics(_dev(np.linspace(0.1, 0.9, 64).astype(np.float32)),
                            _dev(np.ones(64, dtype=np.float32)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,B,fast", [(2, 4096, True), (8, 4096, True), (3, 777, True), (8, 512, False)])
+def test_shard_plan_from_row_sorted_keys(N, B, fast):
+    """fx_dedup (column fast path or generic) + fx_shard_plan(global_keys): every valid lookup's slot
+    lies in its owner's bucket and carries the row's local index; padding lookups get the pad slot;
+    buckets are filled in ascending row order and padded with the owner's pad row."""
+    rng = np.random.default_rng(N * B)
+    vocab = [50, 3, 7000, 911, 12]
+    C = len(vocab)
+    ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)   # id 0 = padding
+    if not fast:
+        vocab = vocab[:3] + vocab[:2]            # repeated tables: columns not sorted -> generic path
+        ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+        base = np.array([0, 50, 53, 0, 50], dtype=np.int64)
+        total = 50 + 3 + 7000
+    else:
+        base = np.concatenate([[0], np.cumsum(vocab)[:-1]]).astype(np.int64)
+        total = int(sum(vocab))
+    pad = np.zeros(C, dtype=np.int32)
+    n = B * C
+    ws = torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    dd = ops.dedup(_dev(ids), _dev(base), _dev(np.array(vocab, np.int32)), _dev(pad), total, ws,
+                   want_uid=True, columns_sorted=fast)
+    cap = int(np.ceil(1.5 * n / N / 64) * 64 + 64)
+    send_idx = torch.empty(N * cap, dtype=torch.int32, device=DEV)
+    uniq_slot = torch.empty(n, dtype=torch.int32, device=DEV)
+    lookup_slot = torch.empty(B, C, dtype=torch.int32, device=DEV)
+    scal = ops.new_scalars(DEV)
+    pws = torch.empty(ops.shard_plan_workspace_ints(n, N), dtype=torch.int32, device=DEV)
+    ops.shard_plan(dd, N, total, cap, send_idx, uniq_slot, lookup_slot, scal, global_keys=True,
+                   workspace=pws)
+    torch.cuda.synchronize()
+    assert int(scal.view(torch.int32)[_lib.SC_ERR]) & _lib.FX_FLAG_A2A_OVERFLOW == 0
+    send, ls = send_idx.cpu().numpy(), lookup_slot.cpu().numpy()
+    rps = -(-total // N)
+    g = ids.astype(np.int64) + base[None, :]
+    valid = ids != 0
+    assert (ls[~valid] == N * cap).all()
+    owner = ls[valid] // cap
+    np.testing.assert_array_equal(owner, g[valid] % N)
+    np.testing.assert_array_equal(send[ls[valid]], g[valid] // N)
+    for o in range(N):
+        bucket = send[o * cap:(o + 1) * cap]
+        k = int((bucket != rps).sum())
+        assert (bucket[k:] == rps).all()
+        rows = bucket[:k].astype(np.int64) * N + o
+        assert (np.diff(rows) > 0).all()                       # ascending, unique
+        want = np.unique(g[valid][g[valid] % N == o])
+        got = rows if fast else rows      # the fast path also ships the tables' padding rows
+        assert set(want).issubset(set(got.tolist()))
+        assert len(got) <= len(want) + C
+    # too small a capacity is flagged, not silently wrong
+    scal2 = ops.new_scalars(DEV)
+    ops.shard_plan(dd, N, total, 8, torch.empty(N * 8, dtype=torch.int32, device=DEV), uniq_slot,
+                   lookup_slot, scal2, global_keys=True, workspace=pws)
+    assert int(scal2.view(torch.int32)[_lib.SC_ERR]) & _lib.FX_FLAG_A2A_OVERFLOW
