@@ -450,8 +450,9 @@ class _TableGroup(object):
         recv = self.dist.all_to_all(sends[0] if len(sends) == 1 else torch.cat(sends, dim=1))
         off = 0
         for p in peers:
-            rows = torch.zeros(N * cap + 1, p.D, dtype=torch.float32, device=self.device)
+            rows = torch.empty(N * cap + 1, p.D, dtype=torch.float32, device=self.device)
             rows[:N * cap] = recv[:, off:off + p.D]
+            rows[N * cap].zero_()                     # the pad slot reads as a zero row
             off += p.D
             sx.rows[id(p)] = rows
         return sx.rows.pop(id(self))
