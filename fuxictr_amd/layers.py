@@ -1062,35 +1062,35 @@ class InnerProductInteraction(nn.Module):
 
     def __init__(self, num_fields, output="product_sum"):
         super(InnerProductInteraction, self).__init__()
-        self._output_type = output
-        if output not in ["product_sum", "bi_interaction", "inner_product", "elementwise_product"]:
+        kinds = ("product_sum", "bi_interaction", "inner_product", "elementwise_product")
+        if output not in kinds:
             raise ValueError("InnerProductInteraction output={} is not supported.".format(output))
+        self._output_type = output
         dev = _alloc_device()
+        # buffers the reference registers as frozen Parameters (same names -> same state_dict keys)
         if output == "inner_product":
-            self.interaction_units = int(num_fields * (num_fields - 1) / 2)
-            self.triu_mask = nn.Parameter(
-                torch.triu(torch.ones(num_fields, num_fields, device=dev), 1).bool(),
-                requires_grad=False)
+            self.interaction_units = num_fields * (num_fields - 1) // 2
+            upper = torch.ones(num_fields, num_fields, device=dev).triu(1).bool()
+            self.triu_mask = nn.Parameter(upper, requires_grad=False)
         elif output == "elementwise_product":
-            self.triu_index = nn.Parameter(
-                torch.triu_indices(num_fields, num_fields, offset=1).to(dev), requires_grad=False)
+            pairs = torch.triu_indices(num_fields, num_fields, offset=1).to(dev)
+            self.triu_index = nn.Parameter(pairs, requires_grad=False)
 
     def forward(self, feature_emb):
-        if self._output_type == "product_sum":
+        kind = self._output_type
+        if kind == "product_sum":
             return _FMFn.apply(feature_emb, None)
-        if self._output_type == "bi_interaction":
-            sum_of_square = torch.sum(feature_emb, dim=1) ** 2
-            square_of_sum = torch.sum(feature_emb ** 2, dim=1)
-            return (sum_of_square - square_of_sum) * 0.5
-        if self._output_type == "inner_product":
-            F_, D_ = feature_emb.shape[1], feature_emb.shape[2]
-            if F_ * D_ <= 4096 and F_ * (F_ - 1) // 2 <= 4096:
+        if kind == "inner_product":
+            n_f, dim = feature_emb.shape[1], feature_emb.shape[2]
+            if n_f * dim <= 4096 and n_f * (n_f - 1) // 2 <= 4096:
                 return _DotInteractFn.apply(feature_emb)
-            ipm = torch.bmm(feature_emb, feature_emb.transpose(1, 2))
-            return torch.masked_select(ipm, self.triu_mask).view(-1, self.interaction_units)
-        emb1 = torch.index_select(feature_emb, 1, self.triu_index[0])
-        emb2 = torch.index_select(feature_emb, 1, self.triu_index[1])
-        return emb1 * emb2
+            gram = torch.bmm(feature_emb, feature_emb.transpose(1, 2))      # beyond the LDS tile
+            return gram.masked_select(self.triu_mask).view(-1, self.interaction_units)
+        if kind == "bi_interaction":      # 0.5 * ((sum_f e)^2 - sum_f e^2), kept per dimension
+            s1 = feature_emb.sum(dim=1)
+            return 0.5 * (s1 * s1 - (feature_emb * feature_emb).sum(dim=1))
+        left, right = (feature_emb.index_select(1, idx) for idx in self.triu_index)
+        return left * right
 
 
 class FactorizationMachine(nn.Module):
@@ -1294,29 +1294,29 @@ class MLP_Block(nn.Module):
                  use_bias=True):
         super(MLP_Block, self).__init__()
         dev = _alloc_device()
-        dense_layers = []
-        if not isinstance(dropout_rates, list):
-            dropout_rates = [dropout_rates] * len(hidden_units)
-        if not isinstance(hidden_activations, list):
-            hidden_activations = [hidden_activations] * len(hidden_units)
-        hidden_activations = get_activation(hidden_activations, hidden_units)
-        hidden_units = [input_dim] + hidden_units
-        if batch_norm and bn_only_once:
-            dense_layers.append(nn.BatchNorm1d(input_dim, device=dev))
-        for idx in range(len(hidden_units) - 1):
-            dense_layers.append(FxLinear(hidden_units[idx], hidden_units[idx + 1], bias=use_bias,
-                                         device=dev))
-            if batch_norm and not bn_only_once:
-                dense_layers.append(nn.BatchNorm1d(hidden_units[idx + 1], device=dev))
-            if hidden_activations[idx]:
-                dense_layers.append(hidden_activations[idx])
-            if dropout_rates[idx] > 0:
-                dense_layers.append(nn.Dropout(p=dropout_rates[idx]))
+        widths = [input_dim] + list(hidden_units)
+        n_hidden = len(hidden_units)
+        drop = list(dropout_rates) if isinstance(dropout_rates, list) else [dropout_rates] * n_hidden
+        names = hidden_activations if isinstance(hidden_activations, list) \
+            else [hidden_activations] * n_hidden
+        acts = get_activation(names, hidden_units)
+        bn_each = batch_norm and not bn_only_once
+        # module ORDER defines the state_dict keys (`mlp.<i>.weight`): [BN once] then per hidden layer
+        # Linear, [BN], [activation], [Dropout]; then the optional output Linear / activation
+        stack = [nn.BatchNorm1d(input_dim, device=dev)] if (batch_norm and bn_only_once) else []
+        for k, (fan_in, fan_out) in enumerate(zip(widths[:-1], widths[1:])):
+            stack.append(FxLinear(fan_in, fan_out, bias=use_bias, device=dev))
+            if bn_each:
+                stack.append(nn.BatchNorm1d(fan_out, device=dev))
+            if acts[k]:
+                stack.append(acts[k])
+            if drop[k] > 0:
+                stack.append(nn.Dropout(p=drop[k]))
         if output_dim is not None:
-            dense_layers.append(FxLinear(hidden_units[-1], output_dim, bias=use_bias, device=dev))
+            stack.append(FxLinear(widths[-1], output_dim, bias=use_bias, device=dev))
         if output_activation is not None:
-            dense_layers.append(get_activation(output_activation))
-        self.mlp = nn.Sequential(*dense_layers)
+            stack.append(get_activation(output_activation))
+        self.mlp = nn.Sequential(*stack)
         self._fused = self._fusable()
 
     def _fusable(self):

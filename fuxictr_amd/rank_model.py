@@ -286,27 +286,24 @@ class BaseModel(nn.Module):
         elif shard not in (None, False, "none"):
             raise ValueError("shard={} is not supported.".format(shard))
         layers.set_dist_context(self._dist)      # tables built below are row-sharded over ranks
+        # training-control settings, kept under the attribute names model code may read
         self._monitor = Monitor(kv=monitor)
-        self._monitor_mode = monitor_mode
-        self._early_stop_patience = early_stop_patience
-        self._eval_steps = eval_steps
-        self._save_best_only = save_best_only
-        self._embedding_regularizer = embedding_regularizer
-        self._net_regularizer = net_regularizer
-        self._reduce_lr_on_plateau = reduce_lr_on_plateau
-        self._verbose = kwargs["verbose"]
-        self._sparse_update = kwargs.get("sparse_update", "exact")
-        self._use_graph = bool(kwargs.get("hip_graph", False))
-        self._device_metrics = bool(kwargs.get("device_metrics", True))
-        self._graph_state = None
-        self._graph_warm = 0
-        self._max_gradient_norm = 10.
-        self.feature_map = feature_map
-        self.output_activation = self.get_output_activation(task)
-        self.model_id = model_id
-        self.model_dir = os.path.join(kwargs["model_root"], feature_map.dataset_id)
-        self.checkpoint = os.path.abspath(os.path.join(self.model_dir, self.model_id + ".model"))
+        for attr, value in (("_monitor_mode", monitor_mode), ("_save_best_only", save_best_only),
+                            ("_early_stop_patience", early_stop_patience),
+                            ("_eval_steps", eval_steps), ("_net_regularizer", net_regularizer),
+                            ("_embedding_regularizer", embedding_regularizer),
+                            ("_reduce_lr_on_plateau", reduce_lr_on_plateau),
+                            ("_verbose", kwargs["verbose"]), ("_max_gradient_norm", 10.),
+                            ("_sparse_update", kwargs.get("sparse_update", "exact")),
+                            ("_use_graph", bool(kwargs.get("hip_graph", False))),
+                            ("_device_metrics", bool(kwargs.get("device_metrics", True))),
+                            ("_graph_state", None), ("_graph_warm", 0)):
+            setattr(self, attr, value)
+        self.feature_map, self.model_id = feature_map, model_id
         self.validation_metrics = kwargs["metrics"]
+        self.output_activation = self.get_output_activation(task)
+        self.model_dir = os.path.join(kwargs["model_root"], feature_map.dataset_id)
+        self.checkpoint = os.path.abspath(os.path.join(self.model_dir, model_id + ".model"))
 
     def compile(self, optimizer, loss, lr):
         self.optimizer = get_optimizer(optimizer, self.parameters(), lr, model=self,
@@ -319,21 +316,22 @@ class BaseModel(nn.Module):
         """rank_model.py:95-118.  The embedding part is computed by fx_reg_stats and carries no
         autograd graph: its gradient (every table row, every step) is applied inside the native
         update kernels; the net part is plain torch on the dense parameters."""
-        reg_term = 0
+        total = 0
         if self._embedding_regularizer and hasattr(self.optimizer, "emb_reg_loss"):
-            reg_term = reg_term + self.optimizer.emb_reg_loss()
-        if self._net_regularizer:
-            net_reg = get_regularizer(self._net_regularizer)
-            emb_params = set()
-            for m_name, module in self.named_modules():
-                if type(module) == FeatureEmbeddingDict:
-                    for p_name, _ in module.named_parameters():
-                        emb_params.add(".".join([m_name, p_name]))
-            for name, param in self.named_parameters():
-                if param.requires_grad and name not in emb_params:
-                    for net_p, net_lambda in net_reg:
-                        reg_term += (net_lambda / net_p) * torch.norm(param, net_p) ** net_p
-        return reg_term
+            total = total + self.optimizer.emb_reg_loss()
+        if not self._net_regularizer:
+            return total
+        # everything that is not a parameter of a FeatureEmbeddingDict module is a "net" parameter
+        table_side = {prefix + "." + pname
+                      for prefix, mod in self.named_modules() if type(mod) == FeatureEmbeddingDict
+                      for pname, _ in mod.named_parameters()}
+        pairs = get_regularizer(self._net_regularizer)
+        for pname, weight in self.named_parameters():
+            if pname in table_side or not weight.requires_grad:
+                continue
+            for order, lam in pairs:
+                total = total + (lam / order) * torch.norm(weight, order) ** order
+        return total
 
     def add_loss(self, return_dict, y_true):
         return self.loss_fn(return_dict["y_pred"], y_true, reduction='mean')
@@ -435,64 +433,63 @@ class BaseModel(nn.Module):
         self.to(device=self.device)
 
     def lr_decay(self, factor=0.1, min_lr=1e-6):
-        for param_group in self.optimizer.param_groups:
-            reduced_lr = max(param_group["lr"] * factor, min_lr)
-            param_group["lr"] = reduced_lr
-        return reduced_lr
+        """rank_model.py:221-234 (the native optimizer picks the new value up in sync_lr)."""
+        new_lr = None
+        for group in self.optimizer.param_groups:
+            new_lr = group["lr"] = max(min_lr, factor * group["lr"])
+        return new_lr
 
     def fit(self, data_generator, epochs=1, validation_data=None,
             max_gradient_norm=10., **kwargs):
+        """rank_model.py:236-270: train for `epochs`, evaluate every `eval_steps` steps, keep the
+        best checkpoint, stop early on a plateau, reload the best weights at the end."""
         self.valid_gen = validation_data
         self._max_gradient_norm = max_gradient_norm
-        self._best_metric = np.inf if self._monitor_mode == "min" else -np.inf
-        self._stopping_steps = 0
-        self._stop_training = False
         self._steps_per_epoch = len(data_generator)
-        self._total_steps = 0
-        self._batch_index = 0
-        self._epoch_index = 0
         if self._eval_steps is None:
             self._eval_steps = self._steps_per_epoch
-        logging.info("Start training: {} batches/epoch".format(self._steps_per_epoch))
-        logging.info("************ Epoch=1 start ************")
-        for epoch in range(epochs):
-            self._epoch_index = epoch
+        maximise = self._monitor_mode != "min"
+        self._best_metric = -np.inf if maximise else np.inf
+        self._stopping_steps = self._total_steps = 0
+        self._batch_index = self._epoch_index = 0
+        self._stop_training = False
+        logging.info("fit: %d epochs x %d batches, evaluation every %d steps", epochs,
+                     self._steps_per_epoch, self._eval_steps)
+        for self._epoch_index in range(epochs):
+            logging.info("epoch %d begins", self._epoch_index + 1)
             self.train_epoch(data_generator)
             if self._stop_training:
                 break
-            else:
-                logging.info("************ Epoch={} end ************".format(self._epoch_index + 1))
-        logging.info("Training finished.")
-        logging.info("Load best model: {}".format(self.checkpoint))
+        logging.info("fit done; restoring the best weights from %s", self.checkpoint)
         self.load_weights(self.checkpoint)
 
     def checkpoint_and_earlystop(self, logs, min_delta=1e-6):
-        monitor_value = self._monitor.get_value(logs)
-        if (self._monitor_mode == "min" and monitor_value > self._best_metric - min_delta) or \
-           (self._monitor_mode == "max" and monitor_value < self._best_metric + min_delta):
-            self._stopping_steps += 1
-            logging.info("Monitor({})={:.6f} STOP!".format(self._monitor_mode, monitor_value))
-            if self._reduce_lr_on_plateau:
-                current_lr = self.lr_decay()
-                logging.info("Reduce learning rate on plateau: {:.6f}".format(current_lr))
+        """rank_model.py:272-298: an evaluation counts as an improvement when the monitored value
+        beats the best one by at least `min_delta`; otherwise patience is consumed (and the
+        learning rate reduced); the checkpoint follows `save_best_only`."""
+        value = self._monitor.get_value(logs)
+        sign = -1.0 if self._monitor_mode == "min" else 1.0
+        improved = sign * (value - self._best_metric) >= min_delta
+        if improved:
+            self._best_metric, self._stopping_steps = value, 0
         else:
-            self._stopping_steps = 0
-            self._best_metric = monitor_value
-            if self._save_best_only:
-                logging.info("Save best model: monitor({})={:.6f}"
-                             .format(self._monitor_mode, monitor_value))
-                self.save_weights(self.checkpoint)
+            self._stopping_steps += 1
+            logging.info("no improvement: monitor(%s) = %.6f (best %.6f)", self._monitor_mode, value,
+                         self._best_metric)
+            if self._reduce_lr_on_plateau:
+                logging.info("learning rate reduced to %.6g", self.lr_decay())
+        if improved or not self._save_best_only:
+            if improved:
+                logging.info("new best monitor(%s) = %.6f, saving", self._monitor_mode, value)
+            self.save_weights(self.checkpoint)
         if self._stopping_steps >= self._early_stop_patience:
             self._stop_training = True
-            logging.info("********* Epoch={} early stop *********".format(self._epoch_index + 1))
-        if not self._save_best_only:
-            self.save_weights(self.checkpoint)
+            logging.info("early stop in epoch %d", self._epoch_index + 1)
 
     def eval_step(self):
-        logging.info('Evaluation @epoch {} - batch {}: '.format(self._epoch_index + 1,
-                                                                 self._batch_index + 1))
-        val_logs = self.evaluate(self.valid_gen, metrics=self._monitor.get_metrics())
-        self.checkpoint_and_earlystop(val_logs)
+        logging.info("evaluation at epoch %d, batch %d", self._epoch_index + 1, self._batch_index + 1)
+        self.checkpoint_and_earlystop(self.evaluate(self.valid_gen,
+                                                    metrics=self._monitor.get_metrics()))
         self.train()
 
     def train(self, mode=True):
@@ -589,81 +586,71 @@ class BaseModel(nn.Module):
         st.graph.replay()
         return st.loss
 
-    def train_epoch(self, data_generator):
-        self._batch_index = 0
-        train_loss = 0
-        self.train()
-        if self._verbose == 0:
-            batch_iterator = data_generator
-        else:
+    def _progress(self, iterable):
+        if self._verbose > 0:
             from tqdm import tqdm
-            batch_iterator = tqdm(data_generator, disable=False, file=sys.stdout)
-        for batch_index, batch_data in enumerate(batch_iterator):
-            self._batch_index = batch_index
+            return tqdm(iterable, disable=False, file=sys.stdout)
+        return iterable
+
+    def train_epoch(self, data_generator):
+        """rank_model.py:325-348."""
+        self.train()
+        window_loss, self._batch_index = 0.0, 0
+        for self._batch_index, batch in enumerate(self._progress(data_generator)):
+            window_loss += self.train_step(batch).item()
             self._total_steps += 1
-            loss = self.train_step(batch_data)
-            train_loss += loss.item()
             if self._total_steps % self._eval_steps == 0:
-                logging.info("Train loss: {:.6f}".format(train_loss / self._eval_steps))
-                train_loss = 0
+                logging.info("mean train loss over the last %d steps: %.6f", self._eval_steps,
+                             window_loss / self._eval_steps)
+                window_loss = 0.0
                 self.eval_step()
             if self._stop_training:
                 break
         self.optimizer.check_errors()
 
-    def evaluate(self, data_generator, metrics=None):
+    def _predict_batches(self, data_generator, with_labels):
+        """eval-mode forward over a generator -> (list of device predictions, list of labels)."""
         self.eval()
+        preds, labels = [], []
         with torch.no_grad():
-            y_pred, y_true, group_id = [], [], []
-            if self._verbose > 0:
-                from tqdm import tqdm
-                data_generator = tqdm(data_generator, disable=False, file=sys.stdout)
-            want = list(metrics if metrics is not None else self.validation_metrics)
-            on_device = (self._device_metrics and self.device.type == "cuda"
-                         and self.feature_map.group_id is None and len(want) > 0
-                         and all(m in ("logloss", "binary_crossentropy", "AUC") for m in want))
-            if on_device:
-                # predictions and labels stay in HBM; one sort + rank-sum pass at the end
-                # (fx_binary_metrics) instead of a D->H copy and list.extend per batch + sklearn
-                preds, trues = [], []
-                for batch_data in data_generator:
-                    return_dict = self.forward(batch_data)
-                    preds.append(return_dict["y_pred"].detach().reshape(-1).float())
+            for batch in self._progress(data_generator):
+                preds.append(self.forward(batch)["y_pred"].detach().reshape(-1).float())
+                if with_labels:
                     # clone: a device loader may hand out views of a buffer it reuses
-                    trues.append(self.get_labels(batch_data).reshape(-1).clone())
-                ll, auc = ops.binary_metrics(torch.cat(preds), torch.cat(trues))
-                val_logs = OrderedDict((m, auc if m == "AUC" else ll) for m in want)
-                logging.info('[Metrics] ' + ' - '.join('{}: {:.6f}'.format(k, v)
-                                                       for k, v in val_logs.items()))
-                return val_logs
-            for batch_data in data_generator:
-                return_dict = self.forward(batch_data)
-                y_pred.extend(return_dict["y_pred"].data.cpu().numpy().reshape(-1))
-                y_true.extend(self.get_labels(batch_data).data.cpu().numpy().reshape(-1))
-                if self.feature_map.group_id is not None:
-                    group_id.extend(self.get_group_id(batch_data).numpy().reshape(-1))
-            y_pred = np.array(y_pred, np.float64)
-            y_true = np.array(y_true, np.float64)
-            group_id = np.array(group_id) if len(group_id) > 0 else None
-            if metrics is not None:
-                val_logs = self.evaluate_metrics(y_true, y_pred, metrics, group_id)
-            else:
-                val_logs = self.evaluate_metrics(y_true, y_pred, self.validation_metrics, group_id)
-            logging.info('[Metrics] ' + ' - '.join('{}: {:.6f}'.format(k, v)
-                                                   for k, v in val_logs.items()))
-            return val_logs
+                    labels.append(self.get_labels(batch).reshape(-1).clone())
+        return preds, labels
+
+    def evaluate(self, data_generator, metrics=None):
+        """rank_model.py:350-381.  logloss / AUC are computed on the device (fx_binary_metrics: one
+        sort + exact rank sums over all predictions) unless group metrics are involved, in which
+        case the reference's host path (float64 + scikit-learn) is used."""
+        wanted = list(self.validation_metrics if metrics is None else metrics)
+        groups = self.feature_map.group_id is not None
+        on_device = (self._device_metrics and self.device.type == "cuda" and not groups and wanted
+                     and set(wanted) <= {"logloss", "binary_crossentropy", "AUC"})
+        if on_device:
+            preds, labels = self._predict_batches(data_generator, True)
+            ll, auc = ops.binary_metrics(torch.cat(preds), torch.cat(labels))
+            val_logs = OrderedDict((m, auc if m == "AUC" else ll) for m in wanted)
+        else:
+            self.eval()
+            p_host, y_host, g_host = [], [], []
+            with torch.no_grad():
+                for batch in self._progress(data_generator):
+                    p_host.append(self.forward(batch)["y_pred"].detach().reshape(-1).cpu().numpy())
+                    y_host.append(self.get_labels(batch).reshape(-1).cpu().numpy())
+                    if groups:
+                        g_host.append(np.asarray(self.get_group_id(batch)).reshape(-1))
+            val_logs = self.evaluate_metrics(np.concatenate(y_host).astype(np.float64),
+                                             np.concatenate(p_host).astype(np.float64), wanted,
+                                             np.concatenate(g_host) if g_host else None)
+        logging.info("metrics: %s", ", ".join("%s=%.6f" % kv for kv in val_logs.items()))
+        return val_logs
 
     def predict(self, data_generator):
-        self.eval()
-        with torch.no_grad():
-            y_pred = []
-            if self._verbose > 0:
-                from tqdm import tqdm
-                data_generator = tqdm(data_generator, disable=False, file=sys.stdout)
-            for batch_data in data_generator:
-                return_dict = self.forward(batch_data)
-                y_pred.extend(return_dict["y_pred"].data.cpu().numpy().reshape(-1))
-            return np.array(y_pred, np.float64)
+        """rank_model.py:383-398 -> float64 numpy vector of probabilities."""
+        preds, _ = self._predict_batches(data_generator, False)
+        return torch.cat(preds).cpu().numpy().astype(np.float64)
 
     def evaluate_metrics(self, y_true, y_pred, metrics, group_id=None):
         return evaluate_metrics(y_true, y_pred, metrics, group_id)
@@ -711,11 +698,8 @@ class BaseModel(nn.Module):
             raise NotImplementedError("task={} is not supported.".format(task))
 
     def count_parameters(self, count_embedding=True):
-        total_params = 0
-        for name, param in self.named_parameters():
-            if not count_embedding and "embedding" in name:
-                continue
-            if param.requires_grad:
-                total_params += param.numel()
-        logging.info("Total number of parameters: {}.".format(total_params))
-        return total_params
+        """rank_model.py:454-470."""
+        n = sum(w.numel() for pname, w in self.named_parameters()
+                if w.requires_grad and (count_embedding or "embedding" not in pname))
+        logging.info("trainable parameters: %d", n)
+        return n
