@@ -341,17 +341,16 @@ class BaseModel(nn.Module):
 
     def reset_parameters(self):
         """rank_model.py:146-167: xavier_normal_ on Linear/Conv1d, then every init_weights()."""
-        def default_reset_params(m):
-            if type(m) in [nn.Linear, nn.Conv1d, FxLinear, _NumericView]:
-                nn.init.xavier_normal_(m.weight)
-                if m.bias is not None:
-                    m.bias.data.fill_(0)
-
-        def custom_reset_params(m):
-            if hasattr(m, 'init_weights'):
-                m.init_weights()
-        self.apply(default_reset_params)
-        self.apply(custom_reset_params)
+        dense_kinds = (nn.Linear, nn.Conv1d, FxLinear, _NumericView)
+        for mod in self.modules():                 # pass 1: Xavier on every dense weight
+            if type(mod) in dense_kinds:
+                nn.init.xavier_normal_(mod.weight)
+                if mod.bias is not None:
+                    mod.bias.data.zero_()
+        for mod in self.modules():                 # pass 2: layers with their own initializer
+            init = getattr(mod, "init_weights", None)
+            if callable(init):
+                init()
 
     def get_inputs(self, inputs, feature_source=None):
         """rank_model.py:169-189; returns a FeatureDict so the embedding layers of this model can
@@ -361,17 +360,11 @@ class BaseModel(nn.Module):
         one asynchronous copy."""
         if isinstance(inputs, FeatureDict) and getattr(inputs, "_fx_ready", False):
             return inputs
+        specs = self.feature_map.features
+        names = [name for name in inputs.keys()
+                 if name not in self.feature_map.labels and specs[name]["type"] != "meta"
+                 and not (feature_source and not_in_whitelist(specs[name]["source"], feature_source))]
         X_dict = FeatureDict()
-        names = []
-        for feature in inputs.keys():
-            if feature in self.feature_map.labels:
-                continue
-            spec = self.feature_map.features[feature]
-            if spec["type"] == "meta":
-                continue
-            if feature_source and not_in_whitelist(spec["source"], feature_source):
-                continue
-            names.append(feature)
         staged = self._stage_host_columns(inputs, names)
         for feature in names:
             X_dict[feature] = staged[feature] if feature in staged \
