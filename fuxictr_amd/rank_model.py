@@ -400,7 +400,9 @@ class BaseModel(nn.Module):
             if slot[1] is not None:
                 slot[1].synchronize()            # the copy that last read this buffer is done
             host = slot[0][:n]
-            torch.cat([inputs[f].reshape(-1) for f in feats], out=host)
+            # concatenate in ordinary memory, then ONE sequential copy into the pinned block
+            # (scattered writes straight into pinned host memory were measured ~7x slower)
+            host.copy_(torch.cat([inputs[f].reshape(-1) for f in feats]))
             dev = host.to(self.device, non_blocking=True)
             slot[1] = torch.cuda.Event()
             slot[1].record(stream)
