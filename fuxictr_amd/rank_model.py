@@ -395,15 +395,17 @@ class BaseModel(nn.Module):
             key = (dtype, self._pin_turn)
             slot = self._pinned.get(key)
             if slot is None or slot[0].numel() < n:
-                slot = [torch.empty(n, dtype=dtype, pin_memory=True), None]
+                pinned = torch.empty(n, dtype=dtype, pin_memory=True)
+                slot = [pinned, None, pinned.numpy()]
                 self._pinned[key] = slot
             if slot[1] is not None:
                 slot[1].synchronize()            # the copy that last read this buffer is done
-            host = slot[0][:n]
-            # concatenate in ordinary memory, then ONE sequential copy into the pinned block
-            # (scattered writes straight into pinned host memory were measured ~7x slower)
-            host.copy_(torch.cat([inputs[f].reshape(-1) for f in feats]))
-            dev = host.to(self.device, non_blocking=True)
+            # gather with numpy straight into the pinned block: measured 0.03 ms for 26 x 4096
+            # int64, where torch.cat(out=pinned) / pinned.copy_() take ~3 ms and a pageable
+            # .to(device) of the concatenation 1.3 ms (scripts/ubench/stage_probe2.py)
+            np.concatenate([inputs[f].detach().numpy().reshape(-1) for f in feats],
+                           out=slot[2][:n])
+            dev = slot[0][:n].to(self.device, non_blocking=True)
             slot[1] = torch.cuda.Event()
             slot[1].record(stream)
             off = 0
