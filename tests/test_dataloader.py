@@ -84,3 +84,52 @@ def test_loader_feeds_the_model_like_host_batches(tmp_path):
     ra = a.evaluate(DeviceNpzDataLoader(fmap, path, batch_size=200, device="cuda:0"))
     rb = b.evaluate([{k: torch.from_numpy(np.asarray(v)) for k, v in full.items()}])
     assert abs(ra["logloss"] - rb["logloss"]) < 1e-9 and abs(ra["AUC"] - rb["AUC"]) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hip_graph", [False, True])
+def test_end_to_end_fit_with_device_loader(tmp_path, hip_graph):
+    """The run_expid flow on the native path: device loaders -> fit (eval every 3 steps, early-stop
+    bookkeeping, best checkpoint) -> evaluate -> predict -> reload; with and without hipGraph replay
+    (ragged last batch included) the losses going down and the two modes agreeing."""
+    from fuxictr_amd import zoo
+    from fuxictr_amd.dataloader import DeviceNpzDataLoader
+    g = Golden("deepfm_adam")
+    m = g.meta
+    rng = np.random.default_rng(11)
+    from make_golden import make_batches
+    w = rng.normal(size=len(g.features))
+
+    def labelled(n):
+        b = make_batches(rng, g.spec, n, 1)[0]
+        z = sum(w[i] * (np.asarray(b[name], dtype=np.float64) % 7 - 3) / 3.0
+                for i, name in enumerate(g.features))
+        b["label"] = (rng.random(n) < 1 / (1 + np.exp(-z))).astype(np.float32)
+        return b
+    train, valid = labelled(1000), labelled(500)
+    np.savez(str(tmp_path / "train.npz"), **train)
+    np.savez(str(tmp_path / "valid.npz"), **valid)
+    fmap = _fmap(g, tmp_path)
+    torch.manual_seed(3)
+    model = zoo.DeepFM(fmap, model_id="e2e%d" % hip_graph, gpu=0, embedding_dim=m["embedding_dim"],
+                       hidden_units=m["hidden"], learning_rate=1e-2, optimizer="adam",
+                       loss="binary_crossentropy", task="binary_classification",
+                       metrics=["logloss", "AUC"], verbose=0, model_root=str(tmp_path),
+                       eval_steps=3, hip_graph=hip_graph)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state0.items()})
+    tr = DeviceNpzDataLoader(fmap, str(tmp_path / "train.npz"), batch_size=128, shuffle=True,
+                             device="cuda:0", seed=5)
+    va = DeviceNpzDataLoader(fmap, str(tmp_path / "valid.npz"), batch_size=256, device="cuda:0")
+    before = model.evaluate(va)
+    model.fit(tr, epochs=3, validation_data=va)
+    after = model.evaluate(va)
+    assert after["logloss"] < before["logloss"] and after["AUC"] > 0.6
+    pred = model.predict(va)
+    assert pred.shape == (500,) and pred.dtype == np.float64 and (pred > 0).all() and (pred < 1).all()
+    other = zoo.DeepFM(fmap, model_id="e2e_reload", gpu=0, embedding_dim=m["embedding_dim"],
+                       hidden_units=m["hidden"], learning_rate=1e-2, optimizer="adam",
+                       loss="binary_crossentropy", task="binary_classification",
+                       metrics=["logloss", "AUC"], verbose=0, model_root=str(tmp_path))
+    other.load_weights(model.checkpoint)
+    np.testing.assert_array_equal(other.predict(va), pred)
+    tmp_path.joinpath("auc_%d.txt" % hip_graph).write_text(repr(after["AUC"]))
