@@ -578,7 +578,9 @@ class BaseModel(nn.Module):
             st = self._graph_state = _GraphStep(self, batch_data)
             return st.probe_loss              # the probe inside _GraphStep WAS this batch's step
         if B != st.B:
-            return self._step_body(batch_data)   # e.g. the last, shorter batch of an epoch
+            # e.g. the last, shorter batch of an epoch: eager, on the stream the parameters'
+            # AccumulateGrad nodes were created on
+            return self._side_stream_step(batch_data)
         st.fill(batch_data)
         st.graph.replay()
         return st.loss
