@@ -73,15 +73,25 @@ def fm_product_sum(feature_emb):
     return ((sum_of_square - square_of_sum) * 0.5).sum(dim=-1, keepdim=True)
 
 
-def mlp_block(state, prefix, x, n_hidden, has_output):
-    """MLP_Block.forward, mlp_block.py:53-96 for Linear+ReLU stacks (no BN / dropout): the
-    nn.Sequential indices are 0,2,4,... for the hidden Linears and 2*n_hidden for the output."""
+def mlp_block(state, prefix, x, n_hidden, has_output, batch_norm=False, training=False):
+    """MLP_Block.forward, mlp_block.py:53-96 for Linear[+BatchNorm1d]+ReLU stacks (no dropout): in
+    the nn.Sequential a hidden layer occupies 2 slots (Linear, ReLU) or 3 (Linear, BN, ReLU); the
+    output Linear follows.  BatchNorm1d defaults: eps 1e-5, momentum 0.1, batch statistics in
+    training (running statistics and num_batches_tracked updated in place), running ones in eval."""
     h = x
+    per = 3 if batch_norm else 2
     for i in range(n_hidden):
-        h = F.relu(F.linear(h, state[prefix + "mlp.%d.weight" % (2 * i)],
-                            state[prefix + "mlp.%d.bias" % (2 * i)]))
+        h = F.linear(h, state[prefix + "mlp.%d.weight" % (per * i)],
+                     state[prefix + "mlp.%d.bias" % (per * i)])
+        if batch_norm:
+            bn = prefix + "mlp.%d." % (per * i + 1)
+            h = F.batch_norm(h, state[bn + "running_mean"], state[bn + "running_var"],
+                             state[bn + "weight"], state[bn + "bias"], training, 0.1, 1e-5)
+            if training:
+                state[bn + "num_batches_tracked"] += 1
+        h = F.relu(h)
     if has_output:
-        k = 2 * n_hidden
+        k = per * n_hidden
         h = F.linear(h, state[prefix + "mlp.%d.weight" % k], state[prefix + "mlp.%d.bias" % k])
     return h
 
@@ -98,11 +108,12 @@ def crossnet_v2(state, prefix, x0, n_layers):
 # ---------------------------------------------------------------------------------------------
 # models (logit before the output activation)
 # ---------------------------------------------------------------------------------------------
-def deepfm_logit(state, features, X, n_hidden):
+def deepfm_logit(state, features, X, n_hidden, batch_norm=False, training=False):
     """DeepFM.forward, model_zoo/DeepFM/DeepFM_torch/src/DeepFM.py:73-88."""
     emb = dict2tensor(features, feature_embedding(state, EMB, features, X))
     y = fm_product_sum(emb) + logistic_regression(state, features, X)   # factorization_machine.py:46-59
-    return y + mlp_block(state, "mlp.", emb.flatten(start_dim=1), n_hidden, True)
+    return y + mlp_block(state, "mlp.", emb.flatten(start_dim=1), n_hidden, True, batch_norm,
+                         training)
 
 
 def dcnv2_logit(state, features, X, n_cross, n_hidden):
@@ -215,7 +226,8 @@ def model_logit(cfg, state, features, X, training=False):
     if cfg["model"] == "DIN":
         return din_logit(state, features, X, cfg, training)
     if cfg["model"] == "DeepFM":
-        return deepfm_logit(state, features, X, cfg["n_hidden"])
+        return deepfm_logit(state, features, X, cfg["n_hidden"], cfg.get("batch_norm", False),
+                            training)
     if cfg["model"] == "DCNv2":
         return dcnv2_logit(state, features, X, cfg["n_cross"], cfg["n_hidden"])
     raise NotImplementedError(cfg["model"])

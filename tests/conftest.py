@@ -46,6 +46,7 @@ class Golden(object):
         m = self.meta
         return {"model": m["model"], "n_hidden": len(m["hidden"]), "n_cross": m.get("n_cross", 0),
                 "n_bottom": len(m.get("bottom", [])), "n_cin": len(m.get("cin", [])),
+                "batch_norm": m.get("batch_norm", False),
                 "din_target_field": ["adgroup_id"], "din_sequence_field": ["click_sequence"]}
 
 
@@ -63,7 +64,7 @@ def assert_weights_close(got, ref, lr, steps, name, tol=2e-5):
 
 GOLDEN_CASES = ["deepfm_adam", "deepfm_adam_clip", "deepfm_sgd", "deepfm_d10", "dcnv2_adam",
                 "din_adam", "dlrm_adam", "xdeepfm_adam", "deepfm_reg",
-                "deepfm_reg_sgd"]
+                "deepfm_reg_sgd", "deepfm_bn"]
 
 
 @pytest.fixture(params=GOLDEN_CASES)

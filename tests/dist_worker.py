@@ -34,7 +34,8 @@ def run(rank, world, case, port, out_path, use_gpu):
                   model_root="/tmp/fx_dist_%d" % rank, shard="row",
                   hip_graph=os.environ.get("FX_HIP_GRAPH", "0") == "1")
     if m["model"] == "DeepFM":
-        model = zoo.DeepFM(fmap, model_id=case, hidden_units=m["hidden"], **common)
+        model = zoo.DeepFM(fmap, model_id=case, hidden_units=m["hidden"],
+                           batch_norm=m.get("batch_norm", False), **common)
     elif m["model"] == "xDeepFM":
         model = zoo.xDeepFM(fmap, model_id=case, dnn_hidden_units=m["hidden"],
                             cin_hidden_units=m["cin"], **common)

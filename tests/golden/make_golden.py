@@ -105,7 +105,8 @@ def run_case(case):
                   net_regularizer=case.get("net_reg", 0))
     if case["model"] == "DeepFM":
         from model_zoo.DeepFM.DeepFM_torch.src import DeepFM
-        model = DeepFM(fmap, model_id=name, hidden_units=case["hidden"], **common)
+        model = DeepFM(fmap, model_id=name, hidden_units=case["hidden"],
+                       batch_norm=case.get("batch_norm", False), **common)
     elif case["model"] == "xDeepFM":
         from model_zoo import xDeepFM
         model = xDeepFM(fmap, model_id=name, dnn_hidden_units=case["hidden"],
@@ -282,6 +283,13 @@ CASES = [
     dict(name="deepfm_reg_sgd", model="DeepFM", n_dense=3, cards=CARDS[:8], embedding_dim=8,
          hidden=[32, 16], B=128, steps=5, lr=5e-2, optimizer="SGD", max_norm=0.05, seed=29,
          emb_scale=1000.0, lr_scale=1000.0, emb_reg="l1_l2(1e-4,1e-2)", net_reg=0),
+    # BatchNorm case trains with SGD: the bias of a Linear that feeds BatchNorm has an exactly-zero
+    # gradient (BN subtracts the batch mean), autograd delivers fp32 summation residue (~1e-9), and
+    # Adam would normalise that residue into +-lr steps whose sign depends on the BLAS build — the
+    # reference's own value of those biases (and of running_mean, which absorbs them) is noise.
+    dict(name="deepfm_bn", model="DeepFM", n_dense=3, cards=CARDS[:8], embedding_dim=8,
+         hidden=[32, 16], B=128, steps=4, lr=5e-2, optimizer="SGD", max_norm=10.0, seed=31,
+         emb_scale=1000.0, lr_scale=1000.0, batch_norm=True),
     dict(name="xdeepfm_adam", model="xDeepFM", n_dense=3, cards=CARDS[:9], embedding_dim=8,
          hidden=[32, 16], cin=[12, 6, 5], B=128, steps=4, lr=1e-2, optimizer="adam", max_norm=10.0,
          seed=17, emb_scale=1000.0, lr_scale=1000.0),

@@ -41,7 +41,7 @@ def patched_reference(monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam", "din_adam", "dlrm_adam",
-                                  "xdeepfm_adam", "deepfm_reg"])
+                                  "xdeepfm_adam", "deepfm_reg", "deepfm_bn"])
 def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp_path):
     g = Golden(case)
     m = g.meta
@@ -56,7 +56,8 @@ def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp
                   net_regularizer=m.get("net_reg", 0))
     if m["model"] == "DeepFM":
         from model_zoo.DeepFM.DeepFM_torch.src import DeepFM as RefModel
-        model = RefModel(fmap, model_id=case, hidden_units=m["hidden"], **common)
+        model = RefModel(fmap, model_id=case, hidden_units=m["hidden"],
+                         batch_norm=m.get("batch_norm", False), **common)
     elif m["model"] == "DIN":
         from model_zoo import DIN as RefModel
         model = RefModel(fmap, model_id=case, dnn_hidden_units=m["hidden"], dnn_activations="relu",

@@ -32,7 +32,8 @@ def build_native(g, tmp_path, sparse_update="exact", optimizer=None, hip_graph=F
                   net_regularizer=m.get("net_reg", 0),
                   sparse_update=sparse_update, hip_graph=hip_graph)
     if m["model"] == "DeepFM":
-        model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"], **common)
+        model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"],
+                           batch_norm=m.get("batch_norm", False), **common)
     elif m["model"] == "xDeepFM":
         model = zoo.xDeepFM(fmap, model_id=m["name"], dnn_hidden_units=m["hidden"],
                             cin_hidden_units=m["cin"], **common)

@@ -26,7 +26,8 @@ def _build(g, tmp_path, monkeypatch, sparse_update="exact"):
                   model_root=str(tmp_path), sparse_update=sparse_update,
                   embedding_regularizer=m.get("emb_reg", 0), net_regularizer=m.get("net_reg", 0))
     if m["model"] == "DeepFM":
-        model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"], **common)
+        model = zoo.DeepFM(fmap, model_id=m["name"], hidden_units=m["hidden"],
+                           batch_norm=m.get("batch_norm", False), **common)
     elif m["model"] == "xDeepFM":
         model = zoo.xDeepFM(fmap, model_id=m["name"], dnn_hidden_units=m["hidden"],
                             cin_hidden_units=m["cin"], **common)
