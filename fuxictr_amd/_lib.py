@@ -48,6 +48,8 @@ SIGNATURES = {
                               i64, i64, vp]),
     "fx_emb_gather_fwd": (i32, [vp, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, vp, i32, vp, i64,
                                 i64, vp, vp]),
+    "fx_emb_seq_pool_fwd": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp, i64,
+                                  vp, vp]),
     "fx_dedup_workspace_bytes": (C.c_size_t, [i64]),
     "fx_dedup": (i32, [vp, i64, i64, i32, vp, vp, vp, i64, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
                        i32, i32, vp]),
@@ -58,6 +60,8 @@ SIGNATURES = {
     "fx_emb_grad_reduce_partials": (i64, [i64, i32]),
     "fx_emb_grad_reduce_scratch_ints": (i64, [i64]),
     "fx_emb_grad_reduce": (i32, [vp, i64, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
+    "fx_emb_grad_reduce_scaled": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, vp, vp,
+                                        vp, vp]),
     "fx_emb_numeric_grad": (i32, [vp, i64, vp, vp, i64, i32, i32, i64, vp, vp, vp]),
     "fx_opt_begin_step": (i32, [vp, vp]),
     "fx_clip_coef": (i32, [C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
@@ -168,3 +172,12 @@ def stream_ptr(device=None):
     captured by torch.cuda.graph)."""
     import torch
     return vp(torch.cuda.current_stream(device).cuda_stream)
+
+
+def row_lanes(D):
+    """Lanes that serve one D-float row (fx_row_geom in csrc/fx_common.h)."""
+    vec = 4 if D % 4 == 0 else (2 if D % 2 == 0 else 1)
+    need, lanes = D // vec, 1
+    while lanes < need:
+        lanes <<= 1
+    return lanes

@@ -191,6 +191,119 @@ extern "C" int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* i
 }
 
 // ---------------------------------------------------------------------------------------------
+// fx_emb_seq_pool_fwd: sequence features behind MaskedSumPooling / MaskedAveragePooling
+// (fuxictr/pytorch/layers/pooling.py:32-47, :59-70) — the [B, L, D] history is never written: one
+// wave per (sample, sequence feature); the wave's 64 lanes are P = 64/lanes position groups of
+// `lanes` lanes (VEC floats each), group p takes positions p, p+P, ...; a butterfly over the
+// groups combines the partial sums in a fixed order.  A position counts towards the mean when
+// its row does not sum to exactly 0 (the reference's mask for mask=None).
+// ---------------------------------------------------------------------------------------------
+struct SeqPoolArgs {
+    const float* table;
+    const int32_t* ids;
+    int64_t ids_ld;
+    const int64_t* col_row_base;
+    const int32_t* col_vocab;
+    const int32_t* seq_col0;
+    const int32_t* seq_len;
+    const int32_t* seq_mode;
+    const int64_t* seq_out_off;
+    float* out;
+    int64_t out_ld;
+    float* denom;
+    int64_t B;
+    fx_scalars* scal;
+    int32_t D, n_seq, lanes_log2;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_seq_pool_fwd(SeqPoolArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int lanes = 1 << a.lanes_log2;
+    const int sub = lane & (lanes - 1);
+    const int p = lane >> a.lanes_log2;
+    const int P = 64 >> a.lanes_log2;
+    const int d0 = sub * VEC;
+    const bool lane_on = d0 < a.D;
+    const int64_t n_items = a.B * a.n_seq;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < n_items;
+         item += (int64_t)gridDim.x * 4) {                       // wave-uniform
+        const int64_t b = item / a.n_seq;
+        const int s = (int)(item - b * a.n_seq);
+        const int c0 = a.seq_col0[s], L = a.seq_len[s];
+        const int32_t* row_ids = a.ids + b * a.ids_ld + c0;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        float cnt = 0.f;
+        for (int l0 = 0; l0 < L; l0 += P) {                      // wave-uniform trip count
+            const int l = l0 + p;
+            float val[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) val[k] = 0.f;
+            if (l < L) {
+                const int32_t id = row_ids[l];
+                if (id >= 0 && id < a.col_vocab[c0 + l]) {
+                    if (lane_on)
+                        fx_load<VEC>(a.table + (a.col_row_base[c0 + l] + id) * a.D + d0, val);
+                } else if (sub == 0) {
+                    atomicOr(&a.scal->err_flag, FX_FLAG_BAD_ID);
+                }
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { rs += val[k]; acc[k] += val[k]; }
+            for (int off = 1; off < lanes; off <<= 1) rs += __shfl_xor(rs, off, 64);
+            cnt += (rs != 0.f) ? 1.f : 0.f;
+        }
+        for (int off = lanes; off < 64; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+            cnt += __shfl_xor(cnt, off, 64);
+        }
+        const float den = cnt + 1e-12f;
+        if (p == 0) {
+            if (a.seq_mode[s] == FX_POOL_MEAN) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+            }
+            if (lane_on) fx_store<VEC>(a.out + b * a.out_ld + a.seq_out_off[s] + d0, acc);
+            if (sub == 0) a.denom[b * a.n_seq + s] = den;
+        }
+    }
+}
+
+extern "C" int fx_emb_seq_pool_fwd(const float* table, int32_t D, const int32_t* ids,
+                                   int64_t ids_ld, const int64_t* col_row_base,
+                                   const int32_t* col_vocab, const int32_t* seq_col0,
+                                   const int32_t* seq_len, const int32_t* seq_mode,
+                                   const int64_t* seq_out_off, int32_t n_seq, float* out,
+                                   int64_t out_ld, float* denom, int64_t B, fx_scalars* scal,
+                                   fx_stream_t stream) {
+    FX_CHECK_ARG(D >= 1 && D <= 256, "fx_emb_seq_pool_fwd: D=%d not in [1,256]", D);
+    FX_CHECK_ARG(n_seq >= 0 && B >= 0, "fx_emb_seq_pool_fwd: negative size");
+    if (B == 0 || n_seq == 0) return FX_OK;
+    const FxRowGeom g = fx_row_geom(D);
+    FX_CHECK_ARG(g.lanes <= 64, "fx_emb_seq_pool_fwd: D=%d needs %d lanes per row (max 64)", D,
+                 g.lanes);
+    FX_CHECK_ARG(table && ids && col_row_base && col_vocab && seq_col0 && seq_len && seq_mode &&
+                     seq_out_off && out && denom && scal, "fx_emb_seq_pool_fwd: null pointer");
+    FX_CHECK_ARG(out_ld % g.vec == 0, "fx_emb_seq_pool_fwd: out_ld=%lld not a multiple of %d",
+                 (long long)out_ld, g.vec);
+    SeqPoolArgs a{table, ids, ids_ld, col_row_base, col_vocab, seq_col0, seq_len, seq_mode,
+                  seq_out_off, out, out_ld, denom, B, scal, D, n_seq, fx_log2i(g.lanes)};
+    int64_t blocks = fx_ceil_div(B * (int64_t)n_seq, 4);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    dim3 grid((unsigned)blocks);
+    hipStream_t s = fx_hip_stream(stream);
+    if (g.vec == 4) hipLaunchKernelGGL(k_emb_seq_pool_fwd<4>, grid, dim3(256), 0, s, a);
+    else if (g.vec == 2) hipLaunchKernelGGL(k_emb_seq_pool_fwd<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_emb_seq_pool_fwd<1>, grid, dim3(256), 0, s, a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // fx_emb_numeric_grad: one 1024-thread block per numeric feature j; thread (grp, d) sums rows
 // b = grp, grp + ngrp, ... then a fixed-order LDS reduction over the groups.
 // ---------------------------------------------------------------------------------------------

@@ -331,23 +331,41 @@ struct ReduceArgs {
     float* sq_partials;
     int32_t* scratch;   // [0] = number of long rows, [1..] = their unique-row indices
     int32_t C, D, lanes_log2;
+    const int32_t* col_denom;   // SCALED kernels only: per id column, index into denom or -1
+    const float* denom;
+    int64_t denom_ld;
 };
 
-template <int VEC>
+// value of lookup position p = b*C + c (SCALED: divided by its sample's pooling denominator)
+template <int VEC, bool SCALED>
+__device__ __forceinline__ void fx_load_lookup(const ReduceArgs& a, uint32_t p, int d0,
+                                               float (&v)[VEC]) {
+    const uint32_t b = p / (uint32_t)a.C, c = p - b * (uint32_t)a.C;
+    fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v);
+    if constexpr (SCALED) {
+        const int32_t j = a.col_denom[c];
+        if (j >= 0) {
+            const float den = a.denom[(int64_t)b * a.denom_ld + j];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[k] = v[k] / den;
+        }
+    }
+}
+
+template <int VEC, bool SCALED>
 __device__ __forceinline__ void fx_accum_lookup(const ReduceArgs& a, uint32_t i, int d0,
                                                 float (&acc)[VEC]) {
     const uint32_t p = a.sorted_pos[i];
     if (p == 0xFFFFFFFFu) return;   // padding_idx / bad-id lookup: contributes nothing
-    const uint32_t b = p / (uint32_t)a.C, c = p - b * (uint32_t)a.C;
     float v[VEC];
-    fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v);
+    fx_load_lookup<VEC, SCALED>(a, p, d0, v);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] += v[k];
 }
 
 // four lookups in flight per lane (positions first, then the four independent row loads), summed
 // in ascending order: same result as the one-at-a-time loop, ~4x fewer dependent latencies
-template <int VEC>
+template <int VEC, bool SCALED>
 __device__ __forceinline__ void fx_accum_run(const ReduceArgs& a, uint32_t beg, uint32_t end,
                                              uint32_t stride, int d0, float (&acc)[VEC]) {
     uint32_t i = beg;
@@ -363,18 +381,17 @@ __device__ __forceinline__ void fx_accum_run(const ReduceArgs& a, uint32_t beg, 
                 for (int k = 0; k < VEC; ++k) v[j][k] = 0.f;
                 continue;
             }
-            const uint32_t b = p[j] / (uint32_t)a.C, c = p[j] - b * (uint32_t)a.C;
-            fx_load<VEC>(a.dout + (int64_t)b * a.dout_ld + a.col_out_off[c] + d0, v[j]);
+            fx_load_lookup<VEC, SCALED>(a, p[j], d0, v[j]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] += v[j][k];
     }
-    for (; i < end; i += stride) fx_accum_lookup<VEC>(a, i, d0, acc);
+    for (; i < end; i += stride) fx_accum_lookup<VEC, SCALED>(a, i, d0, acc);
 }
 
-template <int VEC>
+template <int VEC, bool SCALED>
 __global__ __launch_bounds__(256) void k_emb_grad_reduce_short(ReduceArgs a) {
     const int lanes = 1 << a.lanes_log2;
     const int rpb = 256 >> a.lanes_log2;
@@ -392,11 +409,11 @@ __global__ __launch_bounds__(256) void k_emb_grad_reduce_short(ReduceArgs a) {
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-    fx_accum_run<VEC>(a, beg, end, 1u, d0, acc);
+    fx_accum_run<VEC, SCALED>(a, beg, end, 1u, d0, acc);
     fx_store<VEC>(a.G + u * a.D + d0, acc);
 }
 
-template <int VEC>
+template <int VEC, bool SCALED>
 __global__ __launch_bounds__(256) void k_emb_grad_reduce_long(ReduceArgs a) {
     __shared__ float red[256 * VEC];
     const int lanes = 1 << a.lanes_log2;
@@ -412,7 +429,7 @@ __global__ __launch_bounds__(256) void k_emb_grad_reduce_long(ReduceArgs a) {
         float part[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) part[k] = 0.f;
-        if (lane_on) fx_accum_run<VEC>(a, beg + grp, end, (uint32_t)rpb, d0, part);
+        if (lane_on) fx_accum_run<VEC, SCALED>(a, beg + grp, end, (uint32_t)rpb, d0, part);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) red[k * 256 + threadIdx.x] = part[k];
         __syncthreads();
@@ -465,11 +482,13 @@ extern "C" int64_t fx_emb_grad_reduce_scratch_ints(int64_t n_max) {
     return (n_max <= 0 ? 0 : n_max / (FX_LONG_RUN + 1)) + 2;
 }
 
-extern "C" int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int64_t* col_out_off,
-                                  int32_t C, int32_t D, const uint32_t* sorted_pos,
-                                  const uint32_t* seg_start, const int32_t* n_unique,
-                                  int64_t n_max, float* G, float* sq_partials, int32_t* scratch,
-                                  fx_stream_t stream) {
+extern "C" int fx_emb_grad_reduce_scaled(const float* dout, int64_t dout_ld,
+                                         const int64_t* col_out_off, const int32_t* col_denom,
+                                         const float* denom, int64_t denom_ld, int32_t C,
+                                         int32_t D, const uint32_t* sorted_pos,
+                                         const uint32_t* seg_start, const int32_t* n_unique,
+                                         int64_t n_max, float* G, float* sq_partials,
+                                         int32_t* scratch, fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256 && C >= 1, "fx_emb_grad_reduce: bad C=%d / D=%d", C, D);
     hipStream_t s = fx_hip_stream(stream);
     FX_CHECK_ARG(sq_partials && scratch, "fx_emb_grad_reduce: null sq_partials / scratch");
@@ -480,28 +499,46 @@ extern "C" int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int6
     }
     FX_CHECK_ARG(dout && col_out_off && sorted_pos && seg_start && n_unique && G,
                  "fx_emb_grad_reduce: null pointer");
+    const bool scaled = col_denom != nullptr;
+    FX_CHECK_ARG(!scaled || denom, "fx_emb_grad_reduce_scaled: col_denom without denom");
     const FxRowGeom g = fx_row_geom(D);
     FX_CHECK_ARG(dout_ld % g.vec == 0 || g.vec == 1,
                  "fx_emb_grad_reduce: dout_ld not a multiple of %d", g.vec);
     int ll = 0;
     while ((1 << ll) < g.lanes) ++ll;
     ReduceArgs a{dout, dout_ld, col_out_off, sorted_pos, seg_start, n_unique, G, sq_partials,
-                 scratch, C, D, ll};
+                 scratch, C, D, ll, col_denom, denom, denom_ld};
     // scratch[0] (the long-run counter) must be 0 on entry and is left 0 on return: the last launch
     // resets it (no memset node: as the ROOT node of a captured hipGraph segment a 4-byte
     // hipMemsetAsync was observed not to be ordered before the kernels that follow it)
     const int64_t blocks = fx_ceil_div(n_max, 256 / g.lanes);
     dim3 grid((unsigned)blocks), grid_long(512);
-#define FX_REDUCE_LAUNCH(V)                                                              \
-    hipLaunchKernelGGL(k_emb_grad_reduce_short<V>, grid, dim3(256), 0, s, a);            \
-    hipLaunchKernelGGL(k_emb_grad_reduce_long<V>, grid_long, dim3(256), 0, s, a);        \
+#define FX_REDUCE_LAUNCH(V, S)                                                           \
+    hipLaunchKernelGGL((k_emb_grad_reduce_short<V, S>), grid, dim3(256), 0, s, a);       \
+    hipLaunchKernelGGL((k_emb_grad_reduce_long<V, S>), grid_long, dim3(256), 0, s, a);   \
     hipLaunchKernelGGL(k_rows_sqnorm<V>, grid, dim3(256), 0, s, a);
-    if (g.vec == 4) { FX_REDUCE_LAUNCH(4) }
-    else if (g.vec == 2) { FX_REDUCE_LAUNCH(2) }
-    else { FX_REDUCE_LAUNCH(1) }
+    if (scaled) {
+        if (g.vec == 4) { FX_REDUCE_LAUNCH(4, true) }
+        else if (g.vec == 2) { FX_REDUCE_LAUNCH(2, true) }
+        else { FX_REDUCE_LAUNCH(1, true) }
+    } else {
+        if (g.vec == 4) { FX_REDUCE_LAUNCH(4, false) }
+        else if (g.vec == 2) { FX_REDUCE_LAUNCH(2, false) }
+        else { FX_REDUCE_LAUNCH(1, false) }
+    }
 #undef FX_REDUCE_LAUNCH
     FX_CHECK_LAUNCH();
     return FX_OK;
+}
+
+extern "C" int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int64_t* col_out_off,
+                                  int32_t C, int32_t D, const uint32_t* sorted_pos,
+                                  const uint32_t* seg_start, const int32_t* n_unique,
+                                  int64_t n_max, float* G, float* sq_partials, int32_t* scratch,
+                                  fx_stream_t stream) {
+    return fx_emb_grad_reduce_scaled(dout, dout_ld, col_out_off, nullptr, nullptr, 0, C, D,
+                                     sorted_pos, seg_start, n_unique, n_max, G, sq_partials,
+                                     scratch, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -229,28 +229,27 @@ class _TableGroup(object):
         return self.scal
 
     # -- plans ------------------------------------------------------------------------------
-    def plan_for(self, ordered_features):
-        """ordered_features: features of this group to embed, in feature_map order."""
-        key = tuple(ordered_features)
+    def plan_for(self, ordered_features, pooled=None, tail=None):
+        """ordered_features: features of this group to embed, in feature_map order.
+        pooled: {sequence feature: ops.POOL_SUM | ops.POOL_MEAN} — reduced inside the gather to ONE
+        slot each (fx_emb_seq_pool_fwd); their id columns go last so that the plain gather takes
+        the prefix [0, C_main).  tail: features whose id columns go last without being pooled here
+        (the LR copy sums every column anyway and keeps the SAME column order as the embedding
+        layer's plan, so both share one de-dup / one id exchange)."""
+        pooled = pooled or {}
+        last = set(pooled) | set(tail or ())
+        key = (tuple(ordered_features), tuple(sorted(pooled.items())), tuple(sorted(last)))
         plan = self.plans.get(key)
         if plan is not None:
             return plan
         p = _Plan()
         D = self.D
-        p.id_feats, p.num_feats = [], []
-        p.slot = {}
-        row_base, vocab, pad, out_off, num_off = [], [], [], [], []
+        p.num_feats, p.slot, p.pooled = [], {}, dict(pooled)
+        num_off = []
         slot = 0
-        for f in ordered_features:
+        for f in ordered_features:           # slots follow the feature order
             if f in self.widths:
-                w = self.widths[f]
-                base, V, pidx = self.table_of(f)
-                p.id_feats.append((f, w))
-                for k in range(w):
-                    row_base.append(base)
-                    vocab.append(V)
-                    pad.append(-1 if pidx is None else int(pidx))
-                    out_off.append((slot + k) * D)
+                w = 1 if f in pooled else self.widths[f]
                 p.slot[f] = (slot, w)
                 slot += w
             else:
@@ -258,8 +257,37 @@ class _TableGroup(object):
                 num_off.append(slot * D)
                 p.slot[f] = (slot, 1)
                 slot += 1
+        ids_order = [f for f in ordered_features if f in self.widths and f not in last] + \
+                    [f for f in ordered_features if f in self.widths and f in last]
+        p.id_feats = [(f, self.widths[f]) for f in ids_order]
+        row_base, vocab, pad, out_off, col_denom = [], [], [], [], []
+        seq_col0, seq_len, seq_mode, seq_off = [], [], [], []
+        p.C_main = 0
+        for f, w in p.id_feats:
+            base, V, pidx = self.table_of(f)
+            s0 = p.slot[f][0]
+            if f in pooled:
+                if pooled[f] == ops.POOL_MEAN:
+                    col_denom += [len(seq_col0)] * w
+                else:
+                    col_denom += [-1] * w
+                seq_col0.append(len(row_base))
+                seq_len.append(w)
+                seq_mode.append(pooled[f])
+                seq_off.append(s0 * D)
+            else:
+                col_denom += [-1] * w
+            for k in range(w):
+                row_base.append(base)
+                vocab.append(V)
+                pad.append(-1 if pidx is None else int(pidx))
+                out_off.append((s0 if f in pooled else s0 + k) * D)
+            if f not in pooled:
+                assert p.C_main == len(row_base) - w, "pooled id columns must come last"
+                p.C_main = len(row_base)
         p.n_slots = slot
         p.C = len(row_base)
+        p.n_seq = len(seq_col0)
         p.Fd = len(p.num_feats)
         dev = self.device
         p.col_row_base = torch.tensor(row_base, dtype=torch.int64, device=dev)
@@ -269,6 +297,12 @@ class _TableGroup(object):
         p.col_zero_off = torch.zeros(max(p.C, 1), dtype=torch.int64, device=dev)
         p.num_out_off = torch.tensor(num_off, dtype=torch.int64, device=dev)
         p.num_zero_off = torch.zeros(max(p.Fd, 1), dtype=torch.int64, device=dev)
+        p.seq_col0 = torch.tensor(seq_col0, dtype=torch.int32, device=dev)
+        p.seq_len = torch.tensor(seq_len, dtype=torch.int32, device=dev)
+        p.seq_mode = torch.tensor(seq_mode, dtype=torch.int32, device=dev)
+        p.seq_out_off = torch.tensor(seq_off, dtype=torch.int64, device=dev)
+        p.col_denom = torch.tensor(col_denom, dtype=torch.int32, device=dev) \
+            if any(j >= 0 for j in col_denom) else None
         p.num_rows = [self.numeric.index(f) for f in p.num_feats]
         p.num_full = p.num_rows == list(range(len(self.numeric)))
         p.columns_sorted = all(w == 1 for _, w in p.id_feats) and \
@@ -332,7 +366,7 @@ class _TableGroup(object):
         return dd
 
     def backward(self, plan, ids, dense, dout, dout_ld, col_off, num_off, dd, inputs_cache,
-                 sx=None):
+                 sx=None, denom=None):
         """Sparse + numeric gradients of one forward call (dout: grad of the output record)."""
         D = self.D
         if plan.Fd:
@@ -345,8 +379,9 @@ class _TableGroup(object):
                     self.num_grad = torch.zeros_like(self.num_w)
                 idx = torch.tensor(plan.num_rows, dtype=torch.int64, device=self.device)
                 self.num_grad.index_add_(0, idx, g)
+        col_denom = plan.col_denom if denom is not None else None
         if plan.C and sx is not None:
-            self.shard_backward(plan, sx, dout, dout_ld, col_off)
+            self.shard_backward(plan, sx, dout, dout_ld, col_off, col_denom, denom)
         elif plan.C:
             if dd is None:
                 dd = self.dedup(plan, ids, inputs_cache)
@@ -354,7 +389,7 @@ class _TableGroup(object):
             sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max, D), dtype=torch.float32,
                              device=self.device)
             ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G, sq,
-                                self.reduce_scratch(dd.n_max))
+                                self.reduce_scratch(dd.n_max), col_denom, denom)
             self.pending.append(_PendingGrad(dd, G, sq))
 
     def reduce_scratch(self, n_max):
@@ -457,7 +492,7 @@ class _TableGroup(object):
             sx.rows[id(p)] = rows
         return sx.rows.pop(id(self))
 
-    def shard_backward(self, plan, sx, dout, dout_ld, col_off):
+    def shard_backward(self, plan, sx, dout, dout_ld, col_off, col_denom=None, denom=None):
         """Requester: reduce to local unique keys, ship to owners; owner: reduce across ranks."""
         N, cap, D = self.n_shards, sx.cap, self.D
         dd = sx.dd
@@ -465,7 +500,7 @@ class _TableGroup(object):
         sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max, D), dtype=torch.float32,
                          device=self.device)
         ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G_loc, sq,
-                            self.reduce_scratch(dd.n_max))
+                            self.reduce_scratch(dd.n_max), col_denom, denom)
         gsend = torch.zeros(N * cap + 1, D, dtype=torch.float32, device=self.device)
         ops.scatter_rows(G_loc, sx.uniq_slot, dd.n_unique, dd.n_max, D, gsend)
         # the exchange itself runs after autograd returns (finish_backward, called by the
@@ -526,26 +561,33 @@ def finish_shard_backward(groups):
 
 
 class _EmbGatherFn(torch.autograd.Function):
-    """One launch: all id columns + numeric columns of a group -> [B, n_slots * D]."""
+    """All id columns + numeric columns of a group -> [B, n_slots * D]: one gather launch, plus one
+    pooling launch when sequence features are reduced on the fly (plan.pooled)."""
 
     @staticmethod
     def forward(ctx, anchor, group, plan, ids, dense, dd, inputs, track):
         B = (ids if ids is not None else dense).shape[0]
-        out = torch.empty(B, plan.n_slots * group.D, dtype=torch.float32, device=group.device)
+        D = group.D
+        out = torch.empty(B, plan.n_slots * D, dtype=torch.float32, device=group.device)
         sx = None
         if group.n_shards > 1 and plan.C:
-            # row-sharded: ids -> owners, rows <- owners, then the same gather kernel reads the
-            # received rows through the per-lookup slot matrix
+            # row-sharded: ids -> owners, rows <- owners, then the same kernels read the received
+            # rows through the per-lookup slot matrix
             sx = group.shard_exchange_ids(plan, ids, inputs)
-            rows = group.shard_fetch_rows(sx, track)
-            ops.emb_gather_fwd(rows, group.D, sx.lookup_slot, sx.slot_base, sx.slot_vocab,
-                               plan.col_out_off, dense, group.select_num_w(plan),
-                               plan.num_out_off, out, group.ensure_scal())
+            table = group.shard_fetch_rows(sx, track)
+            src, base, vocab = sx.lookup_slot, sx.slot_base, sx.slot_vocab
         else:
-            ops.emb_gather_fwd(group.table, group.D, ids, plan.col_row_base, plan.col_vocab,
-                               plan.col_out_off, dense, group.select_num_w(plan),
-                               plan.num_out_off, out, group.ensure_scal())
+            table, src, base, vocab = group.table, ids, plan.col_row_base, plan.col_vocab
+        ops.emb_gather_fwd(table, D, src, base, vocab, plan.col_out_off, dense,
+                           group.select_num_w(plan), plan.num_out_off, out, group.ensure_scal(),
+                           n_cols=plan.C_main if plan.n_seq else None)
+        denom = None
+        if plan.n_seq:
+            denom = torch.empty(B, plan.n_seq, dtype=torch.float32, device=group.device)
+            ops.emb_seq_pool_fwd(table, D, src, base, vocab, plan.seq_col0, plan.seq_len,
+                                 plan.seq_mode, plan.seq_out_off, out, denom, group.ensure_scal())
         ctx.group, ctx.plan, ctx.ids, ctx.dense, ctx.dd, ctx.sx = group, plan, ids, dense, dd, sx
+        ctx.denom = denom if plan.col_denom is not None else None
         ctx.inputs = inputs if hasattr(inputs, "cache") else None
         return out
 
@@ -554,7 +596,7 @@ class _EmbGatherFn(torch.autograd.Function):
         dout = dout.contiguous()
         ctx.group.backward(ctx.plan, ctx.ids, ctx.dense, dout, dout.stride(0),
                            ctx.plan.col_out_off, ctx.plan.num_out_off, ctx.dd, ctx.inputs,
-                           sx=ctx.sx)
+                           sx=ctx.sx, denom=ctx.denom)
         return None, None, None, None, None, None, None, None
 
 
@@ -745,21 +787,22 @@ class FeatureEmbeddingDict(nn.Module):
             if feature in self.embedding_layers:
                 present.append(feature)
         present_set = set(present)
-        emb = {}
+        emb, fused = {}, set()
         for D, grp in self._groups.items():
             feats = [f for f in fmap if f in present_set and self._feat_group.get(f) == D]
             if not feats:
                 continue
-            plan = grp.plan_for(feats)
+            plan = grp.plan_for(feats, self._fused_pooling(grp, feats))
             ids, dense = grp.pack_inputs(plan, inputs)
             track = torch.is_grad_enabled() and self.training
             dd = grp.prepare_train(plan, ids, inputs) if (track and grp.n_shards == 1) else None
             anchor = self._anchor(grp)
             out = _EmbGatherFn.apply(anchor, grp, plan, ids, dense, dd, inputs, track)
             rec = out.view(out.shape[0], plan.n_slots, D)
+            fused.update(plan.pooled)
             for f in feats:
                 s, w = plan.slot[f]
-                if fmap[f]["type"] == "sequence":
+                if fmap[f]["type"] == "sequence" and f not in plan.pooled:
                     emb[f] = rec[:, s:s + w, :]
                 else:
                     emb[f] = rec[:, s, :]
@@ -770,13 +813,29 @@ class FeatureEmbeddingDict(nn.Module):
         feature_emb_dict = _EmbDict()
         for f in present:  # reference order = order of `inputs`
             e = emb[f]
-            if f in self.feature_encoders:
+            if f in self.feature_encoders and f not in fused:
                 e = self.feature_encoders[f](e)
                 feature_emb_dict._encoded.add(f)
             feature_emb_dict[f] = e
         feature_emb_dict._records = [v for k, v in emb.items() if isinstance(k, tuple)]
         feature_emb_dict._orig = {f: id(t) for f, t in feature_emb_dict.items()}
         return feature_emb_dict
+
+    def _fused_pooling(self, grp, feats):
+        """Sequence features of `feats` whose encoder is one of the two pooling layers: reduced
+        inside the gather instead of materialising [B, L, D] for torch.sum."""
+        if _lib.row_lanes(grp.D) > 64:
+            return None
+        modes = {}
+        for f in feats:
+            enc = self.feature_encoders[f] if f in self.feature_encoders else None
+            if self._feature_map.features[f]["type"] != "sequence" or f not in grp.widths:
+                continue
+            if type(enc) is MaskedSumPooling:
+                modes[f] = ops.POOL_SUM
+            elif type(enc) is MaskedAveragePooling:
+                modes[f] = ops.POOL_MEAN
+        return modes or None
 
     def _anchor(self, grp):
         for f in grp.tables:
@@ -1005,7 +1064,9 @@ class LogisticRegression(nn.Module):
                 output = output + self.bias
             return output
         grp = groups[0]
-        plan = grp.plan_for(feats)
+        # lr_fwd sums every column (= the sum pooling this layer installs for sequences); their
+        # columns go last like in the embedding layer's pooled plan, so both share one de-dup
+        plan = grp.plan_for(feats, tail=[f for f in feats if fmap[f]["type"] == "sequence"])
         ids, dense = grp.pack_inputs(plan, X)
         track = torch.is_grad_enabled() and self.training
         dd = grp.prepare_train(plan, ids, X) if (track and grp.n_shards == 1) else None

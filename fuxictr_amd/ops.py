@@ -102,10 +102,11 @@ def pack_columns(cols, out, out_col0=0):
 
 
 def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w,
-                   num_out_off, out, scal):
+                   num_out_off, out, scal, n_cols=None):
+    """n_cols: gather only the first n_cols id columns (the rest are pooled sequences)."""
     lib = _lib.load()
     B = out.shape[0]
-    C_ = 0 if ids is None else ids.shape[1]
+    C_ = 0 if ids is None else (ids.shape[1] if n_cols is None else n_cols)
     Fd = 0 if dense is None else dense.shape[1]
     ev = KernelTimer.start()
     check(lib.fx_emb_gather_fwd(ptr(table), D, ptr(ids), 0 if ids is None else ids.stride(0),
@@ -116,6 +117,21 @@ def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, n
     # algorithmic bytes: rows + ids + dense in, the [B,F,D] record out
     KernelTimer.stop("k_emb_gather_fwd", ev,
                      B * (C_ * (4 * D + 4) + Fd * 4 + (C_ + Fd) * 4 * D) if ev else 0)
+    return out
+
+
+POOL_SUM, POOL_MEAN = 0, 1
+
+
+def emb_seq_pool_fwd(table, D, ids, col_row_base, col_vocab, seq_col0, seq_len, seq_mode,
+                     seq_out_off, out, denom, scal):
+    """Pooled sequence features -> their slots of the record `out`; denom [B, n_seq] out."""
+    lib = _lib.load()
+    B, n_seq = denom.shape
+    check(lib.fx_emb_seq_pool_fwd(ptr(table), D, ptr(ids), ids.stride(0), ptr(col_row_base),
+                                  ptr(col_vocab), ptr(seq_col0), ptr(seq_len), ptr(seq_mode),
+                                  ptr(seq_out_off), n_seq, ptr(out), out.stride(0), ptr(denom),
+                                  B, ptr(scal), stream_ptr(out.device)), "fx_emb_seq_pool_fwd")
     return out
 
 
@@ -190,12 +206,22 @@ def emb_grad_reduce_scratch_ints(n_max):
     return int(_lib.load().fx_emb_grad_reduce_scratch_ints(n_max))
 
 
-def emb_grad_reduce(dout, dout_ld, col_out_off, C_, D, dd, G, sq_partials, scratch):
+def emb_grad_reduce(dout, dout_ld, col_out_off, C_, D, dd, G, sq_partials, scratch,
+                    col_denom=None, denom=None):
+    """col_denom / denom: per-column index into the [B, n_seq] pooling denominators (mean-pooled
+    sequence columns), see fx_emb_grad_reduce_scaled."""
     lib = _lib.load()
-    check(lib.fx_emb_grad_reduce(ptr(dout), dout_ld, ptr(col_out_off), C_, D, ptr(dd.sorted_pos),
-                                 ptr(dd.seg_start), ptr(dd.n_unique), dd.n_max, ptr(G),
-                                 ptr(sq_partials), ptr(scratch), stream_ptr(dout.device)),
-          "fx_emb_grad_reduce")
+    if col_denom is None:
+        check(lib.fx_emb_grad_reduce(ptr(dout), dout_ld, ptr(col_out_off), C_, D,
+                                     ptr(dd.sorted_pos), ptr(dd.seg_start), ptr(dd.n_unique),
+                                     dd.n_max, ptr(G), ptr(sq_partials), ptr(scratch),
+                                     stream_ptr(dout.device)), "fx_emb_grad_reduce")
+        return
+    check(lib.fx_emb_grad_reduce_scaled(ptr(dout), dout_ld, ptr(col_out_off), ptr(col_denom),
+                                        ptr(denom), denom.stride(0), C_, D, ptr(dd.sorted_pos),
+                                        ptr(dd.seg_start), ptr(dd.n_unique), dd.n_max, ptr(G),
+                                        ptr(sq_partials), ptr(scratch), stream_ptr(dout.device)),
+          "fx_emb_grad_reduce_scaled")
 
 
 def emb_numeric_grad(dout, dout_ld, num_out_off, dense, D, dnum_w):

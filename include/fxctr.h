@@ -92,6 +92,28 @@ int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* ids, int64_t
                       fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Pooled sequence features, forward.  Replaces the lookup of a sequence feature followed by its
+ * `feature_encoder` (feature_embedding.py:283-295) when that encoder is MaskedSumPooling or
+ * MaskedAveragePooling (pooling.py:59-70, :32-47) — the default encoder of every sequence feature
+ * (feature_processor.py:379).  Sequence s occupies id columns seq_col0[s] .. +seq_len[s] of `ids`
+ * (indices into col_row_base / col_vocab); its [seq_len, D] history is reduced in registers and
+ * only the pooled row is written:
+ *     sum[b,s,:]  = sum_l table[(col_row_base[c] + ids[b,c]) * D + :],  c = seq_col0[s] + l
+ *     denom[b,s]  = #{l : sum_d row_l[d] != 0} + 1e-12          (the reference's inferred mask)
+ *     out[b*out_ld + seq_out_off[s] + :] = sum            (seq_mode[s] == FX_POOL_SUM)
+ *                                        = sum / denom    (seq_mode[s] == FX_POOL_MEAN)
+ * denom [B, n_seq] is kept for the backward (fx_emb_grad_reduce_scaled).  Bad ids as in
+ * fx_emb_gather_fwd.  Rows of more than 64 lanes (D > 256 / 128 / 64 for D % 4 / % 2 / odd) are
+ * rejected.
+ * ------------------------------------------------------------------------------------------ */
+enum { FX_POOL_SUM = 0, FX_POOL_MEAN = 1 };
+int fx_emb_seq_pool_fwd(const float* table, int32_t D, const int32_t* ids, int64_t ids_ld,
+                        const int64_t* col_row_base, const int32_t* col_vocab,
+                        const int32_t* seq_col0, const int32_t* seq_len, const int32_t* seq_mode,
+                        const int64_t* seq_out_off, int32_t n_seq, float* out, int64_t out_ld,
+                        float* denom, int64_t B, fx_scalars* scal, fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Index de-duplication for the sparse backward/update.  Builds, for the B*C lookups of a batch,
  * the list of unique packed-table rows and the (stable) sorted lookup positions of each:
  *     key(b,c) = col_row_base[c] + ids[b,c]       (sentinel total_rows for padding_idx / bad ids)
@@ -163,6 +185,16 @@ int fx_emb_grad_reduce(const float* dout, int64_t dout_ld, const int64_t* col_ou
                        int32_t D, const uint32_t* sorted_pos, const uint32_t* seg_start,
                        const int32_t* n_unique, int64_t n_max, float* G, float* sq_partials,
                        int32_t* scratch, fx_stream_t stream);
+/* The same with a per-lookup divisor: the lookup (b, c) contributes
+ * dout[b*dout_ld + col_out_off[c] + :] / denom[b*denom_ld + col_denom[c]] when col_denom[c] >= 0
+ * (autograd of the mean pooling of fx_emb_seq_pool_fwd: every position of the history receives
+ * dpooled / denom), and the plain value when col_denom[c] < 0.  All id columns of a pooled
+ * sequence carry the pooled slot's offset in col_out_off. */
+int fx_emb_grad_reduce_scaled(const float* dout, int64_t dout_ld, const int64_t* col_out_off,
+                              const int32_t* col_denom, const float* denom, int64_t denom_ld,
+                              int32_t C, int32_t D, const uint32_t* sorted_pos,
+                              const uint32_t* seg_start, const int32_t* n_unique, int64_t n_max,
+                              float* G, float* sq_partials, int32_t* scratch, fx_stream_t stream);
 
 /* Numeric-feature weight gradient: dnum_w[j,d] = sum_b dense[b,j] * dout[b*dout_ld + num_out_off[j] + d]
  * (autograd of the nn.Linear(1,D) at feature_embedding.py:280-282).  Deterministic tree sum. */

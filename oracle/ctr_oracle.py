@@ -28,10 +28,29 @@ LR_EMB = "fm.lr_layer.embedding_layer.embedding_layer.embedding_layers."
 # ---------------------------------------------------------------------------------------------
 # layers
 # ---------------------------------------------------------------------------------------------
-def feature_embedding(state, prefix, features, X):
+def masked_average_pooling(embedding_matrix):
+    """MaskedAveragePooling.forward, pooling.py:32-47 with mask=None: a position counts when its
+    embedding row does not sum to exactly 0 (the padding row); +1e-12 keeps empty histories finite."""
+    sum_out = torch.sum(embedding_matrix, dim=1)
+    mask = embedding_matrix.sum(dim=-1) != 0
+    return sum_out / (mask.float().sum(-1, keepdim=True) + 1.e-12)
+
+
+def masked_sum_pooling(embedding_matrix):
+    """MaskedSumPooling.forward, pooling.py:59-70 (padding rows are zero vectors)."""
+    return torch.sum(embedding_matrix, dim=1)
+
+
+ENCODERS = {"layers.MaskedAveragePooling()": masked_average_pooling,
+            "layers.MaskedSumPooling()": masked_sum_pooling}
+
+
+def feature_embedding(state, prefix, features, X, encode=True):
     """FeatureEmbeddingDict.forward, feature_embedding.py:261-297 -> OrderedDict name -> tensor.
     numeric: x.float().view(-1,1) @ W[D,1]^T (:280-282); categorical/sequence: W[ids.long()]
-    (:283-288).  `share_embedding` aliases are resolved by the state_dict (both keys exist)."""
+    (:283-288), then the feature's `feature_encoder` (:294-295) — encode=False for the D=1 LR copy,
+    which installs its own sum pooling instead (:135-138).  `share_embedding` aliases are resolved
+    by the state_dict (both keys exist)."""
     out = OrderedDict()
     for name, spec in features.items():
         if name not in X or spec["type"] == "meta":
@@ -41,6 +60,8 @@ def feature_embedding(state, prefix, features, X):
             out[name] = F.linear(X[name].float().view(-1, 1), w)
         elif spec["type"] in ("categorical", "sequence"):
             out[name] = F.embedding(X[name].long(), w, padding_idx=spec.get("padding_idx", None))
+            if encode and spec.get("feature_encoder"):
+                out[name] = ENCODERS[spec["feature_encoder"]](out[name])
         else:
             raise NotImplementedError(spec["type"])
     return out
@@ -55,7 +76,7 @@ def dict2tensor(features, emb, flatten_emb=False):
 def logistic_regression(state, features, X, emb_prefix=LR_EMB, bias_key="fm.lr_layer.bias"):
     """LogisticRegression.forward, logistic_regression.py:46-59: a D=1 FeatureEmbedding summed over
     fields + bias (sequence features are sum-pooled first, feature_embedding.py:135-138)."""
-    emb = feature_embedding(state, emb_prefix, features, X)
+    emb = feature_embedding(state, emb_prefix, features, X, encode=False)
     for name, spec in features.items():
         if name in emb and spec["type"] == "sequence":
             emb[name] = emb[name].sum(dim=1)

@@ -33,9 +33,9 @@ def pack_columns(cols, out, out_col0=0):
 
 
 def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w,
-                   num_out_off, out, scal):
+                   num_out_off, out, scal, n_cols=None):
     if ids is not None:
-        for c in range(ids.shape[1]):
+        for c in range(ids.shape[1] if n_cols is None else n_cols):
             rows = ids[:, c].long() + int(col_row_base[c])
             o = int(col_out_off[c])
             out[:, o:o + D] = table[rows]
@@ -43,6 +43,24 @@ def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, n
         for j in range(dense.shape[1]):
             o = int(num_out_off[j])
             out[:, o:o + D] = dense[:, j:j + 1] * num_w[j]
+    return out
+
+
+POOL_SUM, POOL_MEAN = 0, 1
+
+
+def emb_seq_pool_fwd(table, D, ids, col_row_base, col_vocab, seq_col0, seq_len, seq_mode,
+                     seq_out_off, out, denom, scal):
+    for s in range(denom.shape[1]):
+        c0, L = int(seq_col0[s]), int(seq_len[s])
+        rows = table[ids[:, c0:c0 + L].long() + col_row_base[c0:c0 + L].view(1, -1)]   # [B, L, D]
+        den = (rows.sum(-1) != 0).float().sum(-1, keepdim=True) + 1e-12
+        pooled = rows.sum(1)
+        if int(seq_mode[s]) == POOL_MEAN:
+            pooled = pooled / den
+        o = int(seq_out_off[s])
+        out[:, o:o + D] = pooled
+        denom[:, s:s + 1] = den
     return out
 
 
@@ -139,7 +157,8 @@ def _flat_from(t):
     return torch.as_strided(t, (n,), (1,), t.storage_offset())
 
 
-def emb_grad_reduce(dout, dout_ld, col_out_off, C, D, dd, G, sq_partials, scratch):
+def emb_grad_reduce(dout, dout_ld, col_out_off, C, D, dd, G, sq_partials, scratch,
+                    col_denom=None, denom=None):
     nu = int(dd.n_unique)
     flat = _flat_from(dout)
     sq_partials.zero_()
@@ -149,7 +168,10 @@ def emb_grad_reduce(dout, dout_ld, col_out_off, C, D, dd, G, sq_partials, scratc
             p = int(dd.sorted_pos[i])
             b, c = divmod(p, C)
             o = b * dout_ld + int(col_out_off[c])
-            acc += flat[o:o + D]
+            if col_denom is not None and int(col_denom[c]) >= 0:
+                acc += flat[o:o + D] / denom[b, int(col_denom[c])]
+            else:
+                acc += flat[o:o + D]
         G[u] = acc
     sq_partials[0] = float((G[:nu].double() ** 2).sum())
 
@@ -470,7 +492,7 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "sum_parts", "din_concat_fwd", "din_concat_bwd", "din_pool_fwd", "din_pool_bwd",
          "dice_workspace_floats", "dice_fwd", "dice_bwd", "dot_interact_fwd", "dot_interact_bwd",
          "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update",
-         "shard_plan_workspace_ints"]
+         "shard_plan_workspace_ints", "emb_seq_pool_fwd"]
 
 
 def install_plain():
@@ -492,16 +514,6 @@ def install(monkeypatch):
     import fuxictr_amd.rank_model as rm
     me = globals()
     for name in NAMES:
-        monkeypatch.setattr(real, name, me[name])
-    monkeypatch.setattr(rm, "get_device", lambda gpu=-1: torch.device("cpu"))
-    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
-    return
-    for name in ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes", "dedup",
-                 "emb_grad_reduce_partials", "emb_grad_reduce_scratch_ints", "emb_grad_reduce",
-                 "emb_numeric_grad",
-                 "opt_begin_step", "clip_coef", "sparse_adam", "adam_catchup", "sparse_sgd",
-                 "mt_sqnorm", "mt_adam", "mt_sgd", "fm_fwd", "fm_bwd", "lr_fwd", "gemm", "colsum",
-                 "mask_mul", "cross_bwd_prep", "sigmoid_bce"]:
         monkeypatch.setattr(real, name, me[name])
     monkeypatch.setattr(rm, "get_device", lambda gpu=-1: torch.device("cpu"))
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)

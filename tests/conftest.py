@@ -64,7 +64,7 @@ def assert_weights_close(got, ref, lr, steps, name, tol=2e-5):
 
 GOLDEN_CASES = ["deepfm_adam", "deepfm_adam_clip", "deepfm_sgd", "deepfm_d10", "dcnv2_adam",
                 "din_adam", "dlrm_adam", "xdeepfm_adam", "deepfm_reg",
-                "deepfm_reg_sgd", "deepfm_bn"]
+                "deepfm_reg_sgd", "deepfm_bn", "deepfm_seqpool"]
 
 
 @pytest.fixture(params=GOLDEN_CASES)

@@ -54,6 +54,28 @@ def small_seq_spec(dataset_id, L=6):
             "input_length": 0, "labels": ["label"], "features": feats}
 
 
+def pooled_seq_spec(dataset_id, L=7):
+    """Sequence features behind the pooling encoders (the default for every sequence feature,
+    feature_processor.py:379): a mean-pooled history sharing the item table, a sum-pooled one with
+    its own table and max_len, all padded with 0 (some histories empty)."""
+    feats = [
+        {"price": {"source": "item", "type": "numeric"}},
+        {"userid": {"source": "user", "type": "categorical", "padding_idx": 0, "vocab_size": 301}},
+        {"adgroup_id": {"source": "item", "type": "categorical", "padding_idx": 0, "vocab_size": 97}},
+        {"click_sequence": {"source": "user", "type": "sequence",
+                            "feature_encoder": "layers.MaskedAveragePooling()",
+                            "share_embedding": "adgroup_id", "padding_idx": 0, "vocab_size": 97,
+                            "max_len": L}},
+        {"cate_id": {"source": "item", "type": "categorical", "padding_idx": 0, "vocab_size": 23}},
+        {"cate_sequence": {"source": "user", "type": "sequence",
+                           "feature_encoder": "layers.MaskedSumPooling()", "padding_idx": 0,
+                           "vocab_size": 41, "max_len": L + 4}},
+        {"pid": {"source": "context", "type": "categorical", "padding_idx": 0, "vocab_size": 4}},
+    ]
+    return {"dataset_id": dataset_id, "num_fields": len(feats), "total_features": 0,
+            "input_length": 0, "labels": ["label"], "features": feats}
+
+
 def make_batches(rng, spec, B, n, pad_frac=0.02):
     import numpy as np
     batches = []
@@ -88,6 +110,8 @@ def run_case(case):
     name = case["name"]
     if case["model"] == "DIN":
         spec = small_seq_spec(name)
+    elif case.get("schema") == "pooled_seq":
+        spec = pooled_seq_spec(name)
     else:
         spec = small_criteo_spec(name, case["n_dense"], case["cards"])
     os.makedirs(os.path.join(TMP, name), exist_ok=True)
@@ -132,7 +156,10 @@ def run_case(case):
             if "embedding_layers" in k and "lr_layer" not in k and p.shape[0] > 1 \
                     and p.dim() == 2 and p.shape[1] > 1:
                 p.mul_(case.get("emb_scale", 1.0))
-            if "lr_layer" in k and "embedding_layers" in k and p.shape[0] > 1:
+            # (the LR copy of a `share_embedding` feature keeps nn.Embedding's N(0,1) init — the
+            # reference's init_weights skips it, feature_embedding.py:207-209 — leave that one)
+            if "lr_layer" in k and "embedding_layers" in k and p.shape[0] > 1 \
+                    and float(p.abs().mean()) < 1e-2:
                 p.mul_(case.get("lr_scale", 1.0))
     model._max_gradient_norm = case["max_norm"]          # what fit() would set (rank_model.py:251)
     logits = []
@@ -290,6 +317,9 @@ CASES = [
     dict(name="deepfm_bn", model="DeepFM", n_dense=3, cards=CARDS[:8], embedding_dim=8,
          hidden=[32, 16], B=128, steps=4, lr=5e-2, optimizer="SGD", max_norm=10.0, seed=31,
          emb_scale=1000.0, lr_scale=1000.0, batch_norm=True),
+    dict(name="deepfm_seqpool", model="DeepFM", schema="pooled_seq", embedding_dim=8,
+         hidden=[32, 16], B=160, steps=4, lr=1e-2, optimizer="adam", max_norm=10.0, seed=37,
+         emb_scale=1000.0, lr_scale=1000.0),
     dict(name="xdeepfm_adam", model="xDeepFM", n_dense=3, cards=CARDS[:9], embedding_dim=8,
          hidden=[32, 16], cin=[12, 6, 5], B=128, steps=4, lr=1e-2, optimizer="adam", max_norm=10.0,
          seed=17, emb_scale=1000.0, lr_scale=1000.0),

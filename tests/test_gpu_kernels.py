@@ -739,3 +739,90 @@ def test_shard_plan_from_row_sorted_keys(N, B, fast):
     ops.shard_plan(dd, N, total, 8, torch.empty(N * 8, dtype=torch.int32, device=DEV), uniq_slot,
                    lookup_slot, scal2, global_keys=True, workspace=pws)
     assert int(scal2.view(torch.int32)[_lib.SC_ERR]) & _lib.FX_FLAG_A2A_OVERFLOW
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,B,lens", [(16, 4096, [50, 7]), (8, 333, [11]), (10, 100, [3, 64, 1]),
+                                      (1, 257, [5]), (64, 64, [130])])
+def test_seq_pooling_fused_into_the_gather_forward_and_backward(D, B, lens):
+    """fx_emb_seq_pool_fwd + fx_emb_grad_reduce_scaled == F.embedding -> MaskedSum/AveragePooling
+    (pooling.py:32-47, :59-70) and its autograd.  Forward tolerance 1e-6 x magnitude (fp32 sums of
+    <= 130 rows in a different order), mask/denominator bit-exact."""
+    g = torch.Generator().manual_seed(D * 1000 + B)
+    n_seq = len(lens)
+    vocabs = [37, 1000, 11][:n_seq] + [29]             # one table per sequence + one plain column
+    bases = np.concatenate([[0], np.cumsum(vocabs)[:-1]]).tolist()
+    R = int(sum(vocabs))
+    table = torch.randn(R, D, generator=g)
+    for b0 in bases:
+        table[b0].zero_()                               # padding_idx 0 of every table
+    modes = [ops.POOL_MEAN, ops.POOL_SUM, ops.POOL_MEAN][:n_seq]
+    # columns: [plain | seq 0 | seq 1 ...]; slots: seq s -> slot s, plain -> last slot
+    ids_cols, col_base, col_vocab, col_pad, col_off, col_den = [], [], [], [], [], []
+    plain = torch.randint(0, vocabs[-1], (B, 1), generator=g)
+    ids_cols.append(plain)
+    col_base.append(bases[-1]); col_vocab.append(vocabs[-1]); col_pad.append(0)
+    col_off.append(n_seq * D); col_den.append(-1)
+    seq_col0, seq_ids = [], []
+    for s, L in enumerate(lens):
+        x = torch.randint(1, vocabs[s], (B, L), generator=g)
+        n_valid = torch.randint(0, L + 1, (B,), generator=g)       # post-padded, some empty
+        x[torch.arange(L).view(1, -1) >= n_valid.view(-1, 1)] = 0
+        seq_col0.append(sum(c.shape[1] for c in ids_cols))
+        ids_cols.append(x)
+        seq_ids.append(x)
+        col_base += [bases[s]] * L; col_vocab += [vocabs[s]] * L; col_pad += [0] * L
+        col_off += [s * D] * L
+        col_den += [s if modes[s] == ops.POOL_MEAN else -1] * L
+    ids = torch.cat(ids_cols, dim=1).int()
+    C = ids.shape[1]
+    n_slots = n_seq + 1
+    scal = ops.new_scalars(DEV)
+    out = torch.full((B, n_slots * D), 9.0, device=DEV)
+    denom = torch.empty(B, n_seq, device=DEV)
+    d_tab, d_ids = _dev(table), _dev(ids)
+    d_base, d_vocab = _dev(col_base, torch.int64), _dev(col_vocab, torch.int32)
+    d_off = _dev(col_off, torch.int64)
+    ops.emb_gather_fwd(d_tab, D, d_ids, d_base, d_vocab, d_off, None, None, None, out, scal,
+                       n_cols=1)
+    ops.emb_seq_pool_fwd(d_tab, D, d_ids, d_base, d_vocab, _dev(seq_col0, torch.int32),
+                         _dev(lens, torch.int32), _dev(modes, torch.int32),
+                         _dev([s * D for s in range(n_seq)], torch.int64), out, denom, scal)
+    assert int(scal.view(torch.int32)[_lib.SC_ERR]) == 0
+    # the reference formulation, differentiable w.r.t. the table
+    W = table.clone().requires_grad_(True)
+    pieces = []
+    for s, L in enumerate(lens):
+        e = torch.nn.functional.embedding(seq_ids[s] + bases[s], W)
+        pieces.append(O.masked_average_pooling(e) if modes[s] == ops.POOL_MEAN
+                      else O.masked_sum_pooling(e))
+        mask_cnt = (e.sum(-1) != 0).float().sum(-1)
+        assert torch.equal(denom[:, s].cpu(), mask_cnt + 1e-12)
+    pieces.append(torch.nn.functional.embedding(plain[:, 0] + bases[-1], W))
+    ref = torch.stack(pieces, dim=1)
+    got = out.view(B, n_slots, D).cpu()
+    assert torch.equal(got[:, n_seq], ref[:, n_seq].detach())
+    tol = 1e-6 * max(1.0, float(ref.abs().max()))
+    assert float((got - ref.detach()).abs().max()) <= tol
+    # backward: d table through the pooled slots
+    dout = torch.randn(B, n_slots * D, generator=g)
+    ref.backward(dout.view(B, n_slots, D))
+    ws = torch.empty(ops.dedup_workspace_bytes(B * C), dtype=torch.uint8, device=DEV)
+    dd = ops.dedup(d_ids, d_base, d_vocab, _dev(col_pad, torch.int32), R, ws)
+    G = torch.zeros(dd.n_max, D, device=DEV)
+    sq = torch.empty(ops.emb_grad_reduce_partials(dd.n_max, D), device=DEV)
+    scr = torch.zeros(ops.emb_grad_reduce_scratch_ints(dd.n_max), dtype=torch.int32, device=DEV)
+    has_mean = any(j >= 0 for j in col_den)
+    ops.emb_grad_reduce(_dev(dout), n_slots * D, d_off, C, D, dd, G, sq, scr,
+                        _dev(col_den, torch.int32) if has_mean else None,
+                        denom if has_mean else None)
+    nu = int(dd.n_unique.item())
+    rows = dd.uniq_row[:nu].cpu().long()
+    gref = W.grad.clone()
+    for b0 in bases:
+        gref[b0].zero_()           # padding rows: masked by nn.Embedding(padding_idx), never sent
+    touched = torch.zeros(R, dtype=torch.bool)
+    touched[rows] = True
+    assert not (~touched).any() or float(gref[~touched].abs().max()) == 0.0
+    err = float((G[:nu].cpu() - gref[rows]).abs().max())
+    assert err <= 2e-6 * max(1.0, float(gref.abs().max())), err

@@ -85,3 +85,44 @@ def test_wiring_training_trajectory(golden, tmp_path, monkeypatch):
     sd = model.state_dict()
     for k, ref in golden.state1.items():
         assert_weights_close(sd[k].numpy(), ref, golden.meta["lr"], golden.meta["steps"], k)
+
+
+def test_pooled_sequences_are_reduced_inside_the_gather(tmp_path, monkeypatch):
+    """a sequence feature behind MaskedSum/AveragePooling takes ONE slot of the
+    gather record — the pooling launch runs, the torch encoders are never called and the record is
+    handed to the model without a stack/cat pass."""
+    g = Golden("deepfm_seqpool")
+    model = _build(g, tmp_path, monkeypatch)
+    import fuxictr_amd.layers as nat
+    import fuxictr_amd.ops as ops
+    calls = {"pool": 0, "dedup": 0}
+    real_pool, real_dedup = ops.emb_seq_pool_fwd, ops.dedup
+
+    def counting_pool(*a, **k):
+        calls["pool"] += 1
+        return real_pool(*a, **k)
+
+    def counting_dedup(*a, **k):
+        calls["dedup"] += 1
+        return real_dedup(*a, **k)
+    monkeypatch.setattr(ops, "emb_seq_pool_fwd", counting_pool)
+    monkeypatch.setattr(ops, "dedup", counting_dedup)
+
+    def never(self, *a, **k):
+        raise AssertionError("torch pooling encoder called on the native path")
+    monkeypatch.setattr(nat.MaskedAveragePooling, "forward", never)
+    monkeypatch.setattr(nat.MaskedSumPooling, "forward", never)
+    layer = model.embedding_layer.embedding_layer
+    X = model.get_inputs(tb(g.batches[0]))
+    model.train()
+    d = layer(X)
+    (rec, plan), = d._records
+    n_feats = len(g.features)
+    assert plan.n_slots == n_feats and rec.shape[1:] == (n_feats, g.meta["embedding_dim"])
+    assert d["click_sequence"].shape == d["cate_sequence"].shape == d["userid"].shape
+    assert layer.dict2tensor(d).data_ptr() == rec.data_ptr()      # the record itself, no copy
+    model.train_step(tb(g.batches[0]))
+    # per forward: 1 pooling launch for both sequences; per training forward one de-dup per table
+    # group (the LR copy does not share click_sequence's table — use_sharing=False — so its keys
+    # differ from the D=8 group's and it cannot reuse that de-dup here)
+    assert calls["pool"] == 2 and calls["dedup"] == 3, calls
