@@ -821,10 +821,12 @@ class FeatureEmbeddingDict(nn.Module):
         feature_emb_dict._orig = {f: id(t) for f, t in feature_emb_dict.items()}
         return feature_emb_dict
 
+    fuse_pooling = True     # class switch for A/B measurements (scripts/seqpool_bench.py)
+
     def _fused_pooling(self, grp, feats):
         """Sequence features of `feats` whose encoder is one of the two pooling layers: reduced
         inside the gather instead of materialising [B, L, D] for torch.sum."""
-        if _lib.row_lanes(grp.D) > 64:
+        if not self.fuse_pooling or _lib.row_lanes(grp.D) > 64:
             return None
         modes = {}
         for f in feats:
