@@ -185,7 +185,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # FX_SHARD_WORLD1=1 (debug, 1-GPU box): a 1-rank process group and the full row-sharded exchange
+    # path (all-to-all with itself, all-reduce of one) through RCCL
+    world1 = world == 1 and os.environ.get("FX_SHARD_WORLD1") == "1"
+    if world1:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or world1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "gloo":
@@ -197,7 +204,7 @@ def main():
     from fuxictr_amd.layers import FeatureDict
     cards = [max(3, int(c * args.vocab_scale)) for c in synthetic.CRITEO_CARDS]
     parallelism = "single GPU"
-    if world > 1 and not args.replicas:
+    if (world > 1 or world1) and not args.replicas:
         # row-sharded tables (row % world) + all-to-all exchange + dense all-reduce
         model, fmap, spec = build_model(args, local_rank, cards, shard="row")
         parallelism = ("tables row-sharded over %d ranks (RCCL all-to-all of ids / rows / row "

@@ -169,6 +169,7 @@ class _TableGroup(object):
         # row sharding (owner = row % world, local row = row // world)
         self.dist = _DIST
         self.n_shards = _DIST.world if _DIST is not None else 1
+        self.sharded = _DIST is not None      # (a 1-rank context is kept only by FX_SHARD_WORLD1)
         self.rank = _DIST.rank if _DIST is not None else 0
         self.rows_per_shard = 0
         self.a2a_factor = 1.5
@@ -191,7 +192,7 @@ class _TableGroup(object):
         if self.total_rows >= 2 ** 32 - 1:
             raise NotImplementedError("packed table with %d rows exceeds the 2^32-1 row limit "
                                       "of the sparse path" % self.total_rows)
-        if self.total_rows > 0 and self.n_shards > 1:
+        if self.total_rows > 0 and self.sharded:
             # local shard + one all-zero pad row (index rows_per_shard) that padded all-to-all
             # slots point at; it is never part of a de-dup result, so it is never updated
             self.rows_per_shard = -(-self.total_rows // self.n_shards)
@@ -210,7 +211,7 @@ class _TableGroup(object):
     def local_range(self, feature):
         """Rows of this rank's shard that belong to `feature` (contiguous): [lo, hi)."""
         base, V, _ = self.table_of(feature)
-        if self.n_shards == 1:
+        if not self.sharded:
             return base, base + V
         n, r = self.n_shards, self.rank
         lo = max(0, -(-(base - r) // n))
@@ -219,7 +220,7 @@ class _TableGroup(object):
 
     def local_row(self, g):
         """Local index of global packed row g if this rank owns it, else None."""
-        if self.n_shards == 1:
+        if not self.sharded:
             return g
         return g // self.n_shards if g % self.n_shards == self.rank else None
 
@@ -527,7 +528,7 @@ class _TableGroup(object):
     def flush(self):
         """exact mode: replay pending zero-gradient Adam steps for EVERY row (before eval/save)."""
         if self.exact and self.opt_kind == "adam" and self.table is not None:
-            rows = self.rows_per_shard + 1 if self.n_shards > 1 else self.total_rows
+            rows = self.rows_per_shard + 1 if self.sharded else self.total_rows
             ops.adam_catchup(self.table, self.m, self.v, self.last_step, self.D, None,
                              rows, 0, self.scal)
 
@@ -570,7 +571,7 @@ class _EmbGatherFn(torch.autograd.Function):
         D = group.D
         out = torch.empty(B, plan.n_slots * D, dtype=torch.float32, device=group.device)
         sx = None
-        if group.n_shards > 1 and plan.C:
+        if group.sharded and plan.C:
             # row-sharded: ids -> owners, rows <- owners, then the same kernels read the received
             # rows through the per-lookup slot matrix
             sx = group.shard_exchange_ids(plan, ids, inputs)
@@ -725,7 +726,7 @@ class FeatureEmbeddingDict(nn.Module):
                     for _, (base, V, pidx) in grp.tables.items():
                         if pidx is not None and grp.local_row(base + pidx) is not None:
                             grp.table[grp.local_row(base + pidx)].zero_()
-                    if grp.n_shards > 1:
+                    if grp.sharded:
                         grp.table[grp.rows_per_shard].zero_()   # the all-to-all pad row
                 if grp.num_w is not None:
                     grp.num_w.uniform_(-1.0, 1.0)
@@ -747,7 +748,7 @@ class FeatureEmbeddingDict(nn.Module):
                     continue
                 if isinstance(v, _TableView):
                     grp = self._groups[self._feat_group[k]]
-                    if grp.n_shards > 1:
+                    if grp.sharded:
                         # a shard holds every n-th row: initialise the local rows, then restore
                         # the zero padding row if this rank owns it
                         if v.weight.numel():
@@ -795,7 +796,7 @@ class FeatureEmbeddingDict(nn.Module):
             plan = grp.plan_for(feats, self._fused_pooling(grp, feats))
             ids, dense = grp.pack_inputs(plan, inputs)
             track = torch.is_grad_enabled() and self.training
-            dd = grp.prepare_train(plan, ids, inputs) if (track and grp.n_shards == 1) else None
+            dd = grp.prepare_train(plan, ids, inputs) if (track and not grp.sharded) else None
             anchor = self._anchor(grp)
             out = _EmbGatherFn.apply(anchor, grp, plan, ids, dense, dd, inputs, track)
             rec = out.view(out.shape[0], plan.n_slots, D)
@@ -1019,7 +1020,7 @@ class _LRFn(torch.autograd.Function):
         out = torch.empty(B, 1, dtype=torch.float32, device=group.device)
         num_w1 = group.select_num_w(plan)
         sx = None
-        if group.n_shards > 1 and plan.C:
+        if group.sharded and plan.C:
             sx = group.shard_exchange_ids(plan, ids, inputs)
             rows = group.shard_fetch_rows(sx, track)
             ops.lr_fwd(rows, sx.lookup_slot, sx.slot_base, sx.slot_vocab, dense, num_w1, bias,
@@ -1071,7 +1072,7 @@ class LogisticRegression(nn.Module):
         plan = grp.plan_for(feats, tail=[f for f in feats if fmap[f]["type"] == "sequence"])
         ids, dense = grp.pack_inputs(plan, X)
         track = torch.is_grad_enabled() and self.training
-        dd = grp.prepare_train(plan, ids, X) if (track and grp.n_shards == 1) else None
+        dd = grp.prepare_train(plan, ids, X) if (track and not grp.sharded) else None
         return _LRFn.apply(layer._anchor(grp), self.bias, grp, plan, ids, dense, dd, X, track)
 
 

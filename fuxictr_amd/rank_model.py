@@ -281,7 +281,10 @@ class BaseModel(nn.Module):
         if shard in ("row", True):
             from .dist import DistContext
             self._dist = DistContext()
-            if self._dist.world == 1:
+            # one rank: nothing to exchange — unless FX_SHARD_WORLD1=1 keeps the whole exchange path
+            # alive (ids / rows / gradients all-to-all with itself, all-reduce of one), which is
+            # how the RCCL code path is exercised end to end on a 1-GPU box
+            if self._dist.world == 1 and os.environ.get("FX_SHARD_WORLD1") != "1":
                 self._dist = None
         elif shard not in (None, False, "none"):
             raise ValueError("shard={} is not supported.".format(shard))

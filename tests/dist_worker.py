@@ -17,7 +17,16 @@ sys.path.insert(0, HERE)
 def run(rank, world, case, port, out_path, use_gpu):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nccl = os.environ.get("FX_TEST_BACKEND") == "nccl"      # RCCL: one rank per device only
+    if nccl:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def comm(t):            # tensors of the test's own bookkeeping collectives
+        return t.cuda() if nccl else t
     from conftest import Golden
     if not use_gpu:
         import _cpu_emul
@@ -69,7 +78,7 @@ def run(rank, world, case, port, out_path, use_gpu):
     model.train()
     losses = []
     for i in range(m["steps"]):
-        loss = model.train_step(part(g.batches[i])).detach().cpu().reshape(1).clone()
+        loss = comm(model.train_step(part(g.batches[i])).detach().cpu().reshape(1).clone())
         dist.all_reduce(loss)
         losses.append(float(loss) / world)
     model.optimizer.check_errors()
@@ -89,12 +98,15 @@ def run(rank, world, case, port, out_path, use_gpu):
         for k, v in model.state_dict().items():
             assert torch.equal(v, before[k]), k
     full = {k: v.cpu().numpy() for k, v in model.full_state_dict().items()}
+    p0, p1 = comm(p0), comm(p1)
     gp0 = [torch.empty_like(p0) for _ in range(world)]
     gp1 = [torch.empty_like(p1) for _ in range(world)]
     dist.all_gather(gp0, p0)
     dist.all_gather(gp1, p1)
+    gp0, gp1 = [t.cpu() for t in gp0], [t.cpu() for t in gp1]
     if rank == 0:
-        np.savez(out_path, losses=np.asarray(losses), pred0=torch.cat(gp0).numpy(),
+        np.savez(out_path, sharded=np.asarray([model._dist is not None]),
+                 losses=np.asarray(losses), pred0=torch.cat(gp0).numpy(),
                  pred1=torch.cat(gp1).numpy(), **{"state/" + k: v for k, v in full.items()})
     dist.barrier()
     dist.destroy_process_group()

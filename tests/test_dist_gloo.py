@@ -65,3 +65,12 @@ def test_sharded_checkpoint_files_roundtrip(tmp_path):
     g = Golden("deepfm_adam")
     z = run_workers("deepfm_adam", tmp_path, use_gpu=False, env={"FX_TEST_CKPT": "1"})
     check_against_golden(z, g)
+
+
+def test_one_rank_group_runs_the_full_exchange_path(tmp_path):
+    """FX_SHARD_WORLD1=1: a 1-rank process group keeps the sharded path (all-to-all with itself) —
+    the hook that runs the RCCL code path end to end on a 1-GPU box."""
+    g = Golden("deepfm_adam")
+    z = run_workers("deepfm_adam", tmp_path, use_gpu=False, world=1, env={"FX_SHARD_WORLD1": "1"})
+    assert bool(z["sharded"][0])
+    check_against_golden(z, g)
