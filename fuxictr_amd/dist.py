@@ -73,6 +73,10 @@ class DistContext(object):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
+        # FX_GRAPH_COLLECTIVES=1 (opt-in, RCCL only): record the collectives INTO the step's hipGraph
+        # instead of cutting it into segments around them — one graph launch per step
+        self.capture_collectives = (self.backend == "nccl"
+                                    and os.environ.get("FX_GRAPH_COLLECTIVES") == "1")
 
     def _stage(self, t):
         return self.backend == "gloo" and t.is_cuda
@@ -81,7 +85,7 @@ class DistContext(object):
         """send: [world * k, ...] -> recv of the same shape (chunk i goes to rank i)."""
         send = send.contiguous()
         recv = torch.empty_like(send)
-        if self.recorder is not None:
+        if self.recorder is not None and not self.capture_collectives:
             self.recorder.cut(lambda: self._a2a_into(recv, send))
         else:
             self._a2a_into(recv, send)
@@ -97,7 +101,7 @@ class DistContext(object):
             dist.all_to_all_single(recv, send, group=self.group)
 
     def all_reduce_sum(self, t):
-        if self.recorder is not None:
+        if self.recorder is not None and not self.capture_collectives:
             self.recorder.cut(lambda: self._all_reduce_into(t))
         else:
             self._all_reduce_into(t)
