@@ -195,6 +195,10 @@ def main():
     if world > 1 or world1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a HIP error inside ProcessGroupNCCL's watchdog thread (e.g. hipErrorCapturedEvent from an
+        # event query while a hipGraph is being captured — fuxictr_amd/dist.py keeps that from
+        # happening) must not take the benchmark down with it
+        os.environ.setdefault("TORCH_NCCL_RETHROW_CUDA_ERRORS", "0")
         if backend == "gloo":
             dist.init_process_group("gloo")
         else:

@@ -10,6 +10,7 @@ The gloo path (CPU tensors, or GPU tensors staged through the host) exists so th
 is testable with 2 processes in a GPU-less container and on a 1-GPU box.
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -19,27 +20,54 @@ class GraphSegments(object):
     """A training step with collectives, as hipGraph segments with the collectives launched eagerly
     in between: [graph 0] a2a ids [graph 1] a2a rows ... [graph k] all-reduce [graph k+1].
     Nothing about RCCL is captured; every buffer a collective touches was allocated inside the
-    capture (one memory pool shared by all segments), so its address is fixed across replays."""
+    capture (one memory pool shared by all segments), so its address is fixed across replays.
 
-    def __init__(self):
+    The eager collectives run on their own `comm` stream, never on the stream that is captured:
+    ProcessGroupNCCL's watchdog thread polls the completion event of every collective it has not
+    reaped yet (every ~100 ms), and HIP refuses a query of an event whose stream is capturing
+    (hipErrorCapturedEvent) — that kills the watchdog (and with it the process) and invalidates
+    the capture.  For the same reason `settle()` lets the watchdog reap everything launched so far
+    before a capture begins (capture time only; replays never wait)."""
+
+    def __init__(self, comm_stream=None, settle_s=0.0):
         self.pool = torch.cuda.graph_pool_handle()
         self.items = []          # CUDAGraph | callable, in program order
         self._cur = None
+        self.comm = comm_stream
+        self.settle_s = settle_s
+
+    def settle(self):
+        if self.settle_s > 0:
+            torch.cuda.synchronize()
+            time.sleep(self.settle_s)
+
+    def _eager(self, fn):
+        if self.comm is None:
+            fn()
+            return
+        cur = torch.cuda.current_stream()
+        self.comm.wait_stream(cur)
+        with torch.cuda.stream(self.comm):
+            fn()
+        cur.wait_stream(self.comm)
 
     def begin(self):
+        self.settle()
         g = torch.cuda.CUDAGraph()
-        # thread_local: API calls of OTHER threads (the ProcessGroup watchdog polling its events)
-        # must not invalidate the capture; the autograd thread's launches still land in it because
-        # capture is a property of the stream
+        # thread_local: API calls of OTHER threads must not invalidate the capture; the autograd
+        # thread's launches still land in it because capture is a property of the stream
         g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
         self._cur = g
+        delay = float(os.environ.get("FX_SEG_CAPTURE_DELAY", "0"))     # debug: widen the window
+        if delay > 0:
+            time.sleep(delay)
 
     def cut(self, fn):
         """End the current segment, run `fn` eagerly (now, and at this point of every replay),
         start the next segment."""
         self._cur.capture_end()
         self.items.append(self._cur)
-        fn()
+        self._eager(fn)
         self.items.append(fn)
         self.begin()
 
@@ -52,14 +80,14 @@ class GraphSegments(object):
         if os.environ.get("FX_SEG_DEBUG"):
             for i, it in enumerate(self.items):
                 print("[seg %d] %s" % (i, type(it).__name__), flush=True)
-                it.replay() if isinstance(it, torch.cuda.CUDAGraph) else it()
+                it.replay() if isinstance(it, torch.cuda.CUDAGraph) else self._eager(it)
                 torch.cuda.synchronize()
             return
         for it in self.items:
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
             else:
-                it()
+                self._eager(it)
 
 
 class DistContext(object):

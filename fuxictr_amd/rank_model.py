@@ -223,7 +223,9 @@ class _GraphStep(object):
             # row-sharded: hipGraph segments with the collectives launched eagerly in between
             import gc
             from .dist import GraphSegments
-            self.graph = GraphSegments()
+            nccl = model._dist.backend == "nccl"
+            self.graph = GraphSegments(comm_stream=torch.cuda.Stream(dev) if nccl else None,
+                                       settle_s=0.25 if nccl else 0.0)
             gc.collect()
             torch.cuda.empty_cache()
             cur = torch.cuda.current_stream(dev)
