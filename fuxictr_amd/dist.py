@@ -22,12 +22,13 @@ class GraphSegments(object):
     Nothing about RCCL is captured; every buffer a collective touches was allocated inside the
     capture (one memory pool shared by all segments), so its address is fixed across replays.
 
-    The eager collectives run on their own `comm` stream, never on the stream that is captured:
-    ProcessGroupNCCL's watchdog thread polls the completion event of every collective it has not
-    reaped yet (every ~100 ms), and HIP refuses a query of an event whose stream is capturing
-    (hipErrorCapturedEvent) — that kills the watchdog (and with it the process) and invalidates
-    the capture.  For the same reason `settle()` lets the watchdog reap everything launched so far
-    before a capture begins (capture time only; replays never wait)."""
+    WHILE RECORDING, the eager collectives run on their own `comm` stream, never on the stream that
+    is being captured: ProcessGroupNCCL's watchdog thread polls the completion event of every
+    collective it has not reaped yet (every ~100 ms), and HIP refuses a query of an event whose
+    stream is capturing (hipErrorCapturedEvent) — that kills the watchdog (and with it the process)
+    and invalidates the capture.  For the same reason `settle()` lets the watchdog reap everything
+    launched so far before a capture begins.  Replays launch the collectives on the replay stream
+    itself (nothing is capturing then; the two stream hops per collective cost ~25 us each)."""
 
     def __init__(self, comm_stream=None, settle_s=0.0):
         self.pool = torch.cuda.graph_pool_handle()
@@ -80,14 +81,14 @@ class GraphSegments(object):
         if os.environ.get("FX_SEG_DEBUG"):
             for i, it in enumerate(self.items):
                 print("[seg %d] %s" % (i, type(it).__name__), flush=True)
-                it.replay() if isinstance(it, torch.cuda.CUDAGraph) else self._eager(it)
+                it.replay() if isinstance(it, torch.cuda.CUDAGraph) else it()
                 torch.cuda.synchronize()
             return
         for it in self.items:
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
             else:
-                self._eager(it)
+                it()
 
 
 class DistContext(object):
