@@ -45,6 +45,16 @@ __global__ __launch_bounds__(256) void k_build_keys(const int32_t* ids, int64_t 
     }
 }
 
+__global__ __launch_bounds__(256) void k_keys_one_table(const int32_t* ids, int64_t n, int32_t vocab,
+                                                        int32_t pad, uint32_t sentinel,
+                                                        uint32_t* keys) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t id = ids[i];
+        keys[i] = (id >= 0 && id < vocab && id != pad) ? (uint32_t)id : sentinel;
+    }
+}
+
 // Fast path when every id column owns a distinct table and the tables are laid out in column
 // order: keys of column c all lie in [base_c, base_c + V_c), so sorting each column on its own
 // yields the globally sorted array (segment c = [c*B, (c+1)*B)).  Padding / bad-id lookups keep a
@@ -301,6 +311,96 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
     HeadFlag hf{sorted_key, sentinel};
     auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), hf);
     tb = tmp;
+    FX_CHECK_HIP(rocprim::inclusive_scan(temp, tb, in, scan, (size_t)n,
+                                         rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_scatter_unique, dim3((unsigned)blocks), dim3(256), 0, s, sorted_key, scan,
+                       n, sentinel, uniq_row, seg_start, n_unique, sorted_uid);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fx_dedup_sorted_runs: the keys are R consecutive runs, each already ascending (what the owner of
+// a row-sharded table receives: every peer's unique rows in ascending order, pad rows at the tail).
+// A stable merge needs no sort: the output rank of element j of run r is
+//     j + sum_{r' < r} upper_bound(run r', key) + sum_{r' > r} lower_bound(run r', key)
+// — R-1 binary searches per element in ONE launch (the generic path's rocPRIM merge sort takes a
+// block sort + ~8 merge passes, ~55-75 us for 160 K keys; this is bound by L2 latency instead).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_merge_runs(const uint32_t* __restrict__ keys, int n_runs,
+                                                    int run_len, uint32_t* __restrict__ sorted_key,
+                                                    uint32_t* __restrict__ sorted_pos) {
+    const int64_t n = (int64_t)n_runs * run_len;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / run_len);
+        const uint32_t k = keys[i];
+        uint32_t rank = (uint32_t)(i - (int64_t)r * run_len);
+        for (int q = 0; q < n_runs; ++q) {
+            if (q == r) continue;
+            const uint32_t* run = keys + (int64_t)q * run_len;
+            int lo = 0, hi = run_len;
+            if (q < r) {                       // elements <= k come first (stable: earlier run wins)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (run[mid] <= k) lo = mid + 1; else hi = mid;
+                }
+            } else {                           // elements < k come first
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (run[mid] < k) lo = mid + 1; else hi = mid;
+                }
+            }
+            rank += (uint32_t)lo;
+        }
+        sorted_key[rank] = k;
+        sorted_pos[rank] = (uint32_t)i;
+    }
+}
+
+extern "C" int fx_dedup_sorted_runs(const int32_t* ids, int32_t n_runs, int64_t run_len,
+                                    int32_t vocab, int32_t pad, void* workspace,
+                                    size_t workspace_bytes, uint32_t* sorted_key,
+                                    uint32_t* sorted_pos, uint32_t* uniq_row, uint32_t* seg_start,
+                                    int32_t* n_unique, uint32_t* sorted_uid, fx_stream_t stream) {
+    FX_CHECK_ARG(n_runs >= 1 && n_runs <= 4096 && run_len >= 0, "fx_dedup_sorted_runs: bad shape");
+    FX_CHECK_ARG(vocab > 0, "fx_dedup_sorted_runs: vocab must be > 0");
+    FX_CHECK_ARG(n_unique && seg_start, "fx_dedup_sorted_runs: null output");
+    hipStream_t s = fx_hip_stream(stream);
+    const int64_t n = (int64_t)n_runs * run_len;
+    if (n == 0) {
+        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, n_unique, 1);
+        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, reinterpret_cast<int32_t*>(seg_start), 1);
+        FX_CHECK_LAUNCH();
+        return FX_OK;
+    }
+    FX_CHECK_ARG(n < (int64_t)0x7FFFFFFF, "fx_dedup_sorted_runs: too many keys (%lld)", (long long)n);
+    FX_CHECK_ARG(ids && workspace && sorted_key && sorted_pos && uniq_row,
+                 "fx_dedup_sorted_runs: null pointer");
+    size_t sort_bytes = 0, scan_bytes = 0;
+    FX_CHECK_HIP(fx_dedup_temp_bytes(n, &sort_bytes, &scan_bytes));
+    const size_t arr = fx_align_up((size_t)n * sizeof(uint32_t), 256);
+    size_t tmp = fx_align_up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes, 256);
+    FX_CHECK_ARG(workspace_bytes >= 3 * arr + tmp,
+                 "fx_dedup_sorted_runs: workspace too small (%zu < %zu)", workspace_bytes,
+                 3 * arr + tmp);
+    char* w = reinterpret_cast<char*>(workspace);
+    uint32_t* keys_in = reinterpret_cast<uint32_t*>(w);
+    uint32_t* scan = reinterpret_cast<uint32_t*>(w + 2 * arr);
+    void* temp = w + 3 * arr;
+    const uint32_t sentinel = (uint32_t)vocab;       // = total_rows of this one-table key space
+    int64_t blocks = fx_ceil_div(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    // keys: the id itself, sentinel for pad / out-of-range ids (each run stays ascending: its pad
+    // entries sit at the tail and map to the largest key)
+    hipLaunchKernelGGL(k_keys_one_table, dim3((unsigned)blocks), dim3(256), 0, s, ids, n, vocab,
+                       pad, sentinel, keys_in);
+    hipLaunchKernelGGL(k_merge_runs, dim3((unsigned)blocks), dim3(256), 0, s, keys_in,
+                       (int)n_runs, (int)run_len, sorted_key, sorted_pos);
+    FX_CHECK_LAUNCH();
+    HeadFlag hf{sorted_key, sentinel};
+    auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), hf);
+    size_t tb = tmp;
     FX_CHECK_HIP(rocprim::inclusive_scan(temp, tb, in, scan, (size_t)n,
                                          rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(k_scatter_unique, dim3((unsigned)blocks), dim3(256), 0, s, sorted_key, scan,

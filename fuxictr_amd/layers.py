@@ -457,8 +457,9 @@ class _TableGroup(object):
                 torch.zeros(C, dtype=torch.int64, device=dev),
                 torch.full((C,), N * cap + 1, dtype=torch.int32, device=dev))
         sx.own_base, sx.own_vocab, sx.own_pad, sx.slot_base, sx.slot_vocab = consts
-        sx.owner_dd = ops.dedup(sx.recv_idx, sx.own_base, sx.own_vocab, sx.own_pad, rps + 1,
-                                self.owner_ws[1])
+        # what arrived is N ascending runs (each peer's unique rows of this shard, pad rows at the
+        # tail): merged by rank counting, no device sort
+        sx.owner_dd = ops.dedup_sorted_runs(sx.recv_idx, N, rps + 1, rps, self.owner_ws[1])
         if cache is not None:
             cache[ckey] = sx
         return sx

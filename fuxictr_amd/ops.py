@@ -175,6 +175,23 @@ def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=N
     return result
 
 
+def dedup_sorted_runs(ids, n_runs, vocab, pad, workspace, result=None):
+    """De-dup of `n_runs` consecutive ascending runs of ids of one table (rows [0, vocab), `pad`
+    marks empty entries at each run's tail): a merge by rank counting, no sort."""
+    lib = _lib.load()
+    n = ids.numel()
+    assert ids.is_contiguous() and n % n_runs == 0
+    if result is None:
+        result = DedupResult(n, 1, ids.device)
+    check(lib.fx_dedup_sorted_runs(ptr(ids), n_runs, n // n_runs, vocab, pad, ptr(workspace),
+                                   workspace.numel(), ptr(result.sorted_key),
+                                   ptr(result.sorted_pos), ptr(result.uniq_row),
+                                   ptr(result.seg_start), ptr(result.n_unique),
+                                   ptr(result.sorted_uid), stream_ptr(ids.device)),
+          "fx_dedup_sorted_runs")
+    return result
+
+
 def shard_plan_workspace_ints(n_lookups, n_shards):
     return int(_lib.load().fx_shard_plan_workspace_ints(n_lookups, n_shards))
 

@@ -138,6 +138,18 @@ int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
              uint32_t* sorted_pos, uint32_t* uniq_row, uint32_t* seg_start, int32_t* n_unique,
              uint32_t* sorted_uid, int32_t n_shards, int32_t columns_sorted, fx_stream_t stream);
 
+/* The same de-dup for keys that arrive as n_runs consecutive runs of run_len ids of ONE table
+ * (rows [0, vocab), `pad` = the id that means "nothing"), each run ascending with its pad entries at
+ * the tail — what the owner of a row-sharded table receives from its peers (fx_shard_plan's
+ * send_idx).  A stable R-way merge by rank counting replaces the sort; outputs exactly as fx_dedup
+ * (sorted_pos = index into ids; sentinel key = vocab).  Runs that are not ascending give an
+ * unspecified (but memory-safe) result.  Workspace: fx_dedup_workspace_bytes(n_runs * run_len). */
+int fx_dedup_sorted_runs(const int32_t* ids, int32_t n_runs, int64_t run_len, int32_t vocab,
+                         int32_t pad, void* workspace, size_t workspace_bytes,
+                         uint32_t* sorted_key, uint32_t* sorted_pos, uint32_t* uniq_row,
+                         uint32_t* seg_start, int32_t* n_unique, uint32_t* sorted_uid,
+                         fx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Row-sharded tables (new functionality: the reference has no multi-GPU path).
  * With the packed table sharded row-wise over n_shards ranks (owner = row % n_shards, local row =

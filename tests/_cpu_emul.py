@@ -480,6 +480,18 @@ def cin_bwd(X0, Xi, W, dXn, dpool, dX0, accumulate_dx0, dXi, partial):
     partial[0, O * F0 * Mi:] = g.sum((0, 2))
 
 
+def dedup_sorted_runs(ids, n_runs, vocab, pad, workspace, result=None):
+    flat = ids.reshape(-1)
+    run_len = flat.numel() // n_runs
+    for r in range(n_runs):            # the precondition of the merge: every run ascending
+        run = flat[r * run_len:(r + 1) * run_len].long()
+        k = torch.where((run >= 0) & (run < vocab) & (run != pad), run, torch.full_like(run, vocab))
+        assert bool((k[1:] >= k[:-1]).all()), "run %d is not ascending" % r
+    return dedup(flat.view(-1, 1), torch.zeros(1, dtype=torch.int64),
+                 torch.tensor([vocab], dtype=torch.int32), torch.tensor([pad], dtype=torch.int32),
+                 vocab, workspace, result=result)
+
+
 class KernelTimer(object):
     enabled = False
 
@@ -492,7 +504,7 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "sum_parts", "din_concat_fwd", "din_concat_bwd", "din_pool_fwd", "din_pool_bwd",
          "dice_workspace_floats", "dice_fwd", "dice_bwd", "dot_interact_fwd", "dot_interact_bwd",
          "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update",
-         "shard_plan_workspace_ints", "emb_seq_pool_fwd"]
+         "shard_plan_workspace_ints", "emb_seq_pool_fwd", "dedup_sorted_runs"]
 
 
 def install_plain():

@@ -826,3 +826,34 @@ def test_seq_pooling_fused_into_the_gather_forward_and_backward(D, B, lens):
     assert not (~touched).any() or float(gref[~touched].abs().max()) == 0.0
     err = float((G[:nu].cpu() - gref[rows]).abs().max())
     assert err <= 2e-6 * max(1.0, float(gref.abs().max())), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,L,vocab", [(8, 19968, 4220326), (2, 5000, 70001), (1, 777, 50),
+                                       (3, 1, 10), (8, 300, 40)])
+def test_dedup_sorted_runs_equals_the_generic_sort_path(R, L, vocab):
+    """fx_dedup_sorted_runs (merge by rank counting) == fx_dedup (stable rocPRIM sort) on the same
+    keys, every output array bit for bit: R ascending runs with duplicates ACROSS runs, pad ids at
+    the tails, empty and full runs."""
+    rng = np.random.default_rng(R * 1000 + L)
+    pad = vocab - 1                                   # the shard's pad row
+    runs = []
+    for r in range(R):
+        n_valid = [0, L][r] if r < 2 and L > 1 else int(rng.integers(0, L + 1))
+        n_valid = min(n_valid, vocab - 1)
+        vals = np.sort(rng.choice(vocab - 1, size=n_valid, replace=False)) if n_valid else \
+            np.zeros(0, dtype=np.int64)
+        runs.append(np.concatenate([vals, np.full(L - n_valid, pad)]))
+    ids = _dev(np.concatenate(runs), torch.int32)
+    n = R * L
+    ws = torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    a = ops.dedup_sorted_runs(ids, R, vocab, pad, ws)
+    b = ops.dedup(ids.view(-1, 1), _dev([0], torch.int64), _dev([vocab], torch.int32),
+                  _dev([pad], torch.int32), vocab, ws)
+    nu = int(b.n_unique.item())
+    assert int(a.n_unique.item()) == nu
+    assert torch.equal(a.sorted_key, b.sorted_key) and torch.equal(a.sorted_pos, b.sorted_pos)
+    assert torch.equal(a.uniq_row[:nu], b.uniq_row[:nu])
+    assert torch.equal(a.seg_start[:nu + 1], b.seg_start[:nu + 1])
+    ref = np.unique(np.concatenate([r_[r_ != pad] for r_ in runs]))
+    assert np.array_equal(a.uniq_row[:nu].cpu().numpy().astype(np.int64), ref)
