@@ -130,6 +130,19 @@ def _unit_grad(device):
     return g
 
 
+_SCALED_GRADS = {}
+
+
+def _scaled_grad(device, world):
+    """Persistent 1/world root gradient of the sharded step (global-batch mean = mean of the ranks'
+    local means): one multiply in the loss backward instead of div + ones_like + div-backward."""
+    g = _SCALED_GRADS.get((device, world))
+    if g is None:
+        g = _SCALED_GRADS[(device, world)] = torch.full((), 1.0 / world, dtype=torch.float32,
+                                                        device=device)
+    return g
+
+
 class _SigmoidBCEFn(torch.autograd.Function):
     """loss = mean BCE(sigmoid(logit), y); forward also produces dloss/dlogit."""
 
@@ -520,7 +533,10 @@ class BaseModel(nn.Module):
         loss = self.compute_loss(return_dict, y_true)
         if self._dist is not None:
             # global-batch mean = mean of the ranks' local means: scale, then SUM-reduce grads
-            (loss / self._dist.world).backward()
+            if self._dist.world == 1:
+                loss.backward(gradient=_unit_grad(loss.device))
+            else:
+                loss.backward(gradient=_scaled_grad(loss.device, self._dist.world))
         else:
             loss.backward(gradient=_unit_grad(loss.device))
         opt.step()  # global-norm clip (rank_model.py:321) is fused into the update kernels
