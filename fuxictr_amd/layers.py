@@ -16,7 +16,6 @@ into libfxctr.so (include/fxctr.h):
 
 torch is used for device memory, streams, nn.Module bookkeeping and the autograd tape only.
 """
-import os
 from collections import OrderedDict
 from functools import partial  # noqa: F401  (used by eval'ed initializer strings)
 
@@ -347,12 +346,6 @@ class _TableGroup(object):
                        self.dedup_ws[1], columns_sorted=plan.columns_sorted)
         if cache is not None:
             cache[ckey] = dd
-            if ids.is_cuda:
-                # fork point for work that only needs the de-dup (the LR copy's catch-up + lookup
-                # run on a side stream from here, beside the embedding layer's own kernels)
-                ev = torch.cuda.Event()
-                ev.record()
-                cache[("dedup_ev",) + ckey[1:]] = ev
         return dd
 
     def select_num_w(self, plan):
@@ -1080,52 +1073,8 @@ class LogisticRegression(nn.Module):
         plan = grp.plan_for(feats, tail=[f for f in feats if fmap[f]["type"] == "sequence"])
         ids, dense = grp.pack_inputs(plan, X)
         track = torch.is_grad_enabled() and self.training
-        side = self._side_stream(grp, plan, X, track)
-        if side is None:
-            dd = grp.prepare_train(plan, ids, X) if (track and not grp.sharded) else None
-            return _LRFn.apply(layer._anchor(grp), self.bias, grp, plan, ids, dense, dd, X, track)
-        # The first-order term is a chain of tiny launches (catch-up, lookup; in backward two
-        # run-reduces, a norm, the numeric gradients) that leave most of the chip idle: it runs on
-        # a side stream, forked right after the shared de-dup, next to the embedding layer's own
-        # catch-up / gather — and autograd runs its backward on that same stream, next to the
-        # embedding backward.  Joined before anyone reads the result.
-        main = torch.cuda.current_stream(grp.device)
-        with torch.cuda.stream(side):
-            dd = grp.prepare_train(plan, ids, X)
-            out = _LRFn.apply(layer._anchor(grp), self.bias, grp, plan, ids, dense, dd, X, track)
-        main.wait_stream(side)
-        return out
-
-    overlap = os.environ.get("FX_LR_OVERLAP", "1") == "1"
-    _streams = {}
-
-    def _side_stream(self, grp, plan, X, track):
-        """The side stream for this forward, already waiting on the batch's de-dup — or None when
-        there is nothing to overlap with (eval, row-sharded exchange, CPU emulation)."""
-        if not (self.overlap and track and not grp.sharded and grp.device.type == "cuda"):
-            return None
-        cache = getattr(X, "cache", None)
-        ev = None if cache is None else cache.get(("dedup_ev", plan.sig, grp.total_rows))
-        if ev is None:
-            return None               # the de-dup has not been computed by another layer
-        side = LogisticRegression._streams.get(grp.device)
-        if side is None:
-            side = LogisticRegression._streams[grp.device] = torch.cuda.Stream(grp.device)
-        side.wait_event(ev)
-        LogisticRegression._dirty[grp.device] = True
-        return side
-
-    _dirty = {}
-
-
-def join_side_streams():
-    """Make the current stream wait for side-stream work of this step (LogisticRegression's
-    backward runs on its forward's stream; its row gradients are side effects autograd does not
-    know about).  Called by the optimizer before it reads any gradient."""
-    for dev, side in LogisticRegression._streams.items():
-        if LogisticRegression._dirty.get(dev):
-            torch.cuda.current_stream(dev).wait_stream(side)
-            LogisticRegression._dirty[dev] = False
+        dd = grp.prepare_train(plan, ids, X) if (track and not grp.sharded) else None
+        return _LRFn.apply(layer._anchor(grp), self.bias, grp, plan, ids, dense, dd, X, track)
 
 
 class _FMFn(torch.autograd.Function):

@@ -16,7 +16,7 @@ rank_model.py:221-234) and zero_grad() keep working.
 import torch
 
 from . import _lib, ops
-from .layers import FeatureEmbeddingDict, finish_shard_backward, join_side_streams
+from .layers import FeatureEmbeddingDict, finish_shard_backward
 
 
 class _NativeOptimizer(torch.optim.Optimizer):
@@ -203,7 +203,6 @@ class _NativeOptimizer(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closure is not supported by the native optimizer")
-        join_side_streams()                 # the LR copy's backward may still run beside this stream
         if self.dist is not None:           # row-gradient all-to-all(s) + owner-side reduction
             finish_shard_backward([grp for grp in self._groups if grp.dist is not None])
         ps, gs = self._dense_lists()
