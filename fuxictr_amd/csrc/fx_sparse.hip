@@ -11,6 +11,7 @@
 // a batch touches.  All reductions use a fixed order (stable sort by row, ascending lookup
 // position inside a run, fixed trees) so results are run-to-run deterministic.
 #include "fx_common.h"
+#include <stdlib.h>
 
 #include <rocprim/rocprim.hpp>
 
@@ -463,20 +464,19 @@ __device__ __forceinline__ void fx_accum_lookup(const ReduceArgs& a, uint32_t i,
     for (int k = 0; k < VEC; ++k) acc[k] += v[k];
 }
 
-// four lookups in flight per lane (positions first, then the four independent row loads), summed
-// in ascending order: same result as the one-at-a-time loop, ~4x fewer dependent latencies
-template <int VEC, bool SCALED>
-__device__ __forceinline__ void fx_accum_run(const ReduceArgs& a, uint32_t beg, uint32_t end,
-                                             uint32_t stride, int d0, float (&acc)[VEC]) {
-    uint32_t i = beg;
-    for (; i + 3 * stride < end; i += 4 * stride) {
-        uint32_t p[4];
+// N lookups in flight per lane (positions first, then the N independent row loads), summed in
+// ascending order: same result as the one-at-a-time loop with ~N x fewer dependent latencies.
+template <int VEC, bool SCALED, int N>
+__device__ __forceinline__ uint32_t fx_accum_chunks(const ReduceArgs& a, uint32_t i, uint32_t end,
+                                                    uint32_t stride, int d0, float (&acc)[VEC]) {
+    for (; i + (N - 1) * stride < end; i += N * stride) {
+        uint32_t p[N];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p[j] = a.sorted_pos[i + j * stride];
-        float v[4][VEC];
+        for (int j = 0; j < N; ++j) p[j] = a.sorted_pos[i + j * stride];
+        float v[N][VEC];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (p[j] == 0xFFFFFFFFu) {
+        for (int j = 0; j < N; ++j) {
+            if (p[j] == 0xFFFFFFFFu) {   // padding_idx / bad-id lookup: contributes nothing
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) v[j][k] = 0.f;
                 continue;
@@ -484,14 +484,26 @@ __device__ __forceinline__ void fx_accum_run(const ReduceArgs& a, uint32_t beg, 
             fx_load_lookup<VEC, SCALED>(a, p[j], d0, v[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < N; ++j)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] += v[j][k];
     }
-    for (; i < end; i += stride) fx_accum_lookup<VEC, SCALED>(a, i, d0, acc);
+    return i;
 }
 
-template <int VEC, bool SCALED>
+// a run in chunks of INFL lookups, the remainder in halving chunks (INFL/2, ..., 1): at most
+// log2(INFL) extra dependent rounds whatever the run length
+template <int VEC, bool SCALED, int INFL>
+__device__ __forceinline__ void fx_accum_run(const ReduceArgs& a, uint32_t beg, uint32_t end,
+                                             uint32_t stride, int d0, float (&acc)[VEC]) {
+    uint32_t i = fx_accum_chunks<VEC, SCALED, INFL>(a, beg, end, stride, d0, acc);
+    if constexpr (INFL >= 16) i = fx_accum_chunks<VEC, SCALED, 8>(a, i, end, stride, d0, acc);
+    if constexpr (INFL >= 8) i = fx_accum_chunks<VEC, SCALED, 4>(a, i, end, stride, d0, acc);
+    if constexpr (INFL >= 4) i = fx_accum_chunks<VEC, SCALED, 2>(a, i, end, stride, d0, acc);
+    if constexpr (INFL >= 2) fx_accum_chunks<VEC, SCALED, 1>(a, i, end, stride, d0, acc);
+}
+
+template <int VEC, bool SCALED, int INFL>
 __global__ __launch_bounds__(256) void k_emb_grad_reduce_short(ReduceArgs a) {
     const int lanes = 1 << a.lanes_log2;
     const int rpb = 256 >> a.lanes_log2;
@@ -509,11 +521,11 @@ __global__ __launch_bounds__(256) void k_emb_grad_reduce_short(ReduceArgs a) {
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-    fx_accum_run<VEC, SCALED>(a, beg, end, 1u, d0, acc);
+    fx_accum_run<VEC, SCALED, INFL>(a, beg, end, 1u, d0, acc);
     fx_store<VEC>(a.G + u * a.D + d0, acc);
 }
 
-template <int VEC, bool SCALED>
+template <int VEC, bool SCALED, int INFL>
 __global__ __launch_bounds__(256) void k_emb_grad_reduce_long(ReduceArgs a) {
     __shared__ float red[256 * VEC];
     const int lanes = 1 << a.lanes_log2;
@@ -529,7 +541,7 @@ __global__ __launch_bounds__(256) void k_emb_grad_reduce_long(ReduceArgs a) {
         float part[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) part[k] = 0.f;
-        if (lane_on) fx_accum_run<VEC, SCALED>(a, beg + grp, end, (uint32_t)rpb, d0, part);
+        if (lane_on) fx_accum_run<VEC, SCALED, INFL>(a, beg + grp, end, (uint32_t)rpb, d0, part);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) red[k * 256 + threadIdx.x] = part[k];
         __syncthreads();
@@ -613,10 +625,24 @@ extern "C" int fx_emb_grad_reduce_scaled(const float* dout, int64_t dout_ld,
     // hipMemsetAsync was observed not to be ordered before the kernels that follow it)
     const int64_t blocks = fx_ceil_div(n_max, 256 / g.lanes);
     dim3 grid((unsigned)blocks), grid_long(512);
-#define FX_REDUCE_LAUNCH(V, S)                                                           \
-    hipLaunchKernelGGL((k_emb_grad_reduce_short<V, S>), grid, dim3(256), 0, s, a);       \
-    hipLaunchKernelGGL((k_emb_grad_reduce_long<V, S>), grid_long, dim3(256), 0, s, a);   \
+#define FX_REDUCE_LAUNCH_I(V, S, IS, IL)                                                     \
+    hipLaunchKernelGGL((k_emb_grad_reduce_short<V, S, IS>), grid, dim3(256), 0, s, a);          \
+    hipLaunchKernelGGL((k_emb_grad_reduce_long<V, S, IL>), grid_long, dim3(256), 0, s, a);      \
     hipLaunchKernelGGL(k_rows_sqnorm<V>, grid, dim3(256), 0, s, a);
+    // lookups in flight per lane group: experiment switch FX_REDUCE_INFLIGHT = "<short><long>" code
+    static const int infl = []() {
+        const char* e = getenv("FX_REDUCE_INFLIGHT");
+        return e ? atoi(e) : 0;
+    }();
+#define FX_REDUCE_LAUNCH(V, S)                                                                  \
+    switch (infl) {                                                                             \
+        case 44: { FX_REDUCE_LAUNCH_I(V, S, 4, 4) } break;                                      \
+        case 48: { FX_REDUCE_LAUNCH_I(V, S, 4, 8) } break;                                      \
+        case 416: { FX_REDUCE_LAUNCH_I(V, S, 4, 16) } break;                                    \
+        case 88: { FX_REDUCE_LAUNCH_I(V, S, 8, 8) } break;                                      \
+        case 816: { FX_REDUCE_LAUNCH_I(V, S, 8, 16) } break;                                    \
+        default: { FX_REDUCE_LAUNCH_I(V, S, 4, 4) } break;                                      \
+    }
     if (scaled) {
         if (g.vec == 4) { FX_REDUCE_LAUNCH(4, true) }
         else if (g.vec == 2) { FX_REDUCE_LAUNCH(2, true) }
@@ -626,6 +652,7 @@ extern "C" int fx_emb_grad_reduce_scaled(const float* dout, int64_t dout_ld,
         else if (g.vec == 2) { FX_REDUCE_LAUNCH(2, false) }
         else { FX_REDUCE_LAUNCH(1, false) }
     }
+#undef FX_REDUCE_LAUNCH_I
 #undef FX_REDUCE_LAUNCH
     FX_CHECK_LAUNCH();
     return FX_OK;
