@@ -396,8 +396,8 @@ __device__ __forceinline__ void fx_static_for(F&& f) {
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int BM, int BN, bool A_KC, bool B_KC, int W = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
 void k_gemm_f32_pipe(GemmArgs a) {
     using LoaderA = PipeLoader<BM, A_KC>;
     using LoaderB = PipeLoader<BN, B_KC>;
@@ -599,7 +599,22 @@ void k_gemm_f32_pipe(GemmArgs a) {
 
 template <int BM, int BN, bool A_KC, bool B_KC>
 static int fx_gemm_launch_pipe(dim3 grid, hipStream_t s, const GemmArgs& a) {
-    hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC>), grid, dim3(256), 0, s, a);
+    if constexpr (BM * BN <= 64 * 64) {
+        // 64x64 tiles need ~110 VGPRs: 4 waves/SIMD = 4 workgroups per CU (LDS 4 x 34 KB), so the
+        // 1024 tiles of a 4096 x 1024 layer are all resident in ONE round (2 per CU took two)
+        static const int w = []() {   // FX_GEMM_W64=2|3|4 (experiments)
+            const char* e = getenv("FX_GEMM_W64");
+            return e ? atoi(e) : 4;
+        }();
+        if (w == 2)
+            hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, 2>), grid, dim3(256), 0, s, a);
+        else if (w == 3)
+            hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, 3>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, 4>), grid, dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, 2>), grid, dim3(256), 0, s, a);
+    }
     return FX_OK;
 }
 
