@@ -629,20 +629,9 @@ extern "C" int fx_emb_grad_reduce_scaled(const float* dout, int64_t dout_ld,
     hipLaunchKernelGGL((k_emb_grad_reduce_short<V, S, IS>), grid, dim3(256), 0, s, a);          \
     hipLaunchKernelGGL((k_emb_grad_reduce_long<V, S, IL>), grid_long, dim3(256), 0, s, a);      \
     hipLaunchKernelGGL(k_rows_sqnorm<V>, grid, dim3(256), 0, s, a);
-    // lookups in flight per lane group: experiment switch FX_REDUCE_INFLIGHT = "<short><long>" code
-    static const int infl = []() {
-        const char* e = getenv("FX_REDUCE_INFLIGHT");
-        return e ? atoi(e) : 0;
-    }();
-#define FX_REDUCE_LAUNCH(V, S)                                                                  \
-    switch (infl) {                                                                             \
-        case 44: { FX_REDUCE_LAUNCH_I(V, S, 4, 4) } break;                                      \
-        case 48: { FX_REDUCE_LAUNCH_I(V, S, 4, 8) } break;                                      \
-        case 416: { FX_REDUCE_LAUNCH_I(V, S, 4, 16) } break;                                    \
-        case 88: { FX_REDUCE_LAUNCH_I(V, S, 8, 8) } break;                                      \
-        case 816: { FX_REDUCE_LAUNCH_I(V, S, 8, 16) } break;                                    \
-        default: { FX_REDUCE_LAUNCH_I(V, S, 4, 4) } break;                                      \
-    }
+    // lookups in flight per lane group: 4 for the short runs, 8 for the workgroup-per-row kernel
+    // (scripts/reduce_bench.py: 31.5 -> 29.0 us for the three launches at D=16; deeper changes nothing)
+#define FX_REDUCE_LAUNCH(V, S) FX_REDUCE_LAUNCH_I(V, S, 4, 8)
     if (scaled) {
         if (g.vec == 4) { FX_REDUCE_LAUNCH(4, true) }
         else if (g.vec == 2) { FX_REDUCE_LAUNCH(2, true) }

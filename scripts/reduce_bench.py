@@ -1,6 +1,6 @@
 """Micro-benchmark of fx_emb_grad_reduce on the c2 id distribution (26 Criteo-cardinality columns,
 B = 4096, power-law ids): HIP-event time of the three launches for D = 16 and D = 1.
-usage: FX_REDUCE_INFLIGHT=<code> python scripts/reduce_bench.py"""
+usage: python scripts/reduce_bench.py    (DIST=uniform for the no-hot-row case)"""
 import os
 import sys
 
@@ -43,6 +43,4 @@ for D in (16, 1):
         ops.emb_grad_reduce(dout, n_slots * D, offs, 26, D, dd, G, sq, scr)
     e1.record()
     torch.cuda.synchronize()
-    print("INFLIGHT=%s D=%d: %.2f us per call (3 launches)  checksum %.6f" %
-          (os.environ.get("FX_REDUCE_INFLIGHT", "default"), D, e0.elapsed_time(e1) * 1e3 / n,
-           float(G[:nu].double().sum())))
+    print("D=%d: %.2f us per call (3 launches)" % (D, e0.elapsed_time(e1) * 1e3 / n))
