@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ counters of fx_gemm_f32 vs the rocBLAS/hipBLASLt fp32 kernel torch.mm picks, on the tower shapes
 # (scripts/gemm_vs_blas.py): one rocprofv3 --pmc pass (8 SQ slots), kernel-trace only.
+# Keep it to these 8: a pass with GRBM_GUI_ACTIVE + SQ_WAVES added (10 counters) never returned on the GPU box.
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 CTRS="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
 rm -rf /tmp/pmc_gemm
