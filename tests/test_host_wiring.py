@@ -126,3 +126,102 @@ def test_pooled_sequences_are_reduced_inside_the_gather(tmp_path, monkeypatch):
     # group (the LR copy does not share click_sequence's table — use_sharing=False — so its keys
     # differ from the D=8 group's and it cannot reuse that de-dup here)
     assert calls["pool"] == 2 and calls["dedup"] == 3, calls
+
+
+MIXED_SEQ_SPEC = {
+    "dataset_id": "mix", "num_fields": 7, "total_features": 0, "input_length": 0, "labels": ["y"],
+    "features": [
+        {"first": {"source": "", "type": "sequence", "padding_idx": 0, "vocab_size": 14,
+                   "max_len": 3, "feature_encoder": "layers.MaskedAveragePooling()"}},
+        {"price": {"source": "", "type": "numeric"}},
+        {"item": {"source": "", "type": "categorical", "padding_idx": 0, "vocab_size": 31}},
+        {"hist_mean": {"source": "", "type": "sequence", "padding_idx": 0, "vocab_size": 31,
+                       "max_len": 6, "share_embedding": "item",
+                       "feature_encoder": "layers.MaskedAveragePooling()"}},
+        {"hist_raw": {"source": "", "type": "sequence", "padding_idx": 0, "vocab_size": 31,
+                      "max_len": 4, "share_embedding": "item", "feature_encoder": None}},
+        {"one": {"source": "", "type": "sequence", "padding_idx": 0, "vocab_size": 9, "max_len": 1,
+                 "feature_encoder": "layers.MaskedSumPooling()"}},
+        {"user": {"source": "", "type": "categorical", "vocab_size": 12}},
+        {"tags": {"source": "", "type": "sequence", "padding_idx": 0, "vocab_size": 17, "max_len": 9,
+                  "feature_encoder": "layers.MaskedAveragePooling()"}},
+    ]}
+
+
+@pytest.mark.parametrize("D", [10, 8, 3])
+def test_mixed_pooled_and_raw_sequences_forward_and_row_gradients(D, tmp_path, monkeypatch):
+    """Plan logic of SURVEY.md 8f-3 at the layer level, on the kernel emulation: mean-/sum-pooled
+    histories (one sharing the item table, one of length 1, one after the last plain column), a raw
+    [B, L, D] history (DIN style) and plain fields in ONE table group — every entry of the returned
+    dict and the reduced per-row gradients equal torch's embedding + pooling + autograd."""
+    _cpu_emul.install(monkeypatch)
+    import fuxictr_amd.layers as nat
+    from fuxictr_amd.features import FeatureMap
+    fmap = FeatureMap("mix", str(tmp_path))
+    fmap.load_dict(MIXED_SEQ_SPEC, {"embedding_dim": D})
+    layer = nat.FeatureEmbeddingDict(fmap, D, embedding_initializer="partial(nn.init.normal_, std=0.5)")
+    (grp,) = layer.table_groups()
+    grp.opt_kind = "sgd"                      # what the optimizer would set: de-dup the lookups
+    gen = torch.Generator().manual_seed(D)
+    B = 37
+    X = {}
+    for item in MIXED_SEQ_SPEC["features"]:
+        (name, fs), = item.items()
+        if fs["type"] == "numeric":
+            X[name] = torch.rand(B, generator=gen)
+        elif fs["type"] == "sequence":
+            ids = torch.randint(1, fs["vocab_size"], (B, fs["max_len"]), generator=gen)
+            keep = torch.randint(0, fs["max_len"] + 1, (B,), generator=gen)
+            ids[torch.arange(fs["max_len"]).view(1, -1) >= keep.view(-1, 1)] = 0
+            X[name] = ids
+        else:
+            X[name] = torch.randint(0, fs["vocab_size"], (B,), generator=gen)
+    layer.train()
+    out = layer(nat.FeatureDict(X))
+    # torch reference on leaf copies of the same tables
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    feats = {k: v for it in MIXED_SEQ_SPEC["features"] for k, v in it.items()}
+    owner = {"hist_mean": "item", "hist_raw": "item"}
+    ref = {}
+    for name, fs in feats.items():
+        w = sd["embedding_layers.%s.weight" % owner.get(name, name)]
+        if fs["type"] == "numeric":
+            ref[name] = X[name].view(-1, 1) * w.view(1, -1)
+            continue
+        e = torch.nn.functional.embedding(X[name], w, padding_idx=fs.get("padding_idx"))
+        enc = fs.get("feature_encoder")
+        if enc == "layers.MaskedAveragePooling()":
+            e = e.sum(1) / ((e.sum(-1) != 0).float().sum(-1, keepdim=True) + 1e-12)
+        elif enc == "layers.MaskedSumPooling()":
+            e = e.sum(1)
+        ref[name] = e
+    assert list(out.keys()) == list(ref.keys())
+    (rec, plan), = out._records
+    assert plan.n_slots == 7 + 4 and set(plan.pooled) == {"first", "hist_mean", "one", "tags"}
+    assert plan.slot["first"] == (0, 1) and plan.slot["hist_raw"] == (4, 4)     # slots: feature order
+    assert [f for f, _ in plan.id_feats] == ["item", "hist_raw", "user",          # pooled ids last
+                                             "first", "hist_mean", "one", "tags"]
+    for name in ref:
+        assert out[name].shape == ref[name].shape, name
+        np.testing.assert_allclose(out[name].detach().numpy(), ref[name].detach().numpy(),
+                                   atol=1e-6, err_msg=name)
+    # backward: random cotangents on every entry
+    cot = {n: torch.randn(ref[n].shape, generator=gen) for n in ref}
+    sum((out[n] * cot[n]).sum() for n in ref).backward()
+    sum((ref[n] * cot[n]).sum() for n in ref).backward()
+    (pend,) = grp.pending
+    nu = int(pend.dd.n_unique)
+    rows = pend.dd.uniq_row[:nu].long()
+    dense = torch.zeros(grp.total_rows, D)
+    for name, (base, V, pidx) in grp.tables.items():
+        g = sd["embedding_layers.%s.weight" % name].grad.clone()
+        if pidx is not None:
+            g[pidx].zero_()
+        dense[base:base + V] = g
+    np.testing.assert_allclose(pend.G[:nu].numpy(), dense[rows].numpy(), atol=2e-6)
+    untouched = torch.ones(grp.total_rows, dtype=torch.bool)
+    untouched[rows] = False
+    assert float(dense[untouched].abs().max()) == 0.0
+    np.testing.assert_allclose(grp.num_grad.reshape(-1).numpy(),
+                               sd["embedding_layers.price.weight"].grad.reshape(-1).numpy(),
+                               atol=2e-6)
