@@ -678,13 +678,35 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_wide(GemmArgs a) {
         const int64_t m = i / a.N, n = i - m * a.N;
         a.C[m * a.ldc + n] = fx_epilogue(a.epi, red[ii], m, n);
     }
-    if (a.epi.rowsum && blockIdx.x == 0) {
+    if (a.epi.rowsum && blockIdx.x == 0) {     // block-uniform
+        // fused bias gradient: rowsum[m] = sum over the slabs' row sums.  With hundreds of slabs a
+        // one-thread-per-row loop is a chain of dependent loads (64 us for 256 slabs): all 256
+        // threads work, Mp (= pow2 >= M, M <= 256) rows x 256/Mp slab lanes, same fixed LDS tree
         const float* rs = a.ws + (int64_t)a.split_k * total;
-        for (int64_t m = threadIdx.x; m < a.M; m += 256) {
-            float r = 0.f;
-            for (int z = 0; z < a.split_k; ++z) r += rs[(int64_t)z * a.M + m];
-            a.epi.rowsum[m] = r;
+        int mp_log2 = 0;
+        while ((1 << mp_log2) < a.M) ++mp_log2;
+        const int Mp = 1 << mp_log2, ZR = 256 >> mp_log2;
+        const int m = threadIdx.x & (Mp - 1), zr = threadIdx.x >> mp_log2;
+        __syncthreads();                         // red[] is reused: the output tree is fully read
+        float r = 0.f;
+        if (m < a.M) {
+            int z = zr;
+            for (; z + 7 * ZR < a.split_k; z += 8 * ZR) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = rs[(int64_t)(z + u * ZR) * a.M + m];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r += v[u];
+            }
+            for (; z < a.split_k; z += ZR) r += rs[(int64_t)z * a.M + m];
         }
+        red[threadIdx.x] = r;
+        __syncthreads();
+        for (int h = ZR >> 1; h > 0; h >>= 1) {
+            if (zr < h) red[threadIdx.x] += red[threadIdx.x + h * Mp];
+            __syncthreads();
+        }
+        if (zr == 0 && m < a.M) a.epi.rowsum[m] = red[m];
     }
 }
 
