@@ -602,6 +602,36 @@ class _EmbGatherFn(torch.autograd.Function):
         return None, None, None, None, None, None, None, None
 
 
+class _SplitRecordFn(torch.autograd.Function):
+    """The per-feature views of a gather record [B, n_slots, D] as ONE autograd node.  Plain
+    slicing would give every view its own SliceBackward — a zero-filled record-sized gradient plus a
+    copy per view, and an add per extra view — when a model reads the dict entry by entry (DIN:
+    ~10 record-sized launches per step).  Here the backward concatenates the views' gradients
+    (zeros for unused ones) into the record's gradient in one launch.  When the model takes the
+    whole record instead (dict2tensor fast path) this node is never reached."""
+
+    @staticmethod
+    def forward(ctx, rec, bounds):
+        ctx.shape, ctx.bounds = rec.shape, bounds
+        return tuple(rec[:, lo, :] if w is None else rec[:, lo:lo + w, :] for lo, w in bounds)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B, _, D = ctx.shape
+        parts, like = [], next(g for g in grads if g is not None)
+        for (lo, w), g in zip(ctx.bounds, grads):
+            n = 1 if w is None else w
+            if g is None:
+                if parts and isinstance(parts[-1], int):
+                    parts[-1] += n                  # one zero block per run of unused views
+                else:
+                    parts.append(n)
+            else:
+                parts.append(g.reshape(B, n, D))
+        parts = [like.new_zeros(B, p, D) if isinstance(p, int) else p for p in parts]
+        return torch.cat(parts, dim=1), None
+
+
 class FeatureEmbeddingDict(nn.Module):
     """Native drop-in for feature_embedding.py:91-297 (same ctor / forward / dict2tensor)."""
 
@@ -802,12 +832,14 @@ class FeatureEmbeddingDict(nn.Module):
             out = _EmbGatherFn.apply(anchor, grp, plan, ids, dense, dd, inputs, track)
             rec = out.view(out.shape[0], plan.n_slots, D)
             fused.update(plan.pooled)
-            for f in feats:
-                s, w = plan.slot[f]
-                if fmap[f]["type"] == "sequence" and f not in plan.pooled:
-                    emb[f] = rec[:, s:s + w, :]
-                else:
-                    emb[f] = rec[:, s, :]
+            raw_seq = [fmap[f]["type"] == "sequence" and f not in plan.pooled for f in feats]
+            bounds = tuple((plan.slot[f][0], plan.slot[f][1] if r else None)
+                           for f, r in zip(feats, raw_seq))
+            if rec.requires_grad:
+                views = _SplitRecordFn.apply(rec, bounds)
+            else:
+                views = _SplitRecordFn.forward(_NoCtx(), rec, bounds)
+            emb.update(zip(feats, views))
             emb[("__record__", D)] = (rec, plan)
         for f in present:
             if f in self._torch_feats:
@@ -869,33 +901,10 @@ class FeatureEmbeddingDict(nn.Module):
 
     @staticmethod
     def _merged_runs(embedding_dict, names):
-        """Pieces to concatenate for flatten_emb: consecutive untouched [B,D] views of the gather
-        record are taken as ONE slice of it (one view-backward instead of one per feature — DIN
-        replaces only its sequence entries, the other 14 fields stay one run)."""
-        records = getattr(embedding_dict, "_records", None)
-        if not records or len(records) != 1:
-            return [embedding_dict[f] for f in names]
-        rec, plan = records[0]
-        pieces, run = [], None          # run = [lo, hi)
-        def flush():
-            if run is not None:
-                pieces.append(rec[:, run[0]:run[1], :].flatten(start_dim=1))
-        for f in names:
-            ok = (f in plan.slot and plan.slot[f][1] == 1 and f not in embedding_dict._encoded
-                  and embedding_dict._orig.get(f) == id(embedding_dict[f]))
-            if ok:
-                s0 = plan.slot[f][0]
-                if run is not None and run[1] == s0:
-                    run[1] = s0 + 1
-                else:
-                    flush()
-                    run = [s0, s0 + 1]
-            else:
-                flush()
-                run = None
-                pieces.append(embedding_dict[f])
-        flush()
-        return pieces
+        """Pieces to concatenate for flatten_emb.  Untouched entries are views handed out by ONE
+        autograd node (_SplitRecordFn), so concatenating them feature by feature costs one launch
+        forward and one backward, however many there are."""
+        return [embedding_dict[f] for f in names]
 
     @staticmethod
     def _record_slice(embedding_dict, names):
@@ -973,6 +982,11 @@ class FeatureEmbeddingDict(nn.Module):
 
     def numeric_parameters(self):
         return [m.weight for m in self.embedding_layers.values() if isinstance(m, _NumericView)]
+
+
+class _NoCtx(object):
+    """Stand-in ctx for calling an autograd Function's forward outside autograd."""
+    pass
 
 
 class _EmbDict(OrderedDict):

@@ -225,3 +225,47 @@ def test_mixed_pooled_and_raw_sequences_forward_and_row_gradients(D, tmp_path, m
     np.testing.assert_allclose(grp.num_grad.reshape(-1).numpy(),
                                sd["embedding_layers.price.weight"].grad.reshape(-1).numpy(),
                                atol=2e-6)
+
+
+def test_entrywise_reads_of_the_record_share_one_autograd_node(tmp_path, monkeypatch):
+    """Reading the dict entry by entry (DIN style) — including leaving most entries unused — goes
+    through ONE backward node that assembles the record's gradient (zeros for unused views)."""
+    _cpu_emul.install(monkeypatch)
+    import fuxictr_amd.layers as nat
+    from fuxictr_amd.features import FeatureMap
+    fmap = FeatureMap("mix", str(tmp_path))
+    fmap.load_dict(MIXED_SEQ_SPEC, {"embedding_dim": 4})
+    layer = nat.FeatureEmbeddingDict(fmap, 4, embedding_initializer="partial(nn.init.normal_, std=0.5)")
+    (grp,) = layer.table_groups()
+    grp.opt_kind = "sgd"
+    gen = torch.Generator().manual_seed(5)
+    B = 9
+    X = {}
+    for item in MIXED_SEQ_SPEC["features"]:
+        (name, fs), = item.items()
+        if fs["type"] == "numeric":
+            X[name] = torch.rand(B, generator=gen)
+        elif fs["type"] == "sequence":
+            X[name] = torch.randint(1, fs["vocab_size"], (B, fs["max_len"]), generator=gen)
+        else:
+            X[name] = torch.randint(1, fs["vocab_size"], (B,), generator=gen)
+    layer.train()
+    out = layer(nat.FeatureDict(X))
+    nodes = {out[n].grad_fn for n in out}
+    assert len(nodes) == 1 and type(next(iter(nodes))).__name__ == "_SplitRecordFnBackward"
+    calls = []
+    real = grp.backward
+
+    def spy(plan, ids, dense, dout, *a, **k):
+        calls.append(dout.clone())
+        return real(plan, ids, dense, dout, *a, **k)
+    monkeypatch.setattr(grp, "backward", spy)
+    w_raw = torch.randn(B, 4, 4, generator=gen)
+    w_usr = torch.randn(B, 4, generator=gen)
+    ((out["hist_raw"] * w_raw).sum() + (out["user"] * w_usr).sum() + out["user"].sum()).backward()
+    (dout,), (rec, plan) = calls, out._records[0]
+    expect = torch.zeros(B, plan.n_slots, 4)
+    s, w = plan.slot["hist_raw"]
+    expect[:, s:s + w] = w_raw
+    expect[:, plan.slot["user"][0]] = w_usr + 1.0
+    assert torch.equal(dout.view(B, plan.n_slots, 4), expect)
