@@ -774,6 +774,27 @@ __global__ __launch_bounds__(256) void k_gemm_small_n(GemmArgs a, int tb) {
 // per workgroup, K split over blockIdx.y into workspace slabs (reduced, with the epilogue, by
 // k_splitk_reduce).  Narrow outputs (the 64 -> 1 head of the DIN attention MLP has N = 64 and
 // K = B*L = 204800) keep all 256 lanes busy through the row lanes.
+// fused bias gradient of the skinny weight-gradient kernels (M <= 4): slab z's sum of column m of
+// A over [kbeg, kend).  All 256 threads of the block take part (a single thread per row made the
+// k_chunk loads one dependent chain: 40 us for a 400-deep chunk); fixed LDS tree.
+__device__ __forceinline__ void fx_small_m_rowsum(const GemmArgs& a, int z, int64_t kbeg,
+                                                  int64_t kend) {
+    __shared__ float rs[256];
+    for (int m = 0; m < (int)a.M; ++m) {            // block-uniform (M <= 4)
+        float r = 0.f;
+        for (int64_t k = kbeg + threadIdx.x; k < kend; k += 256) r += a.A[k * a.lda + m];
+        rs[threadIdx.x] = r;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) rs[threadIdx.x] += rs[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + m] = rs[0];
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs a, int np_log2) {
     __shared__ float red[4][256];
     const int Np = 1 << np_log2;
@@ -783,11 +804,7 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs a, int np_log2) {
     const int z = blockIdx.y;
     const int64_t kbeg = (int64_t)z * a.k_chunk;
     const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
-    if (a.epi.rowsum && blockIdx.x == 0 && (int64_t)threadIdx.x < a.M) {
-        float r = 0.f;
-        for (int64_t k = kbeg; k < kend; ++k) r += a.A[k * a.lda + threadIdx.x];
-        a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + threadIdx.x] = r;
-    }
+    if (a.epi.rowsum && blockIdx.x == 0) fx_small_m_rowsum(a, z, kbeg, kend);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (n < a.N) {
         for (int64_t k = kbeg + ty; k < kend; k += lanes) {
@@ -823,11 +840,7 @@ __global__ __launch_bounds__(256) void k_gemm_small_m_v4(GemmArgs a) {
     const int z = blockIdx.y;
     const int64_t kbeg = (int64_t)z * a.k_chunk;
     const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
-    if (a.epi.rowsum && blockIdx.x == 0 && (int64_t)threadIdx.x < a.M) {
-        float r = 0.f;
-        for (int64_t k = kbeg; k < kend; ++k) r += a.A[k * a.lda + threadIdx.x];
-        a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + threadIdx.x] = r;
-    }
+    if (a.epi.rowsum && blockIdx.x == 0) fx_small_m_rowsum(a, z, kbeg, kend);
     float4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
