@@ -65,3 +65,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no fallback" in str(e)
     else:
         raise AssertionError("load() must raise when the .so is missing")
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md maps each C-ABI entry point to the reference code it replaces."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in _header_functions() if n not in doc]
+    assert not missing, missing
+
+
+def test_every_entry_point_cites_the_reference_in_the_header():
+    """include/fxctr.h: the comment in front of each declaration group cites reference file:line
+    (or says the function is new functionality / housekeeping)."""
+    text = open(os.path.join(ROOT, "include", "fxctr.h")).read()
+    assert len(re.findall(r"[a-z_]+\.py:\d+", text)) >= 30
