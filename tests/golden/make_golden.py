@@ -215,34 +215,87 @@ def run_case(case):
           out["expect/pred1"][:3], "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def run_c1():
-    """BASELINE.json configs[0]: the reference's own demo (demo/example3_DeepFM_with_npz_input.py,
-    config demo/config/example3_config `DeepFM_test_npz`, data/tiny_npz) run through its own
+DEMOS = {
+    # BASELINE.json configs[0]: demo/example3_DeepFM_with_npz_input.py, its own config and data
+    "c1_tiny_npz": dict(module="model_zoo.DeepFM.DeepFM_torch.src", cls="DeepFM",
+                        config="demo/config/example3_config", expid="DeepFM_test_npz",
+                        data="tiny_npz"),
+    # the model zoo's own smoke configs (model_zoo/<M>/config, `<M>_test`).  DIN_test runs on its own
+    # data/tiny_seq (npz).  The other three name data/tiny_parquet, whose loader needs polars (absent
+    # here): same model config, data swapped to data/tiny_npz.
+    "demo_din_tiny_seq": dict(module="model_zoo", cls="DIN", config="model_zoo/DIN/config",
+                              expid="DIN_test", data="tiny_seq"),
+    "demo_dcnv2_tiny_npz": dict(module="model_zoo", cls="DCNv2", config="model_zoo/DCNv2/config",
+                                expid="DCNv2_test", data="tiny_npz", swap_data=True),
+    "demo_xdeepfm_tiny_npz": dict(module="model_zoo", cls="xDeepFM",
+                                  config="model_zoo/xDeepFM/config", expid="xDeepFM_test",
+                                  data="tiny_npz", swap_data=True),
+    "demo_dlrm_tiny_npz": dict(module="model_zoo", cls="DLRM", config="model_zoo/DLRM/config",
+                               expid="DLRM_test", data="tiny_npz", swap_data=True),
+}
+
+
+def _demo_meta(name, cls, params, n_steps):
+    """The per-model hyper-parameters under the key names tests/conftest.py:Golden.cfg reads."""
+    meta = dict(name=name, model=cls, embedding_dim=params["embedding_dim"],
+                lr=params["learning_rate"], optimizer=params["optimizer"], max_norm=10.0,
+                steps=n_steps, B=params["batch_size"], seed=params["seed"],
+                emb_reg=params["embedding_regularizer"], net_reg=params["net_regularizer"],
+                expid=params.get("model_id"))
+    if cls == "DeepFM":
+        meta["hidden"] = list(params["hidden_units"])
+    elif cls == "DIN":
+        meta.update(hidden=list(params["dnn_hidden_units"]),
+                    att_hidden=list(params["attention_hidden_units"]))
+    elif cls == "DCNv2":
+        meta.update(hidden=list(params["parallel_dnn_hidden_units"]),
+                    n_cross=params["num_cross_layers"])
+    elif cls == "xDeepFM":
+        # (xDeepFM_test says `cin_layer_units`, which the model ignores: it runs the default CIN)
+        meta.update(hidden=list(params["dnn_hidden_units"]),
+                    cin=list(params.get("cin_hidden_units", [16, 16, 16])))
+    elif cls == "DLRM":
+        meta.update(hidden=list(params["top_mlp_units"]), bottom=list(params["bottom_mlp_units"]))
+    return meta
+
+
+def run_demo(name):
+    """One of the reference's own example / smoke configurations run through its own
     RankDataLoader + BaseModel.fit + evaluate.  Stored: the batches fit() actually saw (in shuffled
     order), the validation set, initial/final weights and the reference's logloss/AUC."""
+    import importlib
     import numpy as np
     import torch
     from fuxictr.features import FeatureMap
     from fuxictr.pytorch.dataloaders import RankDataLoader
     from fuxictr.pytorch.torch_utils import seed_everything
     from fuxictr.utils import load_config
-    from model_zoo.DeepFM.DeepFM_torch.src import DeepFM
-    name = "c1_tiny_npz"
-    params = load_config(os.path.join(REF, "demo/config/example3_config"), "DeepFM_test_npz")
+    d = DEMOS[name]
+    Model = getattr(importlib.import_module(d["module"]), d["cls"])
+    data_dir = os.path.join(REF, "data", d["data"])
+    if d.get("swap_data"):
+        import yaml
+        with open(os.path.join(REF, d["config"], "model_config.yaml")) as f:
+            params = yaml.safe_load(f)[d["expid"]]
+        params.update(model_id=d["expid"], dataset_id=d["data"], data_format="npz",
+                      data_root=os.path.join(REF, "data"))
+        for k in ("train", "valid", "test"):
+            params[k + "_data"] = os.path.join(data_dir, k + ".npz")
+    else:
+        params = load_config(os.path.join(REF, d["config"]), d["expid"])
+        for k in ("train_data", "valid_data", "test_data"):
+            params[k] = os.path.join(data_dir, os.path.basename(params[k]))
     params["gpu"] = -1
     params["model_root"] = os.path.join(TMP, name)
     os.makedirs(os.path.join(TMP, name, params["dataset_id"]), exist_ok=True)
     params["num_workers"] = 0
     params["verbose"] = 0
-    for k in ("train_data", "valid_data", "test_data"):
-        params[k] = os.path.join(REF, "data/tiny_npz", os.path.basename(params[k]))
-    data_dir = os.path.join(REF, "data", params["dataset_id"])
     fmap = FeatureMap(params["dataset_id"], data_dir)
     fmap.load(os.path.join(data_dir, "feature_map.json"), params)
     with open(os.path.join(data_dir, "feature_map.json")) as f:
         spec = json.load(f)
     seed_everything(params["seed"])
-    model = DeepFM(fmap, **params)
+    model = Model(fmap, **params)
     out = {}
     for k, v in model.state_dict().items():
         out["state0/" + k] = v.detach().cpu().numpy().copy()
@@ -276,11 +329,7 @@ def run_c1():
     for i, b in enumerate(seen + [valid]):
         for k, v in b.items():
             out["batch%d/%s" % (i, k)] = v.numpy()
-    meta = dict(name=name, model="DeepFM", hidden=list(params["hidden_units"]),
-                embedding_dim=params["embedding_dim"], lr=params["learning_rate"],
-                optimizer=params["optimizer"], max_norm=10.0, steps=len(seen),
-                B=params["batch_size"], seed=params["seed"],
-                emb_reg=params["embedding_regularizer"], net_reg=params["net_regularizer"])
+    meta = _demo_meta(name, d["cls"], params, len(seen))
     meta["spec"] = spec
     meta["torch"] = torch.__version__
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -339,5 +388,6 @@ if __name__ == "__main__":
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    if not only or "c1_tiny_npz" in only:
-        run_c1()
+    for name in DEMOS:
+        if not only or name in only:
+            run_demo(name)

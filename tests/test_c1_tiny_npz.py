@@ -2,7 +2,11 @@
 (demo/config/example3_config, data/tiny_npz, embedding_regularizer 1e-8, one epoch = one step)
 replayed through the native BaseModel.fit / evaluate.  tests/golden/c1_tiny_npz.npz holds the
 batches the reference's own RankDataLoader fed to fit(), its weights before/after and its
-validation logloss / AUC (0.6798385031 / 0.9661458333 — the known answers of SURVEY.md §8c)."""
+validation logloss / AUC (0.6798385031 / 0.9661458333 — the known answers of SURVEY.md §8c).
+The same for the model zoo's own smoke configurations (`DIN_test` on data/tiny_seq: 0.6878952344 /
+0.796875; `xDeepFM_test`: 0.6672440633 / 0.9869791667; `DLRM_test`: 0.6888397238 / 0.65234375;
+`DCNv2_test`: 0.6797173729 / 1.0 — the last three with data/tiny_npz in place of data/tiny_parquet,
+see tests/golden/make_golden.py:DEMOS)."""
 import numpy as np
 import pytest
 import torch
@@ -17,17 +21,44 @@ class Gen(list):
     pass
 
 
+DEMOS = ["c1_tiny_npz", "demo_din_tiny_seq", "demo_xdeepfm_tiny_npz", "demo_dlrm_tiny_npz",
+         "demo_dcnv2_tiny_npz"]      # (the DCNv2 fixture, 7 MB of 560x560 cross weights, is not committed)
+
+
+def _golden(name):
+    import os
+    from conftest import ROOT
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", name + ".npz")):
+        pytest.skip("fixture %s.npz not generated (tests/golden/make_golden.py %s)" % (name, name))
+    return Golden(name)
+
+
 def _model(g, tmp_path, gpu, **kw):
     from fuxictr_amd import zoo
     from fuxictr_amd.features import FeatureMap
     m = g.meta
     fmap = FeatureMap(g.spec["dataset_id"], str(tmp_path))
     fmap.load_dict(g.spec, {"embedding_dim": m["embedding_dim"]})
-    model = zoo.DeepFM(fmap, model_id="DeepFM_test_npz", gpu=gpu, embedding_dim=m["embedding_dim"],
-                       hidden_units=m["hidden"], learning_rate=m["lr"], optimizer=m["optimizer"],
-                       loss="binary_crossentropy", task="binary_classification",
-                       metrics=["logloss", "AUC"], verbose=0, model_root=str(tmp_path),
-                       embedding_regularizer=m["emb_reg"], net_regularizer=m["net_reg"], **kw)
+    common = dict(model_id=m.get("expid") or m["name"], gpu=gpu, embedding_dim=m["embedding_dim"],
+                  learning_rate=m["lr"], optimizer=m["optimizer"], loss="binary_crossentropy",
+                  task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
+                  model_root=str(tmp_path), embedding_regularizer=m["emb_reg"],
+                  net_regularizer=m["net_reg"], **kw)
+    if m["model"] == "DeepFM":
+        model = zoo.DeepFM(fmap, hidden_units=m["hidden"], **common)
+    elif m["model"] == "DIN":
+        model = zoo.DIN(fmap, dnn_hidden_units=m["hidden"], dnn_activations="relu",
+                        attention_hidden_units=m["att_hidden"],
+                        attention_hidden_activations="Dice", din_target_field="adgroup_id",
+                        din_sequence_field="click_sequence", **common)
+    elif m["model"] == "xDeepFM":
+        model = zoo.xDeepFM(fmap, dnn_hidden_units=m["hidden"], cin_hidden_units=m["cin"], **common)
+    elif m["model"] == "DLRM":
+        model = zoo.DLRM(fmap, top_mlp_units=m["hidden"], bottom_mlp_units=m["bottom"],
+                         interaction_op="dot", **common)
+    else:
+        model = zoo.DCNv2(fmap, model_structure="parallel", num_cross_layers=m["n_cross"],
+                          parallel_dnn_hidden_units=m["hidden"], **common)
     sd = {k: torch.from_numpy(v) for k, v in g.state0.items()}
     assert sorted(model.state_dict().keys()) == sorted(sd.keys())
     model.load_state_dict(sd)
@@ -49,8 +80,9 @@ def _fit_and_check(model, g):
         assert_weights_close(sd[k].cpu().numpy(), ref, m["lr"], m["steps"], k, tol=1e-6)
 
 
-def test_oracle_reproduces_the_reference_demo_run():
-    g = Golden("c1_tiny_npz")
+@pytest.mark.parametrize("demo", DEMOS)
+def test_oracle_reproduces_the_reference_demo_run(demo):
+    g = _golden(demo)
     m = g.meta
     label = g.spec["labels"][0]
     tr = O.OracleTrainer(g.cfg(), g.state0, g.features, lr=m["lr"], max_norm=m["max_norm"],
@@ -71,16 +103,18 @@ def test_oracle_reproduces_the_reference_demo_run():
         assert_weights_close(tr.state[k].detach().numpy(), ref, m["lr"], m["steps"], k, tol=1e-6)
 
 
-def test_c1_host_wiring_fit_evaluate(tmp_path, monkeypatch):
+@pytest.mark.parametrize("demo", DEMOS)
+def test_c1_host_wiring_fit_evaluate(demo, tmp_path, monkeypatch):
     _cpu_emul.install(monkeypatch)
     from fuxictr_amd import optim
     monkeypatch.setattr(optim._NativeOptimizer, "__init__", _cpu_opt_init(optim))
-    g = Golden("c1_tiny_npz")
+    g = _golden(demo)
     _fit_and_check(_model(g, tmp_path, gpu=-1), g)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("hip_graph", [False, True])
-def test_c1_native_fit_evaluate_matches_the_reference_demo(tmp_path, hip_graph):
-    g = Golden("c1_tiny_npz")
+@pytest.mark.parametrize("demo", DEMOS)
+def test_c1_native_fit_evaluate_matches_the_reference_demo(demo, tmp_path, hip_graph):
+    g = _golden(demo)
     _fit_and_check(_model(g, tmp_path, gpu=0, hip_graph=hip_graph), g)
