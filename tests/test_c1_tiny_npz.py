@@ -72,9 +72,21 @@ def _fit_and_check(model, g):
     model.fit(train, epochs=1, validation_data=valid)
     logs = model.evaluate(valid)
     assert abs(logs["logloss"] - float(g.expect["valid_logloss"][0])) <= 1e-6
-    assert round(logs["AUC"], 4) == round(float(g.expect["valid_auc"][0]), 4)
     pred = model.predict(valid)
     np.testing.assert_allclose(pred, g.expect["pred1"], atol=1e-6)
+    # AUC to 4 decimals — except for (positive, negative) pairs the reference itself separates by
+    # less than the prediction tolerance: after ONE step from a 1e-4 init all 100 predictions sit
+    # within ~1e-4 of 0.5, and such a pair may order either way under another fp32 summation order
+    # (each flip moves AUC by 1 / (n_pos * n_neg) = 0.0013 here)
+    y = np.asarray(g.batches[-1][g.spec["labels"][0]]).reshape(-1)
+    ref = np.asarray(g.expect["pred1"], dtype=np.float64)
+    pos, neg = ref[y > 0.5], ref[y <= 0.5]
+    near_ties = int((np.abs(pos[:, None] - neg[None, :]) < 2e-6).sum())
+    slack = near_ties / float(len(pos) * len(neg))
+    if near_ties == 0:
+        assert round(logs["AUC"], 4) == round(float(g.expect["valid_auc"][0]), 4)
+    else:
+        assert abs(logs["AUC"] - float(g.expect["valid_auc"][0])) <= slack + 1e-9, (logs, slack)
     sd = model.state_dict()
     for k, ref in g.state1.items():
         assert_weights_close(sd[k].cpu().numpy(), ref, m["lr"], m["steps"], k, tol=1e-6)
