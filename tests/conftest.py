@@ -64,9 +64,16 @@ def assert_weights_close(got, ref, lr, steps, name, tol=2e-5):
 
 GOLDEN_CASES = ["deepfm_adam", "deepfm_adam_clip", "deepfm_sgd", "deepfm_d10", "dcnv2_adam",
                 "din_adam", "dlrm_adam", "xdeepfm_adam", "deepfm_reg",
-                "deepfm_reg_sgd", "deepfm_bn", "deepfm_seqpool"]
+                "deepfm_reg_sgd", "deepfm_bn", "deepfm_seqpool", "dcnv2_mixdim"]
+
+# cases added after the round's last visit to the GPU box: green against the oracle and on the host
+# wiring (CPU), but their `-m gpu` parametrisations have not run yet — a failure there must not stop
+# the suite before the verified tests (non-strict xfail on GPU tests only)
+UNVERIFIED_ON_GPU = {"dcnv2_mixdim"}
 
 
 @pytest.fixture(params=GOLDEN_CASES)
 def golden(request):
+    if request.param in UNVERIFIED_ON_GPU and request.node.get_closest_marker("gpu"):
+        request.applymarker(pytest.mark.xfail(strict=False, reason="case not yet run on the GPU box"))
     return Golden(request.param)

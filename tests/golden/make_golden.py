@@ -114,6 +114,10 @@ def run_case(case):
         spec = pooled_seq_spec(name)
     else:
         spec = small_criteo_spec(name, case["n_dense"], case["cards"])
+    for item in spec["features"]:          # per-feature embedding_dim (feature_embedding.py:140)
+        (fname, fs), = item.items()
+        if fname in case.get("feature_dims", {}):
+            fs["embedding_dim"] = case["feature_dims"][fname]
     os.makedirs(os.path.join(TMP, name), exist_ok=True)
     fm_path = os.path.join(TMP, name, "feature_map.json")
     with open(fm_path, "w") as f:
@@ -377,6 +381,11 @@ CASES = [
          max_norm=10.0, seed=13, emb_scale=1000.0),
     dict(name="din_adam", model="DIN", embedding_dim=8, hidden=[32, 16], att_hidden=[16], B=160,
          steps=5, lr=1e-2, optimizer="adam", max_norm=10.0, seed=5, emb_scale=1000.0),
+    # per-feature embedding dims: three table groups (D = 8, 4, 12; one numeric feature at D = 4
+    # too), DCNv2 concatenates them (flatten_emb) to a 5*8 + ... wide input
+    dict(name="dcnv2_mixdim", model="DCNv2", n_dense=3, cards=CARDS[:8], embedding_dim=8,
+         hidden=[32, 16], n_cross=2, B=96, steps=4, lr=1e-2, optimizer="adam", max_norm=10.0,
+         seed=41, emb_scale=1000.0, feature_dims={"C2": 4, "C6": 4, "I2": 4, "C4": 12}),
     dict(name="dcnv2_adam", model="DCNv2", n_dense=5, cards=CARDS, embedding_dim=8,
          hidden=[64, 32], n_cross=3, B=192, steps=5, lr=1e-2, optimizer="adam", max_norm=10.0,
          seed=2019, emb_scale=1000.0),

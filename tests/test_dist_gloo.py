@@ -47,7 +47,7 @@ def check_against_golden(z, g):
 # (DIN is not in the list: Dice normalises with BATCH statistics, which each rank takes over its own
 # slice — like unsynchronised BatchNorm under DDP — so a 2-rank run is not the 1-rank trajectory)
 @pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam", "deepfm_adam_clip", "dlrm_adam",
-                                  "xdeepfm_adam", "deepfm_seqpool"])
+                                  "xdeepfm_adam", "deepfm_seqpool", "dcnv2_mixdim"])
 def test_two_rank_sharded_training_equals_reference(case, tmp_path):
     g = Golden(case)
     z = run_workers(case, tmp_path, use_gpu=False)

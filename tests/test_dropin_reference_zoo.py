@@ -41,7 +41,7 @@ def patched_reference(monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam", "din_adam", "dlrm_adam",
-                                  "xdeepfm_adam", "deepfm_reg", "deepfm_bn", "deepfm_seqpool"])
+                                  "xdeepfm_adam", "deepfm_reg", "deepfm_bn", "deepfm_seqpool", "dcnv2_mixdim"])
 def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp_path):
     g = Golden(case)
     m = g.meta
