@@ -137,12 +137,24 @@ def deepfm_logit(state, features, X, n_hidden, batch_norm=False, training=False)
                          training)
 
 
-def dcnv2_logit(state, features, X, n_cross, n_hidden):
-    """DCNv2.forward (model_structure='parallel'), model_zoo/DCNv2/src/DCNv2.py:108-132."""
+def dcnv2_logit(state, features, X, n_cross, n_hidden, structure="parallel", n_stacked=0):
+    """DCNv2.forward, model_zoo/DCNv2/src/DCNv2.py:108-132: the cross network on the flattened
+    embeddings, then per model_structure — alone, through the stacked DNN, beside the parallel DNN,
+    or both — into the final Linear.  The two DNNs end on their last hidden layer (output_dim=None)."""
     emb = dict2tensor(features, feature_embedding(state, EMB, features, X), flatten_emb=True)
     cross = crossnet_v2(state, "crossnet.", emb, n_cross)
-    dnn = mlp_block(state, "parallel_dnn.", emb, n_hidden, False)
-    return F.linear(torch.cat([cross, dnn], dim=-1), state["fc.weight"], state["fc.bias"])
+    if structure == "crossnet_only":
+        final = cross
+    elif structure == "stacked":
+        final = mlp_block(state, "stacked_dnn.", cross, n_stacked, False)
+    elif structure == "parallel":
+        final = torch.cat([cross, mlp_block(state, "parallel_dnn.", emb, n_hidden, False)], dim=-1)
+    elif structure == "stacked_parallel":
+        final = torch.cat([mlp_block(state, "stacked_dnn.", cross, n_stacked, False),
+                           mlp_block(state, "parallel_dnn.", emb, n_hidden, False)], dim=-1)
+    else:
+        raise ValueError("model_structure={} not supported!".format(structure))
+    return F.linear(final, state["fc.weight"], state["fc.bias"])
 
 
 def dice(state, prefix, x, training):
@@ -250,7 +262,8 @@ def model_logit(cfg, state, features, X, training=False):
         return deepfm_logit(state, features, X, cfg["n_hidden"], cfg.get("batch_norm", False),
                             training)
     if cfg["model"] == "DCNv2":
-        return dcnv2_logit(state, features, X, cfg["n_cross"], cfg["n_hidden"])
+        return dcnv2_logit(state, features, X, cfg["n_cross"], cfg["n_hidden"],
+                           cfg.get("structure", "parallel"), cfg.get("n_stacked", 0))
     raise NotImplementedError(cfg["model"])
 
 

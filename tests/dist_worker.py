@@ -57,8 +57,8 @@ def run(rank, world, case, port, out_path, use_gpu):
                         attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
                         din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
     else:
-        model = zoo.DCNv2(fmap, model_id=case, model_structure="parallel",
-                          num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"],
+        model = zoo.DCNv2(fmap, model_id=case, model_structure=m.get("structure", "parallel"),
+                          num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"], stacked_dnn_hidden_units=m.get("stacked", []),
                           **common)
     for grp_mod in model.modules():
         if hasattr(grp_mod, "table_groups"):

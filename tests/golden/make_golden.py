@@ -151,9 +151,10 @@ def run_case(case):
                     din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
     else:
         from model_zoo import DCNv2
-        model = DCNv2(fmap, model_id=name, model_structure="parallel",
+        model = DCNv2(fmap, model_id=name, model_structure=case.get("structure", "parallel"),
                       num_cross_layers=case["n_cross"],
-                      parallel_dnn_hidden_units=case["hidden"], **common)
+                      parallel_dnn_hidden_units=case["hidden"],
+                      stacked_dnn_hidden_units=case.get("stacked", []), **common)
     # make the (1e-4 std) tables matter numerically: rescale so logits are O(1)
     with torch.no_grad():
         for k, p in model.named_parameters():
@@ -386,6 +387,14 @@ CASES = [
     dict(name="dcnv2_mixdim", model="DCNv2", n_dense=3, cards=CARDS[:8], embedding_dim=8,
          hidden=[32, 16], n_cross=2, B=96, steps=4, lr=1e-2, optimizer="adam", max_norm=10.0,
          seed=41, emb_scale=1000.0, feature_dims={"C2": 4, "C6": 4, "I2": 4, "C4": 12}),
+    # the other model_structure values of DCNv2.py:78-103: cross -> stacked DNN next to a parallel DNN
+    # (narrow towers keep the fixture small), and the cross network alone
+    dict(name="dcnv2_stacked_parallel", model="DCNv2", structure="stacked_parallel", n_dense=3,
+         cards=CARDS[:6], embedding_dim=4, hidden=[16, 8], stacked=[12, 6], n_cross=2, B=80,
+         steps=4, lr=1e-2, optimizer="adam", max_norm=10.0, seed=43, emb_scale=1000.0),
+    dict(name="dcnv2_crossnet_only", model="DCNv2", structure="crossnet_only", n_dense=3,
+         cards=CARDS[:6], embedding_dim=4, hidden=[], n_cross=3, B=80, steps=4, lr=1e-2,
+         optimizer="adam", max_norm=10.0, seed=47, emb_scale=1000.0),
     dict(name="dcnv2_adam", model="DCNv2", n_dense=5, cards=CARDS, embedding_dim=8,
          hidden=[64, 32], n_cross=3, B=192, steps=5, lr=1e-2, optimizer="adam", max_norm=10.0,
          seed=2019, emb_scale=1000.0),

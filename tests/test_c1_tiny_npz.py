@@ -57,8 +57,9 @@ def _model(g, tmp_path, gpu, **kw):
         model = zoo.DLRM(fmap, top_mlp_units=m["hidden"], bottom_mlp_units=m["bottom"],
                          interaction_op="dot", **common)
     else:
-        model = zoo.DCNv2(fmap, model_structure="parallel", num_cross_layers=m["n_cross"],
-                          parallel_dnn_hidden_units=m["hidden"], **common)
+        model = zoo.DCNv2(fmap, model_structure=m.get("structure", "parallel"), num_cross_layers=m["n_cross"],
+                          parallel_dnn_hidden_units=m["hidden"],
+                          stacked_dnn_hidden_units=m.get("stacked", []), **common)
     sd = {k: torch.from_numpy(v) for k, v in g.state0.items()}
     assert sorted(model.state_dict().keys()) == sorted(sd.keys())
     model.load_state_dict(sd)

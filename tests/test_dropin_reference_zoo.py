@@ -41,7 +41,8 @@ def patched_reference(monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam", "din_adam", "dlrm_adam",
-                                  "xdeepfm_adam", "deepfm_reg", "deepfm_bn", "deepfm_seqpool", "dcnv2_mixdim"])
+                                  "xdeepfm_adam", "deepfm_reg", "deepfm_bn", "deepfm_seqpool", "dcnv2_mixdim", "dcnv2_stacked_parallel",
+                                  "dcnv2_crossnet_only"])
 def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp_path):
     g = Golden(case)
     m = g.meta
@@ -74,8 +75,8 @@ def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp
                          cin_hidden_units=m["cin"], **common)
     else:
         from model_zoo import DCNv2 as RefModel
-        model = RefModel(fmap, model_id=case, model_structure="parallel",
-                         num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"],
+        model = RefModel(fmap, model_id=case, model_structure=m.get("structure", "parallel"),
+                         num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"], stacked_dnn_hidden_units=m.get("stacked", []),
                          **common)
     assert RefModel.__module__.startswith("model_zoo")           # the reference's own class ...
     assert isinstance(model.embedding_layer, (nat.FeatureEmbedding, nat.FeatureEmbeddingDict))  # native

@@ -40,8 +40,8 @@ def _build(g, tmp_path, monkeypatch, sparse_update="exact"):
                         attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
                         din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
     else:
-        model = zoo.DCNv2(fmap, model_id=m["name"], model_structure="parallel",
-                          num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"],
+        model = zoo.DCNv2(fmap, model_id=m["name"], model_structure=m.get("structure", "parallel"),
+                          num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"], stacked_dnn_hidden_units=m.get("stacked", []),
                           **common)
     sd = {k: torch.from_numpy(v) for k, v in g.state0.items()}
     assert sorted(model.state_dict().keys()) == sorted(sd.keys())
