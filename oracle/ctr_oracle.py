@@ -169,9 +169,10 @@ def dice(state, prefix, x, training):
     return p * x + state[prefix + "alpha"] * (1 - p) * x
 
 
-def din_attention(state, prefix, target, seq, mask, training):
-    """DIN_Attention.forward (use_softmax=False), target_attention.py:66-92; the attention MLP is
-    Linear(4E,H) -> Dice(H) -> Linear(H,1) (mlp.0 / mlp.1 / mlp.2)."""
+def din_attention(state, prefix, target, seq, mask, training, use_softmax=False):
+    """DIN_Attention.forward, target_attention.py:66-92; the attention MLP is
+    Linear(4E,H) -> Dice(H) -> Linear(H,1) (mlp.0 / mlp.1 / mlp.2).  use_softmax: masked positions
+    get -1e9 before a softmax over the history (:86-89)."""
     L = seq.size(1)
     E = target.size(-1)
     t = target.unsqueeze(1).expand(-1, L, -1)
@@ -182,6 +183,8 @@ def din_attention(state, prefix, target, seq, mask, training):
     w = F.linear(h, state[prefix + "attention_layer.mlp.2.weight"],
                  state[prefix + "attention_layer.mlp.2.bias"]).view(-1, L)
     w = w * mask.float()
+    if use_softmax:
+        w = (w + -1.e9 * (1 - mask.float())).softmax(dim=-1)
     return (w.unsqueeze(-1) * seq).sum(dim=1)
 
 
@@ -189,12 +192,26 @@ DIN_EMB = "embedding_layer.embedding_layers."
 
 
 def din_logit(state, features, X, cfg, training):
-    """DIN.forward, model_zoo/DIN/src/DIN.py:109-133 (single-name target / sequence fields)."""
+    """DIN.forward, model_zoo/DIN/src/DIN.py:109-133.  A target / sequence entry is a field name or
+    a tuple of names: tuples are concatenated on the last dim (get_embedding, :135-148), the mask
+    comes from the FIRST sequence field, and the pooled vector is split back into embedding_dim-wide
+    pieces that replace the sequence entries."""
     emb = feature_embedding(state, DIN_EMB, features, X)
+
+    def fields(f):
+        return list(f) if isinstance(f, (tuple, list)) else [f]
+
     for idx, (tf, sf) in enumerate(zip(cfg["din_target_field"], cfg["din_sequence_field"])):
-        mask = X[sf].long() != 0
-        emb[sf] = din_attention(state, "attention_layers.%d." % idx, emb[tf], emb[sf], mask,
-                                training)
+        target = torch.cat([emb[f] for f in fields(tf)], dim=-1)
+        seq = torch.cat([emb[f] for f in fields(sf)], dim=-1)
+        mask = X[fields(sf)[0]].long() != 0
+        pooled = din_attention(state, "attention_layers.%d." % idx, target, seq, mask, training,
+                               cfg.get("din_softmax", False))
+        if len(fields(sf)) == 1:
+            emb[fields(sf)[0]] = pooled
+        else:
+            for f, piece in zip(fields(sf), pooled.split(cfg["embedding_dim"], dim=-1)):
+                emb[f] = piece
     x = dict2tensor(features, emb, flatten_emb=True)
     return mlp_block(state, "dnn.", x, cfg["n_hidden"], True)
 

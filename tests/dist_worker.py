@@ -27,7 +27,7 @@ def run(rank, world, case, port, out_path, use_gpu):
 
     def comm(t):            # tensors of the test's own bookkeeping collectives
         return t.cuda() if nccl else t
-    from conftest import Golden
+    from conftest import Golden, _din_fields
     if not use_gpu:
         import _cpu_emul
         _cpu_emul.install_plain()
@@ -54,8 +54,9 @@ def run(rank, world, case, port, out_path, use_gpu):
     elif m["model"] == "DIN":
         model = zoo.DIN(fmap, model_id=case, dnn_hidden_units=m["hidden"],
                         dnn_activations="relu", attention_hidden_units=m["att_hidden"],
-                        attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
-                        din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
+                        attention_hidden_activations="Dice", din_target_field=_din_fields(m, "din_target", "adgroup_id"),
+                        din_sequence_field=_din_fields(m, "din_sequence", "click_sequence"),
+                        din_use_softmax=m.get("din_softmax", False), **common)
     else:
         model = zoo.DCNv2(fmap, model_id=case, model_structure=m.get("structure", "parallel"),
                           num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"], stacked_dnn_hidden_units=m.get("stacked", []),

@@ -76,6 +76,17 @@ def pooled_seq_spec(dataset_id, L=7):
             "input_length": 0, "labels": ["label"], "features": feats}
 
 
+def pair_seq_spec(dataset_id, L=5):
+    """Two aligned histories (item ids and their categories) for DIN's grouped fields:
+    din_target_field (adgroup_id, cate_id) against din_sequence_field (click_sequence, cate_sequence)."""
+    spec = small_seq_spec(dataset_id, L=L)
+    spec["features"].append({"cate_sequence": {"source": "user", "type": "sequence",
+                                               "feature_encoder": None, "share_embedding": "cate_id",
+                                               "padding_idx": 0, "vocab_size": 23, "max_len": L}})
+    spec["num_fields"] = len(spec["features"])
+    return spec
+
+
 def make_batches(rng, spec, B, n, pad_frac=0.02):
     import numpy as np
     batches = []
@@ -108,7 +119,9 @@ def run_case(case):
     from fuxictr.features import FeatureMap
     from fuxictr.pytorch.torch_utils import seed_everything
     name = case["name"]
-    if case["model"] == "DIN":
+    if case["model"] == "DIN" and case.get("schema") == "pair_seq":
+        spec = pair_seq_spec(name)
+    elif case["model"] == "DIN":
         spec = small_seq_spec(name)
     elif case.get("schema") == "pooled_seq":
         spec = pooled_seq_spec(name)
@@ -147,8 +160,12 @@ def run_case(case):
         from model_zoo import DIN
         model = DIN(fmap, model_id=name, dnn_hidden_units=case["hidden"], dnn_activations="relu",
                     attention_hidden_units=case["att_hidden"],
-                    attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
-                    din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
+                    attention_hidden_activations="Dice",
+                    din_target_field=[tuple(f) if isinstance(f, list) else f
+                                      for f in case.get("din_target", ["adgroup_id"])],
+                    din_sequence_field=[tuple(f) if isinstance(f, list) else f
+                                        for f in case.get("din_sequence", ["click_sequence"])],
+                    din_use_softmax=case.get("din_softmax", False), **common)
     else:
         from model_zoo import DCNv2
         model = DCNv2(fmap, model_id=name, model_structure=case.get("structure", "parallel"),
@@ -395,6 +412,11 @@ CASES = [
     dict(name="dcnv2_crossnet_only", model="DCNv2", structure="crossnet_only", n_dense=3,
          cards=CARDS[:6], embedding_dim=4, hidden=[], n_cross=3, B=80, steps=4, lr=1e-2,
          optimizer="adam", max_norm=10.0, seed=47, emb_scale=1000.0),
+    # grouped DIN fields (item, category) attended together, softmax attention weights
+    dict(name="din_pairs_softmax", model="DIN", schema="pair_seq", embedding_dim=4, hidden=[16, 8],
+         att_hidden=[8], B=96, steps=4, lr=1e-2, optimizer="adam", max_norm=10.0, seed=53,
+         emb_scale=1000.0, din_target=[["adgroup_id", "cate_id"]],
+         din_sequence=[["click_sequence", "cate_sequence"]], din_softmax=True),
     dict(name="dcnv2_adam", model="DCNv2", n_dense=5, cards=CARDS, embedding_dim=8,
          hidden=[64, 32], n_cross=3, B=192, steps=5, lr=1e-2, optimizer="adam", max_norm=10.0,
          seed=2019, emb_scale=1000.0),

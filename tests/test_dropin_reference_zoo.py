@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import _cpu_emul
-from conftest import Golden, assert_weights_close
+from conftest import Golden, assert_weights_close, _din_fields
 from test_host_wiring import _cpu_opt_init, tb
 
 REF = "/root/reference"
@@ -42,7 +42,7 @@ def patched_reference(monkeypatch):
 
 @pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam", "din_adam", "dlrm_adam",
                                   "xdeepfm_adam", "deepfm_reg", "deepfm_bn", "deepfm_seqpool", "dcnv2_mixdim", "dcnv2_stacked_parallel",
-                                  "dcnv2_crossnet_only"])
+                                  "dcnv2_crossnet_only", "din_pairs_softmax"])
 def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp_path):
     g = Golden(case)
     m = g.meta
@@ -63,8 +63,9 @@ def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp
         from model_zoo import DIN as RefModel
         model = RefModel(fmap, model_id=case, dnn_hidden_units=m["hidden"], dnn_activations="relu",
                          attention_hidden_units=m["att_hidden"],
-                         attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
-                         din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
+                         attention_hidden_activations="Dice", din_target_field=_din_fields(m, "din_target", "adgroup_id"),
+                         din_sequence_field=_din_fields(m, "din_sequence", "click_sequence"),
+                        din_use_softmax=m.get("din_softmax", False), **common)
     elif m["model"] == "DLRM":
         from model_zoo import DLRM as RefModel
         model = RefModel(fmap, model_id=case, top_mlp_units=m["hidden"],

@@ -13,7 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from conftest import Golden, assert_weights_close  # noqa: E402
+from conftest import Golden, assert_weights_close, _din_fields  # noqa: E402
 from fuxictr_amd import synthetic, zoo  # noqa: E402
 from fuxictr_amd.features import FeatureMap  # noqa: E402
 from oracle import ctr_oracle as O  # noqa: E402
@@ -43,8 +43,9 @@ def build_native(g, tmp_path, sparse_update="exact", optimizer=None, hip_graph=F
     elif m["model"] == "DIN":
         model = zoo.DIN(fmap, model_id=m["name"], dnn_hidden_units=m["hidden"],
                         dnn_activations="relu", attention_hidden_units=m["att_hidden"],
-                        attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
-                        din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
+                        attention_hidden_activations="Dice", din_target_field=_din_fields(m, "din_target", "adgroup_id"),
+                        din_sequence_field=_din_fields(m, "din_sequence", "click_sequence"),
+                        din_use_softmax=m.get("din_softmax", False), **common)
     else:
         model = zoo.DCNv2(fmap, model_id=m["name"], model_structure=m.get("structure", "parallel"),
                           num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"], stacked_dnn_hidden_units=m.get("stacked", []),

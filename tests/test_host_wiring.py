@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import _cpu_emul
-from conftest import Golden, assert_weights_close
+from conftest import Golden, assert_weights_close, _din_fields
 
 
 def _build(g, tmp_path, monkeypatch, sparse_update="exact"):
@@ -37,8 +37,9 @@ def _build(g, tmp_path, monkeypatch, sparse_update="exact"):
     elif m["model"] == "DIN":
         model = zoo.DIN(fmap, model_id=m["name"], dnn_hidden_units=m["hidden"],
                         dnn_activations="relu", attention_hidden_units=m["att_hidden"],
-                        attention_hidden_activations="Dice", din_target_field=["adgroup_id"],
-                        din_sequence_field=["click_sequence"], din_use_softmax=False, **common)
+                        attention_hidden_activations="Dice", din_target_field=_din_fields(m, "din_target", "adgroup_id"),
+                        din_sequence_field=_din_fields(m, "din_sequence", "click_sequence"),
+                        din_use_softmax=m.get("din_softmax", False), **common)
     else:
         model = zoo.DCNv2(fmap, model_id=m["name"], model_structure=m.get("structure", "parallel"),
                           num_cross_layers=m["n_cross"], parallel_dnn_hidden_units=m["hidden"], stacked_dnn_hidden_units=m.get("stacked", []),
