@@ -225,7 +225,7 @@ def dot_interaction(feature_emb):
 
 
 def dlrm_logit(state, features, X, cfg):
-    """DLRM.forward (interaction_op='dot'), model_zoo/DLRM/src/DLRM.py:103-123: sparse-only
+    """DLRM.forward (interaction_op 'dot' or 'cat'), model_zoo/DLRM/src/DLRM.py:103-123: sparse-only
     FeatureEmbedding, bottom MLP (ReLU after its last layer too) on the numeric columns appended as
     an extra field, pairwise dots ++ dense embedding -> top MLP."""
     sparse = OrderedDict((f, s) for f, s in features.items() if s["type"] != "numeric")
@@ -238,6 +238,9 @@ def dlrm_logit(state, features, X, cfg):
             h = F.relu(F.linear(h, state["bottom_mlp.mlp.%d.weight" % (2 * i)],
                                 state["bottom_mlp.mlp.%d.bias" % (2 * i)]))
         emb = torch.cat([emb, h.unsqueeze(1)], dim=1)
+    if cfg.get("interaction_op", "dot") == "cat":            # nn.Flatten(start_dim=1), DLRM.py:88-89
+        inter = emb.flatten(start_dim=1)
+    elif dense_feats:
         inter = torch.cat([dot_interaction(emb), h], dim=-1)
     else:
         inter = dot_interaction(emb)

@@ -51,6 +51,7 @@ class Golden(object):
                 "din_target_field": _din_fields(m, "din_target", "adgroup_id"),
                 "din_sequence_field": _din_fields(m, "din_sequence", "click_sequence"),
                 "din_softmax": m.get("din_softmax", False),
+                "interaction_op": m.get("interaction_op", "dot"),
                 "embedding_dim": m["embedding_dim"]}
 
 
@@ -75,13 +76,14 @@ def assert_weights_close(got, ref, lr, steps, name, tol=2e-5):
 GOLDEN_CASES = ["deepfm_adam", "deepfm_adam_clip", "deepfm_sgd", "deepfm_d10", "dcnv2_adam",
                 "din_adam", "dlrm_adam", "xdeepfm_adam", "deepfm_reg",
                 "deepfm_reg_sgd", "deepfm_bn", "deepfm_seqpool", "dcnv2_mixdim",
-                "dcnv2_stacked_parallel", "dcnv2_crossnet_only", "din_pairs_softmax"]
+                "dcnv2_stacked_parallel", "dcnv2_crossnet_only", "din_pairs_softmax",
+                "dlrm_cat", "dlrm_sparse_only"]
 
 # cases added after the round's last visit to the GPU box: green against the oracle and on the host
 # wiring (CPU), but their `-m gpu` parametrisations have not run yet — a failure there must not stop
 # the suite before the verified tests (non-strict xfail on GPU tests only)
 UNVERIFIED_ON_GPU = {"dcnv2_mixdim", "dcnv2_stacked_parallel", "dcnv2_crossnet_only",
-                     "din_pairs_softmax"}
+                     "din_pairs_softmax", "dlrm_cat", "dlrm_sparse_only"}
 
 
 @pytest.fixture(params=GOLDEN_CASES)

@@ -50,7 +50,7 @@ def run(rank, world, case, port, out_path, use_gpu):
                             cin_hidden_units=m["cin"], **common)
     elif m["model"] == "DLRM":
         model = zoo.DLRM(fmap, model_id=case, top_mlp_units=m["hidden"],
-                         bottom_mlp_units=m["bottom"], interaction_op="dot", **common)
+                         bottom_mlp_units=m["bottom"], interaction_op=m.get("interaction_op", "dot"), **common)
     elif m["model"] == "DIN":
         model = zoo.DIN(fmap, model_id=case, dnn_hidden_units=m["hidden"],
                         dnn_activations="relu", attention_hidden_units=m["att_hidden"],

@@ -155,7 +155,7 @@ def run_case(case):
     elif case["model"] == "DLRM":
         from model_zoo import DLRM
         model = DLRM(fmap, model_id=name, top_mlp_units=case["hidden"],
-                     bottom_mlp_units=case["bottom"], interaction_op="dot", **common)
+                     bottom_mlp_units=case["bottom"], interaction_op=case.get("interaction_op", "dot"), **common)
     elif case["model"] == "DIN":
         from model_zoo import DIN
         model = DIN(fmap, model_id=name, dnn_hidden_units=case["hidden"], dnn_activations="relu",
@@ -397,6 +397,13 @@ CASES = [
     dict(name="dlrm_adam", model="DLRM", n_dense=5, cards=CARDS, embedding_dim=8,
          hidden=[64, 32], bottom=[32, 16], B=192, steps=5, lr=1e-2, optimizer="adam",
          max_norm=10.0, seed=13, emb_scale=1000.0),
+    # DLRM's other interaction ('cat' = flatten) and a schema without numeric features (no bottom MLP)
+    dict(name="dlrm_cat", model="DLRM", interaction_op="cat", n_dense=3, cards=CARDS[:6],
+         embedding_dim=4, hidden=[16, 8], bottom=[8], B=80, steps=4, lr=1e-2, optimizer="adam",
+         max_norm=10.0, seed=59, emb_scale=1000.0),
+    dict(name="dlrm_sparse_only", model="DLRM", n_dense=0, cards=CARDS[:7], embedding_dim=4,
+         hidden=[16, 8], bottom=[8], B=80, steps=4, lr=1e-2, optimizer="adam", max_norm=10.0,
+         seed=61, emb_scale=1000.0),
     dict(name="din_adam", model="DIN", embedding_dim=8, hidden=[32, 16], att_hidden=[16], B=160,
          steps=5, lr=1e-2, optimizer="adam", max_norm=10.0, seed=5, emb_scale=1000.0),
     # per-feature embedding dims: three table groups (D = 8, 4, 12; one numeric feature at D = 4

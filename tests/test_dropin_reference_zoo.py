@@ -42,7 +42,8 @@ def patched_reference(monkeypatch):
 
 @pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam", "din_adam", "dlrm_adam",
                                   "xdeepfm_adam", "deepfm_reg", "deepfm_bn", "deepfm_seqpool", "dcnv2_mixdim", "dcnv2_stacked_parallel",
-                                  "dcnv2_crossnet_only", "din_pairs_softmax"])
+                                  "dcnv2_crossnet_only", "din_pairs_softmax", "dlrm_cat",
+                                  "dlrm_sparse_only"])
 def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp_path):
     g = Golden(case)
     m = g.meta
@@ -69,7 +70,7 @@ def test_reference_zoo_classes_run_on_native_layers(case, patched_reference, tmp
     elif m["model"] == "DLRM":
         from model_zoo import DLRM as RefModel
         model = RefModel(fmap, model_id=case, top_mlp_units=m["hidden"],
-                         bottom_mlp_units=m["bottom"], interaction_op="dot", **common)
+                         bottom_mlp_units=m["bottom"], interaction_op=m.get("interaction_op", "dot"), **common)
     elif m["model"] == "xDeepFM":
         from model_zoo import xDeepFM as RefModel
         model = RefModel(fmap, model_id=case, dnn_hidden_units=m["hidden"],

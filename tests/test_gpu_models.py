@@ -39,7 +39,7 @@ def build_native(g, tmp_path, sparse_update="exact", optimizer=None, hip_graph=F
                             cin_hidden_units=m["cin"], **common)
     elif m["model"] == "DLRM":
         model = zoo.DLRM(fmap, model_id=m["name"], top_mlp_units=m["hidden"],
-                         bottom_mlp_units=m["bottom"], interaction_op="dot", **common)
+                         bottom_mlp_units=m["bottom"], interaction_op=m.get("interaction_op", "dot"), **common)
     elif m["model"] == "DIN":
         model = zoo.DIN(fmap, model_id=m["name"], dnn_hidden_units=m["hidden"],
                         dnn_activations="relu", attention_hidden_units=m["att_hidden"],

@@ -33,7 +33,7 @@ def _build(g, tmp_path, monkeypatch, sparse_update="exact"):
                             cin_hidden_units=m["cin"], **common)
     elif m["model"] == "DLRM":
         model = zoo.DLRM(fmap, model_id=m["name"], top_mlp_units=m["hidden"],
-                         bottom_mlp_units=m["bottom"], interaction_op="dot", **common)
+                         bottom_mlp_units=m["bottom"], interaction_op=m.get("interaction_op", "dot"), **common)
     elif m["model"] == "DIN":
         model = zoo.DIN(fmap, model_id=m["name"], dnn_hidden_units=m["hidden"],
                         dnn_activations="relu", attention_hidden_units=m["att_hidden"],
