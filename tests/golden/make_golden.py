@@ -254,6 +254,15 @@ DEMOS = {
                                   data="tiny_npz", swap_data=True),
     "demo_dlrm_tiny_npz": dict(module="model_zoo", cls="DLRM", config="model_zoo/DLRM/config",
                                expid="DLRM_test", data="tiny_npz", swap_data=True),
+    # the training-control loop of BaseModel.fit (rank_model.py:236-306) over several epochs: the
+    # c1 configuration with a learning rate large enough for the validation AUC to stall, so that
+    # reduce-lr-on-plateau, the best-only checkpoint, early stopping and the final reload of the
+    # best weights all happen (monitor = AUC - logloss keeps the decisions away from AUC's ties)
+    "fit_control_tiny_npz": dict(module="model_zoo.DeepFM.DeepFM_torch.src", cls="DeepFM",
+                                 config="demo/config/example3_config", expid="DeepFM_test_npz",
+                                 data="tiny_npz",
+                                 overrides=dict(epochs=8, learning_rate=0.02, early_stop_patience=3,
+                                                monitor={"AUC": 1, "logloss": -1})),
 }
 
 
@@ -307,6 +316,7 @@ def run_demo(name):
         params = load_config(os.path.join(REF, d["config"]), d["expid"])
         for k in ("train_data", "valid_data", "test_data"):
             params[k] = os.path.join(data_dir, os.path.basename(params[k]))
+    params.update(d.get("overrides", {}))
     params["gpu"] = -1
     params["model_root"] = os.path.join(TMP, name)
     os.makedirs(os.path.join(TMP, name, params["dataset_id"]), exist_ok=True)
@@ -331,8 +341,26 @@ def run_demo(name):
         losses.append(float(loss.item()))
         return loss
     model.train_step = recording_step
+    evals, lrs = [], []
+    inner_eval = model.evaluate
+
+    def recording_eval(gen, metrics=None):
+        logs = inner_eval(gen, metrics=metrics)
+        evals.append([float(logs["logloss"]), float(logs["AUC"])])
+        return logs
+    inner_ckpt = model.checkpoint_and_earlystop
+
+    def recording_ckpt(logs, **kw):
+        inner_ckpt(logs, **kw)
+        lrs.append(float(model.optimizer.param_groups[0]["lr"]))
+    model.evaluate = recording_eval
+    model.checkpoint_and_earlystop = recording_ckpt
     model.fit(train_gen, validation_data=valid_gen, **params)
     model.train_step = inner
+    model.evaluate = inner_eval
+    model.checkpoint_and_earlystop = inner_ckpt
+    out["expect/fit_evals"] = np.asarray(evals, dtype=np.float64)      # per evaluation inside fit
+    out["expect/fit_lrs"] = np.asarray(lrs, dtype=np.float64)          # lr after each of them
     res = model.evaluate(valid_gen)
     valid = {}
     for b in valid_gen:
@@ -352,6 +380,8 @@ def run_demo(name):
         for k, v in b.items():
             out["batch%d/%s" % (i, k)] = v.numpy()
     meta = _demo_meta(name, d["cls"], params, len(seen))
+    meta.update(epochs=params["epochs"], early_stop_patience=params["early_stop_patience"],
+                monitor=params["monitor"], steps_per_epoch=len(train_gen))
     meta["spec"] = spec
     meta["torch"] = torch.__version__
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
