@@ -126,3 +126,38 @@ def test_device_loader_through_the_reference_rankdataloader_hook(patched_referen
             assert set(a) == set(b)
             for k in b:
                 np.testing.assert_array_equal(a[k].numpy().astype(np.float64), b[k].numpy())
+
+
+def test_run_expid_flow_on_native_layers(patched_reference, tmp_path):
+    """The body of the reference's run_expid.py (model_zoo/DeepFM/DeepFM_torch/run_expid.py:47-80:
+    load_config -> FeatureMap -> `src.<model>` -> RankDataLoader -> fit -> evaluate) with
+    `fuxictr_amd.patch.install()` in front of it — INTEGRATION.md section 1 — on the reference's own
+    demo config and data.  Starting from the weights its stock run started from, it ends on that
+    run's validation metrics (SURVEY.md 8c known answer: logloss 0.6798385031, AUC 0.9661458333)."""
+    from fuxictr.features import FeatureMap
+    from fuxictr.pytorch.dataloaders import RankDataLoader
+    from fuxictr.pytorch.torch_utils import seed_everything
+    from fuxictr.utils import load_config
+    from model_zoo.DeepFM.DeepFM_torch import src
+    import fuxictr_amd.layers as nat
+    g = Golden("c1_tiny_npz")
+    params = load_config(os.path.join(REF, "demo/config/example3_config"), "DeepFM_test_npz")
+    params.update(gpu=-1, model_root=str(tmp_path), num_workers=0, verbose=0)
+    for k in ("train_data", "valid_data", "test_data"):
+        params[k] = os.path.join(REF, "data/tiny_npz", os.path.basename(params[k]))
+    seed_everything(seed=params["seed"])
+    data_dir = os.path.join(REF, "data", params["dataset_id"])
+    feature_map = FeatureMap(params["dataset_id"], data_dir)
+    feature_map.load(os.path.join(data_dir, "feature_map.json"), params)
+    model = getattr(src, params["model"])(feature_map, **params)
+    assert type(model).__module__.startswith("model_zoo")
+    assert isinstance(model.embedding_layer, nat.FeatureEmbedding)
+    model.count_parameters()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state0.items()})
+    train_gen, valid_gen = RankDataLoader(feature_map, stage="train", **params).make_iterator()
+    model.fit(train_gen, validation_data=valid_gen, **params)
+    valid_result = model.evaluate(valid_gen)
+    assert abs(valid_result["logloss"] - 0.6798385031) <= 1e-6
+    assert round(valid_result["AUC"], 4) == 0.9661
+    test_gen = RankDataLoader(feature_map, stage="test", **params).make_iterator()
+    assert set(model.evaluate(test_gen)) == {"logloss", "AUC"}
