@@ -161,3 +161,87 @@ def test_run_expid_flow_on_native_layers(patched_reference, tmp_path):
     assert round(valid_result["AUC"], 4) == 0.9661
     test_gen = RankDataLoader(feature_map, stage="test", **params).make_iterator()
     assert set(model.evaluate(test_gen)) == {"logloss", "AUC"}
+
+
+@pytest.fixture
+def stock_reference(monkeypatch):
+    """The reference importable as it is (no patch): its own torch layers, next to the native ones."""
+    for name in ["polars", "h5py", "keras_preprocessing", "keras_preprocessing.sequence"]:
+        if name not in sys.modules:
+            monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    sys.modules["keras_preprocessing.sequence"].pad_sequences = lambda *a, **k: None
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    monkeypatch.syspath_prepend(REF)
+    for k in [k for k in sys.modules if k.startswith(("fuxictr.", "model_zoo")) or k == "fuxictr"]:
+        monkeypatch.delitem(sys.modules, k)
+    _cpu_emul.install(monkeypatch)
+    yield
+    for k in [k for k in sys.modules if k.startswith(("fuxictr.", "model_zoo")) or k == "fuxictr"]:
+        sys.modules.pop(k, None)
+
+
+FILTER_SPEC = {
+    "dataset_id": "flt", "num_fields": 8, "total_features": 0, "input_length": 0, "labels": ["y"],
+    "features": [
+        {"u_id": {"source": "user", "type": "categorical", "padding_idx": 0, "vocab_size": 30}},
+        {"u_age": {"source": "user", "type": "numeric"}},
+        {"i_id": {"source": "item", "type": "categorical", "padding_idx": 0, "vocab_size": 50}},
+        {"i_price": {"source": "item", "type": "numeric"}},
+        {"u_hist": {"source": "user", "type": "sequence", "padding_idx": 0, "vocab_size": 50,
+                    "max_len": 4, "share_embedding": "i_id",
+                    "feature_encoder": "layers.MaskedAveragePooling()"}},
+        {"c_hour": {"source": "context", "type": "categorical", "vocab_size": 24}},
+        {"i_cat": {"source": "item", "type": "categorical", "padding_idx": 0, "vocab_size": 9}},
+        {"qid": {"type": "meta"}},
+    ]}
+
+
+@pytest.mark.parametrize("flatten", [False, True])
+@pytest.mark.parametrize("kw", [
+    {}, {"feature_source": "user"}, {"feature_source": ["item", "context"]},
+    {"feature_type": "categorical"}, {"feature_type": ["numeric", "sequence"]},
+    {"feature_source": "item", "feature_type": "categorical"}, {"feature_source": "context"}])
+def test_feature_filters_match_the_reference_layer(kw, flatten, stock_reference, tmp_path):
+    """FeatureEmbedding.forward(X, feature_source, feature_type, flatten_emb) and
+    FeatureEmbeddingDict.dict2tensor(feature_list=...) (feature_embedding.py:73-88, :230-259, :261-297)
+    against the reference's own stock layer holding the same weights."""
+    from fuxictr.features import FeatureMap as RefFeatureMap
+    from fuxictr.pytorch.layers import FeatureEmbedding as RefEmbedding
+    import fuxictr_amd.layers as nat
+    from fuxictr_amd.features import FeatureMap
+    D = 8
+    rmap = RefFeatureMap("flt", str(tmp_path))
+    p = tmp_path / "feature_map.json"
+    import json
+    p.write_text(json.dumps(FILTER_SPEC))
+    rmap.load(str(p), {"embedding_dim": D})
+    nmap = FeatureMap("flt", str(tmp_path))
+    nmap.load_dict(FILTER_SPEC, {"embedding_dim": D})
+    torch.manual_seed(3)
+    ref = RefEmbedding(rmap, D, embedding_initializer="partial(nn.init.normal_, std=0.5)")
+    ours = nat.FeatureEmbedding(nmap, D)
+    assert sorted(ours.state_dict().keys()) == sorted(ref.state_dict().keys())
+    ours.load_state_dict(ref.state_dict())
+    gen = torch.Generator().manual_seed(11)
+    B = 23
+    X = {"u_id": torch.randint(0, 30, (B,), generator=gen),
+         "u_age": torch.rand(B, generator=gen),
+         "i_id": torch.randint(0, 50, (B,), generator=gen),
+         "i_price": torch.rand(B, generator=gen),
+         "u_hist": torch.randint(0, 50, (B, 4), generator=gen),
+         "c_hour": torch.randint(0, 24, (B,), generator=gen),
+         "i_cat": torch.randint(0, 9, (B,), generator=gen)}
+    ref.eval()
+    ours.eval()
+    with torch.no_grad():
+        want = ref(dict(X), flatten_emb=flatten, **kw)
+        got = ours(nat.FeatureDict(X), flatten_emb=flatten, **kw)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got.numpy(), want.numpy(), atol=1e-6)
+        # dict2tensor with an explicit feature_list on the full dict
+        names = ["i_id", "u_hist", "c_hour"]
+        want2 = ref.embedding_layer.dict2tensor(ref.embedding_layer(dict(X)), flatten_emb=flatten,
+                                                feature_list=names)
+        got2 = ours.embedding_layer.dict2tensor(ours.embedding_layer(nat.FeatureDict(X)),
+                                                flatten_emb=flatten, feature_list=names)
+        np.testing.assert_allclose(got2.numpy(), want2.numpy(), atol=1e-6)
