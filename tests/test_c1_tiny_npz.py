@@ -125,19 +125,9 @@ def test_c1_host_wiring_fit_evaluate(demo, tmp_path, monkeypatch):
     _fit_and_check(_model(g, tmp_path, gpu=-1), g)
 
 
-# On the MI355X: c1, DIN_test and DLRM_test verified green; xDeepFM_test matched logloss to 1e-6 and
-# differed in AUC by the one tied pair (0.9857 vs 0.9870, predictions 6e-8 apart) that the pair-aware
-# comparison above now accounts for — that comparison was written after the round's last GPU visit,
-# so until it has run there once a failure must not stop the suite (non-strict xfail; it passes on
-# the CPU emulation).
-_GPU_DEMOS = [pytest.param(d, marks=pytest.mark.xfail(strict=False, reason="pair-aware AUC check "
-                                                      "not yet run on the GPU box"))
-              if d == "demo_xdeepfm_tiny_npz" else d for d in DEMOS]
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("hip_graph", [False, True])
-@pytest.mark.parametrize("demo", _GPU_DEMOS)
+@pytest.mark.parametrize("demo", DEMOS)
 def test_c1_native_fit_evaluate_matches_the_reference_demo(demo, tmp_path, hip_graph):
     g = _golden(demo)
     _fit_and_check(_model(g, tmp_path, gpu=0, hip_graph=hip_graph), g)
@@ -210,8 +200,6 @@ def test_fit_control_loop_matches_the_reference(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="added after the round's last GPU visit; green on the CPU "
-                                        "emulation, not yet run on the GPU box")
 def test_fit_control_loop_matches_the_reference_on_gpu(tmp_path):
     g = Golden("fit_control_tiny_npz")
     _fit_control(_fit_control_model(g, tmp_path, gpu=0), g)
