@@ -25,7 +25,7 @@ rm -rf $OUT/prof_$TAG
     python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err)
 echo "rocprof exit $?" | tee -a $OUT/summary_$TAG.txt
 cat $OUT/prof_bench_$TAG.json | tee -a $OUT/summary_$TAG.txt
-STATS=$(find $OUT/prof_$TAG -name '*kernel_stats.csv' | head -1)
+STATS=$(ls -t $(find $OUT/prof_$TAG -name '*kernel_stats.csv') 2>/dev/null | head -1)   # newest: merged-back dirs can hold older runs
 if [ -n "$STATS" ]; then cp $STATS $OUT/kernel_stats_$TAG.csv; head -40 $STATS | tee -a $OUT/summary_$TAG.txt; fi
 # keep the merged-back payload small
 find $OUT/prof_$TAG -name '*kernel_trace.csv' -size +20M -delete
