@@ -13,7 +13,9 @@ import os
 import sys
 import types
 
-OUT_DIR = os.path.dirname(os.path.abspath(__file__))
+# FX_GOLDEN_OUT=<dir>: regenerate somewhere else (tests/golden/check_regen.py compares with the
+# committed fixtures)
+OUT_DIR = os.environ.get("FX_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
 TMP = "/tmp/fx_golden"
 
@@ -346,7 +348,9 @@ def run_demo(name):
 
     def recording_eval(gen, metrics=None):
         logs = inner_eval(gen, metrics=metrics)
-        evals.append([float(logs["logloss"]), float(logs["AUC"])])
+        # fit() evaluates with the MONITOR's metrics only (rank_model.py:301): a run monitored on
+        # AUC alone has no logloss here
+        evals.append([float(logs.get("logloss", np.nan)), float(logs.get("AUC", np.nan))])
         return logs
     inner_ckpt = model.checkpoint_and_earlystop
 
@@ -359,8 +363,10 @@ def run_demo(name):
     model.train_step = inner
     model.evaluate = inner_eval
     model.checkpoint_and_earlystop = inner_ckpt
-    out["expect/fit_evals"] = np.asarray(evals, dtype=np.float64)      # per evaluation inside fit
-    out["expect/fit_lrs"] = np.asarray(lrs, dtype=np.float64)          # lr after each of them
+    if evals and not np.isnan(np.asarray(evals)).any():
+        # the training-control record (fit_control_*): every in-fit evaluation + the lr after it
+        out["expect/fit_evals"] = np.asarray(evals, dtype=np.float64)
+        out["expect/fit_lrs"] = np.asarray(lrs, dtype=np.float64)
     res = model.evaluate(valid_gen)
     valid = {}
     for b in valid_gen:
@@ -380,7 +386,7 @@ def run_demo(name):
         for k, v in b.items():
             out["batch%d/%s" % (i, k)] = v.numpy()
     meta = _demo_meta(name, d["cls"], params, len(seen))
-    meta.update(epochs=params["epochs"], early_stop_patience=params["early_stop_patience"],
+    meta.update(epochs=params["epochs"], early_stop_patience=params.get("early_stop_patience", 2),
                 monitor=params["monitor"], steps_per_epoch=len(train_gen))
     meta["spec"] = spec
     meta["torch"] = torch.__version__
