@@ -34,9 +34,14 @@ class DeviceNpzDataLoader(object):
         data = np.load(data_path)
         self._id_cols, self._f_cols = [], []      # (name, first row in the block, width)
         id_rows, f_rows = [], []
+        # `meta` columns (e.g. the group_id of gAUC-style metrics) never enter a kernel: they stay on
+        # the host and are yielded as host tensors, like every column of the reference's loader
+        # (npz_dataloader.py:35-66 keeps all of feature_map's columns)
+        self._meta = {}
         for name, spec in feature_map.features.items():
             arr = data[name]
             if spec["type"] == "meta":
+                self._meta[name] = np.ascontiguousarray(arr)
                 continue
             if spec["type"] in ("categorical", "sequence"):
                 a2 = arr.reshape(arr.shape[0], -1).astype(np.int32, copy=False)
@@ -69,8 +74,10 @@ class DeviceNpzDataLoader(object):
         f_h[:, :n] = np.take(self._floats, idx, axis=1)
         return n
 
-    def _views(self, ids_d, f_d, n):
+    def _views(self, ids_d, f_d, n, idx=None):
         out = {}
+        for name, arr in self._meta.items():
+            out[name] = torch.from_numpy(np.take(arr, idx, axis=0))
         for name, r0, w, is_seq in self._id_cols:
             out[name] = ids_d[r0, :n] if not is_seq else ids_d[r0:r0 + w, :n].t()
         for name, r0, _, _ in self._f_cols:
@@ -87,7 +94,7 @@ class DeviceNpzDataLoader(object):
                 ids_h = np.empty((max(len(self._ids), 1), B), dtype=np.int32)
                 f_h = np.empty((len(self._floats), B), dtype=np.float32)
                 n = self._stage(idx, (ids_h, f_h))
-                yield self._views(torch.from_numpy(ids_h), torch.from_numpy(f_h), n)
+                yield self._views(torch.from_numpy(ids_h), torch.from_numpy(f_h), n, idx)
             return
         # Pinned ring + copy stream, no helper thread: the host is far ahead of the GPU anyway (a
         # step is enqueued in ~0.3 ms and runs ~1.2 ms), so batch i+1 is staged (0.15 ms of
@@ -128,4 +135,4 @@ class DeviceNpzDataLoader(object):
             pending = issue(i + 1) if i + 1 < len(chunks) else None
             torch.cuda.current_stream(self.device).wait_event(ev)
             slot = ring[i % depth]
-            yield self._views(slot[4], slot[5], n)
+            yield self._views(slot[4], slot[5], n, chunks[i])

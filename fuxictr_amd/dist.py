@@ -144,6 +144,38 @@ class DistContext(object):
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
+    def all_gather_cat(self, t):
+        """1-D tensors of ANY length per rank -> their concatenation in rank order, on every rank
+        (evaluation: every rank scores the global validation set, so every rank takes the same
+        lr-decay / early-stop decision)."""
+        t = t.reshape(-1).contiguous()
+        stage = self._stage(t)
+        src = t.cpu() if stage else t
+        if self.backend == "nccl" and not src.is_cuda:      # host-side metric vectors over RCCL
+            return self.all_gather_cat(src.cuda()).cpu()
+        n = torch.tensor([src.numel()], dtype=torch.int64, device=src.device)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(k.item()) for k in sizes]
+        pad = torch.zeros(max(max(sizes), 1), dtype=src.dtype, device=src.device)
+        pad[:src.numel()] = src
+        outs = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(outs, pad, group=self.group)
+        out = torch.cat([o[:k] for o, k in zip(outs, sizes)])
+        return out.to(t.device) if stage else out
+
+    def require_same(self, value, what):
+        """Every forward of a row-sharded model issues collectives, so all ranks must run the same
+        number of them: raise on every rank (instead of deadlocking) when `value` differs."""
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        v = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        vals = [torch.zeros_like(v) for _ in range(self.world)]
+        dist.all_gather(vals, v, group=self.group)
+        vals = [int(k.item()) for k in vals]
+        if len(set(vals)) != 1:
+            raise RuntimeError("row-sharded training needs the same %s on every rank, got %s "
+                               "(per rank)" % (what, vals))
+
     def broadcast(self, t, src=0):
         if self._stage(t):
             c = t.cpu()

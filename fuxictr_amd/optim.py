@@ -51,6 +51,8 @@ class _NativeOptimizer(torch.optim.Optimizer):
         self.scal = ops.new_scalars(self.device, lr=lr, beta1=betas[0], beta2=betas[1], eps=eps)
         self._lr_dev = float(lr)
         self._max_norm = 0.0
+        self._begun = False      # zero_grad() opened a step that step() has not closed yet
+        self._model = model
         self._state_dense = {}   # id(tensor) -> (m, v)
         self._sq_dense = None
         self.dist = None
@@ -111,9 +113,16 @@ class _NativeOptimizer(torch.optim.Optimizer):
             self._lr_dev = lr
 
     def begin_step(self):
-        """Call before the forward of a training step: t += 1, Adam bias corrections."""
+        """Opens a training step BEFORE its forward: t += 1 and the Adam bias corrections on the
+        device (exact mode replays a row's missed steps up to t - 1 when the forward reads it).
+        Idempotent until step() closes the step; zero_grad() calls it, so any training loop of the
+        reference's shape — optimizer.zero_grad(); forward; backward; optimizer.step()
+        (rank_model.py:307-323 and the LongCTR models' own train_step) — advances t correctly."""
+        if self._begun:
+            return
         self.sync_lr()
         ops.opt_begin_step(self.scal)
+        self._begun = True
 
     def flush(self):
         for grp in self._groups:
@@ -203,6 +212,18 @@ class _NativeOptimizer(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closure is not supported by the native optimizer")
+        if not self._begun:
+            raise RuntimeError(
+                "native optimizer: step() without a preceding zero_grad() — the step counter and "
+                "the Adam bias corrections are advanced by zero_grad() before the forward pass "
+                "(call optimizer.zero_grad() at the top of every training step, as "
+                "BaseModel.train_step does)")
+        self._begun = False
+        if self._model is not None and hasattr(self._model, "_max_gradient_norm"):
+            # the global-norm clip (rank_model.py:321) lives inside the update kernels: a train_step
+            # override that reaches step() directly still gets fit()'s max_gradient_norm, table
+            # gradients included (they are invisible to a clip_grad_norm_ over .grad attributes)
+            self.set_max_norm(self._model._max_gradient_norm)
         if self.dist is not None:           # row-gradient all-to-all(s) + owner-side reduction
             finish_shard_backward([grp for grp in self._groups if grp.dist is not None])
         ps, gs = self._dense_lists()
@@ -318,6 +339,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
         for grp in self._groups:
             grp.pending = []
             grp.num_grad = None
+        self.begin_step()
 
 
 class NativeAdam(_NativeOptimizer):

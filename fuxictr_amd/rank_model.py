@@ -337,6 +337,19 @@ class BaseModel(nn.Module):
         total = 0
         if self._embedding_regularizer and hasattr(self.optimizer, "emb_reg_loss"):
             total = total + self.optimizer.emb_reg_loss()
+            # parameters of a FeatureEmbeddingDict that are neither packed tables nor numeric weights
+            # (feature_encoders: the nn.Linear projection of `embedding`-type features, custom
+            # encoders) get the reference's term through autograd (rank_model.py:104-112)
+            pairs = get_regularizer(self._embedding_regularizer)
+            for mod in self.modules():
+                if type(mod) != FeatureEmbeddingDict:
+                    continue
+                native = {id(p) for p in mod.table_parameters() + mod.numeric_parameters()}
+                for weight in mod.parameters():
+                    if id(weight) in native or not weight.requires_grad:
+                        continue
+                    for order, lam in pairs:
+                        total = total + (lam / order) * torch.norm(weight, order) ** order
         if not self._net_regularizer:
             return total
         # everything that is not a parameter of a FeatureEmbeddingDict module is a "net" parameter
@@ -461,6 +474,9 @@ class BaseModel(nn.Module):
         self.valid_gen = validation_data
         self._max_gradient_norm = max_gradient_norm
         self._steps_per_epoch = len(data_generator)
+        if self._dist is not None:
+            # each rank feeds ITS shard of the data; the step count must agree (collectives)
+            self._dist.require_same(self._steps_per_epoch, "number of training batches per epoch")
         if self._eval_steps is None:
             self._eval_steps = self._steps_per_epoch
         maximise = self._monitor_mode != "min"
@@ -517,8 +533,7 @@ class BaseModel(nn.Module):
 
     def _step_body(self, batch_data):
         opt = self.optimizer
-        ops.opt_begin_step(opt.scal)     # t += 1, Adam bias corrections (device side)
-        opt.zero_grad()
+        opt.zero_grad()                  # also opens the step: t += 1, Adam bias corrections
         act = self.output_activation
         fused = (isinstance(act, FxSigmoid) and self.loss_fn is _bce_loss
                  and type(self).add_loss is BaseModel.add_loss)
@@ -648,9 +663,16 @@ class BaseModel(nn.Module):
         groups = self.feature_map.group_id is not None
         on_device = (self._device_metrics and self.device.type == "cuda" and not groups and wanted
                      and set(wanted) <= {"logloss", "binary_crossentropy", "AUC"})
+        if self._dist is not None:
+            # every rank scores the GLOBAL validation set (its shard's predictions are gathered),
+            # so checkpoint_and_earlystop takes the same decision everywhere
+            self._dist.require_same(len(data_generator), "number of evaluation batches")
         if on_device:
             preds, labels = self._predict_batches(data_generator, True)
-            ll, auc = ops.binary_metrics(torch.cat(preds), torch.cat(labels))
+            preds, labels = torch.cat(preds), torch.cat(labels)
+            if self._dist is not None:
+                preds, labels = (self._dist.all_gather_cat(t) for t in (preds, labels))
+            ll, auc = ops.binary_metrics(preds, labels)
             val_logs = OrderedDict((m, auc if m == "AUC" else ll) for m in wanted)
         else:
             self.eval()
@@ -661,9 +683,15 @@ class BaseModel(nn.Module):
                     y_host.append(self.get_labels(batch).reshape(-1).cpu().numpy())
                     if groups:
                         g_host.append(np.asarray(self.get_group_id(batch)).reshape(-1))
-            val_logs = self.evaluate_metrics(np.concatenate(y_host).astype(np.float64),
-                                             np.concatenate(p_host).astype(np.float64), wanted,
-                                             np.concatenate(g_host) if g_host else None)
+            y_all, p_all = np.concatenate(y_host), np.concatenate(p_host)
+            g_all = np.concatenate(g_host) if g_host else None
+            if self._dist is not None:
+                y_all, p_all = (self._dist.all_gather_cat(torch.from_numpy(a)).numpy()
+                                for a in (y_all, p_all))
+                if g_all is not None:
+                    g_all = self._dist.all_gather_cat(torch.from_numpy(g_all)).numpy()
+            val_logs = self.evaluate_metrics(y_all.astype(np.float64), p_all.astype(np.float64),
+                                             wanted, g_all)
         logging.info("metrics: %s", ", ".join("%s=%.6f" % kv for kv in val_logs.items()))
         return val_logs
 
@@ -689,6 +717,11 @@ class BaseModel(nn.Module):
 
     def load_weights(self, checkpoint):
         self.to(self.device)
+        if getattr(self, "optimizer", None) is not None and hasattr(self.optimizer, "flush"):
+            # exact mode: settle every row's pending zero-gradient replays BEFORE the tables are
+            # overwritten — otherwise they would be applied on top of the loaded weights at the next
+            # flush, and e.g. fit()'s final evaluation would not see exactly the saved checkpoint
+            self.optimizer.flush()
         path = self._shard_path(checkpoint)
         if self._dist is not None and not os.path.exists(path):
             # a full (reference-layout) checkpoint: every rank picks its rows out of it

@@ -73,6 +73,35 @@ def run(rank, world, case, port, out_path, use_gpu):
         lo, hi = rank * n // world, (rank + 1) * n // world
         return {k: torch.from_numpy(np.asarray(v)[lo:hi]) for k, v in b.items()}
 
+    if os.environ.get("FX_TEST_FIT") == "1":
+        # BaseModel.fit across ranks: every rank feeds its shard of the batches and ITS shard of the
+        # validation set; the evaluations must see the GLOBAL validation set on every rank so that
+        # lr decay / early stop / best checkpoint agree (no rank may leave the loop alone)
+        class Gen(list):
+            pass
+        train = Gen(part(b) for b in g.batches[:-1])
+        valid = Gen([part(g.batches[-1])])
+        model._monitor_mode = "max"
+        model.fit(train, epochs=4, validation_data=valid, max_gradient_norm=m["max_norm"])
+        logs = model.evaluate(valid)
+        mine = torch.tensor([model._best_metric, float(model.optimizer.param_groups[0]["lr"]),
+                             float(model._total_steps), float(model._stop_training),
+                             float(model._epoch_index), logs["AUC"], logs["logloss"]],
+                            dtype=torch.float64)
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allv, comm(mine))
+        # the global-set metric, recomputed from the gathered shard predictions
+        model.eval()
+        with torch.no_grad():
+            p = model.forward(part(g.batches[-1]))["y_pred"].reshape(-1).double().cpu()
+        gp = [torch.empty_like(p) for _ in range(world)]
+        dist.all_gather(gp, comm(p))
+        if rank == 0:
+            np.savez(out_path, fit=torch.stack([t.cpu() for t in allv]).numpy(),
+                     pred=torch.cat([t.cpu() for t in gp]).numpy())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     model.eval()
     with torch.no_grad():
         p0 = model.forward(part(g.batches[-1]))["y_pred"].reshape(-1).cpu()

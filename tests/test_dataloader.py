@@ -133,3 +133,27 @@ def test_end_to_end_fit_with_device_loader(tmp_path, hip_graph):
     other.load_weights(model.checkpoint)
     np.testing.assert_array_equal(other.predict(va), pred)
     tmp_path.joinpath("auc_%d.txt" % hip_graph).write_text(repr(after["AUC"]))
+
+
+def test_loader_keeps_meta_columns_on_the_host(tmp_path):
+    """A `meta` column (group_id of the group metrics) is yielded with every batch, as the
+    reference's NpzDataLoader does — BaseModel.get_group_id reads it (rank_model.py:206-208)."""
+    import copy
+    from fuxictr_amd.dataloader import DeviceNpzDataLoader
+    from fuxictr_amd.features import FeatureMap
+    g = Golden("deepfm_adam")
+    path, full = _write_npz(tmp_path, g, 300)
+    full = dict(full)
+    full["uid"] = np.arange(300, dtype=np.int64) * 7
+    np.savez(path, **full)
+    spec = copy.deepcopy(g.spec)
+    spec["features"].append({"uid": {"type": "meta"}})
+    spec["group_id"] = "uid"
+    fmap = FeatureMap(spec["dataset_id"], str(tmp_path))
+    fmap.load_dict(spec, {"embedding_dim": g.meta["embedding_dim"]})
+    dl = DeviceNpzDataLoader(fmap, path, batch_size=64, shuffle=True, device="cpu", seed=1)
+    key = next(k for k, s in g.features.items() if s["type"] == "numeric")
+    for batch in dl:
+        assert "uid" in batch and not batch["uid"].is_cuda
+        rows = batch["uid"].numpy() // 7                      # the samples this batch holds
+        np.testing.assert_array_equal(batch[key].numpy(), full[key][rows].astype(np.float32))

@@ -74,3 +74,18 @@ def test_one_rank_group_runs_the_full_exchange_path(tmp_path):
     z = run_workers("deepfm_adam", tmp_path, use_gpu=False, world=1, env={"FX_SHARD_WORLD1": "1"})
     assert bool(z["sharded"][0])
     check_against_golden(z, g)
+
+
+def test_fit_takes_the_same_decisions_on_every_rank(tmp_path):
+    """BaseModel.fit under shard='row' (ADVICE r1): each rank evaluates the GLOBAL validation set
+    (shard predictions gathered), so best metric, lr, step count, stop flag and epoch agree on all
+    ranks, and the metric equals scikit-learn's on the gathered predictions."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    g = Golden("deepfm_adam")
+    z = run_workers("deepfm_adam", tmp_path, use_gpu=False, env={"FX_TEST_FIT": "1"})
+    fit = z["fit"]
+    assert fit.shape[0] == 2
+    np.testing.assert_array_equal(fit[0], fit[1])
+    y = np.asarray(g.batches[-1]["label"], dtype=np.float64)
+    assert abs(fit[0, 5] - roc_auc_score(y, z["pred"])) < 1e-9
+    assert abs(fit[0, 6] - log_loss(y, z["pred"])) < 1e-6

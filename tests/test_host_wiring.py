@@ -270,3 +270,29 @@ def test_entrywise_reads_of_the_record_share_one_autograd_node(tmp_path, monkeyp
     expect[:, s:s + w] = w_raw
     expect[:, plan.slot["user"][0]] = w_usr + 1.0
     assert torch.equal(dout.view(B, plan.n_slots, 4), expect)
+
+
+def test_optimizer_step_protocol_of_a_train_step_override(tmp_path, monkeypatch):
+    """A train_step override of the reference's shape (LongCTR models: optimizer.zero_grad();
+    forward; loss.backward(); optimizer.step()) drives the native optimizer correctly: zero_grad()
+    opens the step (t += 1, bias corrections), step() closes it and picks up fit()'s
+    max_gradient_norm; step() without zero_grad() raises instead of silently applying 0-size
+    updates."""
+    g = Golden("deepfm_adam_clip")
+    a = _build(g, tmp_path, monkeypatch)
+    b = _build(g, tmp_path, monkeypatch)
+    a.train()
+    b.train()
+    b._max_gradient_norm = g.meta["max_norm"]
+    for i in range(g.meta["steps"]):
+        batch = tb(g.batches[i])
+        la = float(a.train_step(batch).item())
+        b.optimizer.zero_grad()                       # the override's own loop
+        out = b.forward(batch)
+        loss = b.compute_loss(out, b.get_labels(batch))
+        loss.backward()
+        b.optimizer.step()
+        assert abs(float(loss.item()) - la) <= 1e-6, (i, float(loss.item()), la)
+        assert abs(la - float(g.expect["loss"][i])) <= 1e-4
+    with pytest.raises(RuntimeError, match="zero_grad"):
+        b.optimizer.step()
