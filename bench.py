@@ -8,9 +8,13 @@ Adam, nothing skipped.  Inputs are resident in HBM before the timed region.
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` launched plainly starts N ranks itself (torch.distributed.run, 127.0.0.1).
+
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel: the fp32 MFMA GEMM, timed live
-with HIP events inside the timed region) and `cpu_baseline` (the oracle's dense-semantics step —
-a restatement of the reference — timed on this box's host cores; rank 0, N=1 only).
+with HIP events), `roofline_sparse` (the whole embedding path of the step against SURVEY 8d's bytes),
+`dcnv2` (the configs[2] step measured in the same run: the metric names both models) and
+`cpu_baseline` (the oracle's dense-semantics step — a restatement of the reference — timed on this
+box's host cores; rank 0, N=1 only).
 """
 import argparse
 import json
@@ -50,6 +54,10 @@ def parse():
                          "rate incl. host batch assembly + H2D); not the headline number")
     ap.add_argument("--host-inputs", action="store_true",
                     help="feed host (DataLoader-style) tensors each step: the PCIe-inclusive rate")
+    ap.add_argument("--pool", type=int, default=512,
+                    help="distinct synthetic batches cycled (bounded by warmup + steps + 24)")
+    ap.add_argument("--no-dcnv2", action="store_true",
+                    help="skip the DCNv2 (configs[2]) sub-measurement of the default DeepFM run")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the step eagerly instead of replaying a captured hipGraph")
     return ap.parse_args()
@@ -86,33 +94,28 @@ def build_model(args, device_index, cards, shard=None):
     return model, fmap, spec
 
 
-def _pick_threads():
-    """Host threads for the CPU baseline: the fastest of a few counts on a memory-bound pass (what
-    the reference's dense Adam is); all visible cores is often NOT the fastest on a big box."""
+def _host_cores():
     try:
-        avail = len(os.sched_getaffinity(0))
+        return len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    x = torch.ones(64 << 20)
-    best, best_t = 1, None
-    for n in sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)}):
-        torch.set_num_threads(n)
-        x.mul_(1.0)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            x.mul_(1.0001)
-        dt = time.perf_counter() - t0
-        if best_t is None or dt < best_t:
-            best, best_t = n, dt
-    return best
+        return os.cpu_count() or 1
+
+
+# what the survey measured with the REAL, unmodified reference on 8 host cores of the build
+# container (it cannot run on the GPU box: /root/reference does not travel)
+REFERENCE_MEASURED = {"DeepFM": {"value": 2069.0, "ms_per_step": 1980.0},
+                      "DCNv2": {"value": 2169.0, "ms_per_step": 1889.0},
+                      "DIN": {"value": 8654.0, "ms_per_step": 473.0}}
 
 
 def cpu_baseline(args, cards, n_steps):
     """The oracle (restatement of the reference, dense [V,D] grads + dense Adam over every row)
-    on the host cores, same workload shape, a bounded number of steps."""
+    on the host cores, same workload shape, a bounded number of steps.  The thread count is
+    calibrated on the STEP itself (one step per candidate count; all visible cores is usually not
+    the fastest for a step that is a 16 GB memory stream)."""
     from fuxictr_amd import synthetic
     from oracle import ctr_oracle as O
-    torch.set_num_threads(_pick_threads())
+    avail = _host_cores()
     g = torch.Generator().manual_seed(0)
     _, spec = synthetic.criteo_feature_map(cards=cards, embedding_dim=16)
     features = {k: v for item in spec["features"] for k, v in item.items()}
@@ -150,62 +153,97 @@ def cpu_baseline(args, cards, n_steps):
     tr = O.OracleTrainer(cfg, state, features, lr=1e-3, max_norm=10.0)
     del state
     rng = np.random.default_rng(1)
-    batches = [{k: torch.from_numpy(v) for k, v in
+
+    def batch():
+        return {k: torch.from_numpy(v) for k, v in
                 synthetic.criteo_batch(rng, args.batch, cards=cards, dist=args.dist).items()}
-               for _ in range(n_steps + 1)]
-    tr.train_step(batches[0], batches[0]["label"])          # warm-up (allocates grads/moments)
+
+    def one_step():
+        b = batch()
+        t0 = time.perf_counter()
+        tr.train_step(b, b["label"])
+        return time.perf_counter() - t0
+    torch.set_num_threads(min(avail, 32))
+    one_step()                                              # warm-up (allocates grads/moments)
+    t_begin = time.perf_counter()
+    best, best_t, tried = None, None, {}
+    for n in sorted({min(avail, c) for c in (8, 16, 32, 64, avail)}):
+        torch.set_num_threads(n)
+        dt = one_step()
+        tried[n] = round(1e3 * dt, 1)
+        if best_t is None or dt < best_t:
+            best, best_t = n, dt
+        if time.perf_counter() - t_begin > 15.0:            # calibration is bounded too
+            break
+    torch.set_num_threads(best)
     t0 = time.perf_counter()
     done = 0
-    for b in batches[1:]:
-        tr.train_step(b, b["label"])
+    while done < n_steps or (done < 3):
+        one_step_dt = one_step()
         done += 1
-        if time.perf_counter() - t0 > 30.0:                  # bounded sample
+        if time.perf_counter() - t0 > 20.0:                  # bounded sample
             break
     dt = time.perf_counter() - t0
-    n_steps = done
-    return {"value": args.batch * n_steps / dt, "unit": "samples/sec",
+    # batch generation (numpy, ~2 ms) is inside dt: < 0.2 % of a ~1.5 s step
+    return {"value": args.batch * done / dt, "unit": "samples/sec",
             "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d dense-Adam training steps of the oracle (%s, batch %d, full vocab) "
-                      "after 1 warm-up, %.1f s" % (n_steps, args.model, args.batch, dt),
-            "ms_per_step": 1e3 * dt / n_steps}
+            "sample": "%d dense-Adam training steps of the oracle (%s, batch %d, full vocab) after "
+                      "1 warm-up and a thread-count calibration on the step itself (ms per step by "
+                      "threads: %s), %.1f s" % (done, args.model, args.batch, tried, dt),
+            "ms_per_step": 1e3 * dt / done, "host_cores": avail,
+            "reference_measured": dict(REFERENCE_MEASURED.get(args.model, {}),
+                                       note="the real reference, 8 cores of the build container "
+                                            "(BASELINE.md section 2); not re-measurable on the GPU "
+                                            "box")}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    # debug hook for 1-GPU boxes: FX_BENCH_BACKEND=gloo puts every rank on cuda:0 and stages the
-    # collectives through the host (RCCL refuses two ranks on one device)
-    backend = os.environ.get("FX_BENCH_BACKEND", "nccl")
-    if backend == "gloo":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    # FX_SHARD_WORLD1=1 (debug, 1-GPU box): a 1-rank process group and the full row-sharded exchange
-    # path (all-to-all with itself, all-reduce of one) through RCCL
-    world1 = world == 1 and os.environ.get("FX_SHARD_WORLD1") == "1"
-    if world1:
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-    if world > 1 or world1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # a HIP error inside ProcessGroupNCCL's watchdog thread (e.g. hipErrorCapturedEvent from an
-        # event query while a hipGraph is being captured — fuxictr_amd/dist.py keeps that from
-        # happening) must not take the benchmark down with it
-        os.environ.setdefault("TORCH_NCCL_RETHROW_CUDA_ERRORS", "0")
-        if backend == "gloo":
-            dist.init_process_group("gloo")
+def _spawn_ranks(args):
+    """`bench.py --gpus N` launched plainly: start N ranks of this script with torch.distributed.run
+    (what the driver does for N > 1) and pass its exit code on."""
+    import socket
+    import subprocess
+    if torch.cuda.device_count() < args.gpus and os.environ.get("FX_BENCH_BACKEND") != "gloo":
+        sys.exit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus,
+                                                                         torch.cuda.device_count()))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def make_pool(args, rank, cards, spec, dev, n_pool):
+    """Synthetic batches resident in HBM (ids int64 / dense fp32 / label fp32 — what the reference's
+    get_inputs would hold after .to(device)); distinct per rank and per step.  n_pool distinct
+    batches are drawn so that the rows a timed run touches (table + Adam state, ~25 K unique rows x
+    408 B per batch) do NOT stay resident in the 256 MB Infinity Cache: every step reads rows it has
+    not seen recently, as a real stream does."""
+    from fuxictr_amd import synthetic
+    rng = np.random.default_rng(1000 + rank)
+    pool = []
+    for _ in range(n_pool):
+        if args.model == "DIN":
+            b = synthetic.taobao_batch(rng, args.batch, spec, dist=args.dist)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            b = synthetic.criteo_batch(rng, args.batch, cards=cards, dist=args.dist)
+        if args.host_inputs:
+            # what the reference's DataLoader yields: host tensors, int64 ids / float64 numerics
+            pool.append({k: torch.from_numpy(v.astype(np.float64) if v.dtype == np.float32 else v)
+                         for k, v in b.items()})
+        else:
+            pool.append({k: torch.from_numpy(v).to(dev) for k, v in b.items()})
+    return pool
 
+
+def measure(args, rank, local_rank, world, world1, dev, dist):
+    """Build args.model, warm up, time exactly args.steps steps, then the instrumented pass.
+    -> dict(dt, ktimes, launch, parallelism, cards, timing_mode, rows)."""
     from fuxictr_amd import ops, synthetic
-    from fuxictr_amd.layers import FeatureDict
     cards = [max(3, int(c * args.vocab_scale)) for c in synthetic.CRITEO_CARDS]
     parallelism = "single GPU"
     if (world > 1 or world1) and not args.replicas:
@@ -220,23 +258,8 @@ def main():
         if world > 1:
             parallelism = "%d independent replicas (--replicas; no data-path collective)" % world
     model.train()
-
-    # synthetic batches, resident in HBM (ids int64 / dense fp32 / label fp32 — what the
-    # reference's get_inputs would hold after .to(device)); distinct per rank and per step
-    rng = np.random.default_rng(1000 + rank)
-    n_pool = 8
-    pool = []
-    for _ in range(n_pool):
-        if args.model == "DIN":
-            b = synthetic.taobao_batch(rng, args.batch, spec, dist=args.dist)
-        else:
-            b = synthetic.criteo_batch(rng, args.batch, cards=cards, dist=args.dist)
-        if args.host_inputs:
-            # what the reference's DataLoader yields: host tensors, int64 ids / float64 numerics
-            pool.append({k: torch.from_numpy(v.astype(np.float64) if v.dtype == np.float32 else v)
-                         for k, v in b.items()})
-        else:
-            pool.append({k: torch.from_numpy(v).to(dev) for k, v in b.items()})
+    n_pool = min(args.pool, max(8, args.warmup + args.steps + 24))
+    pool = make_pool(args, rank, cards, spec, dev, n_pool)
 
     loader_iter = None
     if args.loader:
@@ -248,7 +271,6 @@ def main():
         npz_path = "/tmp/fx_bench_loader_%d.npz" % rank
         np.savez(npz_path, **big)
         del big
-
         loader = DeviceNpzDataLoader(fmap, npz_path, batch_size=args.batch, shuffle=True,
                                      device=dev, seed=rank)
 
@@ -287,104 +309,223 @@ def main():
             step_i += 1
         sync()
     ops.KernelTimer.reset()
-    # eager mode: the roofline kernels are timed with HIP events inside the timed region itself;
-    # graph mode: events cannot sit inside a replayed graph, so the same kernels are timed in an
-    # instrumented eager pass right after the timed region (same process, same buffers)
-    ops.KernelTimer.enabled = (not model._use_graph) and not args.no_kernel_timing
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.train_step(next_batch(step_i))
         step_i += 1
     sync()
     dt = time.perf_counter() - t0
-    ops.KernelTimer.enabled = False
     model.optimizer.check_errors()
-    timing_mode = "hip events inside the timed region (eager launches)"
-    if model._use_graph and not args.no_kernel_timing:
-        # the eager pass runs on the default stream; the parameters' AccumulateGrad nodes were
-        # created on the capture stream — harmless here, silence the per-parameter warning
+    timing_mode = None
+    if not args.no_kernel_timing:
+        # Per-kernel HIP events cannot sit inside a replayed hipGraph, so the same kernels are timed
+        # in an instrumented EAGER pass over the next batches of the pool (same process, same
+        # buffers).  Every step of it is enqueued behind ~4 ms of queued device work
+        # (torch.cuda._sleep), so the host runs ahead of the device and an event pair brackets the
+        # kernel itself, not the launch latency of an idle stream (which made round 1's 8 us gather
+        # read as 59 us).
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        model._use_graph = False
+        use_graph, model._use_graph = model._use_graph, False
+        n_inst = min(args.steps, 20)
+        spin = int(4e-3 * 2.4e9)
+        for _ in range(2):                             # eager warm-up of the instrumented path
+            model.train_step(pool[step_i % n_pool])
+            step_i += 1
+        sync()
         ops.KernelTimer.enabled = True
-        for _ in range(min(args.steps, 20)):
+        for _ in range(n_inst):
+            torch.cuda._sleep(spin)
             model.train_step(pool[step_i % n_pool])
             step_i += 1
         sync()
         ops.KernelTimer.enabled = False
-        model._use_graph = True
-        timing_mode = ("hip events around the same kernels in an eager pass of %d steps right "
-                       "after the timed region (the timed region replays a hipGraph)"
-                       % min(args.steps, 20))
+        model._use_graph = use_graph
+        timing_mode = ("HIP events around the same kernels in an eager pass of %d steps right "
+                       "after the timed region, each step enqueued behind ~4 ms of queued device work "
+                       "so that the events bracket the kernel alone (the timed region itself "
+                       "replays a hipGraph)" % n_inst)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ktimes = ops.KernelTimer.summary()
+    ops.KernelTimer.reset()
+    launch = launch_note or ("hipGraph replay" if model._use_graph else "eager")
+    rows = sum(cards) + len(cards)
+    del model, pool
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"dt": dt, "ktimes": ktimes, "launch": launch, "parallelism": parallelism,
+            "cards": cards, "timing_mode": timing_mode, "rows": rows, "n_pool": n_pool}
+
+
+def _traffic(model, batch, world):
+    """Fabric-side bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc cannot run
+    inside this process); only valid for the exact workload it was collected on."""
+    if model != "DeepFM" or batch != 4096 or world != 1:
+        return None, None
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(here, name)) as f:
+                return json.load(f)["traffic_bytes_per_launch"], name
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
+def rooflines(m, args, world):
+    """roofline objects from the instrumented pass of one measured workload."""
+    out = {}
+    kt = m["ktimes"]
+    g = kt.get("k_gemm_f32")
+    n_inst = max(1, min(args.steps, 20))
+    if g and g["total_ms"] > 0:
+        ach = g["work"] / (g["total_ms"] * 1e-3) / 1e12
+        traffic, src = _traffic(args.model, args.batch, world)
+        out["roofline"] = {"kernel": "k_gemm_f32_pipe (fp32 MFMA GEMM, MLP/CrossNet fwd+bwd)",
+                           "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                           "traffic": traffic,
+                           "traffic_unit": "bytes per launch (L2 fabric requests incl. Infinity-"
+                                           "Cache hits; profiles/%s)" % src if src else None,
+                           "launches": g["launches"], "avg_launch_us": g["avg_us"],
+                           "gemm_us_per_step": 1e3 * g["total_ms"] / n_inst,
+                           "timing": m["timing_mode"]}
+        shapes = {}
+        for k, v in kt.items():
+            if k.startswith("gemm ") and v["total_ms"] > 0:
+                tf = v["work"] / (v["total_ms"] * 1e-3) / 1e12
+                shapes[k[5:]] = {"launches_per_step": v["launches"] / n_inst,
+                                 "avg_launch_us": round(v["avg_us"], 2),
+                                 "tflops": round(tf, 1),
+                                 "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 3)}
+        out["roofline"]["by_shape_MxNxK"] = shapes
+    sp = kt.get("sparse_path")
+    if sp and sp["total_ms"] > 0:
+        # SURVEY.md 8d: train-step upper bound (no duplicates) per sample — 12 532 B DeepFM/xDeepFM
+        # (gather 1924 + 26 x (384 + 24) sparse Adam), 11 804 B models without the LR copy
+        per_sample = 12532 if args.model in ("DeepFM", "xDeepFM") else 11804
+        if args.model == "DIN":
+            per_sample = 4352 + 64 * 384
+        us_step = 1e3 * sp["total_ms"] / n_inst
+        ach = per_sample * args.batch / (us_step * 1e-6) / 1e9
+        out["roofline_sparse"] = {
+            "kernels": "de-dup + catch-up + gather(+LR/FM) + gradient run-reduce + sparse-row Adam "
+                       "(every launch of the embedding path of one step)",
+            "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": ach / PEAK_HBM_GBS, "traffic": None,
+            "algorithmic_bytes_per_sample": per_sample, "us_per_step": us_step,
+            "launches_per_step": sp["launches"] / n_inst}
+    e = kt.get("k_emb_gather_fwd")
+    if e and e["total_ms"] > 0:
+        ach = e["work"] / (e["total_ms"] * 1e-3) / 1e9
+        out["roofline_gather"] = {"kernel": "k_emb_gather_fwd", "bound": "hbm", "achieved": ach,
+                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                                  "launches": e["launches"], "avg_launch_us": e["avg_us"]}
+    return out
+
+
+def workload_name(args, rows):
+    if args.model == "DIN":
+        return ("configs[3]: DIN on synthetic Taobao-shape sequences (14 categorical + "
+                "click_sequence len 50 sharing adgroup_id, emb_dim 16, attention [64] Dice, dnn "
+                "[512,128,64]), Adam, full training step")
+    return ("configs[%d]: %s on synthetic Criteo (26 sparse + 13 dense, %d rows, emb_dim 16, %s), "
+            "Adam, full training step"
+            % ({"DeepFM": 1, "DCNv2": 2, "DLRM": 4}.get(args.model, 1), args.model, rows,
+               {"DCNv2": "MLP 4x1024, 3 cross layers",
+                "DLRM": "bottom MLP [512,256,16], dot interaction, top MLP [1024,1024,512,256]",
+                "xDeepFM": "MLP 4x1024, CIN [16,16,16]"}.get(args.model, "MLP 4x1024")))
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _spawn_ranks(args)                                  # does not return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d — the line must report the GPUs it ran on"
+                 % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # debug hook for 1-GPU boxes: FX_BENCH_BACKEND=gloo puts every rank on cuda:0 and stages the
+    # collectives through the host (RCCL refuses two ranks on one device)
+    backend = os.environ.get("FX_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    # FX_SHARD_WORLD1=1 (debug, 1-GPU box): a 1-rank process group and the full row-sharded exchange
+    # path (all-to-all with itself, all-reduce of one) through RCCL
+    world1 = world == 1 and os.environ.get("FX_SHARD_WORLD1") == "1"
+    if world1:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or world1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a HIP error inside ProcessGroupNCCL's watchdog thread (e.g. hipErrorCapturedEvent from an
+        # event query while a hipGraph is being captured — fuxictr_amd/dist.py keeps that from
+        # happening) must not take the benchmark down with it
+        os.environ.setdefault("TORCH_NCCL_RETHROW_CUDA_ERRORS", "0")
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    m = measure(args, rank, local_rank, world, world1, dev, dist)
+    second = None
+    if (args.model == "DeepFM" and world == 1 and not world1 and not args.no_dcnv2
+            and not args.loader and not args.host_inputs):
+        # BASELINE.json's metric names both models: the c3 DCNv2 step (CrossNet 624x624 GEMMs) is
+        # measured in the same run and reported as a sub-object of the same line
+        import copy
+        args2 = copy.copy(args)
+        args2.model = "DCNv2"
+        m2 = measure(args2, rank, local_rank, world, world1, dev, dist)
+        second = (args2, m2)
 
     if rank == 0:
         global_batch = args.batch * world
-        value = global_batch * args.steps / dt
+        value = global_batch * args.steps / m["dt"]
         out = {
             "metric": "samples/sec at batch 4096, Criteo-shape DeepFM/DCNv2, 1/2/4/8 MI355X",
             "value": value, "unit": "samples/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * m["dt"] / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("configs[3]: DIN on synthetic Taobao-shape sequences (14 "
-                                    "categorical + click_sequence len 50 sharing adgroup_id, "
-                                    "emb_dim 16, attention [64] Dice, dnn [512,128,64]), Adam, "
-                                    "full training step") if args.model == "DIN" else
-                                   "configs[%d]: %s on synthetic Criteo (26 sparse + 13 dense, "
-                                   "%d rows, emb_dim 16, %s), Adam, full training step"
-                                   % ({"DeepFM": 1, "DCNv2": 2, "DLRM": 4}.get(args.model, 1),
-                                      args.model, sum(cards) + len(cards),
-                                      {"DCNv2": "MLP 4x1024, 3 cross layers",
-                                       "DLRM": "bottom MLP [512,256,16], dot interaction, "
-                                               "top MLP [1024,1024,512,256]",
-                                       "xDeepFM": "MLP 4x1024, CIN [16,16,16]"}.get(
-                                          args.model, "MLP 4x1024")),
+            "config": {"workload": workload_name(args, m["rows"]),
                        "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "id_distribution": args.dist, "sparse_update": args.sparse_update,
-                       "launch": launch_note or ("hipGraph replay" if model._use_graph else "eager"),
+                       "launch": m["launch"],
+                       "distinct_batches": m["n_pool"],
                        "inputs": ("host tensors per step (DataLoader-style; one pinned staging "
                                   "copy per dtype) - PCIe-inclusive, NOT the headline number")
                        if args.host_inputs else
                        ("DeviceNpzDataLoader over a 64-batch synthetic .npz, shuffled (host column "
                         "gather + pinned H2D on a copy stream, prefetched) - end-to-end, NOT the "
-                        "headline number") if args.loader else "resident in HBM",
-                       "parallelism": parallelism},
+                        "headline number") if args.loader else
+                       "resident in HBM (%d distinct batches cycled: the rows touched exceed the "
+                       "256 MB Infinity Cache)" % m["n_pool"],
+                       "parallelism": m["parallelism"]},
         }
-        g = ktimes.get("k_gemm_f32")
-        traffic = None
-        if args.model == "DeepFM" and args.batch == 4096 and world == 1:
-            # fabric-side bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run
-            # inside this process); only valid for the exact workload it was collected on
-            try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                       "r01_pmc_traffic.json")) as f:
-                    traffic = json.load(f)["traffic_bytes_per_launch"]
-            except (OSError, ValueError, KeyError):
-                traffic = None
-        if g and g["total_ms"] > 0:
-            ach = g["work"] / (g["total_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "k_gemm_f32 (fp32 MFMA GEMM, MLP/CrossNet fwd+bwd)",
-                               "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                               "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric "
-                               "requests incl. Infinity-Cache hits; profiles/r01_pmc_traffic.txt)",
-                               "launches": g["launches"],
-                               "avg_launch_us": g["avg_us"], "timing": timing_mode,
-                               "gemm_share_of_instrumented_step": None}
-        e = ktimes.get("k_emb_gather_fwd")
-        if e and e["total_ms"] > 0:
-            ach = e["work"] / (e["total_ms"] * 1e-3) / 1e9
-            out["roofline_gather"] = {"kernel": "k_emb_gather_fwd", "bound": "hbm", "achieved": ach,
-                                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                      "frac": ach / PEAK_HBM_GBS, "traffic": None,
-                                      "launches": e["launches"], "avg_launch_us": e["avg_us"]}
+        out.update(rooflines(m, args, world))
+        if second is not None:
+            args2, m2 = second
+            sub = {"workload": workload_name(args2, m2["rows"]),
+                   "value": args.batch * args.steps / m2["dt"], "unit": "samples/sec",
+                   "ms_per_step": 1e3 * m2["dt"] / args.steps, "launch": m2["launch"]}
+            sub.update(rooflines(m2, args2, world))
+            out["dcnv2"] = sub
         if world == 1 and not args.no_cpu_baseline and args.model in ("DeepFM", "DCNv2"):
-            del pool
-            out["cpu_baseline"] = cpu_baseline(args, cards, args.cpu_baseline_steps)
+            out["cpu_baseline"] = cpu_baseline(args, m["cards"], args.cpu_baseline_steps)
+        assert out["n_gpus"] == args.gpus
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

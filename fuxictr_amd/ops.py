@@ -17,8 +17,11 @@ _DT = {torch.float32: _lib.FX_F32, torch.float64: _lib.FX_F64,
 
 class KernelTimer(object):
     """Opt-in HIP-event timing of individual launches on torch's current stream (the stream the
-    kernels are launched on).  bench.py enables it to measure the roofline kernels live inside the
-    timed region; it is off (zero cost) otherwise."""
+    kernels are launched on).  bench.py enables it for an instrumented pass in which every step is
+    enqueued behind a few milliseconds of queued device work (`torch.cuda._sleep`), so the host is
+    ahead of the device and an event pair brackets the kernel alone — not the launch latency of an
+    idle stream.  It is off (zero cost) otherwise.  `group`: a second key the launch is also
+    accumulated under (e.g. "sparse_path", or a GEMM's shape)."""
     enabled = False
     records = {}     # name -> list of (start_event, end_event, work)
 
@@ -31,12 +34,14 @@ class KernelTimer(object):
         return ev
 
     @classmethod
-    def stop(cls, name, ev, work):
+    def stop(cls, name, ev, work, group=None):
         if ev is None:
             return
         end = torch.cuda.Event(enable_timing=True)
         end.record()
         cls.records.setdefault(name, []).append((ev, end, work))
+        if group is not None:
+            cls.records.setdefault(group, []).append((ev, end, work))
 
     @classmethod
     def summary(cls):
@@ -52,6 +57,22 @@ class KernelTimer(object):
     @classmethod
     def reset(cls):
         cls.records = {}
+
+
+def _timed(name, group=None):
+    """Decorator: time the wrapped C-ABI call under `name` (and `group`) when KernelTimer is on."""
+    def deco(fn):
+        def wrapper(*a, **kw):
+            if not KernelTimer.enabled:
+                return fn(*a, **kw)
+            ev = KernelTimer.start()
+            out = fn(*a, **kw)
+            KernelTimer.stop(name, ev, 0, group)
+            return out
+        wrapper.__name__ = fn.__name__
+        wrapper.__doc__ = fn.__doc__
+        return wrapper
+    return deco
 
 
 def _need_cuda(t, name):
@@ -116,13 +137,15 @@ def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, n
                                 stream_ptr(out.device)), "fx_emb_gather_fwd")
     # algorithmic bytes: rows + ids + dense in, the [B,F,D] record out
     KernelTimer.stop("k_emb_gather_fwd", ev,
-                     B * (C_ * (4 * D + 4) + Fd * 4 + (C_ + Fd) * 4 * D) if ev else 0)
+                     B * (C_ * (4 * D + 4) + Fd * 4 + (C_ + Fd) * 4 * D) if ev else 0,
+                     "sparse_path")
     return out
 
 
 POOL_SUM, POOL_MEAN = 0, 1
 
 
+@_timed("emb_seq_pool_fwd", "sparse_path")
 def emb_seq_pool_fwd(table, D, ids, col_row_base, col_vocab, seq_col0, seq_len, seq_mode,
                      seq_out_off, out, denom, scal):
     """Pooled sequence features -> their slots of the record `out`; denom [B, n_seq] out."""
@@ -159,6 +182,7 @@ class DedupResult(object):
         self.C = C_
 
 
+@_timed("dedup", "sparse_path")
 def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None,
           n_shards=1, want_uid=False, columns_sorted=False):
     lib = _lib.load()
@@ -175,6 +199,7 @@ def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=N
     return result
 
 
+@_timed("dedup_sorted_runs", "sparse_path")
 def dedup_sorted_runs(ids, n_runs, vocab, pad, workspace, result=None):
     """De-dup of `n_runs` consecutive ascending runs of ids of one table (rows [0, vocab), `pad`
     marks empty entries at each run's tail): a merge by rank counting, no sort."""
@@ -223,6 +248,7 @@ def emb_grad_reduce_scratch_ints(n_max):
     return int(_lib.load().fx_emb_grad_reduce_scratch_ints(n_max))
 
 
+@_timed("emb_grad_reduce", "sparse_path")
 def emb_grad_reduce(dout, dout_ld, col_out_off, C_, D, dd, G, sq_partials, scratch,
                     col_denom=None, denom=None):
     """col_denom / denom: per-column index into the [B, n_seq] pooling denominators (mean-pooled
@@ -263,12 +289,14 @@ def clip_coef(parts, scal):
                            len(parts), ptr(scal), stream_ptr(scal.device)), "fx_clip_coef")
 
 
+@_timed("sparse_adam", "sparse_path")
 def sparse_adam(table, m, v, last_step, D, dd, G, scal):
     check(_lib.load().fx_sparse_adam(ptr(table), ptr(m), ptr(v), ptr(last_step), D,
                                      ptr(dd.uniq_row), ptr(dd.n_unique), dd.n_max, ptr(G),
                                      ptr(scal), stream_ptr(table.device)), "fx_sparse_adam")
 
 
+@_timed("adam_catchup", "sparse_path")
 def adam_catchup(table, m, v, last_step, D, dd, total_rows, upto_offset, scal):
     """dd=None: every row of the table (flush); else only the unique rows of dd."""
     lib = _lib.load()
@@ -283,6 +311,7 @@ def adam_catchup(table, m, v, last_step, D, dd, total_rows, upto_offset, scal):
               "fx_adam_catchup")
 
 
+@_timed("sparse_sgd", "sparse_path")
 def sparse_sgd(table, D, dd, G, scal, last_step=None):
     check(_lib.load().fx_sparse_sgd(ptr(table), ptr(last_step), D, ptr(dd.uniq_row),
                                     ptr(dd.n_unique), dd.n_max, ptr(G), ptr(scal),
@@ -357,6 +386,7 @@ def fm_bwd(emb, F, D, g, demb, accumulate=False):
     return demb
 
 
+@_timed("lr_fwd", "sparse_path")
 def lr_fwd(table1, ids, col_row_base, col_vocab, dense, num_w1, bias, out, scal):
     B = out.shape[0]
     C_ = 0 if ids is None else ids.shape[1]
@@ -392,7 +422,8 @@ def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul
     check(lib.fx_gemm_f32(1 if transa else 0, 1 if transb else 0, M, N, K, ptr(A), A.stride(0),
                           ptr(B_), B_.stride(0), ptr(C_), C_.stride(0), C.byref(epi), split_k,
                           ptr(workspace), stream_ptr(C_.device)), "fx_gemm_f32")
-    KernelTimer.stop("k_gemm_f32", ev, 2.0 * M * N * K if ev else 0)
+    KernelTimer.stop("k_gemm_f32", ev, 2.0 * M * N * K if ev else 0,
+                     "gemm %dx%dx%d" % (M, N, K) if ev else None)
     return C_
 
 
