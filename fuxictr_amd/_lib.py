@@ -20,6 +20,8 @@ FX_NUMGRAD_CHUNKS = 16
 FX_REG_BLOCKS = 1024
 FX_REG_CROSS_BLOCKS = 256
 FX_PACK_MAX_COLS = 64
+FX_PACKM_MAX_COLS = 96
+FX_MAX_TABLES = 4
 FX_CLIP_MAX_PARTS = 16
 
 # indices of the 4-byte words of struct fx_scalars (include/fxctr.h)
@@ -31,6 +33,12 @@ SC_WORDS = 16
 vp = C.c_void_p
 i32 = C.c_int32
 i64 = C.c_int64
+
+
+class RowState(C.Structure):
+    """struct fx_row_state"""
+    _fields_ = [("table", vp), ("m", vp), ("v", vp), ("last_step", vp), ("G", vp), ("D", i32),
+                ("reserved", i32)]
 
 
 class GemmEpilogue(C.Structure):
@@ -101,6 +109,16 @@ SIGNATURES = {
     "fx_dice_workspace_floats": (i64, [i32]),
     "fx_dice_fwd": (i32, [vp, i64, i32, vp, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp, vp]),
     "fx_dice_bwd": (i32, [vp, vp, i64, i32, vp, C.c_float, i32, vp, vp, vp, vp, vp]),
+    "fx_dedup_catchup": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
+                               vp, C.POINTER(RowState), i32, i32, vp, vp]),
+    "fx_emb_fm_fwd": (i32, [vp, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, vp, i32, vp, i64, i64,
+                            vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "fx_emb_fm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp,
+                            vp, vp, i64, vp, i32, i64, vp, vp, vp, vp]),
+    "fx_sparse_adam_multi": (i32, [C.POINTER(RowState), i32, vp, vp, i64, vp, vp]),
+    "fx_sparse_sgd_multi": (i32, [C.POINTER(RowState), i32, vp, vp, i64, vp, vp]),
+    "fx_pack_columns_multi": (i32, [C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp),
+                                    C.POINTER(i32), C.POINTER(i64), i32, i64, vp]),
 }
 
 _lib = None

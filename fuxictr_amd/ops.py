@@ -16,61 +16,70 @@ _DT = {torch.float32: _lib.FX_F32, torch.float64: _lib.FX_F64,
 
 
 class KernelTimer(object):
-    """Opt-in HIP-event timing of individual launches on torch's current stream (the stream the
-    kernels are launched on).  bench.py enables it for an instrumented pass in which every step is
-    enqueued behind a few milliseconds of queued device work (`torch.cuda._sleep`), so the host is
-    ahead of the device and an event pair brackets the kernel alone — not the launch latency of an
-    idle stream.  It is off (zero cost) otherwise.  `group`: a second key the launch is also
-    accumulated under (e.g. "sparse_path", or a GEMM's shape)."""
-    enabled = False
-    records = {}     # name -> list of (start_event, end_event, work)
+    """Opt-in kernel timing for bench.py's roofline objects, off (zero cost) otherwise.
+
+    Per-launch HIP events are useless at this kernel size on this platform: an event pair around
+    one launch adds ~10 us (measured: 87.7 us for a GEMM rocprofv3 times at 75 us, 12.5 us for the
+    8.5 us gather, even with the stream kept busy).  So the launches of ONE eager training step are
+    RECORDED (entry point + its live arguments) and then each recorded launch is REPLAYED `reps`
+    times back to back between one event pair, the host running ahead behind a queued spin kernel:
+    average = kernel duration + the ~1.3 us dependent-launch boundary — what rocprofv3's kernel
+    trace reports, within a few per cent."""
+    recording = False
+    calls = []       # (name, group, work, fn, args, kwargs)
 
     @classmethod
-    def start(cls):
-        if not cls.enabled:
-            return None
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        return ev
+    def note(cls, name, group, work, fn, args, kwargs):
+        cls.calls.append((name, group, work, fn, args, kwargs))
 
     @classmethod
-    def stop(cls, name, ev, work, group=None):
-        if ev is None:
-            return
-        end = torch.cuda.Event(enable_timing=True)
-        end.record()
-        cls.records.setdefault(name, []).append((ev, end, work))
-        if group is not None:
-            cls.records.setdefault(group, []).append((ev, end, work))
-
-    @classmethod
-    def summary(cls):
-        """name -> dict(launches, total_ms, avg_us, work) after a device synchronize."""
+    def replay(cls, reps=20):
+        """-> name/group -> dict(launches, total_ms, avg_us, work) per recorded step."""
+        was, cls.recording = cls.recording, False
+        spans = []
+        try:
+            for name, group, work, fn, args, kwargs in cls.calls:
+                fn(*args, **kwargs)                                   # warm (allocations, caches)
+                torch.cuda._sleep(int(1.5e-3 * 2.4e9))                # host gets ahead of the device
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn(*args, **kwargs)
+                e1.record()
+                spans.append((name, group, work, e0, e1))
+            torch.cuda.synchronize()
+        finally:
+            cls.recording = was
         out = {}
-        for name, recs in cls.records.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-            out[name] = {"launches": len(recs), "total_ms": ms,
-                         "avg_us": 1e3 * ms / max(len(recs), 1),
-                         "work": float(sum(w for _, _, w in recs))}
+        for name, group, work, e0, e1 in spans:
+            ms = e0.elapsed_time(e1) / reps
+            for key in (name, group):
+                if key is None:
+                    continue
+                o = out.setdefault(key, {"launches": 0, "total_ms": 0.0, "work": 0.0})
+                o["launches"] += 1
+                o["total_ms"] += ms
+                o["work"] += float(work)
+        for o in out.values():
+            o["avg_us"] = 1e3 * o["total_ms"] / max(o["launches"], 1)
         return out
 
     @classmethod
     def reset(cls):
-        cls.records = {}
+        cls.calls = []
 
 
-def _timed(name, group=None):
-    """Decorator: time the wrapped C-ABI call under `name` (and `group`) when KernelTimer is on."""
+def _timed(name, group=None, work=None):
+    """Decorator: when KernelTimer is recording, note this C-ABI call (it still runs normally)."""
     def deco(fn):
         def wrapper(*a, **kw):
-            if not KernelTimer.enabled:
-                return fn(*a, **kw)
-            ev = KernelTimer.start()
-            out = fn(*a, **kw)
-            KernelTimer.stop(name, ev, 0, group)
-            return out
+            if KernelTimer.recording:
+                KernelTimer.note(name, group, work(*a, **kw) if work else 0, fn, a, kw)
+            return fn(*a, **kw)
         wrapper.__name__ = fn.__name__
         wrapper.__doc__ = fn.__doc__
+        wrapper.__wrapped__ = fn
         return wrapper
     return deco
 
@@ -122,6 +131,16 @@ def pack_columns(cols, out, out_col0=0):
     return out
 
 
+def _gather_bytes(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w,
+                  num_out_off, out, scal, n_cols=None):
+    # algorithmic bytes (SURVEY.md 8d): rows + ids + dense in, the [B,F,D] record out
+    B = out.shape[0]
+    C_ = 0 if ids is None else (ids.shape[1] if n_cols is None else n_cols)
+    Fd = 0 if dense is None else dense.shape[1]
+    return B * (C_ * (4 * D + 4) + Fd * 4 + (C_ + Fd) * 4 * D)
+
+
+@_timed("k_emb_gather_fwd", "sparse_path", _gather_bytes)
 def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w,
                    num_out_off, out, scal, n_cols=None):
     """n_cols: gather only the first n_cols id columns (the rest are pooled sequences)."""
@@ -129,16 +148,11 @@ def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, n
     B = out.shape[0]
     C_ = 0 if ids is None else (ids.shape[1] if n_cols is None else n_cols)
     Fd = 0 if dense is None else dense.shape[1]
-    ev = KernelTimer.start()
     check(lib.fx_emb_gather_fwd(ptr(table), D, ptr(ids), 0 if ids is None else ids.stride(0),
                                 ptr(col_row_base), ptr(col_vocab), ptr(col_out_off), C_,
                                 ptr(dense), 0 if dense is None else dense.stride(0), ptr(num_w),
                                 ptr(num_out_off), Fd, ptr(out), out.stride(0), B, ptr(scal),
                                 stream_ptr(out.device)), "fx_emb_gather_fwd")
-    # algorithmic bytes (SURVEY.md 8d): rows + ids + dense in, the [B,F,D] record out
-    KernelTimer.stop("k_emb_gather_fwd", ev,
-                     B * (C_ * (4 * D + 4) + Fd * 4 + (C_ + Fd) * 4 * D) if ev else 0,
-                     "sparse_path")
     return out
 
 
@@ -402,6 +416,17 @@ def lr_fwd(table1, ids, col_row_base, col_vocab, dense, num_w1, bias, out, scal)
 def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul=None, mask=None,
          add=None, split_k=1, workspace=None, rowsum=None):
     """C = epilogue(op(A) . op(B)).  A, B, C: 2-D fp32 with unit inner stride."""
+    if KernelTimer.recording:
+        M_, N_ = C_.shape
+        K_ = A.shape[0] if transa else A.shape[1]
+        KernelTimer.note("k_gemm_f32", "gemm %dx%dx%d" % (M_, N_, K_), 2.0 * M_ * N_ * K_, _gemm,
+                         (A, B_, C_, transa, transb, bias, act, zout, mul, mask, add, split_k,
+                          workspace, rowsum), {})
+    return _gemm(A, B_, C_, transa, transb, bias, act, zout, mul, mask, add, split_k, workspace,
+                 rowsum)
+
+
+def _gemm(A, B_, C_, transa, transb, bias, act, zout, mul, mask, add, split_k, workspace, rowsum):
     lib = _lib.load()
     M, N = C_.shape
     K = A.shape[0] if transa else A.shape[1]
@@ -418,12 +443,9 @@ def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul
         epi.add, epi.ldadd = add.data_ptr(), add.stride(0)
     if rowsum is not None:
         epi.rowsum = rowsum.data_ptr()
-    ev = KernelTimer.start()
     check(lib.fx_gemm_f32(1 if transa else 0, 1 if transb else 0, M, N, K, ptr(A), A.stride(0),
                           ptr(B_), B_.stride(0), ptr(C_), C_.stride(0), C.byref(epi), split_k,
                           ptr(workspace), stream_ptr(C_.device)), "fx_gemm_f32")
-    KernelTimer.stop("k_gemm_f32", ev, 2.0 * M * N * K if ev else 0,
-                     "gemm %dx%dx%d" % (M, N, K) if ev else None)
     return C_
 
 

@@ -455,6 +455,97 @@ int fx_binary_metrics(const float* y_pred, const float* y_true, int64_t n, void*
                       size_t workspace_bytes, double* out_logloss_sum, uint64_t* out_counts,
                       fx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused sparse front end / back end (csrc/fx_fused.hip).  For a FeatureEmbeddingDict whose id
+ * columns own disjoint tables laid out in column order (every categorical schema of the BASELINE
+ * configs) the per-step embedding work collapses to a handful of launches; the entry points above
+ * stay as the general path (sequence columns, row-sharded tables, B > 8192).
+ *
+ * fx_row_state: one packed table with its optimizer state; several of them may share one id plan
+ * (the D=16 tables of FeatureEmbedding and the D=1 tables LogisticRegression builds at
+ * logistic_regression.py:44 have identical row layouts).
+ *
+ * fx_dedup_catchup = fx_dedup (column fast path) + fx_opt_begin_step + fx_adam_catchup, 2 launches:
+ *   launch 1 sorts every id column in LDS and, when begin_scal != NULL, opens the optimizer step
+ *   (step += 1, Adam bias corrections: torch.optim.Adam as stepped at rank_model.py:322);
+ *   launch 2 derives uniq_row / seg_start / n_unique / sorted_uid (as fx_dedup) and replays the
+ *   missed zero-gradient Adam steps of every unique row up to step + upto_offset in each of the
+ *   n_tables (<= 4) table groups, so the lookup that follows reads the rows dense Adam would hold.
+ *   n_tables = 0: de-dup only.  workspace: >= 2 * round_up(4*B*C, 256) bytes.  B <= 8192, C <= 256.
+ *
+ * fx_emb_fm_fwd = fx_emb_gather_fwd + fx_lr_fwd + fx_fm_fwd in ONE launch, one wave per sample:
+ *   out     the [B, F, D] record (feature_embedding.py:261-297, :230-259), written once
+ *   lr_out  [B]  sum_c table1[col_row_base[c] + ids[b,c]] + sum_j dense[b,j] num_w1[j] + bias1
+ *                (LogisticRegression.forward, logistic_regression.py:46-59); NULL = not wanted
+ *   fm_out  [B]  0.5 * sum_d ((sum_f e_fd)^2 - sum_f e_fd^2) over all C + Fd fields of the record
+ *                (InnerProductInteraction "product_sum", inner_product.py:55-62); NULL = not wanted
+ *   fm_lr_out [B] fm_out + lr_out (FactorizationMachine.forward, factorization_machine.py:46-59)
+ *   S       [B, D] the per-dimension field sums, kept for fx_emb_fm_bwd; NULL = not wanted
+ *
+ * fx_emb_fm_bwd: autograd of the above, 2 launches.  Launch 1 reduces, per unique row u (runs of
+ *   sorted_pos given by seg_start, as fx_emb_grad_reduce):
+ *     G[u,:]  = sum over the row's lookups (b,c) of
+ *               drec[b, col_out_off[c] + :] + g_fm[b] * (S[b,:] - rec[b, col_out_off[c] + :])
+ *     G1[u]   = sum over the row's lookups of g_lr[b]                       (the D=1 table's row)
+ *   and the fixed-order partial sums of ||G||^2 / ||G1||^2 (fx_emb_grad_reduce_partials(n_max, D)
+ *   entries each) for clip_grad_norm_ (rank_model.py:321).  drec (gradient of the record from the
+ *   layers that read it), g_fm, g_lr may each be NULL (that term is absent).  The sorted lookups
+ *   of a workgroup's rows are split evenly over its lane groups, so hot rows of tiny tables cost
+ *   no more than cold ones; the result is deterministic.
+ *   Launch 2: dnum_w[j,:] = sum_b dense[b,j] * (value of slot num_out_off[j]), dnum_w1[j] =
+ *   sum_b dense[b,j] g_lr[b], dbias1 = sum_b g_lr[b]  (autograd of feature_embedding.py:280-282
+ *   and logistic_regression.py:55-58).
+ *
+ * fx_sparse_adam_multi / fx_sparse_sgd_multi: fx_sparse_adam / fx_sparse_sgd for every table group
+ *   of one de-dup result in one launch (tables[t].G = that group's reduced gradient).
+ *
+ * fx_pack_columns_multi: fx_pack_columns with one destination per column (outs_host[c] = address of
+ *   out[0, first column], out_lds_host[c] its row stride, out_dtypes_host[c] FX_I32 | FX_F32), so the
+ *   id block, the numeric block and the label of a batch (rank_model.py:169-204, feature_embedding.py
+ *   :280-291) are cast in ONE launch.  <= 96 columns per call.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fx_row_state {
+    float* table;       /* [rows, D] */
+    float* m;           /* Adam moments (NULL for SGD) */
+    float* v;
+    int32_t* last_step; /* [rows] step of the row's last update (NULL: not tracked) */
+    const float* G;     /* [n_max, D] reduced gradient, update entry points only */
+    int32_t D;
+    int32_t reserved;
+} fx_row_state;
+
+int fx_dedup_catchup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
+                     const int64_t* col_row_base, const int32_t* col_vocab, const int32_t* col_pad,
+                     void* workspace, size_t workspace_bytes, uint32_t* sorted_key,
+                     uint32_t* sorted_pos, uint32_t* uniq_row, uint32_t* seg_start,
+                     int32_t* n_unique, uint32_t* sorted_uid /* or NULL */,
+                     fx_scalars* begin_scal /* or NULL */, const fx_row_state* tables_host,
+                     int32_t n_tables, int32_t upto_offset, const fx_scalars* scal,
+                     fx_stream_t stream);
+int fx_emb_fm_fwd(const float* table, int32_t D, const int32_t* ids, int64_t ids_ld,
+                  const int64_t* col_row_base, const int32_t* col_vocab, const int64_t* col_out_off,
+                  int32_t C, const float* dense, int64_t dense_ld, const float* num_w,
+                  const int64_t* num_out_off, int32_t Fd, float* out, int64_t out_ld, int64_t B,
+                  const float* table1, const float* num_w1, const float* bias1, float* lr_out,
+                  float* fm_out, float* fm_lr_out, float* S, fx_scalars* scal, fx_stream_t stream);
+int fx_emb_fm_bwd(const float* drec, int64_t drec_ld, const float* rec, int64_t rec_ld,
+                  const float* S, const float* g_fm, const float* g_lr, const int64_t* col_out_off,
+                  int32_t C, int32_t D, const uint32_t* sorted_pos, const uint32_t* seg_start,
+                  const int32_t* n_unique, int64_t n_max, float* G, float* sq_partials, float* G1,
+                  float* sq1_partials, const float* dense, int64_t dense_ld,
+                  const int64_t* num_out_off, int32_t Fd, int64_t B, float* dnum_w, float* dnum_w1,
+                  float* dbias1, fx_stream_t stream);
+int fx_sparse_adam_multi(const fx_row_state* tables_host, int32_t n_tables, const uint32_t* uniq_row,
+                         const int32_t* n_unique, int64_t n_max, const fx_scalars* scal,
+                         fx_stream_t stream);
+int fx_sparse_sgd_multi(const fx_row_state* tables_host, int32_t n_tables, const uint32_t* uniq_row,
+                        const int32_t* n_unique, int64_t n_max, const fx_scalars* scal,
+                        fx_stream_t stream);
+int fx_pack_columns_multi(const void* const* cols_host, const int32_t* dtypes_host,
+                          const int32_t* widths_host, void* const* outs_host,
+                          const int32_t* out_dtypes_host, const int64_t* out_lds_host, int32_t ncols,
+                          int64_t B, fx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,7 +57,9 @@ def feature_embedding(state, prefix, features, X, encode=True):
             continue
         w = state[prefix + name + ".weight"]
         if spec["type"] == "numeric":
-            out[name] = F.linear(X[name].float().view(-1, 1), w)
+            # x.float() in the reference; .to(w.dtype) is the same in fp32 and lets OracleTrainer64
+            # evaluate the identical graph in float64
+            out[name] = F.linear(X[name].to(w.dtype).view(-1, 1), w)
         elif spec["type"] in ("categorical", "sequence"):
             out[name] = F.embedding(X[name].long(), w, padding_idx=spec.get("padding_idx", None))
             if encode and spec.get("feature_encoder"):
@@ -220,7 +222,7 @@ def dot_interaction(feature_emb):
     """InnerProductInteraction 'inner_product', inner_product.py:63-66."""
     F_ = feature_emb.shape[1]
     ipm = torch.bmm(feature_emb, feature_emb.transpose(1, 2))
-    mask = torch.triu(torch.ones(F_, F_), 1).bool()
+    mask = torch.triu(torch.ones(F_, F_, device=feature_emb.device), 1).bool()
     return torch.masked_select(ipm, mask).view(-1, F_ * (F_ - 1) // 2)
 
 
@@ -233,7 +235,7 @@ def dlrm_logit(state, features, X, cfg):
     emb = dict2tensor(sparse, feature_embedding(state, EMB, sparse, X))
     if dense_feats:
         dense_x = torch.cat([X[k].float().view(-1, 1) for k in dense_feats], dim=-1)
-        h = dense_x
+        h = dense_x.to(state["bottom_mlp.mlp.0.weight"].dtype)     # (fp32; fp64 in OracleTrainer64)
         for i in range(cfg["n_bottom"] + 1):
             h = F.relu(F.linear(h, state["bottom_mlp.mlp.%d.weight" % (2 * i)],
                                 state["bottom_mlp.mlp.%d.bias" % (2 * i)]))
@@ -343,8 +345,12 @@ class OracleTrainer(object):
     """State + dense Adam, one `train_step` == BaseModel.train_step (rank_model.py:307-323)."""
 
     def __init__(self, cfg, state, features, lr=1e-3, max_norm=10.0, optimizer="adam",
-                 emb_reg=None, net_reg=None):
+                 emb_reg=None, net_reg=None, device="cpu"):
+        """device: "cpu" is THE oracle.  A HIP device runs the identical functional code on ATen's
+        GPU kernels — what the reference itself executes with `gpu: 0` — and is used by the tests
+        only as a yardstick for how far the reference's own two back ends drift apart."""
         self.cfg, self.features = cfg, features
+        self.device = torch.device(device)
         self.emb_reg, self.net_reg = emb_reg or [], net_reg or []   # [(p_norm, weight)]
         self.lr, self.max_norm, self.kind = lr, max_norm, optimizer
         self.state = OrderedDict()
@@ -360,9 +366,9 @@ class OracleTrainer(object):
                 continue
             t = torch.as_tensor(t)
             if "running_" in k or "num_batches_tracked" in k:      # BatchNorm buffers
-                self.state[k] = t.detach().clone()
+                self.state[k] = t.detach().clone().to(self.device)
                 continue
-            self.state[k] = t.detach().clone().float().requires_grad_(True)
+            self.state[k] = t.detach().clone().float().to(self.device).requires_grad_(True)
         self.params, self.is_emb = [], []
         seen = set()
         for k, t in self.state.items():
@@ -375,7 +381,13 @@ class OracleTrainer(object):
         self.v = [torch.zeros_like(p) for p in self.params]
         self.step = 0
 
+    def _to_dev(self, X):
+        if self.device.type == "cpu":
+            return X
+        return {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in X.items()}
+
     def train_step(self, X, y):
+        X, y = self._to_dev(X), y.to(self.device)
         for p in self.params:
             p.grad = None                                   # optimizer.zero_grad()
         prob = torch.sigmoid(model_logit(self.cfg, self.state, self.features, X, training=True))
@@ -400,5 +412,56 @@ class OracleTrainer(object):
                 reg_term = reg_term + (lam / norm_p) * torch.norm(p, norm_p) ** norm_p
         return reg_term
 
+    def logits(self, X):
+        with torch.no_grad():
+            return model_logit(self.cfg, self.state, self.features, self._to_dev(X),
+                               training=False).reshape(-1).float().cpu()
+
     def predict(self, X):
-        return predict(self.cfg, self.state, self.features, X)
+        return predict(self.cfg, self.state, self.features, self._to_dev(X)).cpu()
+
+
+class OracleTrainer64(OracleTrainer):
+    """The SAME algorithm with the forward / backward evaluated in float64: gradients are rounded to
+    fp32 once, then the identical fp32 clip + Adam/SGD on the fp32 master weights.  Not a second
+    reference — a yardstick for the reference's own conditioning: how far two correctly rounded
+    evaluations of one training step drift apart (Adam's lr*m/(sqrt(v)+eps) turns gradient elements
+    that are cancellation residue into +-lr steps), which bounds what "equal to the reference after k
+    steps" can mean for ANY fp32 implementation (tests/baseline_shapes.py)."""
+
+    def train_step(self, X, y):
+        twin, st64 = {}, OrderedDict()
+        for k, t in self.state.items():
+            if id(t) not in twin:
+                if t.is_floating_point():
+                    twin[id(t)] = t.detach().double().requires_grad_(t.requires_grad)
+                else:
+                    twin[id(t)] = t.clone()
+            st64[k] = twin[id(t)]
+        X64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v)
+               for k, v in X.items()}
+        self_state, self.state = self.state, st64           # regularization_loss reads self.params
+        try:
+            prob = torch.sigmoid(model_logit(self.cfg, st64, self.features, X64, training=True))
+            loss = bce_mean(prob, y.double().view(-1, 1))
+            for p, emb in zip(self.params, self.is_emb):
+                for norm_p, lam in (self.emb_reg if emb else self.net_reg):
+                    loss = loss + (lam / norm_p) * torch.norm(twin[id(p)], norm_p) ** norm_p
+        finally:
+            self.state = self_state
+        loss.backward()
+        grads = [twin[id(p)].grad.float() if twin[id(p)].grad is not None else torch.zeros_like(p)
+                 for p in self.params]
+        total = clip_grad_norm(grads, self.max_norm)
+        self.step += 1
+        with torch.no_grad():
+            for p, g, m, v in zip(self.params, grads, self.m, self.v):
+                if self.kind == "adam":
+                    adam_dense(p, g, m, v, self.step, self.lr)
+                else:
+                    p.add_(g, alpha=-self.lr)
+            for k, t in self.state.items():                  # BatchNorm / Dice running statistics
+                if not t.requires_grad:
+                    t.copy_(st64[k].to(t.dtype))
+        return float(loss.detach()), total
+

@@ -19,3 +19,4 @@ def test_harness_on_the_emulation(case, dist, tmp_path, monkeypatch):
     res = BS.run_parity(case, dist, model, features, cfg, spec, cards, O, B=512, steps=6,
                         holdout=8192)
     assert res["loss_first_last"][1] < res["loss_first_last"][0] + 0.05
+    assert res["native"]["max"] <= res["bounds"]["max"]
