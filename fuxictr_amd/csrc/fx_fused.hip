@@ -774,7 +774,8 @@ extern "C" int fx_emb_fm_bwd(const float* drec, int64_t drec_ld, const float* re
     const FxRowGeom g = fx_row_geom(D);
     FX_CHECK_ARG(g.lanes <= 64, "fx_emb_fm_bwd: D=%d needs %d lanes per row (max 64)", D, g.lanes);
     FX_CHECK_ARG(g_fm == nullptr || (rec && S), "fx_emb_fm_bwd: FM term without rec / S");
-    FX_CHECK_ARG(drec != nullptr || g_fm != nullptr, "fx_emb_fm_bwd: no upstream gradient at all");
+    FX_CHECK_ARG(drec != nullptr || g_fm != nullptr || g_lr != nullptr,
+                 "fx_emb_fm_bwd: no upstream gradient at all");
     FX_CHECK_ARG((drec == nullptr || drec_ld % g.vec == 0) && (rec == nullptr || rec_ld % g.vec == 0),
                  "fx_emb_fm_bwd: leading dimensions not a multiple of %d", g.vec);
     hipStream_t s = fx_hip_stream(stream);

@@ -166,6 +166,7 @@ class _TableGroup(object):
         self._reduce_scratch = {}
         self._await_exchange = []     # row-gradient buffers waiting for their all-to-all
         self.dedup_ws = None
+        self.opt = None               # the native optimizer this group is attached to
         # row sharding (owner = row % world, local row = row // world)
         self.dist = _DIST
         self.n_shards = _DIST.world if _DIST is not None else 1
@@ -333,11 +334,22 @@ class _TableGroup(object):
             cache[ckey] = (ids, dense)
         return ids, dense
 
+    def row_state(self, G=None):
+        return ops.RowState(self.table, self.m, self.v, self.last_step, self.D, G)
+
+    def fast_columns(self, plan, B):
+        """The fused column path (csrc/fx_fused.hip) applies: every id column owns its own table, in
+        column order, unsharded, batch small enough for one in-LDS sort per column."""
+        return (not self.sharded and plan.n_seq == 0 and plan.columns_sorted and B <= 8192
+                and plan.C <= 256 and _lib.row_lanes(self.D) <= 64)
+
     def dedup(self, plan, ids, inputs):
         cache = getattr(inputs, "cache", None)
         ckey = ("dedup", plan.sig, self.total_rows)
         if cache is not None and ckey in cache:
             return cache[ckey]
+        if self.opt is not None:
+            self.opt.flush_begin()
         n = ids.shape[0] * ids.shape[1]
         if self.dedup_ws is None or self.dedup_ws[0] != n:
             self.dedup_ws = (n, torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8,
@@ -356,14 +368,38 @@ class _TableGroup(object):
         idx = torch.tensor(plan.num_rows, dtype=torch.int64, device=self.device)
         return self.num_w.index_select(0, idx)
 
-    def prepare_train(self, plan, ids, inputs):
-        """De-dup the batch's rows; in exact mode bring them up to date before they are read."""
+    def prepare_train(self, plan, ids, inputs, peers=()):
+        """De-dup the batch's rows; in exact mode bring them up to date before they are read.
+        peers: other table groups that are looked up with the SAME id plan in this step (the D=1
+        tables of LogisticRegression): their rows are caught up in the same launch."""
         if plan.C == 0 or self.opt_kind is None:
             return None
-        dd = self.dedup(plan, ids, inputs)
-        if self.exact and self.opt_kind == "adam":
-            ops.adam_catchup(self.table, self.m, self.v, self.last_step, self.D, dd,
-                             self.total_rows, -1, self.scal)
+        cache = getattr(inputs, "cache", None)
+        ckey = ("dedup", plan.sig, self.total_rows)
+        todo = [g for g in (self,) + tuple(peers)
+                if g.exact and g.opt_kind == "adam"
+                and not (cache is not None and ("caughtup", id(g), ckey) in cache)]
+        dd = cache.get(ckey) if cache is not None else None
+        if dd is None and self.fast_columns(plan, ids.shape[0]):
+            n = ids.shape[0] * ids.shape[1]
+            if self.dedup_ws is None or self.dedup_ws[0] != n:
+                self.dedup_ws = (n, torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8,
+                                                device=self.device))
+            begin = self.opt.take_begin() if self.opt is not None else None
+            dd = ops.dedup_catchup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad,
+                                   self.dedup_ws[1], [g.row_state() for g in todo], self.scal,
+                                   begin_scal=begin)
+            if cache is not None:
+                cache[ckey] = dd
+                for g in todo:
+                    cache[("caughtup", id(g), ckey)] = True
+            return dd
+        if dd is None:
+            dd = self.dedup(plan, ids, inputs)
+        for g in todo:
+            ops.adam_catchup(g.table, g.m, g.v, g.last_step, g.D, dd, g.total_rows, -1, g.scal)
+            if cache is not None:
+                cache[("caughtup", id(g), ckey)] = True
         return dd
 
     def backward(self, plan, ids, dense, dout, dout_ld, col_off, num_off, dd, inputs_cache,
@@ -373,13 +409,7 @@ class _TableGroup(object):
         if plan.Fd:
             g = torch.empty(plan.Fd, D, dtype=torch.float32, device=self.device)
             ops.emb_numeric_grad(dout, dout_ld, num_off, dense, D, g)
-            if plan.num_full and self.num_grad is None:
-                self.num_grad = g
-            else:
-                if self.num_grad is None:
-                    self.num_grad = torch.zeros_like(self.num_w)
-                idx = torch.tensor(plan.num_rows, dtype=torch.int64, device=self.device)
-                self.num_grad.index_add_(0, idx, g)
+            self.add_num_grad(plan, g)
         col_denom = plan.col_denom if denom is not None else None
         if plan.C and sx is not None:
             self.shard_backward(plan, sx, dout, dout_ld, col_off, col_denom, denom)
@@ -392,6 +422,16 @@ class _TableGroup(object):
             ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G, sq,
                                 self.reduce_scratch(dd.n_max), col_denom, denom)
             self.pending.append(_PendingGrad(dd, G, sq))
+
+    def add_num_grad(self, plan, g):
+        """g [plan.Fd, D]: gradient of the numeric weights used by `plan`."""
+        if plan.num_full and self.num_grad is None:
+            self.num_grad = g
+        else:
+            if self.num_grad is None:
+                self.num_grad = torch.zeros_like(self.num_w)
+            idx = torch.tensor(plan.num_rows, dtype=torch.int64, device=self.device)
+            self.num_grad.index_add_(0, idx, g)
 
     def reduce_scratch(self, n_max):
         """Persistent scratch of fx_emb_grad_reduce (word 0 zero on entry, left zero on return)."""
@@ -424,6 +464,8 @@ class _TableGroup(object):
                                             device=dev))
         # unique GLOBAL rows in ascending order (the column fast path applies); owners and slots are
         # derived by counting in fx_shard_plan(global_keys), no owner-major device sort
+        if self.opt is not None:
+            self.opt.flush_begin()
         dd = ops.dedup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad, self.total_rows,
                        self.dedup_ws[1], want_uid=True, columns_sorted=plan.columns_sorted)
         cap = self.a2a_cap(n)
@@ -600,6 +642,85 @@ class _EmbGatherFn(torch.autograd.Function):
                            ctx.plan.col_out_off, ctx.plan.num_out_off, ctx.dd, ctx.inputs,
                            sx=ctx.sx, denom=ctx.denom)
         return None, None, None, None, None, None, None, None
+
+
+class _EmbFMFn(torch.autograd.Function):
+    """The fused sparse front end (csrc/fx_fused.hip): gather + numeric expansion, and — when the
+    model has them — the first-order term of LogisticRegression (logistic_regression.py:46-59) and
+    the FM second-order term (inner_product.py:55-62), ONE launch; outputs = (record [B, F*D],
+    lr_out, fm_out, fm_lr_out = fm + lr), the last three [B,1] or None.  Backward: ONE balanced
+    run-reduce for the D-float rows and the D=1 rows with the FM gradient folded in and the clip-norm
+    partials fused, plus one launch for the numeric weights / LR bias."""
+
+    @staticmethod
+    def forward(ctx, anchor, lr_anchor, lr_bias, group, plan, lr_group, lr_plan, ids, dense, dd,
+                inputs, want_fm):
+        ctx.set_materialize_grads(False)
+        B = (ids if ids is not None else dense).shape[0]
+        D = group.D
+        dev = group.device
+        out = torch.empty(B, plan.n_slots * D, dtype=torch.float32, device=dev)
+        want_lr = lr_group is not None
+        lr_out = torch.empty(B, 1, dtype=torch.float32, device=dev) if want_lr else None
+        fm_out = torch.empty(B, 1, dtype=torch.float32, device=dev) if want_fm else None
+        fm_lr = torch.empty(B, 1, dtype=torch.float32, device=dev) if (want_fm and want_lr) else None
+        S = torch.empty(B, D, dtype=torch.float32, device=dev) if want_fm else None
+        ops.emb_fm_fwd(group.table, D, ids, plan.col_row_base, plan.col_vocab, plan.col_out_off,
+                       dense, group.select_num_w(plan), plan.num_out_off, out, group.ensure_scal(),
+                       table1=lr_group.table if want_lr else None,
+                       num_w1=lr_group.select_num_w(lr_plan) if want_lr else None,
+                       bias1=lr_bias if want_lr else None, lr_out=lr_out, fm_out=fm_out,
+                       fm_lr_out=fm_lr, S=S)
+        ctx.group, ctx.plan, ctx.lr_group, ctx.lr_plan = group, plan, lr_group, lr_plan
+        ctx.ids, ctx.dense, ctx.dd, ctx.out, ctx.S = ids, dense, dd, out, S
+        ctx.inputs = inputs if hasattr(inputs, "cache") else None
+        ctx.has_bias = lr_bias is not None
+        return out, lr_out, fm_out, fm_lr
+
+    @staticmethod
+    def backward(ctx, d_out, d_lr, d_fm, d_fm_lr):
+        group, plan, lr_group, lr_plan = ctx.group, ctx.plan, ctx.lr_group, ctx.lr_plan
+
+        def both(a, b):
+            if a is None:
+                return b
+            return a if b is None else a + b
+        g_fm, g_lr = both(d_fm, d_fm_lr), both(d_lr, d_fm_lr)
+        none = (None,) * 12
+        if d_out is None and g_fm is None and g_lr is None:
+            return none
+        D, dev = group.D, group.device
+        B = ctx.out.shape[0]
+        d_out = d_out.contiguous() if d_out is not None else None
+        g_fm = g_fm.contiguous() if g_fm is not None else None
+        g_lr = g_lr.contiguous() if g_lr is not None else None
+        dd = ctx.dd
+        if dd is None and plan.C:
+            dd = group.dedup(plan, ctx.ids, ctx.inputs)
+        G = sq = G1 = sq1 = None
+        if plan.C:
+            G = torch.empty(dd.n_max, D, dtype=torch.float32, device=dev)
+            nparts = ops.emb_grad_reduce_partials(dd.n_max, D)
+            sq = torch.empty(nparts, dtype=torch.float32, device=dev)
+            if g_lr is not None:
+                G1 = torch.empty(dd.n_max, 1, dtype=torch.float32, device=dev)
+                sq1 = torch.empty(nparts, dtype=torch.float32, device=dev)
+        dnum = torch.empty(plan.Fd, D, dtype=torch.float32, device=dev) if plan.Fd else None
+        dnum1 = torch.empty(plan.Fd, 1, dtype=torch.float32, device=dev) \
+            if (plan.Fd and g_lr is not None) else None
+        dbias = torch.empty(1, dtype=torch.float32, device=dev) \
+            if (ctx.has_bias and g_lr is not None) else None
+        ops.emb_fm_bwd(d_out, ctx.out, ctx.S, g_fm, g_lr, plan.col_out_off, plan.C, D, dd, G, sq,
+                       G1, sq1, ctx.dense, plan.num_out_off, B, dnum, dnum1, dbias)
+        if plan.C:
+            group.pending.append(_PendingGrad(dd, G, sq))
+            if G1 is not None:
+                lr_group.pending.append(_PendingGrad(dd, G1, sq1))
+        if dnum is not None:
+            group.add_num_grad(plan, dnum)
+        if dnum1 is not None:
+            lr_group.add_num_grad(lr_plan, dnum1)
+        return (None, None, dbias) + (None,) * 9
 
 
 class _SplitRecordFn(torch.autograd.Function):
@@ -827,10 +948,29 @@ class FeatureEmbeddingDict(nn.Module):
             plan = grp.plan_for(feats, self._fused_pooling(grp, feats))
             ids, dense = grp.pack_inputs(plan, inputs)
             track = torch.is_grad_enabled() and self.training
-            dd = grp.prepare_train(plan, ids, inputs) if (track and not grp.sharded) else None
             anchor = self._anchor(grp)
-            out = _EmbGatherFn.apply(anchor, grp, plan, ids, dense, dd, inputs, track)
+            B_ = (ids if ids is not None else dense).shape[0]
+            front = None
+            if self.fuse_front and grp.fast_columns(plan, B_) and len(self._groups) == 1:
+                # the fused front end: gather (+ first-order term + FM term), one launch
+                lr_mod, lr_grp, lr_plan = self._lr_peer_for(plan, feats, inputs)
+                peers = (lr_grp,) if lr_grp is not None else ()
+                dd = grp.prepare_train(plan, ids, inputs, peers) if track else None
+                want_fm = bool(self._fuse_fm) and plan.n_slots == plan.C + plan.Fd
+                out, lr_out, fm_out, fm_lr = _EmbFMFn.apply(
+                    anchor, lr_mod.embedding_layer.embedding_layer._anchor(lr_grp)
+                    if lr_grp is not None else None,
+                    lr_mod.bias if lr_grp is not None else None, grp, plan, lr_grp, lr_plan, ids,
+                    dense, dd, inputs, want_fm)
+                front = {"lr_mod": lr_mod, "lr": lr_out, "fm": fm_out, "fm_lr": fm_lr}
+                if lr_grp is not None and hasattr(inputs, "cache"):
+                    inputs.cache[("lr_out", id(lr_mod))] = lr_out
+            else:
+                dd = grp.prepare_train(plan, ids, inputs) if (track and not grp.sharded) else None
+                out = _EmbGatherFn.apply(anchor, grp, plan, ids, dense, dd, inputs, track)
             rec = out.view(out.shape[0], plan.n_slots, D)
+            if front is not None:
+                rec._fx_fused = front
             fused.update(plan.pooled)
             raw_seq = [fmap[f]["type"] == "sequence" and f not in plan.pooled for f in feats]
             bounds = tuple((plan.slot[f][0], plan.slot[f][1] if r else None)
@@ -856,6 +996,32 @@ class FeatureEmbeddingDict(nn.Module):
         return feature_emb_dict
 
     fuse_pooling = True     # class switch for A/B measurements (scripts/seqpool_bench.py)
+    fuse_front = True       # class switch: the fused front / back end of csrc/fx_fused.hip
+    _lr_peer = None         # the model's LogisticRegression, set by link_fusion()
+    _fuse_fm = False        # the model contains a product_sum interaction over this layer's record
+
+    def _lr_peer_for(self, plan, feats, inputs):
+        """-> (LogisticRegression module, its D=1 table group, its plan) when the model's first-order
+        layer looks up the SAME id columns / numeric columns as `plan` (then both share one de-dup
+        and one launch), else (None, None, None)."""
+        lr = self._lr_peer
+        if lr is None or not hasattr(inputs, "cache"):
+            return None, None, None
+        layer = lr.embedding_layer.embedding_layer
+        groups = layer.table_groups()
+        fmap = layer._feature_map.features
+        lr_feats = [f for f in fmap if f in inputs and f in layer.embedding_layers]
+        if (len(groups) != 1 or layer._torch_feats or lr_feats != list(feats)
+                or groups[0].D != 1 or groups[0].sharded
+                or lr.training != self.training):
+            return None, None, None
+        lr_grp = groups[0]
+        lr_plan = lr_grp.plan_for(lr_feats, tail=[f for f in lr_feats
+                                                   if fmap[f]["type"] == "sequence"])
+        if lr_plan.sig != plan.sig or lr_plan.pack_sig != plan.pack_sig \
+                or lr_plan.num_feats != plan.num_feats:
+            return None, None, None
+        return lr, lr_grp, lr_plan
 
     def _fused_pooling(self, grp, feats):
         """Sequence features of `feats` whose encoder is one of the two pooling layers: reduced
@@ -1069,6 +1235,9 @@ class LogisticRegression(nn.Module):
                                                 use_sharing=False)
 
     def forward(self, X):
+        cached = X.cache.pop(("lr_out", id(self)), None) if hasattr(X, "cache") else None
+        if cached is not None:
+            return cached        # computed by the embedding layer's fused launch (_EmbFMFn)
         layer = self.embedding_layer.embedding_layer
         groups = layer.table_groups()
         fmap = layer._feature_map.features
@@ -1158,6 +1327,9 @@ class InnerProductInteraction(nn.Module):
     def forward(self, feature_emb):
         kind = self._output_type
         if kind == "product_sum":
+            fused = getattr(feature_emb, "_fx_fused", None)
+            if fused is not None and fused["fm"] is not None:
+                return fused["fm"]       # computed together with the gather (_EmbFMFn)
             return _FMFn.apply(feature_emb, None)
         if kind == "inner_product":
             n_f, dim = feature_emb.shape[1], feature_emb.shape[2]
@@ -1181,6 +1353,11 @@ class FactorizationMachine(nn.Module):
         self.lr_layer = LogisticRegression(feature_map, use_bias=True)
 
     def forward(self, X, feature_emb):
+        fused = getattr(feature_emb, "_fx_fused", None)
+        if fused is not None and fused["lr_mod"] is self.lr_layer and fused["fm_lr"] is not None:
+            if hasattr(X, "cache"):
+                X.cache.pop(("lr_out", id(self.lr_layer)), None)
+            return fused["fm_lr"]        # gather + LR + FM came out of ONE launch (_EmbFMFn)
         lr_out = self.lr_layer(X)
         return _FMFn.apply(feature_emb, lr_out)
 
@@ -1647,3 +1824,24 @@ class CrossNetV2(nn.Module):
         for lin in self.cross_layers:
             wb += [lin.weight, lin.bias]
         return _CrossNetV2Fn.apply(X_0, *wb)
+
+
+
+def link_fusion(model):
+    """Called by BaseModel.compile(): tell the model's embedding layer which LogisticRegression
+    and which FM-style interaction read the same batch, so that their work rides along in the
+    embedding layer's launches (_EmbFMFn).  Only the unambiguous case is linked: ONE
+    FeatureEmbeddingDict besides the one LogisticRegression owns."""
+    lrs = [m for m in model.modules() if isinstance(m, LogisticRegression)]
+    lr_layers = {id(lr.embedding_layer.embedding_layer) for lr in lrs}
+    mains = [m for m in model.modules()
+             if isinstance(m, FeatureEmbeddingDict) and id(m) not in lr_layers]
+    if len(mains) != 1:
+        return
+    main = mains[0]
+    # (through __dict__: a plain attribute assignment would register the LR module as a submodule of
+    # the embedding layer and duplicate its state_dict keys)
+    main.__dict__["_lr_peer"] = lrs[0] if len(lrs) == 1 else None
+    main.__dict__["_fuse_fm"] = any(isinstance(m, FactorizationMachine)
+                        or (isinstance(m, InnerProductInteraction)
+                            and m._output_type == "product_sum") for m in model.modules())

@@ -595,3 +595,131 @@ def binary_metrics(y_pred, y_true):
                          "case.")
     auc = (s2 - n_pos * (n_pos + 1)) / (2 * n_pos * n_neg)     # exact integers, one rounding
     return float(ll.item()) / n, auc
+
+
+# ---- fused sparse front end / back end (csrc/fx_fused.hip) ----------------------------------------
+class RowState(object):
+    """One packed table + its optimizer state (struct fx_row_state)."""
+    __slots__ = ("table", "m", "v", "last_step", "G", "D")
+
+    def __init__(self, table, m, v, last_step, D, G=None):
+        self.table, self.m, self.v, self.last_step, self.D, self.G = table, m, v, last_step, D, G
+
+
+def _row_states(states):
+    arr = (_lib.RowState * max(len(states), 1))()
+    for i, s in enumerate(states):
+        arr[i].table = s.table.data_ptr()
+        arr[i].m = s.m.data_ptr() if s.m is not None else None
+        arr[i].v = s.v.data_ptr() if s.v is not None else None
+        arr[i].last_step = s.last_step.data_ptr() if s.last_step is not None else None
+        arr[i].G = s.G.data_ptr() if s.G is not None else None
+        arr[i].D = int(s.D)
+    return arr
+
+
+@_timed("dedup_catchup", "sparse_path")
+def dedup_catchup(ids, col_row_base, col_vocab, col_pad, workspace, states, scal, begin_scal=None,
+                  upto_offset=-1, want_uid=False, result=None):
+    """Column fast path of the de-dup + (optionally) the fused begin-step + the exact-mode catch-up
+    of every table group in `states` (list of RowState); 2 launches.  -> DedupResult."""
+    lib = _lib.load()
+    B, C_ = ids.shape
+    if result is None:
+        result = DedupResult(B * C_, C_, ids.device, want_uid=want_uid)
+    check(lib.fx_dedup_catchup(ptr(ids), ids.stride(0), B, C_, ptr(col_row_base), ptr(col_vocab),
+                               ptr(col_pad), ptr(workspace), workspace.numel(),
+                               ptr(result.sorted_key), ptr(result.sorted_pos), ptr(result.uniq_row),
+                               ptr(result.seg_start), ptr(result.n_unique), ptr(result.sorted_uid),
+                               ptr(begin_scal), _row_states(states), len(states), upto_offset,
+                               ptr(scal), stream_ptr(ids.device)), "fx_dedup_catchup")
+    return result
+
+
+def _emb_fm_bytes(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w, num_out_off,
+                  out, scal, table1=None, **kw):
+    B = out.shape[0]
+    C_ = 0 if ids is None else ids.shape[1]
+    Fd = 0 if dense is None else dense.shape[1]
+    # SURVEY.md 8d: rows + ids + dense in (+ the 4-byte first-order rows), the record out
+    return B * (C_ * (4 * D + 4) + Fd * 4 + (C_ * 4 if table1 is not None else 0)
+                + (C_ + Fd) * 4 * D)
+
+
+@_timed("k_emb_fm_fwd", "sparse_path", _emb_fm_bytes)
+def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w, num_out_off, out,
+               scal, table1=None, num_w1=None, bias1=None, lr_out=None, fm_out=None, fm_lr_out=None,
+               S=None):
+    """Gather + numeric expansion (+ first-order term) (+ FM second-order term), one launch."""
+    lib = _lib.load()
+    B = out.shape[0]
+    C_ = 0 if ids is None else ids.shape[1]
+    Fd = 0 if dense is None else dense.shape[1]
+    check(lib.fx_emb_fm_fwd(ptr(table), D, ptr(ids), 0 if ids is None else ids.stride(0),
+                            ptr(col_row_base), ptr(col_vocab), ptr(col_out_off), C_, ptr(dense),
+                            0 if dense is None else dense.stride(0), ptr(num_w), ptr(num_out_off),
+                            Fd, ptr(out), out.stride(0), B, ptr(table1), ptr(num_w1), ptr(bias1),
+                            ptr(lr_out), ptr(fm_out), ptr(fm_lr_out), ptr(S), ptr(scal),
+                            stream_ptr(out.device)), "fx_emb_fm_fwd")
+    return out
+
+
+@_timed("emb_fm_bwd", "sparse_path")
+def emb_fm_bwd(drec, rec, S, g_fm, g_lr, col_out_off, C_, D, dd, G, sq_partials, G1, sq1_partials,
+               dense, num_out_off, B, dnum_w, dnum_w1, dbias1):
+    """Backward of emb_fm_fwd: unique-row gradients of the D-float table (and of the D=1 table),
+    their squared-norm partials, numeric weight / LR bias gradients; 2 launches."""
+    Fd = 0 if dense is None else dense.shape[1]
+    check(_lib.load().fx_emb_fm_bwd(
+        ptr(drec), 0 if drec is None else drec.stride(0), ptr(rec),
+        0 if rec is None else rec.stride(0), ptr(S), ptr(g_fm), ptr(g_lr), ptr(col_out_off), C_, D,
+        ptr(dd.sorted_pos) if dd is not None else vp(0),
+        ptr(dd.seg_start) if dd is not None else vp(0),
+        ptr(dd.n_unique) if dd is not None else vp(0), dd.n_max if dd is not None else 0, ptr(G),
+        ptr(sq_partials), ptr(G1), ptr(sq1_partials), ptr(dense),
+        0 if dense is None else dense.stride(0), ptr(num_out_off), Fd, B, ptr(dnum_w), ptr(dnum_w1),
+        ptr(dbias1), stream_ptr((rec if rec is not None else drec).device)), "fx_emb_fm_bwd")
+
+
+@_timed("sparse_update_multi", "sparse_path")
+def sparse_update_multi(kind, states, dd, scal):
+    """Row update (kind 'adam' | 'sgd') of every table group in `states` (RowState with .G)."""
+    lib = _lib.load()
+    fn = lib.fx_sparse_adam_multi if kind == "adam" else lib.fx_sparse_sgd_multi
+    check(fn(_row_states(states), len(states), ptr(dd.uniq_row), ptr(dd.n_unique), dd.n_max,
+             ptr(scal), stream_ptr(scal.device)), "fx_sparse_%s_multi" % kind)
+
+
+def pack_columns_multi(items):
+    """items: list of (column tensor [B] | [B,w], destination matrix, first destination column);
+    every column is cast into its destination (int32 or float32) in ONE launch per 96 columns."""
+    lib = _lib.load()
+    if not items:
+        return
+    B = items[0][1].shape[0]
+    i = 0
+    while i < len(items):
+        chunk = items[i:i + _lib.FX_PACKM_MAX_COLS]
+        cols, dts, ws, outs, odts, olds = [], [], [], [], [], []
+        for t, out, col0 in chunk:
+            _need_cuda(t, "input column")
+            if t.dtype not in _DT or out.dtype not in (torch.int32, torch.float32):
+                raise _lib.FxError("unsupported dtype %s -> %s" % (t.dtype, out.dtype))
+            if not t.is_contiguous():
+                t = t.contiguous()
+            if t.shape[0] != B or out.shape[0] != B:
+                raise _lib.FxError("input column has %d rows, expected %d" % (t.shape[0], B))
+            cols.append(t)
+            dts.append(_DT[t.dtype])
+            ws.append(1 if t.dim() == 1 else int(t.shape[1]))
+            outs.append(out.data_ptr() + col0 * out.element_size())
+            odts.append(_DT[out.dtype])
+            olds.append(out.stride(0))
+        oarr = (vp * len(outs))()
+        for k, a in enumerate(outs):
+            oarr[k] = a
+        check(lib.fx_pack_columns_multi(_lib.ptr_array(cols), _lib.i32_array(dts),
+                                        _lib.i32_array(ws), oarr, _lib.i32_array(odts),
+                                        _lib.i64_array(olds), len(cols), B,
+                                        stream_ptr(chunk[0][1].device)), "fx_pack_columns_multi")
+        i += len(chunk)

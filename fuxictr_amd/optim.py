@@ -52,6 +52,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
         self._lr_dev = float(lr)
         self._max_norm = 0.0
         self._begun = False      # zero_grad() opened a step that step() has not closed yet
+        self._begin_pending = False   # ... and its device-side part has not been launched yet
         self._model = model
         self._state_dense = {}   # id(tensor) -> (m, v)
         self._sq_dense = None
@@ -81,6 +82,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
     # -- setup --------------------------------------------------------------------------------
     def _attach(self, grp):
         grp.scal = self.scal
+        grp.opt = self
         grp.opt_kind = self.kind
         # dense_reg: every row is stepped every step, so there is nothing to catch up
         grp.exact = self.kind == "adam" and self.sparse_update == "exact" and not self.dense_reg
@@ -121,8 +123,23 @@ class _NativeOptimizer(torch.optim.Optimizer):
         if self._begun:
             return
         self.sync_lr()
-        ops.opt_begin_step(self.scal)
+        # the device-side part (t += 1, bias corrections) rides along in the first de-dup launch of
+        # the step (fx_dedup_catchup); whoever needs it earlier calls flush_begin()
+        self._begin_pending = True
         self._begun = True
+
+    def take_begin(self):
+        """-> the scalar block if the step's device-side opening is still due (the caller's kernel
+        performs it), else None."""
+        if self._begin_pending:
+            self._begin_pending = False
+            return self.scal
+        return None
+
+    def flush_begin(self):
+        if self._begin_pending:
+            self._begin_pending = False
+            ops.opt_begin_step(self.scal)
 
     def flush(self):
         for grp in self._groups:
@@ -219,6 +236,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 "(call optimizer.zero_grad() at the top of every training step, as "
                 "BaseModel.train_step does)")
         self._begun = False
+        self.flush_begin()
         if self._model is not None and hasattr(self._model, "_max_gradient_norm"):
             # the global-norm clip (rank_model.py:321) lives inside the update kernels: a train_step
             # override that reaches step() directly still gets fit()'s max_gradient_norm, table
@@ -277,9 +295,20 @@ class _NativeOptimizer(torch.optim.Optimizer):
         ops.clip_coef(parts, self.scal)
         if ps:
             self._dense_update(ps, gs)
+        # table groups that were reduced against the SAME de-dup result (the D=16 tables and the D=1
+        # tables of LogisticRegression) are updated by one launch
+        buckets = {}
         for grp in self._groups:
             for rec in grp.pending:
-                self._sparse_update(grp, rec)
+                buckets.setdefault(id(rec.dd), []).append((grp, rec))
+        for items in buckets.values():
+            if len(items) > 1 and len(items) <= _lib.FX_MAX_TABLES:
+                ops.sparse_update_multi(self.kind, [g.row_state(G=r.G) for g, r in items],
+                                        items[0][1].dd, self.scal)
+            else:
+                for grp, rec in items:
+                    self._sparse_update(grp, rec)
+        for grp in self._groups:
             if self.dense_reg and grp.table is not None:
                 ops.reg_dense_update(grp.table, grp.m, grp.v, grp.last_step, grp.D,
                                      self.kind == "adam", self.scal)

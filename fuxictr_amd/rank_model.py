@@ -264,12 +264,16 @@ class _GraphStep(object):
 
         def col(f):
             return staged[f] if f in staged else batch[f].to(dev)
+        items = []
         for _, id_names, num_names, s_ids, s_dense in self.packs:
-            if s_ids is not None:
-                ops.pack_columns([col(f) for f in id_names], s_ids)
-            if s_dense is not None:
-                ops.pack_columns([col(f) for f in num_names], s_dense)
-        ops.pack_columns([y if key == id(batch) else batch[self.label].to(dev)], self.y)
+            for dst, cols_ in ((s_ids, id_names), (s_dense, num_names)):
+                c0 = 0
+                for f in cols_ if dst is not None else ():
+                    t = col(f)
+                    items.append((t, dst, c0))
+                    c0 += 1 if t.dim() == 1 else t.shape[1]
+        items.append((y if key == id(batch) else batch[self.label].to(dev), self.y, 0))
+        ops.pack_columns_multi(items)      # ids + numerics + label of the batch: one launch
 
 
 class BaseModel(nn.Module):
@@ -329,6 +333,7 @@ class BaseModel(nn.Module):
                                        emb_reg=get_regularizer(self._embedding_regularizer)
                                        if self._embedding_regularizer else None)
         self.loss_fn = get_loss(loss)
+        layers.link_fusion(self)
 
     def regularization_loss(self):
         """rank_model.py:95-118.  The embedding part is computed by fx_reg_stats and carries no
@@ -368,7 +373,10 @@ class BaseModel(nn.Module):
         return self.loss_fn(return_dict["y_pred"], y_true, reduction='mean')
 
     def compute_loss(self, return_dict, y_true):
-        return self.add_loss(return_dict, y_true) + self.regularization_loss()
+        loss, reg = self.add_loss(return_dict, y_true), self.regularization_loss()
+        if isinstance(reg, int) and reg == 0:
+            return loss               # no regularizer: no "loss + 0" launch
+        return loss + reg
 
     def reset_parameters(self):
         """rank_model.py:146-167: xavier_normal_ on Linear/Conv1d, then every init_weights()."""

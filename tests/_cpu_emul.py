@@ -166,6 +166,8 @@ def emb_grad_reduce(dout, dout_ld, col_out_off, C, D, dd, G, sq_partials, scratc
         acc = torch.zeros(D)
         for i in range(int(dd.seg_start[u]), int(dd.seg_start[u + 1])):
             p = int(dd.sorted_pos[i])
+            if p == 0xFFFFFFFF:          # padding_idx / bad id of the column fast path
+                continue
             b, c = divmod(p, C)
             o = b * dout_ld + int(col_out_off[c])
             if col_denom is not None and int(col_denom[c]) >= 0:
@@ -492,8 +494,135 @@ def dedup_sorted_runs(ids, n_runs, vocab, pad, workspace, result=None):
                  vocab, workspace, result=result)
 
 
+
+
+# ---- fused sparse front end / back end (csrc/fx_fused.hip) ----------------------------------------
+class RowState(object):
+    def __init__(self, table, m, v, last_step, D, G=None):
+        self.table, self.m, self.v, self.last_step, self.D, self.G = table, m, v, last_step, D, G
+
+
+def dedup_catchup(ids, col_row_base, col_vocab, col_pad, workspace, states, scal, begin_scal=None,
+                  upto_offset=-1, want_uid=False, result=None):
+    if begin_scal is not None:
+        opt_begin_step(begin_scal)
+    # the column fast path keeps padding / bad-id lookups inside their column (key = pad id or 0,
+    # position 0xFFFFFFFF = "contributes nothing"): emulated on top of the generic de-dup
+    B, C = ids.shape
+    keys = ids.long().clamp(min=0)
+    bad = (ids < 0) | (ids >= col_vocab.view(1, -1))
+    keys = torch.where(bad, torch.zeros_like(keys), keys) + col_row_base.view(1, -1)
+    invalid = bad | (ids == col_pad.view(1, -1))
+    skey_cols, spos_cols = [], []
+    for c in range(C):
+        k = keys[:, c]
+        # real items first among equal keys, like the in-LDS sort (fill items carry the largest key)
+        order = torch.sort(k * 2 + invalid[:, c].long(), stable=True)[1]
+        skey_cols.append(k[order])
+        pos = torch.arange(B) * C + c
+        pos = torch.where(invalid[:, c], torch.full_like(pos, 0xFFFFFFFF), pos)
+        spos_cols.append(pos[order])
+    skey, spos = torch.cat(skey_cols), torch.cat(spos_cols)
+    uniq, counts = torch.unique_consecutive(skey, return_counts=True)
+    dd = DedupResult()
+    n = B * C
+    dd.sorted_key = skey.int()
+    dd.sorted_pos = spos          # int64 holding 0xFFFFFFFF for "no position"
+    dd.uniq_row = torch.zeros(n, dtype=torch.int64)
+    dd.uniq_row[:len(uniq)] = uniq
+    dd.seg_start = torch.zeros(n + 1, dtype=torch.int32)
+    dd.seg_start[1:len(uniq) + 1] = torch.cumsum(counts, 0).int()
+    dd.n_unique = torch.tensor([len(uniq)], dtype=torch.int32)
+    dd.n_max, dd.C = n, C
+    dd.sorted_uid = torch.repeat_interleave(torch.arange(len(uniq)), counts).int() if want_uid \
+        else None
+    for st in states:
+        adam_catchup(st.table, st.m, st.v, st.last_step, st.D, dd, st.table.shape[0], upto_offset,
+                     scal)
+    return dd
+
+
+def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w, num_out_off, out,
+               scal, table1=None, num_w1=None, bias1=None, lr_out=None, fm_out=None, fm_lr_out=None,
+               S=None):
+    emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w, num_out_off,
+                   out, scal)
+    lr = None
+    if lr_out is not None or fm_lr_out is not None:
+        lr = torch.empty(out.shape[0], 1)
+        lr_fwd(table1, ids, col_row_base, col_vocab, dense, num_w1, bias1, lr, scal)
+        if lr_out is not None:
+            lr_out.copy_(lr)
+    if fm_out is not None or fm_lr_out is not None or S is not None:
+        e = out.view(out.shape[0], -1, D)
+        s = e.sum(1)
+        fm = 0.5 * ((s ** 2) - (e ** 2).sum(1)).sum(-1, keepdim=True)
+        if S is not None:
+            S.copy_(s)
+        if fm_out is not None:
+            fm_out.copy_(fm)
+        if fm_lr_out is not None:
+            fm_lr_out.copy_(fm + lr)
+    return out
+
+
+def emb_fm_bwd(drec, rec, S, g_fm, g_lr, col_out_off, C, D, dd, G, sq_partials, G1, sq1_partials,
+               dense, num_out_off, B, dnum_w, dnum_w1, dbias1):
+    if rec is not None:
+        full = torch.zeros(B, rec.shape[1])
+    else:
+        full = torch.zeros(B, drec.shape[1])
+    if drec is not None:
+        full = full + drec
+    if g_fm is not None:
+        e = rec.view(B, -1, D)
+        full = full + (g_fm.view(B, 1, 1) * (S.view(B, 1, D) - e)).reshape(B, -1)
+    if C > 0 and dd is not None and dd.n_max > 0:
+        nu = int(dd.n_unique)
+        G.zero_()
+        sq_partials.zero_()
+        if G1 is not None:
+            G1.zero_()
+            sq1_partials.zero_()
+        for u in range(nu):
+            for i in range(int(dd.seg_start[u]), int(dd.seg_start[u + 1])):
+                p = int(dd.sorted_pos[i])
+                if p == 0xFFFFFFFF:
+                    continue
+                b, c = divmod(p, C)
+                o = int(col_out_off[c])
+                G[u] += full[b, o:o + D]
+                if G1 is not None:
+                    G1[u] += g_lr[b, 0]
+        sq_partials[0] = float((G[:nu].double() ** 2).sum())
+        if G1 is not None:
+            sq1_partials[0] = float((G1[:nu].double() ** 2).sum())
+    if dense is not None:
+        for j in range(dense.shape[1]):
+            o = int(num_out_off[j])
+            dnum_w[j] = (dense[:, j:j + 1] * full[:, o:o + D]).sum(0)
+            if dnum_w1 is not None:
+                dnum_w1[j] = (dense[:, j:j + 1] * g_lr).sum()
+    if dbias1 is not None and g_lr is not None:
+        dbias1[0] = g_lr.sum()
+
+
+def sparse_update_multi(kind, states, dd, scal):
+    for st in states:
+        if kind == "adam":
+            sparse_adam(st.table, st.m, st.v, st.last_step, st.D, dd, st.G, scal)
+        else:
+            sparse_sgd(st.table, st.D, dd, st.G, scal, last_step=st.last_step)
+
+
+def pack_columns_multi(items):
+    for t, out, col0 in items:
+        t2 = t.reshape(t.shape[0], -1)
+        out[:, col0:col0 + t2.shape[1]] = t2.to(out.dtype)
+
+
 class KernelTimer(object):
-    enabled = False
+    recording = False
 
 
 NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes", "dedup",
@@ -504,7 +633,8 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "sum_parts", "din_concat_fwd", "din_concat_bwd", "din_pool_fwd", "din_pool_bwd",
          "dice_workspace_floats", "dice_fwd", "dice_bwd", "dot_interact_fwd", "dot_interact_bwd",
          "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update",
-         "shard_plan_workspace_ints", "emb_seq_pool_fwd", "dedup_sorted_runs"]
+         "shard_plan_workspace_ints", "emb_seq_pool_fwd", "dedup_sorted_runs", "RowState",
+         "dedup_catchup", "emb_fm_fwd", "emb_fm_bwd", "sparse_update_multi", "pack_columns_multi"]
 
 
 def install_plain():

@@ -188,12 +188,16 @@ def run_parity(case, dist, model, features, cfg, spec, cards, oracle_mod, B=4096
 
     def yard(fn):
         return max(fn(k) for k in yards)
+    # mean |dlogit| over 64 k samples is the stable statistic (slack x); the maximum is an extreme
+    # value (slack + 1); AUC / logloss differences are signed sums of those errors and scatter by up
+    # to ~6x between one yardstick and the other on ONE seed (scripts/parity_probe.py over 4 model
+    # seeds: native, ref64 and refgpu have the same RMS deviation), hence 10 x there
     bound = {"loss": max(loss_tol, slack * yard(lambda k: res["loss"][k])),
-             "max": max(logit_tol, slack * yard(lambda k: res[k]["max"])),
+             "max": max(logit_tol, (slack + 1) * yard(lambda k: res[k]["max"])),
              "mean": max(0.1 * logit_tol, slack * yard(lambda k: res[k]["mean"])),
-             "auc": max(metric_tol, slack * yard(lambda k: abs(res[k]["auc"] - ref["auc"]))),
+             "auc": max(metric_tol, 10 * yard(lambda k: abs(res[k]["auc"] - ref["auc"]))),
              "logloss": max(metric_tol,
-                            slack * yard(lambda k: abs(res[k]["logloss"] - ref["logloss"])))}
+                            10 * yard(lambda k: abs(res[k]["logloss"] - ref["logloss"])))}
     res["bounds"] = bound
     assert res["loss"]["native"] <= bound["loss"], ("loss trajectory", res)
     assert res["native"]["max"] <= bound["max"], ("trained logits (max)", res)
@@ -205,11 +209,11 @@ def run_parity(case, dist, model, features, cfg, spec, cards, oracle_mod, B=4096
     # model (reference checkpoint keys), forward on the hold-out
     model.load_state_dict({k: v.detach().cpu().clone() for k, v in tr.state.items()})
     model.eval()
-    worst = 0.0
-    for b in test[:4]:
-        t = tb(b)
-        worst = max(worst, float(np.abs(logits_of(model, t)[0] - tr.logits(t).numpy()).max()))
-    res["logit_trained_same_weights"] = worst
-    assert worst <= logit_tol, ("forward at the oracle's trained weights", res)
+    same = describe(np.concatenate([logits_of(model, tb(b))[0] for b in test]))
+    res["same_weights"] = same
+    assert same["max"] <= logit_tol, ("forward at the oracle's trained weights", res)
+    # ... and with it AUC / logloss of the TRAINED model to 4 decimals (the north-star's wording)
+    assert abs(same["auc"] - ref["auc"]) < metric_tol, ("AUC at the same trained weights", res)
+    assert abs(same["logloss"] - ref["logloss"]) < metric_tol, ("logloss, same weights", res)
     model.optimizer.check_errors()
     return res
