@@ -113,8 +113,10 @@ SIGNATURES = {
                                vp, C.POINTER(RowState), i32, i32, vp, vp]),
     "fx_emb_fm_fwd": (i32, [vp, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, vp, i32, vp, i64, i64,
                             vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "fx_emb_fm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp,
-                            vp, vp, i64, vp, i32, i64, vp, vp, vp, vp]),
+    "fx_emb_fm_bwd_partials": (i64, [i64, i32]),
+    "fx_emb_fm_bwd_workspace_floats": (i64, [i64, i32, i32]),
+    "fx_emb_fm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp, vp,
+                            vp, vp, vp, i64, vp, i32, i64, vp, vp, vp, vp, vp]),
     "fx_sparse_adam_multi": (i32, [C.POINTER(RowState), i32, vp, vp, i64, vp, vp]),
     "fx_sparse_sgd_multi": (i32, [C.POINTER(RowState), i32, vp, vp, i64, vp, vp]),
     "fx_pack_columns_multi": (i32, [C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp),

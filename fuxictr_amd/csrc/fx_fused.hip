@@ -28,7 +28,6 @@
 // ---------------------------------------------------------------------------------------------
 // shared device pieces
 // ---------------------------------------------------------------------------------------------
-#define FX_REPLAY_MAX2 256   // same truncation as k_adam_catchup (fx_sparse.hip)
 
 struct FxTableDev {
     float* table;
@@ -41,58 +40,68 @@ struct FxTableDev {
 
 #define FX_MAX_TABLES 4
 
-// zero-gradient Adam replay of one row (see k_adam_catchup): lanes sub < lanes of the group
+// zero-gradient Adam replay of one row (see k_adam_catchup), in two halves so that a lane group can
+// issue the loads of EVERY table group before it waits for any of them: the rows live in multi-GB
+// tables, every access is a TLB miss + an HBM access (~8 us per dependent round trip measured: the
+// chain last_step -> m,v -> p of k_adam_catchup costs 25 us for 25 K rows), so the state of a row —
+// last_step, m, v AND p, of the D-float table and of the D=1 table — is requested in one go.
+template <int VEC>
+struct FxRowRegs {
+    float p[VEC], m[VEC], v[VEC];
+    int last;
+    bool on;       // this lane holds elements of the row
+    bool act;      // this lane takes part at all (sub < lanes of the table)
+};
+
+template <int VEC, bool WANT_LAST = true>
+__device__ __forceinline__ void fx_row_load(const FxTableDev& t, int64_t row, int sub,
+                                            FxRowRegs<VEC>& r) {
+    const int lanes = 1 << t.lanes_log2;
+    r.act = sub < lanes;
+    const int d0 = sub * VEC;
+    r.on = r.act && d0 < t.D;
+    r.last = 0;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) r.p[k] = r.m[k] = r.v[k] = 0.f;
+    if (WANT_LAST && r.act) r.last = t.last_step[row];
+    if (r.on) {
+        const int64_t o = row * t.D + d0;
+        fx_load<VEC>(t.m + o, r.m);
+        fx_load<VEC>(t.v + o, r.v);
+        fx_load<VEC>(t.table + o, r.p);
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void fx_catchup_finish(const FxTableDev& t, int64_t row, int sub,
+                                                  FxRowRegs<VEC>& r, const fx_scalars& sc, int upto,
+                                                  double lb1, double lb2) {
+    if (!r.act) return;
+    const int last = r.last;
+    const int k_steps = upto - last;
+    if (k_steps <= 0) return;
+    if (r.on) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) any = any || (r.m[k] != 0.f) || (r.v[k] != 0.f);
+        if (any) {
+            fx_adam_replay<VEC>(r.p, r.m, r.v, last, k_steps, sc, lb1, lb2);
+            const int64_t o = row * t.D + sub * VEC;
+            fx_store<VEC>(t.table + o, r.p);
+            fx_store<VEC>(t.m + o, r.m);
+            fx_store<VEC>(t.v + o, r.v);
+        }
+    }
+    if (sub == 0) t.last_step[row] = upto;
+}
+
 template <int VEC>
 __device__ __forceinline__ void fx_catchup_row(const FxTableDev& t, int64_t row, int sub,
                                                const fx_scalars& sc, int upto, double lb1,
                                                double lb2) {
-    const int lanes = 1 << t.lanes_log2;
-    if (sub >= lanes) return;
-    const int last = t.last_step[row];
-    const int k_steps = upto - last;
-    if (k_steps <= 0) return;
-    const int d0 = sub * VEC;
-    if (d0 < t.D) {
-        float p[VEC], m[VEC], v[VEC];
-        const int64_t o = row * t.D + d0;
-        fx_load<VEC>(t.m + o, m);
-        fx_load<VEC>(t.v + o, v);
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) any = any || (m[k] != 0.f) || (v[k] != 0.f);
-        if (any) {
-            const float w1 = 1.f - sc.beta1;
-            fx_load<VEC>(t.table + o, p);
-            const int kk = k_steps < FX_REPLAY_MAX2 ? k_steps : FX_REPLAY_MAX2;
-            float pw1 = (float)exp2(lb1 * (double)last);
-            float pw2 = (float)exp2(lb2 * (double)last);
-            for (int j = 0; j < kk; ++j) {
-                pw1 *= sc.beta1;
-                pw2 *= sc.beta2;
-                const float step_size = sc.lr / (1.f - pw1);
-                const float bc2s = sqrtf(1.f - pw2);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    m[k] = m[k] + w1 * (0.f - m[k]);
-                    v[k] = v[k] * sc.beta2;
-                    p[k] = p[k] - step_size * (m[k] / (sqrtf(v[k]) / bc2s + sc.eps));
-                }
-            }
-            if (k_steps > kk) {
-                const float f1 = (float)exp2(lb1 * (double)(k_steps - kk));
-                const float f2 = (float)exp2(lb2 * (double)(k_steps - kk));
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    m[k] *= f1;
-                    v[k] *= f2;
-                }
-            }
-            fx_store<VEC>(t.table + o, p);
-            fx_store<VEC>(t.m + o, m);
-            fx_store<VEC>(t.v + o, v);
-        }
-    }
-    if (sub == 0) t.last_step[row] = upto;
+    FxRowRegs<VEC> r;
+    fx_row_load<VEC>(t, row, sub, r);
+    fx_catchup_finish<VEC>(t, row, sub, r, sc, upto, lb1, lb2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -229,6 +238,16 @@ __global__ __launch_bounds__(256) void k_finish_catchup(FinishArgs a) {
             }
         }
         if (!head) continue;
+        if (a.n_tables == 2 && a.t[0].vec == 4 && a.t[1].vec == 1) {
+            // the D-float tables + the D=1 tables of LogisticRegression: all eight loads in flight
+            FxRowRegs<4> r0;
+            FxRowRegs<1> r1;
+            fx_row_load<4>(a.t[0], (int64_t)k, sub, r0);
+            fx_row_load<1>(a.t[1], (int64_t)k, sub, r1);
+            fx_catchup_finish<4>(a.t[0], (int64_t)k, sub, r0, sc, upto, lb1, lb2);
+            fx_catchup_finish<1>(a.t[1], (int64_t)k, sub, r1, sc, upto, lb1, lb2);
+            continue;
+        }
         for (int t = 0; t < a.n_tables; ++t) {
             const FxTableDev& tb = a.t[t];
             if (tb.vec == 4) fx_catchup_row<4>(tb, (int64_t)k, sub, sc, upto, lb1, lb2);
@@ -487,18 +506,30 @@ extern "C" int fx_emb_fm_fwd(const float* table, int32_t D, const int32_t* ids, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// fx_emb_fm_bwd, launch 1: gradient of every unique row.
-// Workgroup w owns the unique rows [w*RPB, (w+1)*RPB) and therefore ONE contiguous range of the
-// sorted lookups; that range is cut into NG = 256/lanes equal pieces, lane group g sums the lookups
-// of piece g in ascending order.  A row that lies inside one piece is finished by its group; a row
-// spread over several pieces (a hot row of a tiny table: ~1365 lookups at B = 4096) is combined
-// from the groups' partial sums in group order by the group in whose piece it starts.  Every group
-// handles the same number of lookups whatever the run lengths are, and the summation order is a
-// function of the data layout only (deterministic).
+// fx_emb_fm_bwd: gradient of every unique row, balanced over the SORTED LOOKUPS.
+//
 // Value of lookup (b,c):  drec[b, off_c + d]  +  g_fm[b] * (S[b,d] - rec[b, off_c + d])   [D-float row]
 //                         g_lr[b]                                                          [D=1 row]
 // the second term being d/de of 0.5 * sum_d((sum_f e)^2 - sum_f e^2) (inner_product.py:56-62).
+//
+// A row's lookups are a run of the sorted array; run lengths go from 1 to ~B (the hot row of a
+// 3-row table holds 2800 of 4096 lookups under the power-law ids), so handing out ROWS leaves a few
+// workgroups with thousands of dependent loads (first version: 280 us, the rest of the chip idle).
+// Here workgroup k takes the sorted lookups [k*T, (k+1)*T), lane group g the T/NG lookups of piece
+// g — every lane group of the launch issues the same FX_BWD_INFL independent row loads, once.
+// A run that lies inside one piece is finished by its lane group (ascending order, as
+// fx_emb_grad_reduce sums it); pieces of a longer run are combined in group order inside the
+// workgroup (LDS), and the two open ends of a workgroup — the run that began in an earlier
+// workgroup, the run that goes on into the next — are left as "edges" that launch 2 combines in
+// workgroup order.  Every sum has a fixed order given the data layout: deterministic.
+//
+// Launch 1 also reduces the numeric features' partial sums over NC row chunks (extra workgroups);
+// launch 2: edge combine + numeric finals (dnum_w, dnum_w1, dbias1).
 // ---------------------------------------------------------------------------------------------
+#define FX_BWD_T 256        // sorted lookups per workgroup of launch 1
+#define FX_BWD_INFL 4       // lookups per lane group (= FX_BWD_T / NG at D = 16), all in flight
+#define FX_BWD_NC 16        // row chunks of the numeric-gradient partial sums
+
 struct EmbFmBwdArgs {
     const float* drec;
     int64_t drec_ld;
@@ -509,13 +540,29 @@ struct EmbFmBwdArgs {
     const float* g_lr;
     const int64_t* col_out_off;
     const uint32_t* sorted_pos;
+    const uint32_t* sorted_uid;
     const uint32_t* seg_start;
     const int32_t* n_unique;
     float* G;
     float* sq_partials;
     float* G1;
     float* sq1_partials;
-    int32_t C, D, lanes_log2;
+    // edges of launch-1 workgroups (workspace): per workgroup k
+    float* edgeF;      // [nb, D]   partial of the run that began before the workgroup's range
+    float* edgeL;      // [nb, D]   partial of the run that goes on past it
+    float* edgeF1;     // [nb]      the same for the D=1 table
+    float* edgeL1;
+    int32_t* edge_row; // [nb, 3]   rowF, rowL (unique-row index or -1), wholeF (range = one run)
+    // numeric features
+    const float* dense;
+    int64_t dense_ld;
+    const int64_t* num_out_off;
+    float* num_part;   // [NC, Fd*D + Fd + 1] partial sums (workspace)
+    float* dnum_w;
+    float* dnum_w1;
+    float* dbias1;
+    int64_t B, n;      // n = B*C sorted lookups
+    int32_t C, D, Fd, lanes_log2, nb, n_num_blocks;
 };
 
 template <int VEC, bool FM, bool LR>
@@ -540,236 +587,323 @@ __device__ __forceinline__ void fx_lookup_value(const EmbFmBwdArgs& a, uint32_t 
     }
 }
 
-#define FX_BWD_INFL 4     // lookups in flight per lane group
+// numeric partial sums: workgroup (j, chunk); j < Fd: feature j (and its D=1 twin), j == Fd: LR bias
+template <bool FM, bool LR>
+__device__ __forceinline__ void fx_numeric_partial(const EmbFmBwdArgs& a, int job, float* red) {
+    const int nj = a.Fd + 1;
+    const int j = job % nj, chunk = job / nj;
+    int Dp = 1;
+    while (Dp < a.D) Dp <<= 1;
+    if (Dp > 256) Dp = 256;
+    const int d = threadIdx.x % Dp, grp = threadIdx.x / Dp, ngrp = 256 / Dp;
+    const int64_t rows = (a.B + FX_BWD_NC - 1) / FX_BWD_NC;
+    const int64_t b0 = (int64_t)chunk * rows;
+    const int64_t b1 = (b0 + rows < a.B) ? b0 + rows : a.B;
+    float acc = 0.f, acc1 = 0.f;
+    const int stride = a.Fd * a.D + a.Fd + 1;
+    float* out = a.num_part + (int64_t)chunk * stride;
+    if (j < a.Fd) {
+        const int64_t off = a.num_out_off[j];
+        for (int dd0 = 0; dd0 < a.D; dd0 += Dp) {                  // (one pass unless D > 256)
+            const int dcol = dd0 + d;
+            acc = 0.f;
+            for (int64_t b = b0 + grp; b < b1; b += 8 * ngrp) {   // 8 independent rows in flight
+                float x[8], v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t bb = b + (int64_t)u * ngrp;
+                    x[u] = 0.f;
+                    v[u] = 0.f;
+                    if (bb < b1 && dcol < a.D) {
+                        x[u] = a.dense[bb * a.dense_ld + j];
+                        float t = a.drec ? a.drec[bb * a.drec_ld + off + dcol] : 0.f;
+                        if constexpr (FM)
+                            t += a.g_fm[bb] * (a.S[bb * a.D + dcol] - a.rec[bb * a.rec_ld + off + dcol]);
+                        v[u] = t;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fmaf(x[u], v[u], acc);
+            }
+            red[threadIdx.x] = acc;
+            __syncthreads();
+            for (int s = ngrp >> 1; s > 0; s >>= 1) {
+                if (grp < s) red[threadIdx.x] += red[threadIdx.x + s * Dp];
+                __syncthreads();
+            }
+            if (grp == 0 && dcol < a.D) out[(int64_t)j * a.D + dcol] = red[d];
+            __syncthreads();
+        }
+        if constexpr (LR) {
+            for (int64_t b = b0 + threadIdx.x; b < b1; b += 256)
+                acc1 = fmaf(a.dense[b * a.dense_ld + j], a.g_lr[b], acc1);
+        }
+    } else {
+        if constexpr (LR) {
+            for (int64_t b = b0 + threadIdx.x; b < b1; b += 256) acc1 += a.g_lr[b];
+        }
+    }
+    if constexpr (LR) {
+        red[threadIdx.x] = acc1;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[(int64_t)a.Fd * a.D + j] = red[0];   // j == Fd: the bias slot
+    }
+}
 
 template <int VEC, bool FM, bool LR>
 __global__ __launch_bounds__(256) void k_emb_fm_bwd(EmbFmBwdArgs a) {
-    // open pieces: F = a piece's first row started in an earlier piece, L = its last row goes on
+    // open pieces: F = the piece's first run began before the piece, L = its last run goes on
     __shared__ float openF[256 * VEC], openL[256 * VEC];
     __shared__ float openF1[256], openL1[256];
-    __shared__ int32_t rowF[256], rowL[256];          // indexed by lane group; -1 = none
-    __shared__ int32_t wholeF[256];                   // 1: the piece is one row from end to end
-    __shared__ uint32_t segs[257];
-    __shared__ float red4[4];
+    __shared__ int32_t rowF[256], rowL[256], wholeF[256];     // per lane group; row = -1: none
+    __shared__ float red[256];
+    if ((int)blockIdx.x >= a.nb) {                               // block-uniform
+        fx_numeric_partial<FM, LR>(a, (int)blockIdx.x - a.nb, red);
+        return;
+    }
     const int lanes = 1 << a.lanes_log2;
-    const int NG = 256 >> a.lanes_log2;               // lane groups = unique rows per workgroup
+    const int NG = 256 >> a.lanes_log2;
     const int sub = threadIdx.x & (lanes - 1);
     const int g = threadIdx.x >> a.lanes_log2;
     const int d0 = sub * VEC;
     const bool lane_on = d0 < a.D;
-    const int nu = *a.n_unique;
-    const int64_t u0 = (int64_t)blockIdx.x * NG;
+    const int64_t s0 = (int64_t)blockIdx.x * FX_BWD_T;
+    const int64_t s1 = (s0 + FX_BWD_T < a.n) ? s0 + FX_BWD_T : a.n;
+    const int64_t len = s1 - s0;
+    const int64_t lo = s0 + (len * g) / NG, hi = s0 + (len * (g + 1)) / NG;
     float sq = 0.f, sq1 = 0.f;
-    if (u0 < nu) {                                     // block-uniform
-        const int nrows = (int)((u0 + NG <= nu) ? NG : nu - u0);
-        for (int t = threadIdx.x; t <= nrows; t += 256) segs[t] = a.seg_start[u0 + t];
-        if (sub == 0) {
-            rowF[g] = -1;
-            rowL[g] = -1;
-            wholeF[g] = 0;
-        }
-        __syncthreads();
-        const uint32_t s0 = segs[0], s1 = segs[nrows];
-        const uint32_t len = s1 - s0;
-        const uint32_t lo = s0 + (uint32_t)(((uint64_t)len * (uint32_t)g) / (uint32_t)NG);
-        const uint32_t hi = s0 + (uint32_t)(((uint64_t)len * (uint32_t)(g + 1)) / (uint32_t)NG);
-        if (lo < hi) {
-            // row of the first lookup of the piece: largest r with segs[r] <= lo
-            int r = 0;
-            {
-                int l = 0, h = nrows;                  // segs[l] <= lo < segs[h]
-                while (h - l > 1) {
-                    const int mid = (l + h) >> 1;
-                    if (segs[mid] <= lo) l = mid; else h = mid;
-                }
-                r = l;
-            }
-            bool first_open = lo > segs[r];
+    if (sub == 0) {
+        rowF[g] = -1;
+        rowL[g] = -1;
+        wholeF[g] = 0;
+    }
+    if (lo < hi) {
+        int64_t i = lo;
+        while (i < hi) {
+            const uint32_t u = a.sorted_uid[i];
+            const int64_t rbeg = a.seg_start[u], rend = a.seg_start[u + 1];
+            const int64_t end = rend < hi ? rend : hi;
             float acc[VEC], acc1 = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-            uint32_t i = lo;
-            while (i < hi) {
-                const uint32_t rend = segs[r + 1];
-                const uint32_t end = rend < hi ? rend : hi;
-                // lookups [i, end) of row r, FX_BWD_INFL at a time, summed in ascending order
-                while (i < end) {
-                    uint32_t p[FX_BWD_INFL];
-                    float v[FX_BWD_INFL][VEC], v1[FX_BWD_INFL];
+            for (int64_t i2 = i; i2 < end; i2 += FX_BWD_INFL) {
+                uint32_t p[FX_BWD_INFL];
+                float v[FX_BWD_INFL][VEC], v1[FX_BWD_INFL];
 #pragma unroll
-                    for (int j = 0; j < FX_BWD_INFL; ++j)
-                        p[j] = (i + j < end) ? a.sorted_pos[i + j] : 0xFFFFFFFFu;
+                for (int j = 0; j < FX_BWD_INFL; ++j)
+                    p[j] = (i2 + j < end) ? a.sorted_pos[i2 + j] : 0xFFFFFFFFu;
 #pragma unroll
-                    for (int j = 0; j < FX_BWD_INFL; ++j)
-                        fx_lookup_value<VEC, FM, LR>(a, p[j], d0, lane_on, v[j], v1[j]);
+                for (int j = 0; j < FX_BWD_INFL; ++j)
+                    fx_lookup_value<VEC, FM, LR>(a, p[j], d0, lane_on, v[j], v1[j]);
 #pragma unroll
-                    for (int j = 0; j < FX_BWD_INFL; ++j) {
+                for (int j = 0; j < FX_BWD_INFL; ++j) {
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] += v[j][k];
-                        acc1 += v1[j];
-                    }
-                    i = (i + FX_BWD_INFL < end) ? i + FX_BWD_INFL : end;
-                }
-                if (end == rend) {                     // row r ends inside this piece
-                    if (first_open) {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) openF[k * 256 + threadIdx.x] = acc[k];
-                        if (sub == 0) {
-                            openF1[g] = acc1;
-                            rowF[g] = r;
-                        }
-                        first_open = false;
-                    } else {
-                        if (lane_on) {
-                            fx_store<VEC>(a.G + (u0 + r) * a.D + d0, acc);
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) sq = fmaf(acc[k], acc[k], sq);
-                        }
-                        if constexpr (LR) {
-                            if (sub == 0) {
-                                a.G1[u0 + r] = acc1;
-                                sq1 = fmaf(acc1, acc1, sq1);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-                    acc1 = 0.f;
-                    ++r;
-                } else {                               // the piece ends inside row r
-                    if (first_open) {                  // ... and began inside it: one row, whole piece
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) openF[k * 256 + threadIdx.x] = acc[k];
-                        if (sub == 0) {
-                            openF1[g] = acc1;
-                            rowF[g] = r;
-                            wholeF[g] = 1;
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) openL[k * 256 + threadIdx.x] = acc[k];
-                        if (sub == 0) {
-                            openL1[g] = acc1;
-                            rowL[g] = r;
-                        }
-                    }
+                    for (int k = 0; k < VEC; ++k) acc[k] += v[j][k];
+                    acc1 += v1[j];
                 }
             }
+            const bool began_before = rbeg < lo, goes_on = rend > hi;
+            if (!began_before && !goes_on) {                     // the whole run: final
+                if (lane_on) {
+                    fx_store<VEC>(a.G + (int64_t)u * a.D + d0, acc);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) sq = fmaf(acc[k], acc[k], sq);
+                }
+                if constexpr (LR) {
+                    if (sub == 0) {
+                        a.G1[u] = acc1;
+                        sq1 = fmaf(acc1, acc1, sq1);
+                    }
+                }
+            } else if (began_before) {                           // tail (or middle) of a run
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) openF[k * 256 + threadIdx.x] = acc[k];
+                if (sub == 0) {
+                    openF1[g] = acc1;
+                    rowF[g] = (int32_t)u;
+                    wholeF[g] = goes_on ? 1 : 0;
+                }
+            } else {                                             // head of a run that goes on
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) openL[k * 256 + threadIdx.x] = acc[k];
+                if (sub == 0) {
+                    openL1[g] = acc1;
+                    rowL[g] = (int32_t)u;
+                }
+            }
+            i = end;
         }
-        __syncthreads();
-        // a row spread over several pieces: the group whose piece holds its first lookups adds the
-        // later pieces' partial sums in group order
-        if (rowL[g] >= 0) {
-            const int r = rowL[g];
-            float tot[VEC], tot1 = openL1[g];
+    }
+    __syncthreads();
+    // chains inside the workgroup.  A chain starts at a head (rowL[g]) or, for the run that began
+    // in an earlier workgroup, at lane group 0's openF; it absorbs the following pieces' openF of the
+    // same run while they are "whole", and the first non-whole one ends it.
+    const bool head = rowL[g] >= 0;
+    // (the first NON-EMPTY piece: pieces in front of it are empty when the range is shorter than NG)
+    const bool inherited = (lo == s0) && (lo < hi) && rowF[g] >= 0;
+    if (sub == 0 && g == 0) {
+        a.edge_row[3 * blockIdx.x + 0] = -1;
+        a.edge_row[3 * blockIdx.x + 1] = -1;
+        a.edge_row[3 * blockIdx.x + 2] = 0;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool mine = pass == 0 ? inherited : head;
+        if (!mine) continue;
+        const int r = pass == 0 ? rowF[g] : rowL[g];
+        float tot[VEC], tot1;
+        bool ended;
+        if (pass == 0) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) tot[k] = openF[k * 256 + threadIdx.x];
+            tot1 = openF1[g];
+            ended = !wholeF[g];
+        } else {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) tot[k] = openL[k * 256 + threadIdx.x];
-            for (int h = g + 1; h < NG; ++h) {
-                if (rowF[h] != r) {
-                    if (rowF[h] < 0 && rowL[h] < 0) continue;      // an empty piece
-                    break;
-                }
-                const int th = (h << a.lanes_log2) + sub;
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) tot[k] += openF[k * 256 + th];
-                tot1 += openF1[h];
-                if (!wholeF[h]) break;
+            tot1 = openL1[g];
+            ended = false;
+        }
+        for (int h = g + 1; h < NG && !ended; ++h) {
+            if (rowF[h] != r) {
+                if (rowF[h] < 0 && rowL[h] < 0) continue;          // an empty piece (len < NG)
+                break;                                             // (cannot happen: runs are contiguous)
             }
+            const int th = (h << a.lanes_log2) + sub;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) tot[k] += openF[k * 256 + th];
+            tot1 += openF1[h];
+            ended = !wholeF[h];
+        }
+        if (pass == 1 && ended) {                                // began and ended in this workgroup
             if (lane_on) {
-                fx_store<VEC>(a.G + (u0 + r) * a.D + d0, tot);
+                fx_store<VEC>(a.G + (int64_t)r * a.D + d0, tot);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) sq = fmaf(tot[k], tot[k], sq);
             }
             if constexpr (LR) {
                 if (sub == 0) {
-                    a.G1[u0 + r] = tot1;
+                    a.G1[r] = tot1;
+                    sq1 = fmaf(tot1, tot1, sq1);
+                }
+            }
+        } else {                                                 // an edge for launch 2
+            float* e = (pass == 0 ? a.edgeF : a.edgeL) + (int64_t)blockIdx.x * a.D;
+            if (lane_on) fx_store<VEC>(e + d0, tot);
+            if (sub == 0) {
+                if constexpr (LR) (pass == 0 ? a.edgeF1 : a.edgeL1)[blockIdx.x] = tot1;
+                a.edge_row[3 * blockIdx.x + pass] = r;
+                if (pass == 0) a.edge_row[3 * blockIdx.x + 2] = ended ? 0 : 1;
+            }
+        }
+    }
+    // ||G||^2 of the rows finished here, fixed order
+    __syncthreads();
+    {
+        float* red4 = red;
+        const float tot = fx_block_sum_256(sq, red4);
+        if (threadIdx.x == 0) a.sq_partials[blockIdx.x] = tot;
+        if constexpr (LR) {
+            __syncthreads();
+            const float t1 = fx_block_sum_256(sq1, red4);
+            if (threadIdx.x == 0) a.sq1_partials[blockIdx.x] = t1;
+        }
+    }
+}
+
+// launch 2.  Workgroups [0, ncomb): lane group q combines the run whose head is the edgeL of launch-1
+// workgroup q (+ the edgeF of the workgroups after it); last workgroup: numeric finals.
+template <int VEC, bool LR>
+__global__ __launch_bounds__(256) void k_emb_fm_bwd_finish(EmbFmBwdArgs a, int ncomb) {
+    __shared__ float red4[4];
+    if ((int)blockIdx.x >= ncomb) {                              // numeric finals (block-uniform)
+        const int stride = a.Fd * a.D + a.Fd + 1;
+        for (int t = threadIdx.x; t < stride; t += 256) {
+            float s = 0.f;
+            for (int c = 0; c < FX_BWD_NC; ++c) s += a.num_part[(int64_t)c * stride + t];
+            if (t < a.Fd * a.D) { if (a.dnum_w) a.dnum_w[t] = s; }
+            else if (t < a.Fd * a.D + a.Fd) { if (LR && a.dnum_w1) a.dnum_w1[t - a.Fd * a.D] = s; }
+            else { if (LR && a.dbias1) a.dbias1[0] = s; }
+        }
+        return;
+    }
+    const int lanes = 1 << a.lanes_log2;
+    const int NG = 256 >> a.lanes_log2;
+    const int sub = threadIdx.x & (lanes - 1);
+    const int d0 = sub * VEC;
+    const bool lane_on = d0 < a.D;
+    const int q = (int)blockIdx.x * NG + (threadIdx.x >> a.lanes_log2);
+    float sq = 0.f, sq1 = 0.f;
+    if (q < a.nb) {
+        const int r = a.edge_row[3 * q + 1];
+        if (r >= 0) {
+            float tot[VEC], tot1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) tot[k] = 0.f;
+            if (lane_on) fx_load<VEC>(a.edgeL + (int64_t)q * a.D + d0, tot);
+            if constexpr (LR) tot1 = a.edgeL1[q];
+            for (int h = q + 1; h < a.nb; ++h) {
+                if (a.edge_row[3 * h + 0] != r) break;
+                if (lane_on) {
+                    float e[VEC];
+                    fx_load<VEC>(a.edgeF + (int64_t)h * a.D + d0, e);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) tot[k] += e[k];
+                }
+                if constexpr (LR) tot1 += a.edgeF1[h];
+                if (!a.edge_row[3 * h + 2]) break;
+            }
+            if (lane_on) {
+                fx_store<VEC>(a.G + (int64_t)r * a.D + d0, tot);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) sq = fmaf(tot[k], tot[k], sq);
+            }
+            if constexpr (LR) {
+                if (sub == 0) {
+                    a.G1[r] = tot1;
                     sq1 = fmaf(tot1, tot1, sq1);
                 }
             }
         }
     }
-    // ||G||^2 of this workgroup's rows, fixed order (zero for workgroups past the last unique row)
     const float tot = fx_block_sum_256(sq, red4);
-    if (threadIdx.x == 0) a.sq_partials[blockIdx.x] = tot;
+    if (threadIdx.x == 0) a.sq_partials[a.nb + blockIdx.x] = tot;
     if constexpr (LR) {
         __syncthreads();
-        const float tot1 = fx_block_sum_256(sq1, red4);
-        if (threadIdx.x == 0) a.sq1_partials[blockIdx.x] = tot1;
+        const float t1 = fx_block_sum_256(sq1, red4);
+        if (threadIdx.x == 0) a.sq1_partials[a.nb + blockIdx.x] = t1;
     }
 }
 
-// launch 2: numeric weights (nn.Linear(1,D) per numeric feature, feature_embedding.py:153-154),
-// their D=1 twins of LogisticRegression, and the LR bias.  Block j < Fd: feature j; block Fd: bias.
-struct NumGradArgs {
-    const float* drec;
-    int64_t drec_ld;
-    const float* rec;
-    int64_t rec_ld;
-    const float* S;
-    const float* g_fm;
-    const float* g_lr;
-    const float* dense;
-    int64_t dense_ld;
-    const int64_t* num_out_off;
-    float* dnum_w;
-    float* dnum_w1;
-    float* dbias1;
-    int64_t B;
-    int32_t Fd, D, Dp;
-};
+static inline int64_t fx_bwd_nb(int64_t n_lookups) { return fx_ceil_div(n_lookups > 0 ? n_lookups : 1, FX_BWD_T); }
+static inline int64_t fx_bwd_ncomb(int64_t n_lookups, int32_t D) {
+    return fx_ceil_div(fx_bwd_nb(n_lookups), 256 / fx_row_geom(D).lanes);
+}
 
-__global__ __launch_bounds__(1024) void k_emb_fm_numgrad(NumGradArgs a) {
-    __shared__ float red[1024];
-    __shared__ float red1[1024];
-    const int j = blockIdx.x;
-    const int d = threadIdx.x % a.Dp;
-    const int grp = threadIdx.x / a.Dp;
-    const int ngrp = 1024 / a.Dp;
-    float acc = 0.f, acc1 = 0.f;
-    if (j < a.Fd) {
-        const int64_t off = a.num_out_off[j];
-        for (int64_t b = grp; b < a.B; b += ngrp) {
-            const float x = a.dense[b * a.dense_ld + j];
-            if (d < a.D) {
-                float v = a.drec ? a.drec[b * a.drec_ld + off + d] : 0.f;
-                if (a.g_fm) v += a.g_fm[b] * (a.S[b * a.D + d] - a.rec[b * a.rec_ld + off + d]);
-                acc = fmaf(x, v, acc);
-            }
-            if (d == 0 && a.g_lr) acc1 = fmaf(x, a.g_lr[b], acc1);
-        }
-    } else if (a.g_lr) {
-        for (int64_t b = threadIdx.x; b < a.B; b += 1024) acc1 += a.g_lr[b];
-    }
-    red[threadIdx.x] = acc;
-    red1[threadIdx.x] = acc1;
-    __syncthreads();
-    if (j < a.Fd) {
-        for (int s = ngrp >> 1; s > 0; s >>= 1) {
-            if (grp < s) {
-                red[threadIdx.x] += red[threadIdx.x + s * a.Dp];
-                red1[threadIdx.x] += red1[threadIdx.x + s * a.Dp];
-            }
-            __syncthreads();
-        }
-        if (grp == 0 && d < a.D) a.dnum_w[(int64_t)j * a.D + d] = red[d];
-        if (threadIdx.x == 0 && a.dnum_w1) a.dnum_w1[j] = red1[0];
-    } else {
-        for (int s = 512; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red1[threadIdx.x] += red1[threadIdx.x + s];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0 && a.dbias1) a.dbias1[0] = red1[0];
-    }
+extern "C" int64_t fx_emb_fm_bwd_partials(int64_t n_lookups, int32_t D) {
+    if (D < 1 || D > 256) return 1;
+    return fx_bwd_nb(n_lookups) + fx_bwd_ncomb(n_lookups, D);
+}
+
+extern "C" int64_t fx_emb_fm_bwd_workspace_floats(int64_t n_lookups, int32_t D, int32_t Fd) {
+    if (D < 1 || D > 256 || Fd < 0) return 0;
+    const int64_t nb = fx_bwd_nb(n_lookups);
+    return nb * (2 * (int64_t)D + 2 + 3) + (int64_t)FX_BWD_NC * ((int64_t)Fd * D + Fd + 1) + 16;
 }
 
 extern "C" int fx_emb_fm_bwd(const float* drec, int64_t drec_ld, const float* rec, int64_t rec_ld,
                              const float* S, const float* g_fm, const float* g_lr,
                              const int64_t* col_out_off, int32_t C, int32_t D,
-                             const uint32_t* sorted_pos, const uint32_t* seg_start,
-                             const int32_t* n_unique, int64_t n_max, float* G, float* sq_partials,
-                             float* G1, float* sq1_partials, const float* dense, int64_t dense_ld,
-                             const int64_t* num_out_off, int32_t Fd, int64_t B, float* dnum_w,
-                             float* dnum_w1, float* dbias1, fx_stream_t stream) {
+                             const uint32_t* sorted_pos, const uint32_t* sorted_uid,
+                             const uint32_t* seg_start, const int32_t* n_unique, int64_t n_max,
+                             float* G, float* sq_partials, float* G1, float* sq1_partials,
+                             const float* dense, int64_t dense_ld, const int64_t* num_out_off,
+                             int32_t Fd, int64_t B, float* dnum_w, float* dnum_w1, float* dbias1,
+                             float* workspace, fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256 && C >= 0 && Fd >= 0 && B >= 0, "fx_emb_fm_bwd: bad sizes");
     const FxRowGeom g = fx_row_geom(D);
     FX_CHECK_ARG(g.lanes <= 64, "fx_emb_fm_bwd: D=%d needs %d lanes per row (max 64)", D, g.lanes);
@@ -778,40 +912,67 @@ extern "C" int fx_emb_fm_bwd(const float* drec, int64_t drec_ld, const float* re
                  "fx_emb_fm_bwd: no upstream gradient at all");
     FX_CHECK_ARG((drec == nullptr || drec_ld % g.vec == 0) && (rec == nullptr || rec_ld % g.vec == 0),
                  "fx_emb_fm_bwd: leading dimensions not a multiple of %d", g.vec);
+    FX_CHECK_ARG(workspace, "fx_emb_fm_bwd: null workspace");
+    const bool sparse = C > 0 && n_max > 0;
+    const bool numeric = Fd > 0 || (g_lr && dbias1);
+    if (!sparse && !numeric) return FX_OK;
+    if (sparse) {
+        FX_CHECK_ARG(col_out_off && sorted_pos && sorted_uid && seg_start && n_unique && G &&
+                         sq_partials, "fx_emb_fm_bwd: null sparse argument");
+        FX_CHECK_ARG(g_lr == nullptr || (G1 && sq1_partials), "fx_emb_fm_bwd: g_lr without G1");
+        FX_CHECK_ARG(n_max == B * (int64_t)C, "fx_emb_fm_bwd: n_max must be B*C (one entry per lookup)");
+    }
+    FX_CHECK_ARG(!numeric || Fd == 0 || (dense && num_out_off && dnum_w),
+                 "fx_emb_fm_bwd: null numeric argument");
     hipStream_t s = fx_hip_stream(stream);
     int ll = 0;
     while ((1 << ll) < g.lanes) ++ll;
-    if (C > 0 && n_max > 0) {
-        FX_CHECK_ARG(col_out_off && sorted_pos && seg_start && n_unique && G && sq_partials,
-                     "fx_emb_fm_bwd: null sparse argument");
-        FX_CHECK_ARG(g_lr == nullptr || (G1 && sq1_partials), "fx_emb_fm_bwd: g_lr without G1");
-        EmbFmBwdArgs a{drec, drec_ld, rec, rec_ld, S, g_fm, g_lr, col_out_off, sorted_pos, seg_start,
-                       n_unique, G, sq_partials, G1, sq1_partials, C, D, ll};
-        const int64_t blocks = fx_ceil_div(n_max, 256 / g.lanes);
-        dim3 grid((unsigned)blocks);
+    EmbFmBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.drec = drec; a.drec_ld = drec_ld; a.rec = rec; a.rec_ld = rec_ld; a.S = S;
+    a.g_fm = g_fm; a.g_lr = g_lr; a.col_out_off = col_out_off;
+    a.sorted_pos = sorted_pos; a.sorted_uid = sorted_uid; a.seg_start = seg_start;
+    a.n_unique = n_unique; a.G = G; a.sq_partials = sq_partials; a.G1 = G1;
+    a.sq1_partials = sq1_partials;
+    a.dense = dense; a.dense_ld = dense_ld; a.num_out_off = num_out_off;
+    a.dnum_w = dnum_w; a.dnum_w1 = dnum_w1; a.dbias1 = dbias1;
+    a.B = B; a.n = sparse ? n_max : 0; a.C = C; a.D = D; a.Fd = Fd; a.lanes_log2 = ll;
+    const int nb = sparse ? (int)fx_bwd_nb(n_max) : 0;
+    const int ncomb = sparse ? (int)fx_bwd_ncomb(n_max, D) : 0;
+    a.nb = nb;
+    a.n_num_blocks = numeric ? (Fd + 1) * FX_BWD_NC : 0;
+    // workspace carve (floats): edgeF | edgeL | edgeF1 | edgeL1 | edge_row (ints) | num_part
+    float* w = workspace;
+    const int64_t nbw = fx_bwd_nb(n_max > 0 ? n_max : 1);
+    a.edgeF = w; w += nbw * D;
+    a.edgeL = w; w += nbw * D;
+    a.edgeF1 = w; w += nbw;
+    a.edgeL1 = w; w += nbw;
+    a.edge_row = reinterpret_cast<int32_t*>(w); w += nbw * 3;
+    w = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(w) + 15) & ~(uintptr_t)15);
+    a.num_part = w;
+    dim3 grid1((unsigned)(nb + a.n_num_blocks)), grid2((unsigned)(ncomb + (numeric ? 1 : 0)));
 #define FX_BWD_LAUNCH(V)                                                                          \
     do {                                                                                          \
-        if (g_fm && g_lr) hipLaunchKernelGGL((k_emb_fm_bwd<V, true, true>), grid, dim3(256), 0, s, a);   \
-        else if (g_fm) hipLaunchKernelGGL((k_emb_fm_bwd<V, true, false>), grid, dim3(256), 0, s, a);     \
-        else if (g_lr) hipLaunchKernelGGL((k_emb_fm_bwd<V, false, true>), grid, dim3(256), 0, s, a);     \
-        else hipLaunchKernelGGL((k_emb_fm_bwd<V, false, false>), grid, dim3(256), 0, s, a);              \
+        if (g_fm && g_lr) {                                                                       \
+            hipLaunchKernelGGL((k_emb_fm_bwd<V, true, true>), grid1, dim3(256), 0, s, a);         \
+            hipLaunchKernelGGL((k_emb_fm_bwd_finish<V, true>), grid2, dim3(256), 0, s, a, ncomb); \
+        } else if (g_fm) {                                                                        \
+            hipLaunchKernelGGL((k_emb_fm_bwd<V, true, false>), grid1, dim3(256), 0, s, a);        \
+            hipLaunchKernelGGL((k_emb_fm_bwd_finish<V, false>), grid2, dim3(256), 0, s, a, ncomb); \
+        } else if (g_lr) {                                                                        \
+            hipLaunchKernelGGL((k_emb_fm_bwd<V, false, true>), grid1, dim3(256), 0, s, a);        \
+            hipLaunchKernelGGL((k_emb_fm_bwd_finish<V, true>), grid2, dim3(256), 0, s, a, ncomb); \
+        } else {                                                                                  \
+            hipLaunchKernelGGL((k_emb_fm_bwd<V, false, false>), grid1, dim3(256), 0, s, a);       \
+            hipLaunchKernelGGL((k_emb_fm_bwd_finish<V, false>), grid2, dim3(256), 0, s, a, ncomb); \
+        }                                                                                         \
     } while (0)
-        if (g.vec == 4) FX_BWD_LAUNCH(4);
-        else if (g.vec == 2) FX_BWD_LAUNCH(2);
-        else FX_BWD_LAUNCH(1);
+    if (g.vec == 4) FX_BWD_LAUNCH(4);
+    else if (g.vec == 2) FX_BWD_LAUNCH(2);
+    else FX_BWD_LAUNCH(1);
 #undef FX_BWD_LAUNCH
-        FX_CHECK_LAUNCH();
-    }
-    if (Fd > 0 || (g_lr && dbias1)) {
-        FX_CHECK_ARG(Fd == 0 || (dense && num_out_off && dnum_w), "fx_emb_fm_bwd: null numeric argument");
-        int Dp = 1;
-        while (Dp < D) Dp <<= 1;
-        NumGradArgs na{drec, drec_ld, rec, rec_ld, S, g_fm, g_lr, dense, dense_ld, num_out_off,
-                       dnum_w, g_lr ? dnum_w1 : nullptr, g_lr ? dbias1 : nullptr, B, Fd, D, Dp};
-        const int nb = Fd + ((g_lr && dbias1) ? 1 : 0);
-        hipLaunchKernelGGL(k_emb_fm_numgrad, dim3(nb), dim3(1024), 0, s, na);
-        FX_CHECK_LAUNCH();
-    }
+    FX_CHECK_LAUNCH();
     return FX_OK;
 }
 
@@ -873,6 +1034,34 @@ __device__ __forceinline__ void fx_update_row(const FxTableDev& t, int64_t u, in
     if (sub == 0 && t.last_step) t.last_step[row] = sc.step;
 }
 
+// the Adam half of fx_update_row on registers that are already loaded
+template <int VEC>
+__device__ __forceinline__ void fx_adam_finish(const FxTableDev& t, int64_t row, int sub,
+                                               FxRowRegs<VEC>& r, float (&g)[VEC],
+                                               const fx_scalars& sc) {
+    if (!r.act) return;
+    if (r.on) {
+        if (sc.reg_l1 != 0.f || sc.reg_l2 != 0.f) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) g[k] += fx_reg_grad2(r.p[k], sc.reg_l1, sc.reg_l2);
+        }
+        const float w1 = 1.f - sc.beta1, w2 = 1.f - sc.beta2;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float gk = g[k] * sc.clip_coef;
+            r.m[k] = r.m[k] + w1 * (gk - r.m[k]);
+            r.v[k] = fmaf(w2 * gk, gk, r.v[k] * sc.beta2);
+            const float denom = sqrtf(r.v[k]) / sc.bc2_sqrt + sc.eps;
+            r.p[k] = r.p[k] - sc.step_size * (r.m[k] / denom);
+        }
+        const int64_t o = row * t.D + sub * VEC;
+        fx_store<VEC>(t.table + o, r.p);
+        fx_store<VEC>(t.m + o, r.m);
+        fx_store<VEC>(t.v + o, r.v);
+    }
+    if (sub == 0 && t.last_step) t.last_step[row] = sc.step;
+}
+
 template <bool ADAM>
 __global__ __launch_bounds__(256) void k_sparse_update_multi(MultiOptArgs a) {
     const int glanes = 1 << a.group_log2;
@@ -883,6 +1072,18 @@ __global__ __launch_bounds__(256) void k_sparse_update_multi(MultiOptArgs a) {
     for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.group_log2); u < nu;
          u += (int64_t)gridDim.x * rpb) {
         const int64_t row = a.uniq_row[u];
+        if (ADAM && a.n_tables == 2 && a.t[0].vec == 4 && a.t[1].vec == 1) {
+            FxRowRegs<4> r0;
+            FxRowRegs<1> r1;
+            float g0[4] = {0.f, 0.f, 0.f, 0.f}, g1[1] = {0.f};
+            fx_row_load<4, false>(a.t[0], row, sub, r0);
+            fx_row_load<1, false>(a.t[1], row, sub, r1);
+            if (r0.on) fx_load<4>(a.t[0].G + u * a.t[0].D + sub * 4, g0);
+            if (r1.on) fx_load<1>(a.t[1].G + u * a.t[1].D + sub, g1);
+            fx_adam_finish<4>(a.t[0], row, sub, r0, g0, sc);
+            fx_adam_finish<1>(a.t[1], row, sub, r1, g1, sc);
+            continue;
+        }
         for (int t = 0; t < a.n_tables; ++t) {
             const FxTableDev& tb = a.t[t];
             if (tb.vec == 4) fx_update_row<4, ADAM>(tb, u, row, sub, sc);

@@ -1102,8 +1102,8 @@ __global__ __launch_bounds__(256) void k_sparse_adam(RowOptArgs a) {
 // batch touched since last_step[row].  With g = 0 the per-step update is
 //     m *= beta1 ; v *= beta2 ; p -= lr/(1-beta1^j) * m / (sqrt(v)/sqrt(1-beta2^j) + eps)
 // whose magnitude decays like (beta1/sqrt(beta2))^j ~ 0.9^j, so after FX_REPLAY_MAX steps the
-// remaining terms are below fp32 resolution of the accumulated update; the tail only decays m, v.
-#define FX_REPLAY_MAX 256
+// remaining terms are below fp32 resolution of the accumulated update; the tail only decays m, v
+// (fx_adam_replay in fx_common.h).
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_adam_catchup(RowOptArgs a) {
@@ -1114,7 +1114,6 @@ __global__ __launch_bounds__(256) void k_adam_catchup(RowOptArgs a) {
     const fx_scalars sc = *a.scal;
     const int upto = sc.step + a.upto_offset;
     const int64_t n = a.uniq_row ? (int64_t)(*a.n_unique) : a.total_rows;
-    const float w1 = 1.f - sc.beta1;
     const double lb1 = log2((double)sc.beta1), lb2 = log2((double)sc.beta2);
     for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2); u < n;
          u += (int64_t)gridDim.x * rpb) {
@@ -1132,30 +1131,7 @@ __global__ __launch_bounds__(256) void k_adam_catchup(RowOptArgs a) {
             for (int k = 0; k < VEC; ++k) any = any || (m[k] != 0.f) || (v[k] != 0.f);
             if (any) {
                 fx_load<VEC>(a.table + o, p);
-                const int kk = k_steps < FX_REPLAY_MAX ? k_steps : FX_REPLAY_MAX;
-                float pw1 = (float)exp2(lb1 * (double)last);  // beta1^last
-                float pw2 = (float)exp2(lb2 * (double)last);
-                for (int j = 0; j < kk; ++j) {
-                    pw1 *= sc.beta1;
-                    pw2 *= sc.beta2;
-                    const float step_size = sc.lr / (1.f - pw1);
-                    const float bc2s = sqrtf(1.f - pw2);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        m[k] = m[k] + w1 * (0.f - m[k]);
-                        v[k] = v[k] * sc.beta2;
-                        p[k] = p[k] - step_size * (m[k] / (sqrtf(v[k]) / bc2s + sc.eps));
-                    }
-                }
-                if (k_steps > kk) {
-                    const float f1 = (float)exp2(lb1 * (double)(k_steps - kk));
-                    const float f2 = (float)exp2(lb2 * (double)(k_steps - kk));
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        m[k] *= f1;
-                        v[k] *= f2;
-                    }
-                }
+                fx_adam_replay<VEC>(p, m, v, last, k_steps, sc, lb1, lb2);
                 fx_store<VEC>(a.table + o, p);
                 fx_store<VEC>(a.m + o, m);
                 fx_store<VEC>(a.v + o, v);

@@ -388,7 +388,7 @@ class _TableGroup(object):
             begin = self.opt.take_begin() if self.opt is not None else None
             dd = ops.dedup_catchup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad,
                                    self.dedup_ws[1], [g.row_state() for g in todo], self.scal,
-                                   begin_scal=begin)
+                                   begin_scal=begin, want_uid=True)
             if cache is not None:
                 cache[ckey] = dd
                 for g in todo:
@@ -695,12 +695,16 @@ class _EmbFMFn(torch.autograd.Function):
         g_fm = g_fm.contiguous() if g_fm is not None else None
         g_lr = g_lr.contiguous() if g_lr is not None else None
         dd = ctx.dd
-        if dd is None and plan.C:
-            dd = group.dedup(plan, ctx.ids, ctx.inputs)
+        if plan.C and (dd is None or dd.sorted_uid is None):
+            # (no optimizer attached / a cached de-dup without uid: redo it on the column path)
+            ws_ = torch.empty(ops.dedup_workspace_bytes(ctx.ids.numel()), dtype=torch.uint8,
+                              device=dev)
+            dd = ops.dedup_catchup(ctx.ids, plan.col_row_base, plan.col_vocab, plan.col_pad, ws_, [],
+                                   group.ensure_scal(), want_uid=True)
         G = sq = G1 = sq1 = None
         if plan.C:
             G = torch.empty(dd.n_max, D, dtype=torch.float32, device=dev)
-            nparts = ops.emb_grad_reduce_partials(dd.n_max, D)
+            nparts = ops.emb_fm_bwd_partials(dd.n_max, D)
             sq = torch.empty(nparts, dtype=torch.float32, device=dev)
             if g_lr is not None:
                 G1 = torch.empty(dd.n_max, 1, dtype=torch.float32, device=dev)
@@ -710,8 +714,10 @@ class _EmbFMFn(torch.autograd.Function):
             if (plan.Fd and g_lr is not None) else None
         dbias = torch.empty(1, dtype=torch.float32, device=dev) \
             if (ctx.has_bias and g_lr is not None) else None
+        ws = _Workspace.get(dev, ops.emb_fm_bwd_workspace_floats(dd.n_max if plan.C else 0, D,
+                                                                 plan.Fd), tag="emb_fm_bwd")
         ops.emb_fm_bwd(d_out, ctx.out, ctx.S, g_fm, g_lr, plan.col_out_off, plan.C, D, dd, G, sq,
-                       G1, sq1, ctx.dense, plan.num_out_off, B, dnum, dnum1, dbias)
+                       G1, sq1, ctx.dense, plan.num_out_off, B, dnum, dnum1, dbias, ws)
         if plan.C:
             group.pending.append(_PendingGrad(dd, G, sq))
             if G1 is not None:
@@ -1365,6 +1371,10 @@ class FactorizationMachine(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # dense tower
 # ------------------------------------------------------------------------------------------------
+import os as _os
+_FORCE_SPLITK = int(_os.environ.get("FX_DW_SPLITK", "0"))
+
+
 def _split_k_for(M, N, K):
     """Split the contraction when the output grid alone cannot fill 256 CUs (weight gradients):
     aim for ~512 workgroups of 64x64 (2 per CU); every extra split costs a partial-slab round trip."""
@@ -1373,6 +1383,8 @@ def _split_k_for(M, N, K):
         # slab reduce handles hundreds of slabs in one small launch
         return max(1, min(512 if N <= 256 else 256, K // 16))
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if _FORCE_SPLITK:                  # FX_DW_SPLITK=<n>: experiment switch
+        return max(1, min(_FORCE_SPLITK, K // 256))
     if tiles >= 448:
         return 1
     s = max(1, min(-(-512 // tiles), K // 256))
@@ -1384,11 +1396,12 @@ class _Workspace(object):
     _bufs = {}
 
     @classmethod
-    def get(cls, device, n):
-        buf = cls._bufs.get(device)
+    def get(cls, device, n, tag=None):
+        buf = cls._bufs.get((device, tag))
         if buf is None or buf.numel() < n:
-            buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
-            cls._bufs[device] = buf
+            buf = torch.empty(max(n, 1 << 20 if tag is None else 1), dtype=torch.float32,
+                              device=device)
+            cls._bufs[(device, tag)] = buf
         return buf
 
 

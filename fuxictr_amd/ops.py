@@ -664,21 +664,30 @@ def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w
     return out
 
 
+def emb_fm_bwd_partials(n_lookups, D):
+    return int(_lib.load().fx_emb_fm_bwd_partials(n_lookups, D))
+
+
+def emb_fm_bwd_workspace_floats(n_lookups, D, Fd):
+    return int(_lib.load().fx_emb_fm_bwd_workspace_floats(n_lookups, D, Fd))
+
+
 @_timed("emb_fm_bwd", "sparse_path")
 def emb_fm_bwd(drec, rec, S, g_fm, g_lr, col_out_off, C_, D, dd, G, sq_partials, G1, sq1_partials,
-               dense, num_out_off, B, dnum_w, dnum_w1, dbias1):
+               dense, num_out_off, B, dnum_w, dnum_w1, dbias1, workspace):
     """Backward of emb_fm_fwd: unique-row gradients of the D-float table (and of the D=1 table),
-    their squared-norm partials, numeric weight / LR bias gradients; 2 launches."""
+    their squared-norm partials, numeric weight / LR bias gradients; 2 launches.  dd must carry
+    sorted_uid (dedup_catchup(..., want_uid=True))."""
     Fd = 0 if dense is None else dense.shape[1]
+    have = dd is not None and C_ > 0
     check(_lib.load().fx_emb_fm_bwd(
         ptr(drec), 0 if drec is None else drec.stride(0), ptr(rec),
         0 if rec is None else rec.stride(0), ptr(S), ptr(g_fm), ptr(g_lr), ptr(col_out_off), C_, D,
-        ptr(dd.sorted_pos) if dd is not None else vp(0),
-        ptr(dd.seg_start) if dd is not None else vp(0),
-        ptr(dd.n_unique) if dd is not None else vp(0), dd.n_max if dd is not None else 0, ptr(G),
-        ptr(sq_partials), ptr(G1), ptr(sq1_partials), ptr(dense),
+        ptr(dd.sorted_pos) if have else vp(0), ptr(dd.sorted_uid) if have else vp(0),
+        ptr(dd.seg_start) if have else vp(0), ptr(dd.n_unique) if have else vp(0),
+        dd.n_max if have else 0, ptr(G), ptr(sq_partials), ptr(G1), ptr(sq1_partials), ptr(dense),
         0 if dense is None else dense.stride(0), ptr(num_out_off), Fd, B, ptr(dnum_w), ptr(dnum_w1),
-        ptr(dbias1), stream_ptr((rec if rec is not None else drec).device)), "fx_emb_fm_bwd")
+        ptr(dbias1), ptr(workspace), stream_ptr(workspace.device)), "fx_emb_fm_bwd")
 
 
 @_timed("sparse_update_multi", "sparse_path")

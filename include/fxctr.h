@@ -482,19 +482,21 @@ int fx_binary_metrics(const float* y_pred, const float* y_true, int64_t n, void*
  *   fm_lr_out [B] fm_out + lr_out (FactorizationMachine.forward, factorization_machine.py:46-59)
  *   S       [B, D] the per-dimension field sums, kept for fx_emb_fm_bwd; NULL = not wanted
  *
- * fx_emb_fm_bwd: autograd of the above, 2 launches.  Launch 1 reduces, per unique row u (runs of
- *   sorted_pos given by seg_start, as fx_emb_grad_reduce):
+ * fx_emb_fm_bwd: autograd of the above, 2 launches.  Per unique row u (runs of sorted_pos given by
+ *   seg_start / sorted_uid, as produced by fx_dedup_catchup with sorted_uid != NULL):
  *     G[u,:]  = sum over the row's lookups (b,c) of
  *               drec[b, col_out_off[c] + :] + g_fm[b] * (S[b,:] - rec[b, col_out_off[c] + :])
  *     G1[u]   = sum over the row's lookups of g_lr[b]                       (the D=1 table's row)
- *   and the fixed-order partial sums of ||G||^2 / ||G1||^2 (fx_emb_grad_reduce_partials(n_max, D)
- *   entries each) for clip_grad_norm_ (rank_model.py:321).  drec (gradient of the record from the
- *   layers that read it), g_fm, g_lr may each be NULL (that term is absent).  The sorted lookups
- *   of a workgroup's rows are split evenly over its lane groups, so hot rows of tiny tables cost
- *   no more than cold ones; the result is deterministic.
- *   Launch 2: dnum_w[j,:] = sum_b dense[b,j] * (value of slot num_out_off[j]), dnum_w1[j] =
+ *   and the fixed-order partial sums of ||G||^2 / ||G1||^2 (fx_emb_fm_bwd_partials(n_max, D) entries
+ *   each) for clip_grad_norm_ (rank_model.py:321).  drec (gradient of the record from the layers
+ *   that read it), g_fm, g_lr may each be NULL (that term is absent).  The work is handed out by
+ *   SORTED LOOKUP, 256 per workgroup, not by row: the hot row of a 3-row table (2800 of 4096
+ *   lookups) costs what 2800 cold rows cost; a run cut by a workgroup boundary is finished by
+ *   launch 2 in workgroup order, so the result is deterministic.  n_max must be B*C.
+ *   Numeric features: dnum_w[j,:] = sum_b dense[b,j] * (value of slot num_out_off[j]), dnum_w1[j] =
  *   sum_b dense[b,j] g_lr[b], dbias1 = sum_b g_lr[b]  (autograd of feature_embedding.py:280-282
- *   and logistic_regression.py:55-58).
+ *   and logistic_regression.py:55-58), partial sums in launch 1, finals in launch 2.
+ *   workspace: fx_emb_fm_bwd_workspace_floats(n_max, D, Fd) floats.
  *
  * fx_sparse_adam_multi / fx_sparse_sgd_multi: fx_sparse_adam / fx_sparse_sgd for every table group
  *   of one de-dup result in one launch (tables[t].G = that group's reduced gradient).
@@ -528,13 +530,16 @@ int fx_emb_fm_fwd(const float* table, int32_t D, const int32_t* ids, int64_t ids
                   const int64_t* num_out_off, int32_t Fd, float* out, int64_t out_ld, int64_t B,
                   const float* table1, const float* num_w1, const float* bias1, float* lr_out,
                   float* fm_out, float* fm_lr_out, float* S, fx_scalars* scal, fx_stream_t stream);
+int64_t fx_emb_fm_bwd_partials(int64_t n_lookups, int32_t D);
+int64_t fx_emb_fm_bwd_workspace_floats(int64_t n_lookups, int32_t D, int32_t Fd);
 int fx_emb_fm_bwd(const float* drec, int64_t drec_ld, const float* rec, int64_t rec_ld,
                   const float* S, const float* g_fm, const float* g_lr, const int64_t* col_out_off,
-                  int32_t C, int32_t D, const uint32_t* sorted_pos, const uint32_t* seg_start,
-                  const int32_t* n_unique, int64_t n_max, float* G, float* sq_partials, float* G1,
-                  float* sq1_partials, const float* dense, int64_t dense_ld,
-                  const int64_t* num_out_off, int32_t Fd, int64_t B, float* dnum_w, float* dnum_w1,
-                  float* dbias1, fx_stream_t stream);
+                  int32_t C, int32_t D, const uint32_t* sorted_pos, const uint32_t* sorted_uid,
+                  const uint32_t* seg_start, const int32_t* n_unique, int64_t n_max, float* G,
+                  float* sq_partials, float* G1, float* sq1_partials, const float* dense,
+                  int64_t dense_ld, const int64_t* num_out_off, int32_t Fd, int64_t B,
+                  float* dnum_w, float* dnum_w1, float* dbias1, float* workspace,
+                  fx_stream_t stream);
 int fx_sparse_adam_multi(const fx_row_state* tables_host, int32_t n_tables, const uint32_t* uniq_row,
                          const int32_t* n_unique, int64_t n_max, const fx_scalars* scal,
                          fx_stream_t stream);

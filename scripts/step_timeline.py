@@ -8,7 +8,11 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "k_opt_begin_step" in r["Kernel_Name"]]
+# a step starts with the batch's pack launch (k_pack_columns_multi, outside the graph); older traces:
+# with the optimizer's begin-step kernel
+marker = "k_pack_columns_multi" if any("k_pack_columns_multi" in r["Kernel_Name"] for r in rows) \
+    else "k_opt_begin_step"
+starts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 lo, hi = starts[-back - 1], starts[-back]
 step = rows[lo:hi]
 t0 = int(step[0]["Start_Timestamp"])

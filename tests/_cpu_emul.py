@@ -534,8 +534,7 @@ def dedup_catchup(ids, col_row_base, col_vocab, col_pad, workspace, states, scal
     dd.seg_start[1:len(uniq) + 1] = torch.cumsum(counts, 0).int()
     dd.n_unique = torch.tensor([len(uniq)], dtype=torch.int32)
     dd.n_max, dd.C = n, C
-    dd.sorted_uid = torch.repeat_interleave(torch.arange(len(uniq)), counts).int() if want_uid \
-        else None
+    dd.sorted_uid = torch.repeat_interleave(torch.arange(len(uniq)), counts).int()
     for st in states:
         adam_catchup(st.table, st.m, st.v, st.last_step, st.D, dd, st.table.shape[0], upto_offset,
                      scal)
@@ -566,8 +565,16 @@ def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w
     return out
 
 
+def emb_fm_bwd_partials(n_lookups, D):
+    return 4
+
+
+def emb_fm_bwd_workspace_floats(n_lookups, D, Fd):
+    return 16
+
+
 def emb_fm_bwd(drec, rec, S, g_fm, g_lr, col_out_off, C, D, dd, G, sq_partials, G1, sq1_partials,
-               dense, num_out_off, B, dnum_w, dnum_w1, dbias1):
+               dense, num_out_off, B, dnum_w, dnum_w1, dbias1, workspace=None):
     if rec is not None:
         full = torch.zeros(B, rec.shape[1])
     else:
@@ -634,7 +641,8 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "dice_workspace_floats", "dice_fwd", "dice_bwd", "dot_interact_fwd", "dot_interact_bwd",
          "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update",
          "shard_plan_workspace_ints", "emb_seq_pool_fwd", "dedup_sorted_runs", "RowState",
-         "dedup_catchup", "emb_fm_fwd", "emb_fm_bwd", "sparse_update_multi", "pack_columns_multi"]
+         "dedup_catchup", "emb_fm_fwd", "emb_fm_bwd", "sparse_update_multi", "pack_columns_multi",
+         "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats"]
 
 
 def install_plain():

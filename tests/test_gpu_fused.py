@@ -197,9 +197,11 @@ def test_emb_fm_bwd_equals_autograd(D, B, mode, terms):
     ws = torch.empty(ops.dedup_workspace_bytes(B * C), dtype=torch.uint8, device=DEV)
     scal = ops.new_scalars(DEV)
     dd = ops.dedup_catchup(_dev(ids, torch.int32), _dev(bases, torch.int64),
-                           _dev(vocabs, torch.int32), _dev(pads, torch.int32), ws, [], scal)
+                           _dev(vocabs, torch.int32), _dev(pads, torch.int32), ws, [], scal,
+                           want_uid=True)
     n_max = dd.n_max
-    nparts = ops.emb_grad_reduce_partials(n_max, D)
+    nparts = ops.emb_fm_bwd_partials(n_max, D)
+    wsf = torch.empty(ops.emb_fm_bwd_workspace_floats(n_max, D, Fd), device=DEV)
     G = torch.full((n_max, D), 9.0, device=DEV)
     sq = torch.full((nparts,), 9.0, device=DEV)
     G1 = torch.full((n_max, 1), 9.0, device=DEV) if g_lr is not None else None
@@ -213,7 +215,8 @@ def test_emb_fm_bwd_equals_autograd(D, B, mode, terms):
     for rep in range(2):                                     # run-to-run determinism
         ops.emb_fm_bwd(d(drec), d(rec), d(S), d(g_fm), d(g_lr),
                        _dev([s * D for s in slots_c], torch.int64), C, D, dd, G, sq, G1, sq1,
-                       _dev(dense), _dev([s * D for s in slots_n], torch.int64), B, dnum, dnum1, dbias)
+                       _dev(dense), _dev([s * D for s in slots_n], torch.int64), B, dnum, dnum1, dbias,
+                       wsf)
         torch.cuda.synchronize()
         snap = (G.clone(), sq.clone(), None if G1 is None else G1.clone())
         if rep:
@@ -256,22 +259,26 @@ def test_emb_fm_bwd_equals_the_unfused_reduce_bitwise_on_short_runs():
     ws = torch.empty(ops.dedup_workspace_bytes(B * C), dtype=torch.uint8, device=DEV)
     scal = ops.new_scalars(DEV)
     dd = ops.dedup_catchup(_dev(ids, torch.int32), _dev(bases, torch.int64),
-                           _dev(vocabs, torch.int32), _dev([0, 0, 0], torch.int32), ws, [], scal)
+                           _dev(vocabs, torch.int32), _dev([0, 0, 0], torch.int32), ws, [], scal,
+                           want_uid=True)
     off = _dev([0, D, 2 * D], torch.int64)
-    nparts = ops.emb_grad_reduce_partials(dd.n_max, D)
-    Ga, sqa = torch.zeros(dd.n_max, D, device=DEV), torch.zeros(nparts, device=DEV)
-    Gb, sqb = torch.zeros(dd.n_max, D, device=DEV), torch.zeros(nparts, device=DEV)
+    Ga = torch.zeros(dd.n_max, D, device=DEV)
+    sqa = torch.zeros(ops.emb_grad_reduce_partials(dd.n_max, D), device=DEV)
+    Gb = torch.zeros(dd.n_max, D, device=DEV)
+    sqb = torch.zeros(ops.emb_fm_bwd_partials(dd.n_max, D), device=DEV)
+    wsf = torch.empty(ops.emb_fm_bwd_workspace_floats(dd.n_max, D, 0), device=DEV)
     scratch = torch.zeros(ops.emb_grad_reduce_scratch_ints(dd.n_max), dtype=torch.int32, device=DEV)
     ops.emb_grad_reduce(_dev(drec), C * D, off, C, D, dd, Ga, sqa, scratch)
     ops.emb_fm_bwd(_dev(drec), None, None, None, None, off, C, D, dd, Gb, sqb, None, None, None,
-                   None, B, None, None, None)
+                   None, B, None, None, None, wsf)
     torch.cuda.synchronize()
     nu = int(dd.n_unique.item())
     assert torch.equal(Ga[:nu], Gb[:nu])
 
 
+@pytest.mark.parametrize("dims", [(16, 1, 10), (16, 1)])
 @pytest.mark.parametrize("kind", ["adam", "sgd"])
-def test_sparse_update_multi_equals_one_launch_per_table(kind):
+def test_sparse_update_multi_equals_one_launch_per_table(kind, dims):
     rng = np.random.default_rng(11)
     vocabs = [5, 40, 3000]
     bases, R = _schema(vocabs)
@@ -284,7 +291,7 @@ def test_sparse_update_multi_equals_one_launch_per_table(kind):
     dd = ops.dedup_catchup(_dev(ids, torch.int32), _dev(bases, torch.int64),
                            _dev(vocabs, torch.int32), _dev([0, 0, 0], torch.int32), ws, [], scal)
     states_a, states_b = [], []
-    for D in (16, 1, 10):
+    for D in dims:
         t, m, v = _tables(rng, R, D)
         last = torch.zeros(R, dtype=torch.int32)
         G = torch.randn(dd.n_max, D)
