@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--model", default="DeepFM", choices=["DeepFM", "DCNv2", "DIN", "DLRM", "xDeepFM"])
     ap.add_argument("--dist", default="powerlaw", choices=["powerlaw", "uniform"])
     ap.add_argument("--sparse-update", default="exact", choices=["exact", "lazy"])
+    ap.add_argument("--emb-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="storage of the embedding tables (bf16: opt-in, NOT the headline number — "
+                         "the reference computes and stores fp32)")
     ap.add_argument("--vocab-scale", type=float, default=1.0,
                     help="scale every table: 3.7 = configs[4]'s 125 M rows (8 GB at D=16)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4)
@@ -72,7 +75,8 @@ def build_model(args, device_index, cards, shard=None):
     common = dict(gpu=device_index, embedding_dim=16, learning_rate=1e-3, optimizer="adam",
                   loss="binary_crossentropy", task="binary_classification",
                   metrics=["logloss", "AUC"], verbose=0, model_root="/tmp/fx_bench",
-                  sparse_update=args.sparse_update, hip_graph=not args.no_graph, shard=shard)
+                  sparse_update=args.sparse_update, hip_graph=not args.no_graph, shard=shard,
+                  emb_dtype=args.emb_dtype)
     torch.manual_seed(2019)
     if args.model == "DeepFM":
         model = zoo.DeepFM(fmap, model_id="bench", hidden_units=[1024] * 4, **common)
@@ -507,6 +511,10 @@ def main():
             "config": {"workload": workload_name(args, m["rows"]),
                        "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "id_distribution": args.dist, "sparse_update": args.sparse_update,
+                       "emb_dtype": args.emb_dtype + (" (tables stored bf16, all arithmetic and "
+                                                      "optimizer state fp32; NOT the headline "
+                                                      "configuration)" if args.emb_dtype != "fp32"
+                                                      else ""),
                        "launch": m["launch"],
                        "distinct_batches": m["n_pool"],
                        "inputs": ("host tensors per step (DataLoader-style; one pinned staging "

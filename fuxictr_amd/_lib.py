@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfxctr.so")
 
 FX_OK = 0
-FX_F32, FX_F64, FX_I32, FX_I64 = 0, 1, 2, 3
+FX_F32, FX_F64, FX_I32, FX_I64, FX_BF16 = 0, 1, 2, 3, 4
 FX_FLAG_BAD_ID = 1
 FX_FLAG_A2A_OVERFLOW = 2
 FX_MT_BLOCKS = 96
@@ -38,7 +38,7 @@ i64 = C.c_int64
 class RowState(C.Structure):
     """struct fx_row_state"""
     _fields_ = [("table", vp), ("m", vp), ("v", vp), ("last_step", vp), ("G", vp), ("D", i32),
-                ("reserved", i32)]
+                ("table_dtype", i32)]
 
 
 class GemmEpilogue(C.Structure):
@@ -111,7 +111,7 @@ SIGNATURES = {
     "fx_dice_bwd": (i32, [vp, vp, i64, i32, vp, C.c_float, i32, vp, vp, vp, vp, vp]),
     "fx_dedup_catchup": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
                                vp, C.POINTER(RowState), i32, i32, vp, vp]),
-    "fx_emb_fm_fwd": (i32, [vp, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, vp, i32, vp, i64, i64,
+    "fx_emb_fm_fwd": (i32, [vp, i32, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, vp, i32, vp, i64, i64,
                             vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "fx_emb_fm_bwd_partials": (i64, [i64, i32]),
     "fx_emb_fm_bwd_workspace_floats": (i64, [i64, i32, i32]),
@@ -119,6 +119,7 @@ SIGNATURES = {
                             vp, vp, vp, i64, vp, i32, i64, vp, vp, vp, vp, vp]),
     "fx_sparse_adam_multi": (i32, [C.POINTER(RowState), i32, vp, vp, i64, vp, vp]),
     "fx_sparse_sgd_multi": (i32, [C.POINTER(RowState), i32, vp, vp, i64, vp, vp]),
+    "fx_adam_catchup_all": (i32, [C.POINTER(RowState), i64, i32, vp, vp]),
     "fx_pack_columns_multi": (i32, [C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp),
                                     C.POINTER(i32), C.POINTER(i64), i32, i64, vp]),
 }

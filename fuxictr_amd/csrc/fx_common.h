@@ -108,6 +108,59 @@ __device__ __forceinline__ float fx_block_sum_256(float x, float* red) {
     if (threadIdx.x == 0) r = (red[0] + red[1]) + (red[2] + red[3]);
     return r;
 }
+// ---- bf16 table storage (opt-in `emb_dtype: bf16`): rows are read as bf16 and widened, arithmetic and
+// optimizer state stay fp32, results are rounded to nearest-even on the way back -----------------
+__device__ __forceinline__ float fx_bf16_to_f32(uint16_t h) {
+    return __uint_as_float((uint32_t)h << 16);
+}
+__device__ __forceinline__ uint16_t fx_f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                             // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+// element `off` of a table of fp32 (bf16 == 0) or bf16 (bf16 != 0) values: VEC consecutive elements
+template <int VEC>
+__device__ __forceinline__ void fx_tab_load(const void* base, int bf16, int64_t off, float (&r)[VEC]) {
+    if (!bf16) {
+        fx_load<VEC>(reinterpret_cast<const float*>(base) + off, r);
+        return;
+    }
+    const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + off;
+    if constexpr (VEC == 4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);             // one 8-byte load
+        r[0] = __uint_as_float(t.x << 16);
+        r[1] = __uint_as_float(t.x & 0xffff0000u);
+        r[2] = __uint_as_float(t.y << 16);
+        r[3] = __uint_as_float(t.y & 0xffff0000u);
+    } else if constexpr (VEC == 2) {
+        const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+        r[0] = __uint_as_float(t << 16);
+        r[1] = __uint_as_float(t & 0xffff0000u);
+    } else {
+        r[0] = fx_bf16_to_f32(p[0]);
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void fx_tab_store(void* base, int bf16, int64_t off, const float (&r)[VEC]) {
+    if (!bf16) {
+        fx_store<VEC>(reinterpret_cast<float*>(base) + off, r);
+        return;
+    }
+    uint16_t* p = reinterpret_cast<uint16_t*>(base) + off;
+    if constexpr (VEC == 4) {
+        uint2 t;
+        t.x = (uint32_t)fx_f32_to_bf16(r[0]) | ((uint32_t)fx_f32_to_bf16(r[1]) << 16);
+        t.y = (uint32_t)fx_f32_to_bf16(r[2]) | ((uint32_t)fx_f32_to_bf16(r[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = t;
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<uint32_t*>(p) =
+            (uint32_t)fx_f32_to_bf16(r[0]) | ((uint32_t)fx_f32_to_bf16(r[1]) << 16);
+    } else {
+        p[0] = fx_f32_to_bf16(r[0]);
+    }
+}
+
 // ---- exact-mode Adam: replay of k missed zero-gradient steps of one row -----------------------------
 // A dense torch.optim.Adam moves a row that no batch touches: with g = 0, step j after `last` does
 //     m *= beta1 ; v *= beta2 ; p -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps),  t = last + j.

@@ -30,12 +30,12 @@
 // ---------------------------------------------------------------------------------------------
 
 struct FxTableDev {
-    float* table;
+    void* table;           // fp32, or bf16 when `bf16` is set (moments / gradients are always fp32)
     float* m;
     float* v;
     int32_t* last_step;
     const float* G;        // update kernels only
-    int32_t D, vec, lanes_log2;
+    int32_t D, vec, lanes_log2, bf16;
 };
 
 #define FX_MAX_TABLES 4
@@ -68,7 +68,7 @@ __device__ __forceinline__ void fx_row_load(const FxTableDev& t, int64_t row, in
         const int64_t o = row * t.D + d0;
         fx_load<VEC>(t.m + o, r.m);
         fx_load<VEC>(t.v + o, r.v);
-        fx_load<VEC>(t.table + o, r.p);
+        fx_tab_load<VEC>(t.table, t.bf16, o, r.p);
     }
 }
 
@@ -87,7 +87,7 @@ __device__ __forceinline__ void fx_catchup_finish(const FxTableDev& t, int64_t r
         if (any) {
             fx_adam_replay<VEC>(r.p, r.m, r.v, last, k_steps, sc, lb1, lb2);
             const int64_t o = row * t.D + sub * VEC;
-            fx_store<VEC>(t.table + o, r.p);
+            fx_tab_store<VEC>(t.table, t.bf16, o, r.p);
             fx_store<VEC>(t.m + o, r.m);
             fx_store<VEC>(t.v + o, r.v);
         }
@@ -279,6 +279,11 @@ static int fx_fill_tables(const fx_row_state* tables_host, int32_t n_tables, FxT
         out[t].last_step = h.last_step;
         out[t].G = h.G;
         out[t].D = h.D;
+        out[t].bf16 = h.table_dtype == FX_BF16 ? 1 : 0;
+        if (h.table_dtype != FX_F32 && h.table_dtype != FX_BF16) {
+            fx_set_error("%s: table %d has table_dtype %d (FX_F32 or FX_BF16)", who, t, h.table_dtype);
+            return FX_ERR_INVALID;
+        }
         out[t].vec = g.vec;
         out[t].lanes_log2 = ll;
         if (ll > gl) gl = ll;
@@ -360,7 +365,7 @@ extern "C" int fx_dedup_catchup(const int32_t* ids, int64_t ids_ld, int64_t B, i
 // three scalars per sample is written.
 // ---------------------------------------------------------------------------------------------
 struct EmbFmArgs {
-    const float* table;
+    const void* table;     // fp32, or bf16 when `bf16` is set
     const int32_t* ids;
     int64_t ids_ld;
     const int64_t* col_row_base;
@@ -381,7 +386,7 @@ struct EmbFmArgs {
     float* fm_lr_out;
     float* S;
     fx_scalars* scal;
-    int32_t D, C, Fd, lanes_log2;
+    int32_t D, C, Fd, lanes_log2, bf16;
 };
 
 template <int VEC>
@@ -409,7 +414,8 @@ __global__ __launch_bounds__(256) void k_emb_fm_fwd(EmbFmArgs a) {
                 const int32_t id = a.ids[b * a.ids_ld + r];
                 off = a.col_out_off[r];
                 if (id >= 0 && id < a.col_vocab[r]) {
-                    if (lane_on) fx_load<VEC>(a.table + (a.col_row_base[r] + id) * a.D + d0, val);
+                    if (lane_on)
+                        fx_tab_load<VEC>(a.table, a.bf16, (a.col_row_base[r] + id) * a.D + d0, val);
                 } else if (sub == 0) {
                     atomicOr(&a.scal->err_flag, FX_FLAG_BAD_ID);
                 }
@@ -467,7 +473,8 @@ __global__ __launch_bounds__(256) void k_emb_fm_fwd(EmbFmArgs a) {
     }
 }
 
-extern "C" int fx_emb_fm_fwd(const float* table, int32_t D, const int32_t* ids, int64_t ids_ld,
+extern "C" int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, const int32_t* ids,
+                             int64_t ids_ld,
                              const int64_t* col_row_base, const int32_t* col_vocab,
                              const int64_t* col_out_off, int32_t C, const float* dense,
                              int64_t dense_ld, const float* num_w, const int64_t* num_out_off,
@@ -476,6 +483,8 @@ extern "C" int fx_emb_fm_fwd(const float* table, int32_t D, const int32_t* ids, 
                              float* lr_out, float* fm_out, float* fm_lr_out, float* S,
                              fx_scalars* scal, fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256, "fx_emb_fm_fwd: D=%d not in [1,256]", D);
+    FX_CHECK_ARG(table_dtype == FX_F32 || table_dtype == FX_BF16,
+                 "fx_emb_fm_fwd: table_dtype must be FX_F32 or FX_BF16");
     FX_CHECK_ARG(C >= 0 && Fd >= 0 && B >= 0, "fx_emb_fm_fwd: negative size");
     if (B == 0 || C + Fd == 0) return FX_OK;
     const FxRowGeom g = fx_row_geom(D);
@@ -493,7 +502,7 @@ extern "C" int fx_emb_fm_fwd(const float* table, int32_t D, const int32_t* ids, 
     while ((1 << ll) < g.lanes) ++ll;
     EmbFmArgs a{table, ids, ids_ld, col_row_base, col_vocab, col_out_off, dense, dense_ld, num_w,
                 num_out_off, out, out_ld, B, table1, num_w1, bias1, lr_out, fm_out, fm_lr_out, S,
-                scal, D, C, Fd, ll};
+                scal, D, C, Fd, ll, table_dtype == FX_BF16 ? 1 : 0};
     int64_t blocks = fx_ceil_div(B, 4);
     if (blocks > 256 * 32) blocks = 256 * 32;
     dim3 grid((unsigned)blocks);
@@ -1003,7 +1012,7 @@ __device__ __forceinline__ void fx_update_row(const FxTableDev& t, int64_t u, in
     if (d0 < t.D) {
         float p[VEC], g[VEC];
         const int64_t o = row * t.D + d0;
-        fx_load<VEC>(t.table + o, p);
+        fx_tab_load<VEC>(t.table, t.bf16, o, p);
         fx_load<VEC>(t.G + u * t.D + d0, g);
         if (sc.reg_l1 != 0.f || sc.reg_l2 != 0.f) {
 #pragma unroll
@@ -1029,7 +1038,7 @@ __device__ __forceinline__ void fx_update_row(const FxTableDev& t, int64_t u, in
 #pragma unroll
             for (int k = 0; k < VEC; ++k) p[k] = p[k] - scale * g[k];
         }
-        fx_store<VEC>(t.table + o, p);
+        fx_tab_store<VEC>(t.table, t.bf16, o, p);
     }
     if (sub == 0 && t.last_step) t.last_step[row] = sc.step;
 }
@@ -1055,7 +1064,7 @@ __device__ __forceinline__ void fx_adam_finish(const FxTableDev& t, int64_t row,
             r.p[k] = r.p[k] - sc.step_size * (r.m[k] / denom);
         }
         const int64_t o = row * t.D + sub * VEC;
-        fx_store<VEC>(t.table + o, r.p);
+        fx_tab_store<VEC>(t.table, t.bf16, o, r.p);
         fx_store<VEC>(t.m + o, r.m);
         fx_store<VEC>(t.v + o, r.v);
     }
@@ -1136,6 +1145,46 @@ extern "C" int fx_sparse_sgd_multi(const fx_row_state* tables_host, int32_t n_ta
                                    const fx_scalars* scal, fx_stream_t stream) {
     return fx_sparse_update_multi(false, tables_host, n_tables, uniq_row, n_unique, n_max, scal,
                                   stream, "fx_sparse_sgd_multi");
+}
+
+// ---------------------------------------------------------------------------------------------
+// fx_adam_catchup_all: flush of the exact mode for fp32 or bf16 tables — every row of the table is
+// brought up to step + upto_offset (before evaluate / save / a learning-rate change).
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_catchup_all(FxTableDev t, int64_t total_rows,
+                                                     const fx_scalars* scal, int upto_offset) {
+    const int lanes = 1 << t.lanes_log2;
+    const int sub = threadIdx.x & (lanes - 1);
+    const int64_t rpb = 256 >> t.lanes_log2;
+    const fx_scalars sc = *scal;
+    const int upto = sc.step + upto_offset;
+    const double lb1 = log2((double)sc.beta1), lb2 = log2((double)sc.beta2);
+    for (int64_t row = (int64_t)blockIdx.x * rpb + (threadIdx.x >> t.lanes_log2); row < total_rows;
+         row += (int64_t)gridDim.x * rpb) {
+        if (t.last_step[row] >= upto) continue;
+        fx_catchup_row<VEC>(t, row, sub, sc, upto, lb1, lb2);
+    }
+}
+
+extern "C" int fx_adam_catchup_all(const fx_row_state* table_host, int64_t total_rows,
+                                   int32_t upto_offset, const fx_scalars* scal,
+                                   fx_stream_t stream) {
+    FX_CHECK_ARG(table_host && scal, "fx_adam_catchup_all: null pointer");
+    if (total_rows <= 0) return FX_OK;
+    FxTableDev t;
+    int gl = 0;
+    const int st = fx_fill_tables(table_host, 1, &t, &gl, "fx_adam_catchup_all", true);
+    if (st != FX_OK) return st;
+    int64_t blocks = fx_ceil_div(total_rows, 256 >> t.lanes_log2);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    dim3 grid((unsigned)blocks);
+    hipStream_t s = fx_hip_stream(stream);
+    if (t.vec == 4) hipLaunchKernelGGL(k_catchup_all<4>, grid, dim3(256), 0, s, t, total_rows, scal, (int)upto_offset);
+    else if (t.vec == 2) hipLaunchKernelGGL(k_catchup_all<2>, grid, dim3(256), 0, s, t, total_rows, scal, (int)upto_offset);
+    else hipLaunchKernelGGL(k_catchup_all<1>, grid, dim3(256), 0, s, t, total_rows, scal, (int)upto_offset);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

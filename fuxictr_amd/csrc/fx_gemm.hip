@@ -597,6 +597,19 @@ void k_gemm_f32_pipe(GemmArgs a) {
     }
 }
 
+// (Round 2 experiment, removed again: a variant that kept k-contiguous operands in their global
+// layout in LDS — T[r][36], one ds_write_b128 per staging float4, one ds_read_b128 per lane and 8-k
+// block, i.e. 12 instead of 48 LDS instructions per 16 MFMAs of a 64x64 tile — measured the SAME
+// as this kernel on every tower shape (78.9 vs 78.7 us at 4096x1024x1024, identical K slope,
+// profiles/r02_gemm_probe.txt): the 64x64 loop is not bound by LDS traffic or instruction issue.)
+static int fx_gemm_pipe_mode() {   // FX_GEMM_PIPE=0 falls back to the unpipelined kernel (A/B runs)
+    static const int mode = []() {
+        const char* e = getenv("FX_GEMM_PIPE");
+        return e ? atoi(e) : 1;
+    }();
+    return mode;
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC>
 static int fx_gemm_launch_pipe(dim3 grid, hipStream_t s, const GemmArgs& a) {
     if constexpr (BM * BN <= 64 * 64) {
@@ -943,14 +956,6 @@ static void fx_gemm_dispatch_layout(bool a_kc, bool b_kc, bool av, bool bv, dim3
     else if (a_kc) fx_gemm_dispatch_vec<BM, BN, true, false>(av, bv, grid, s, a);
     else if (b_kc) fx_gemm_dispatch_vec<BM, BN, false, true>(av, bv, grid, s, a);
     else fx_gemm_dispatch_vec<BM, BN, false, false>(av, bv, grid, s, a);
-}
-
-static int fx_gemm_pipe_mode() {   // FX_GEMM_PIPE=0 falls back to the unpipelined kernel (A/B runs)
-    static const int mode = []() {
-        const char* e = getenv("FX_GEMM_PIPE");
-        return e ? atoi(e) : 1;
-    }();
-    return mode;
 }
 
 extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,

@@ -34,6 +34,23 @@ def set_dist_context(ctx):
     _DIST = ctx
 
 
+_EMB_DTYPE = torch.float32
+
+
+def set_emb_dtype(name):
+    """Storage type of the D > 1 embedding tables built from now on (BaseModel kwarg `emb_dtype`):
+    'fp32' (the reference's) or 'bf16' (opt-in: rows are read as bf16, every sum / the Adam state /
+    the update arithmetic stay fp32, updated rows are rounded to nearest-even)."""
+    global _EMB_DTYPE
+    key = str(name or "fp32").lower()
+    if key in ("fp32", "float32", "f32"):
+        _EMB_DTYPE = torch.float32
+    elif key in ("bf16", "bfloat16"):
+        _EMB_DTYPE = torch.bfloat16
+    else:
+        raise ValueError("emb_dtype={} is not supported.".format(name))
+
+
 def set_default_device(device):
     """Device on which native layers allocate their tables (set by BaseModel.__init__)."""
     global _DEFAULT_DEVICE
@@ -193,6 +210,8 @@ class _TableGroup(object):
         if self.total_rows >= 2 ** 32 - 1:
             raise NotImplementedError("packed table with %d rows exceeds the 2^32-1 row limit "
                                       "of the sparse path" % self.total_rows)
+        if self.total_rows > 0 and self.sharded and _EMB_DTYPE != torch.float32:
+            raise NotImplementedError("emb_dtype=bf16 with shard='row' is not implemented")
         if self.total_rows > 0 and self.sharded:
             # local shard + one all-zero pad row (index rows_per_shard) that padded all-to-all
             # slots point at; it is never part of a de-dup result, so it is never updated
@@ -200,8 +219,9 @@ class _TableGroup(object):
             self.table = torch.zeros(self.rows_per_shard + 1, self.D, dtype=torch.float32,
                                      device=self.device)
         elif self.total_rows > 0:
-            self.table = torch.empty(self.total_rows, self.D, dtype=torch.float32,
-                                     device=self.device)
+            # (the D=1 tables of LogisticRegression stay fp32: 4-byte rows gain nothing from bf16)
+            dt = _EMB_DTYPE if self.D > 1 else torch.float32
+            self.table = torch.empty(self.total_rows, self.D, dtype=dt, device=self.device)
         if self.numeric:
             self.num_w = torch.empty(len(self.numeric), self.D, dtype=torch.float32,
                                      device=self.device)
@@ -572,8 +592,11 @@ class _TableGroup(object):
         """exact mode: replay pending zero-gradient Adam steps for EVERY row (before eval/save)."""
         if self.exact and self.opt_kind == "adam" and self.table is not None:
             rows = self.rows_per_shard + 1 if self.sharded else self.total_rows
-            ops.adam_catchup(self.table, self.m, self.v, self.last_step, self.D, None,
-                             rows, 0, self.scal)
+            if self.table.dtype == torch.bfloat16:
+                ops.adam_catchup_all(self.row_state(), rows, 0, self.scal)
+            else:
+                ops.adam_catchup(self.table, self.m, self.v, self.last_step, self.D, None,
+                                 rows, 0, self.scal)
 
 
 def finish_shard_backward(groups):
@@ -972,6 +995,10 @@ class FeatureEmbeddingDict(nn.Module):
                 if lr_grp is not None and hasattr(inputs, "cache"):
                     inputs.cache[("lr_out", id(lr_mod))] = lr_out
             else:
+                if grp.table is not None and grp.table.dtype != torch.float32:
+                    raise NotImplementedError(
+                        "emb_dtype=bf16 is implemented for the fused column path only (every id "
+                        "feature categorical with its own table, one embedding dim, batch <= 8192)")
                 dd = grp.prepare_train(plan, ids, inputs) if (track and not grp.sharded) else None
                 out = _EmbGatherFn.apply(anchor, grp, plan, ids, dense, dd, inputs, track)
             rec = out.view(out.shape[0], plan.n_slots, D)
@@ -1376,8 +1403,10 @@ _FORCE_SPLITK = int(_os.environ.get("FX_DW_SPLITK", "0"))
 
 
 def _split_k_for(M, N, K):
-    """Split the contraction when the output grid alone cannot fill 256 CUs (weight gradients):
-    aim for ~512 workgroups of 64x64 (2 per CU); every extra split costs a partial-slab round trip."""
+    """Split the contraction when the output grid alone cannot fill 256 CUs (weight gradients): aim
+    for ~1024 workgroups of 64x64 — the 4 per CU the 64x64 kernel keeps resident (measured,
+    profiles/r02_gemm_probe.txt, GEMM + slab reduce: 1024x1024x4096 85.2 us at 2 splits, 80.9 at 4;
+    1024x624x4096 82.0 / 64.6; 624x624x4096 62.9 / 50.6 / 48.8 at 2 / 4 / 8)."""
     if M <= 4:                      # skinny weight gradient: column-parallel reduction kernel
         # enough K slabs to put >= 4 workgroups on every CU (N/256 column blocks x slabs); the wide
         # slab reduce handles hundreds of slabs in one small launch
@@ -1385,10 +1414,15 @@ def _split_k_for(M, N, K):
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     if _FORCE_SPLITK:                  # FX_DW_SPLITK=<n>: experiment switch
         return max(1, min(_FORCE_SPLITK, K // 256))
-    if tiles >= 448:
+    if tiles >= 768:
         return 1
-    s = max(1, min(-(-512 // tiles), K // 256))
-    return min(s, 256 if tiles <= 4 else 16)
+    if tiles <= 4:
+        return max(1, min(-(-512 // tiles), K // 256, 256))
+    want = 1024.0 / tiles
+    s = 1
+    while s * 1.5 < want:          # nearest power of two (log scale)
+        s *= 2
+    return max(1, min(s, K // 256, 16))
 
 
 class _Workspace(object):

@@ -615,6 +615,7 @@ def _row_states(states):
         arr[i].last_step = s.last_step.data_ptr() if s.last_step is not None else None
         arr[i].G = s.G.data_ptr() if s.G is not None else None
         arr[i].D = int(s.D)
+        arr[i].table_dtype = _lib.FX_BF16 if s.table.dtype == torch.bfloat16 else _lib.FX_F32
     return arr
 
 
@@ -642,7 +643,8 @@ def _emb_fm_bytes(table, D, ids, col_row_base, col_vocab, col_out_off, dense, nu
     C_ = 0 if ids is None else ids.shape[1]
     Fd = 0 if dense is None else dense.shape[1]
     # rows + ids + dense in (+ the 4-byte first-order rows), the record out
-    return B * (C_ * (4 * D + 4) + Fd * 4 + (C_ * 4 if table1 is not None else 0)
+    eb = 2 if (table is not None and table.dtype == torch.bfloat16) else 4
+    return B * (C_ * (eb * D + 4) + Fd * 4 + (C_ * 4 if table1 is not None else 0)
                 + (C_ + Fd) * 4 * D)
 
 
@@ -655,7 +657,8 @@ def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w
     B = out.shape[0]
     C_ = 0 if ids is None else ids.shape[1]
     Fd = 0 if dense is None else dense.shape[1]
-    check(lib.fx_emb_fm_fwd(ptr(table), D, ptr(ids), 0 if ids is None else ids.stride(0),
+    tdt = _lib.FX_BF16 if (table is not None and table.dtype == torch.bfloat16) else _lib.FX_F32
+    check(lib.fx_emb_fm_fwd(ptr(table), tdt, D, ptr(ids), 0 if ids is None else ids.stride(0),
                             ptr(col_row_base), ptr(col_vocab), ptr(col_out_off), C_, ptr(dense),
                             0 if dense is None else dense.stride(0), ptr(num_w), ptr(num_out_off),
                             Fd, ptr(out), out.stride(0), B, ptr(table1), ptr(num_w1), ptr(bias1),
@@ -688,6 +691,12 @@ def emb_fm_bwd(drec, rec, S, g_fm, g_lr, col_out_off, C_, D, dd, G, sq_partials,
         dd.n_max if have else 0, ptr(G), ptr(sq_partials), ptr(G1), ptr(sq1_partials), ptr(dense),
         0 if dense is None else dense.stride(0), ptr(num_out_off), Fd, B, ptr(dnum_w), ptr(dnum_w1),
         ptr(dbias1), ptr(workspace), stream_ptr(workspace.device)), "fx_emb_fm_bwd")
+
+
+def adam_catchup_all(state, total_rows, upto_offset, scal):
+    """Exact-mode flush of one table (fp32 or bf16): every row up to step + upto_offset."""
+    check(_lib.load().fx_adam_catchup_all(_row_states([state]), total_rows, upto_offset, ptr(scal),
+                                          stream_ptr(scal.device)), "fx_adam_catchup_all")
 
 
 @_timed("sparse_update_multi", "sparse_path")

@@ -69,6 +69,9 @@ class _NativeOptimizer(torch.optim.Optimizer):
             self._attach(grp)
             if grp.dist is not None:
                 self.dist = grp.dist
+        if self.dense_reg and any(g.table is not None and g.table.dtype != torch.float32
+                                  for g in self._groups):
+            raise NotImplementedError("embedding_regularizer with emb_dtype=bf16 is not implemented")
         if self.dense_reg and self.dist is not None:
             raise NotImplementedError("embedding_regularizer with row-sharded tables is not "
                                       "implemented")
@@ -88,8 +91,8 @@ class _NativeOptimizer(torch.optim.Optimizer):
         grp.exact = self.kind == "adam" and self.sparse_update == "exact" and not self.dense_reg
         grp.dense_reg = self.dense_reg
         if self.kind == "adam" and grp.table is not None:
-            grp.m = torch.zeros_like(grp.table)
-            grp.v = torch.zeros_like(grp.table)
+            grp.m = torch.zeros_like(grp.table, dtype=torch.float32)     # fp32 state, also for
+            grp.v = torch.zeros_like(grp.table, dtype=torch.float32)     # bf16 tables
         if (self.kind == "adam" or self.dense_reg) and grp.table is not None:
             grp.last_step = torch.zeros(grp.table.shape[0], dtype=torch.int32, device=grp.device)
         if self.dense_reg and grp.table is not None:
@@ -302,7 +305,8 @@ class _NativeOptimizer(torch.optim.Optimizer):
             for rec in grp.pending:
                 buckets.setdefault(id(rec.dd), []).append((grp, rec))
         for items in buckets.values():
-            if len(items) > 1 and len(items) <= _lib.FX_MAX_TABLES:
+            if len(items) <= _lib.FX_MAX_TABLES and (
+                    len(items) > 1 or items[0][0].table.dtype != torch.float32):
                 ops.sparse_update_multi(self.kind, [g.row_state(G=r.G) for g, r in items],
                                         items[0][1].dd, self.scal)
             else:

@@ -308,6 +308,7 @@ class BaseModel(nn.Module):
         elif shard not in (None, False, "none"):
             raise ValueError("shard={} is not supported.".format(shard))
         layers.set_dist_context(self._dist)      # tables built below are row-sharded over ranks
+        layers.set_emb_dtype(kwargs.get("emb_dtype", "fp32"))   # storage of the D > 1 tables
         # training-control settings, kept under the attribute names model code may read
         self._monitor = Monitor(kv=monitor)
         for attr, value in (("_monitor_mode", monitor_mode), ("_save_best_only", save_best_only),

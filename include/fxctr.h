@@ -32,7 +32,7 @@ extern "C" {
 typedef void* fx_stream_t; /* hipStream_t; NULL = the null stream */
 
 enum { FX_OK = 0, FX_ERR_INVALID = 1, FX_ERR_HIP = 2, FX_ERR_UNSUPPORTED = 3 };
-enum { FX_F32 = 0, FX_F64 = 1, FX_I32 = 2, FX_I64 = 3 };
+enum { FX_F32 = 0, FX_F64 = 1, FX_I32 = 2, FX_I64 = 3, FX_BF16 = 4 };
 
 /* bits of fx_scalars.err_flag (sticky, set by kernels, read by the host at its own sync points) */
 enum { FX_FLAG_BAD_ID = 1, FX_FLAG_A2A_OVERFLOW = 2 };
@@ -473,6 +473,12 @@ int fx_binary_metrics(const float* y_pred, const float* y_true, int64_t n, void*
  *   n_tables (<= 4) table groups, so the lookup that follows reads the rows dense Adam would hold.
  *   n_tables = 0: de-dup only.  workspace: >= 2 * round_up(4*B*C, 256) bytes.  B <= 8192, C <= 256.
  *
+ * bf16 table storage (BASELINE north_star "vectorised fp32/bf16 gathers"; opt-in `emb_dtype: bf16`):
+ *   table_dtype = FX_BF16 makes `table` a bf16 [rows, D] array — a row of D = 16 is 32 bytes, read by
+ *   4 lanes as 8-byte loads and widened; every sum (FM, first-order term), the Adam moments and the
+ *   update arithmetic stay fp32; updated rows are rounded to nearest-even bf16.  The D=1 table of
+ *   the first-order term is always fp32.
+ *
  * fx_emb_fm_fwd = fx_emb_gather_fwd + fx_lr_fwd + fx_fm_fwd in ONE launch, one wave per sample:
  *   out     the [B, F, D] record (feature_embedding.py:261-297, :230-259), written once
  *   lr_out  [B]  sum_c table1[col_row_base[c] + ids[b,c]] + sum_j dense[b,j] num_w1[j] + bias1
@@ -501,19 +507,22 @@ int fx_binary_metrics(const float* y_pred, const float* y_true, int64_t n, void*
  * fx_sparse_adam_multi / fx_sparse_sgd_multi: fx_sparse_adam / fx_sparse_sgd for every table group
  *   of one de-dup result in one launch (tables[t].G = that group's reduced gradient).
  *
+ * fx_adam_catchup_all: fx_adam_catchup over EVERY row of one table (uniq_row = NULL there), for fp32
+ *   or bf16 tables: the flush of the exact mode before evaluate / save / a learning-rate change.
+ *
  * fx_pack_columns_multi: fx_pack_columns with one destination per column (outs_host[c] = address of
  *   out[0, first column], out_lds_host[c] its row stride, out_dtypes_host[c] FX_I32 | FX_F32), so the
  *   id block, the numeric block and the label of a batch (rank_model.py:169-204, feature_embedding.py
  *   :280-291) are cast in ONE launch.  <= 96 columns per call.
  * ------------------------------------------------------------------------------------------ */
 typedef struct fx_row_state {
-    float* table;       /* [rows, D] */
+    void* table;        /* [rows, D], fp32 or bf16 (table_dtype) */
     float* m;           /* Adam moments (NULL for SGD) */
     float* v;
     int32_t* last_step; /* [rows] step of the row's last update (NULL: not tracked) */
     const float* G;     /* [n_max, D] reduced gradient, update entry points only */
     int32_t D;
-    int32_t reserved;
+    int32_t table_dtype; /* FX_F32 | FX_BF16: storage of `table` only; m, v, G are fp32 */
 } fx_row_state;
 
 int fx_dedup_catchup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
@@ -524,7 +533,7 @@ int fx_dedup_catchup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
                      fx_scalars* begin_scal /* or NULL */, const fx_row_state* tables_host,
                      int32_t n_tables, int32_t upto_offset, const fx_scalars* scal,
                      fx_stream_t stream);
-int fx_emb_fm_fwd(const float* table, int32_t D, const int32_t* ids, int64_t ids_ld,
+int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, const int32_t* ids, int64_t ids_ld,
                   const int64_t* col_row_base, const int32_t* col_vocab, const int64_t* col_out_off,
                   int32_t C, const float* dense, int64_t dense_ld, const float* num_w,
                   const int64_t* num_out_off, int32_t Fd, float* out, int64_t out_ld, int64_t B,
@@ -546,6 +555,8 @@ int fx_sparse_adam_multi(const fx_row_state* tables_host, int32_t n_tables, cons
 int fx_sparse_sgd_multi(const fx_row_state* tables_host, int32_t n_tables, const uint32_t* uniq_row,
                         const int32_t* n_unique, int64_t n_max, const fx_scalars* scal,
                         fx_stream_t stream);
+int fx_adam_catchup_all(const fx_row_state* table_host, int64_t total_rows, int32_t upto_offset,
+                        const fx_scalars* scal, fx_stream_t stream);
 int fx_pack_columns_multi(const void* const* cols_host, const int32_t* dtypes_host,
                           const int32_t* widths_host, void* const* outs_host,
                           const int32_t* out_dtypes_host, const int64_t* out_lds_host, int32_t ncols,

@@ -246,9 +246,9 @@ def reg_dense_update(table, m, v, last_step, D, adam, scal):
 def sparse_adam(table, m, v, last_step, D, dd, G, scal):
     nu = int(dd.n_unique)
     rows = dd.uniq_row[:nu].long()
-    p, mm, vv = table[rows], m[rows], v[rows]
+    p, mm, vv = table[rows].float(), m[rows], v[rows]          # bf16 tables: fp32 arithmetic,
     _adam(p, mm, vv, (G[:nu] + _reg(p, scal)) * scal[SC.SC_CLIP], scal)
-    table[rows], m[rows], v[rows] = p, mm, vv
+    table[rows], m[rows], v[rows] = p.to(table.dtype), mm, vv  # ... rounded on the way back
     last_step[rows] = _step(scal)
 
 
@@ -259,11 +259,13 @@ def adam_catchup(table, m, v, last_step, D, dd, total_rows, upto_offset, scal):
                        float(scal[SC.SC_EPS]), float(scal[SC.SC_LR]))
     for r in rows.tolist():
         last = int(last_step[r])
+        p = table[r].float()
         for t in range(last + 1, upto + 1):
             m[r] *= b1
             v[r] *= b2
-            table[r] -= lr / (1 - b1 ** t) * (m[r] / (v[r].sqrt() / math.sqrt(1 - b2 ** t) + eps))
+            p -= lr / (1 - b1 ** t) * (m[r] / (v[r].sqrt() / math.sqrt(1 - b2 ** t) + eps))
         if upto > last:
+            table[r] = p.to(table.dtype)
             last_step[r] = upto
 
 
@@ -614,6 +616,11 @@ def emb_fm_bwd(drec, rec, S, g_fm, g_lr, col_out_off, C, D, dd, G, sq_partials, 
         dbias1[0] = g_lr.sum()
 
 
+def adam_catchup_all(state, total_rows, upto_offset, scal):
+    adam_catchup(state.table, state.m, state.v, state.last_step, state.D, None, total_rows,
+                 upto_offset, scal)
+
+
 def sparse_update_multi(kind, states, dd, scal):
     for st in states:
         if kind == "adam":
@@ -642,7 +649,7 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update",
          "shard_plan_workspace_ints", "emb_seq_pool_fwd", "dedup_sorted_runs", "RowState",
          "dedup_catchup", "emb_fm_fwd", "emb_fm_bwd", "sparse_update_multi", "pack_columns_multi",
-         "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats"]
+         "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats", "adam_catchup_all"]
 
 
 def install_plain():

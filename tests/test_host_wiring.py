@@ -296,3 +296,43 @@ def test_optimizer_step_protocol_of_a_train_step_override(tmp_path, monkeypatch)
         assert abs(la - float(g.expect["loss"][i])) <= 1e-4
     with pytest.raises(RuntimeError, match="zero_grad"):
         b.optimizer.step()
+
+
+def test_bf16_table_storage_wiring(tmp_path, monkeypatch):
+    """`emb_dtype: bf16` on the emulated kernels: D > 1 tables are bf16, the D=1 LR tables and the
+    Adam state stay fp32, a reference (fp32) checkpoint loads into it, the forward equals the oracle
+    on the widened weights, a few training steps run through the fused path."""
+    from oracle import ctr_oracle as O
+    g = Golden("deepfm_adam")
+    _cpu_emul.install(monkeypatch)
+    from fuxictr_amd import optim, zoo
+    from fuxictr_amd.features import FeatureMap
+    monkeypatch.setattr(optim._NativeOptimizer, "__init__", _cpu_opt_init(optim))
+    m = g.meta
+    fmap = FeatureMap(g.spec["dataset_id"], str(tmp_path))
+    fmap.load_dict(g.spec, {"embedding_dim": m["embedding_dim"]})
+    model = zoo.DeepFM(fmap, model_id="bf16", gpu=-1, embedding_dim=m["embedding_dim"],
+                       hidden_units=m["hidden"], learning_rate=m["lr"], optimizer="adam",
+                       loss="binary_crossentropy", task="binary_classification",
+                       metrics=["logloss", "AUC"], verbose=0, model_root=str(tmp_path),
+                       emb_dtype="bf16")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state0.items()})
+    main = model.embedding_layer.embedding_layer.table_groups()[0]
+    lr_grp = model.fm.lr_layer.embedding_layer.embedding_layer.table_groups()[0]
+    assert main.table.dtype == torch.bfloat16 and lr_grp.table.dtype == torch.float32
+    assert main.m.dtype == torch.float32
+    wide = {k: v.detach().float().clone() for k, v in model.state_dict().items()}
+    tr = O.OracleTrainer(g.cfg(), wide, g.features, lr=m["lr"], max_norm=m["max_norm"])
+    b = tb(g.batches[-1])
+    model.eval()
+    with torch.no_grad():
+        p = model.forward(b)["y_pred"]
+    np.testing.assert_allclose(p._fx_logit.reshape(-1).numpy(), tr.logits(b).numpy(), atol=5e-6)
+    model.train()
+    model._max_gradient_norm = m["max_norm"]
+    for i in range(3):
+        loss = float(model.train_step(tb(g.batches[i])).item())
+        ref = tr.train_step(tb(g.batches[i]), tb(g.batches[i])["label"])[0]
+        assert abs(loss - ref) < 2e-2, (i, loss, ref)       # bf16 rounding of the rows, not exactness
+    model.eval()       # flush through adam_catchup_all
+    assert main.table.dtype == torch.bfloat16
