@@ -325,9 +325,10 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         # Per-kernel durations cannot be observed inside a replayed hipGraph, and an event pair around
         # a single launch adds ~10 us on this platform.  So ONE eager step over the next batch of the
         # pool is RECORDED (every native entry point with its live arguments) and each recorded launch
-        # is then replayed 20x back to back between one event pair (ops.KernelTimer): the average is
-        # the kernel's duration plus the ~1.3 us dependent-launch boundary, i.e. what rocprofv3's
-        # kernel trace of the same command reports (profiles/).
+        # group (one GEMM shape, the sparse path) is captured in step order into one hipGraph that is
+        # replayed 20x between one event pair (ops.KernelTimer): the average is the kernel's duration
+        # plus the ~1.3 us dependent-launch boundary, i.e. what rocprofv3's kernel trace of the timed
+        # region reports (profiles/).
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         use_graph, model._use_graph = model._use_graph, False
         for _ in range(2):                             # eager warm-up of the non-graph path
@@ -343,9 +344,11 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         ktimes = ops.KernelTimer.replay(reps=20)
         ops.KernelTimer.reset()
         model._use_graph = use_graph
-        timing_mode = ("every native launch of one eager step recorded, then replayed 20x back to "
-                       "back between one HIP-event pair on the launch stream (the timed region itself "
-                       "replays a hipGraph); average = kernel + dependent-launch boundary")
+        timing_mode = ("every native launch of one eager step recorded; the launches of one GEMM "
+                       "shape (of the sparse path) are captured in step order into a hipGraph that "
+                       "is replayed 20x between one HIP-event pair on the launch stream (the timed "
+                       "region itself replays a hipGraph); average = kernel + dependent-launch "
+                       "boundary")
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -485,3 +485,112 @@ extern "C" int fx_dice_bwd(const float* Z, const float* dY, int64_t N, int32_t H
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Dice across ranks (row-sharded training: every rank holds B/N samples of the global batch).  The
+// reference normalises with the statistics of the WHOLE batch (activations.py:40-51), so the two
+// column reductions are split from their consumers: local sums -> (the host all-reduces them) ->
+// apply with the global row count.  Same kernels as fx_dice_fwd / fx_dice_bwd.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dice_sums_final(const float* partial, int chunks, int H,
+                                                         int nt, float* sums) {
+    __shared__ float red[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int h = blockIdx.x * 16 + tx;
+    for (int k = 0; k < nt; ++k) {
+        const float s = fx_chunk_sum(partial, nt, k, chunks, H, h, ty, red);
+        if (ty == 0 && h < H) sums[k * H + h] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dice_stats_from_sums(const float* sums, int H, double n_total,
+                                                              float momentum, float* stats,
+                                                              float* running_mean,
+                                                              float* running_var) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= H) return;
+    const double mean = (double)sums[h] / n_total;
+    double var = (double)sums[H + h] / n_total - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[h] = (float)mean;
+    stats[H + h] = (float)var;
+    if (running_mean) {
+        const double unb = n_total > 1.0 ? var * n_total / (n_total - 1.0) : var;
+        running_mean[h] = (float)((1.0 - momentum) * running_mean[h] + momentum * mean);
+        running_var[h] = (float)((1.0 - momentum) * running_var[h] + momentum * unb);
+    }
+}
+
+extern "C" int fx_dice_local_sums(const float* Z, int64_t N, int32_t H, float* sums,
+                                  float* workspace, fx_stream_t stream) {
+    FX_CHECK_ARG(N >= 1 && H >= 1, "fx_dice_local_sums: bad sizes");
+    FX_CHECK_ARG(Z && sums && workspace, "fx_dice_local_sums: null pointer");
+    hipStream_t s = fx_hip_stream(stream);
+    const int64_t rows = fx_ceil_div(N, FX_STAT_CHUNKS);
+    if (H % 4 == 0 && (reinterpret_cast<uintptr_t>(Z) & 15) == 0)
+        hipLaunchKernelGGL(k_dice_reduce_v4<0>, dim3((unsigned)fx_ceil_div(H, 64), FX_STAT_CHUNKS),
+                           dim3(256), 0, s, Z, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, 0.f, N, (int)H, rows, workspace);
+    else
+        hipLaunchKernelGGL(k_dice_reduce<0>, dim3((unsigned)fx_ceil_div(H, 64), FX_STAT_CHUNKS),
+                           dim3(256), 0, s, Z, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, 0.f, N, (int)H, rows, workspace);
+    hipLaunchKernelGGL(k_dice_sums_final, dim3((unsigned)fx_ceil_div(H, 16)), dim3(256), 0, s,
+                       workspace, (int)FX_STAT_CHUNKS, (int)H, 2, sums);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+extern "C" int fx_dice_fwd_from_sums(const float* Z, int64_t N, int32_t H, const float* alpha,
+                                     float eps, float momentum, const float* sums, int64_t n_total,
+                                     float* running_mean, float* running_var, float* stats,
+                                     float* Y, fx_stream_t stream) {
+    FX_CHECK_ARG(N >= 1 && H >= 1 && n_total >= N, "fx_dice_fwd_from_sums: bad sizes");
+    FX_CHECK_ARG(Z && alpha && sums && stats && Y, "fx_dice_fwd_from_sums: null pointer");
+    hipStream_t s = fx_hip_stream(stream);
+    hipLaunchKernelGGL(k_dice_stats_from_sums, dim3((unsigned)fx_ceil_div(H, 256)), dim3(256), 0, s,
+                       sums, (int)H, (double)n_total, momentum, stats, running_mean, running_var);
+    const int64_t n = N * H;
+    int64_t blocks = fx_ceil_div(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_dice_fwd, dim3((unsigned)blocks), dim3(256), 0, s, Z, stats, alpha, eps, n,
+                       (int)H, Y);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+extern "C" int fx_dice_bwd_local_sums(const float* Z, const float* dY, int64_t N, int32_t H,
+                                      const float* alpha, float eps, const float* stats,
+                                      float* sums3, float* workspace, fx_stream_t stream) {
+    FX_CHECK_ARG(N >= 1 && H >= 1, "fx_dice_bwd_local_sums: bad sizes");
+    FX_CHECK_ARG(Z && dY && alpha && stats && sums3 && workspace,
+                 "fx_dice_bwd_local_sums: null pointer");
+    hipStream_t s = fx_hip_stream(stream);
+    const int chunks = FX_STAT_CHUNKS - 1;
+    const int64_t rows2 = fx_ceil_div(N, chunks);
+    if (H % 4 == 0 && ((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(dY)) & 15) == 0)
+        hipLaunchKernelGGL(k_dice_reduce_v4<1>, dim3((unsigned)fx_ceil_div(H, 64), chunks), dim3(256),
+                           0, s, Z, dY, stats, alpha, eps, N, (int)H, rows2, workspace);
+    else
+        hipLaunchKernelGGL(k_dice_reduce<1>, dim3((unsigned)fx_ceil_div(H, 64), chunks), dim3(256), 0,
+                           s, Z, dY, stats, alpha, eps, N, (int)H, rows2, workspace);
+    hipLaunchKernelGGL(k_dice_sums_final, dim3((unsigned)fx_ceil_div(H, 16)), dim3(256), 0, s,
+                       workspace, chunks, (int)H, 3, sums3);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+extern "C" int fx_dice_bwd_from_sums(const float* Z, const float* dY, int64_t N, int32_t H,
+                                     const float* alpha, float eps, const float* stats,
+                                     const float* sums3, int64_t n_total, float* dZ,
+                                     fx_stream_t stream) {
+    FX_CHECK_ARG(N >= 1 && H >= 1 && n_total >= N, "fx_dice_bwd_from_sums: bad sizes");
+    FX_CHECK_ARG(Z && dY && alpha && stats && sums3 && dZ, "fx_dice_bwd_from_sums: null pointer");
+    const int64_t n = N * H;
+    int64_t blocks = fx_ceil_div(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_dice_bwd, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), Z, dY,
+                       stats, alpha, sums3, eps, n, (int)H, n_total, 1, dZ);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}

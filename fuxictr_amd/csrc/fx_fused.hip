@@ -694,6 +694,9 @@ __global__ __launch_bounds__(256) void k_emb_fm_bwd(EmbFmBwdArgs a) {
         int64_t i = lo;
         while (i < hi) {
             const uint32_t u = a.sorted_uid[i];
+            // generic de-dup results (fx_dedup, not the column path) put the padding / bad-id lookups
+            // at the END of the sorted array with uid 0xFFFFFFFF: nothing follows them
+            if (u == 0xFFFFFFFFu) break;
             const int64_t rbeg = a.seg_start[u], rend = a.seg_start[u + 1];
             const int64_t end = rend < hi ? rend : hi;
             float acc[VEC], acc1 = 0.f;

@@ -197,6 +197,13 @@ __global__ __launch_bounds__(256) void k_scatter_unique(const uint32_t* key, con
 
 static inline size_t fx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Device-wide sort of the generic path (sequence columns, owner side of the sharded path): Onesweep
+// radix passes over only the key bits in use.  rocPRIM's default picks its merge sort below 1 M
+// items — measured for c4's 262 K lookups: a block sort + 16 merge launches + a 75 us copy-back,
+// ~200 us of the 0.87 ms DIN step (profiles/r02_step_timeline_din_before.txt).
+using FxSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::default_config, 0>;
+
 static hipError_t fx_dedup_temp_bytes(int64_t n, size_t* sort_bytes, size_t* scan_bytes) {
     // size queries are host-only but not free; a training loop asks for the same n every step
     static thread_local int64_t c_n = -1;
@@ -207,8 +214,8 @@ static hipError_t fx_dedup_temp_bytes(int64_t n, size_t* sort_bytes, size_t* sca
         return hipSuccess;
     }
     uint32_t* nul = nullptr;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, *sort_bytes, nul, nul, nul, nul, (size_t)n,
-                                             0u, 32u, (hipStream_t)0);
+    hipError_t e = rocprim::radix_sort_pairs<FxSortConfig>(nullptr, *sort_bytes, nul, nul, nul, nul,
+                                                           (size_t)n, 0u, 32u, (hipStream_t)0);
     if (e != hipSuccess) return e;
     HeadFlag hf{nullptr, 0};
     auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), hf);
@@ -306,8 +313,11 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
                            (int)C, col_row_base, col_vocab, col_pad, sentinel, (uint32_t)n_shards,
                            (uint32_t)rows_per_shard, keys_in, pos_in);
         FX_CHECK_LAUNCH();
-        FX_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, sorted_key, pos_in, sorted_pos,
-                                               (size_t)n, 0u, 32u, s));
+        // only the bits the key space needs (keys <= sentinel): c4's 2.8 M rows take 22 of 32 bits
+        unsigned end_bit = 1;
+        while (end_bit < 32 && (sentinel >> end_bit) != 0u) ++end_bit;
+        FX_CHECK_HIP(rocprim::radix_sort_pairs<FxSortConfig>(temp, tb, keys_in, sorted_key, pos_in,
+                                                             sorted_pos, (size_t)n, 0u, end_bit, s));
     }
     HeadFlag hf{sorted_key, sentinel};
     auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), hf);

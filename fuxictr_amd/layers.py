@@ -358,10 +358,16 @@ class _TableGroup(object):
         return ops.RowState(self.table, self.m, self.v, self.last_step, self.D, G)
 
     def fast_columns(self, plan, B):
-        """The fused column path (csrc/fx_fused.hip) applies: every id column owns its own table, in
-        column order, unsharded, batch small enough for one in-LDS sort per column."""
+        """The column path of the de-dup (fx_dedup_catchup) applies: every id column owns its own
+        table, in column order, unsharded, batch small enough for one in-LDS sort per column."""
         return (not self.sharded and plan.n_seq == 0 and plan.columns_sorted and B <= 8192
                 and plan.C <= 256 and _lib.row_lanes(self.D) <= 64)
+
+    def fused_front(self, plan):
+        """The fused gather(+LR+FM) / balanced backward kernels apply: any unsharded plan whose id
+        columns each fill one slot of the record (categorical columns and the positions of RAW
+        sequences alike; pooled sequences keep the pooling kernels)."""
+        return not self.sharded and plan.n_seq == 0 and _lib.row_lanes(self.D) <= 64
 
     def dedup(self, plan, ids, inputs):
         cache = getattr(inputs, "cache", None)
@@ -375,7 +381,7 @@ class _TableGroup(object):
             self.dedup_ws = (n, torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8,
                                             device=self.device))
         dd = ops.dedup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad, self.total_rows,
-                       self.dedup_ws[1], columns_sorted=plan.columns_sorted)
+                       self.dedup_ws[1], columns_sorted=plan.columns_sorted, want_uid=True)
         if cache is not None:
             cache[ckey] = dd
         return dd
@@ -719,11 +725,7 @@ class _EmbFMFn(torch.autograd.Function):
         g_lr = g_lr.contiguous() if g_lr is not None else None
         dd = ctx.dd
         if plan.C and (dd is None or dd.sorted_uid is None):
-            # (no optimizer attached / a cached de-dup without uid: redo it on the column path)
-            ws_ = torch.empty(ops.dedup_workspace_bytes(ctx.ids.numel()), dtype=torch.uint8,
-                              device=dev)
-            dd = ops.dedup_catchup(ctx.ids, plan.col_row_base, plan.col_vocab, plan.col_pad, ws_, [],
-                                   group.ensure_scal(), want_uid=True)
+            dd = group.dedup(plan, ctx.ids, ctx.inputs)      # (no optimizer attached)
         G = sq = G1 = sq1 = None
         if plan.C:
             G = torch.empty(dd.n_max, D, dtype=torch.float32, device=dev)
@@ -980,7 +982,7 @@ class FeatureEmbeddingDict(nn.Module):
             anchor = self._anchor(grp)
             B_ = (ids if ids is not None else dense).shape[0]
             front = None
-            if self.fuse_front and grp.fast_columns(plan, B_) and len(self._groups) == 1:
+            if self.fuse_front and grp.fused_front(plan) and len(self._groups) == 1:
                 # the fused front end: gather (+ first-order term + FM term), one launch
                 lr_mod, lr_grp, lr_plan = self._lr_peer_for(plan, feats, inputs)
                 peers = (lr_grp,) if lr_grp is not None else ()
@@ -1517,10 +1519,25 @@ class _DiceFn(torch.autograd.Function):
         stats = torch.empty(2 * H, dtype=torch.float32, device=z.device)
         y = torch.empty_like(z)
         ws = torch.empty(ops.dice_workspace_floats(H), dtype=torch.float32, device=z.device)
-        ops.dice_fwd(z, alpha, mod.bn.eps, mod.bn.momentum, mod.training, mod.bn.running_mean,
-                     mod.bn.running_var, stats, y, ws)
+        dist = _DIST if (mod.training and _DIST is not None and _DIST.world > 1) else None
+        n_total = N
+        if dist is not None:
+            # row-sharded training: this rank holds a slice of the global batch, the reference
+            # normalises with the statistics of the WHOLE batch (activations.py:40-51) — local
+            # column sums, one small all-reduce ([2H + 1] floats), then the gate
+            sums = torch.empty(2 * H + 1, dtype=torch.float32, device=z.device)
+            ops.dice_local_sums(z, sums, ws)
+            sums[2 * H] = float(N)
+            dist.all_reduce_sum(sums)
+            n_total = int(round(float(sums[2 * H].item())))
+            ops.dice_fwd_from_sums(z, alpha, mod.bn.eps, mod.bn.momentum, sums, n_total,
+                                   mod.bn.running_mean, mod.bn.running_var, stats, y)
+        else:
+            ops.dice_fwd(z, alpha, mod.bn.eps, mod.bn.momentum, mod.training, mod.bn.running_mean,
+                         mod.bn.running_var, stats, y, ws)
         ctx.save_for_backward(z, alpha, stats)
         ctx.training, ctx.eps = mod.training, mod.bn.eps
+        ctx.dist, ctx.n_total = dist, n_total
         return y
 
     @staticmethod
@@ -1528,8 +1545,16 @@ class _DiceFn(torch.autograd.Function):
         z, alpha, stats = ctx.saved_tensors
         N, H = z.shape
         dz = torch.empty_like(z)
-        dalpha = torch.empty(H, dtype=torch.float32, device=z.device)
         ws = torch.empty(ops.dice_workspace_floats(H), dtype=torch.float32, device=z.device)
+        if ctx.dist is not None:
+            dy = dy.contiguous()
+            sums3 = torch.empty(3 * H, dtype=torch.float32, device=z.device)
+            ops.dice_bwd_local_sums(z, dy, alpha, ctx.eps, stats, sums3, ws)
+            dalpha = sums3[:H].clone()          # local part; summed with the other dense gradients
+            ctx.dist.all_reduce_sum(sums3[H:])  # sum dzhat, sum dzhat*zhat over the global batch
+            ops.dice_bwd_from_sums(z, dy, alpha, ctx.eps, stats, sums3, ctx.n_total, dz)
+            return dz, dalpha, None
+        dalpha = torch.empty(H, dtype=torch.float32, device=z.device)
         ops.dice_bwd(z, dy.contiguous(), alpha, ctx.eps, ctx.training, stats, dz, dalpha, ws)
         return dz, dalpha, None
 

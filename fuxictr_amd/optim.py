@@ -72,9 +72,6 @@ class _NativeOptimizer(torch.optim.Optimizer):
         if self.dense_reg and any(g.table is not None and g.table.dtype != torch.float32
                                   for g in self._groups):
             raise NotImplementedError("embedding_regularizer with emb_dtype=bf16 is not implemented")
-        if self.dense_reg and self.dist is not None:
-            raise NotImplementedError("embedding_regularizer with row-sharded tables is not "
-                                      "implemented")
         if self.dist is not None:
             # data-parallel dense side: every rank starts from rank 0's tower / numeric weights
             with torch.no_grad():
@@ -182,6 +179,11 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 abs_.append(grp.reg_partials[nb:2 * nb])
         ops.sum_parts(sqs, sq)
         ops.sum_parts(abs_, ab)
+        if self.dist is not None:
+            # row-sharded tables: every rank summed ITS rows; the loss term is the global sum
+            both = torch.cat([sq, ab])
+            self.dist.all_reduce_sum(both)
+            sq, ab = both[0:1], both[1:2]
         term = (0.5 * self.reg_l2) * sq[0] + self.reg_l1 * ab[0]
         for grp in self._groups:
             if grp.num_w is not None:
@@ -210,6 +212,10 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 continue
             if self.dense_reg:
                 g = self._reg_grad(grp.num_w)
+                if self.dist is not None:
+                    # replicated weights: every rank adds the same term and the dense gradients are
+                    # SUM-reduced (the data part was pre-scaled by 1/world through the loss)
+                    g = g / self.dist.world
                 ps.append(grp.num_w)
                 gs.append(g if grp.num_grad is None else g + grp.num_grad)
             elif grp.num_grad is not None:
@@ -258,6 +264,18 @@ class _NativeOptimizer(torch.optim.Optimizer):
             # rows are disjoint across ranks, so the SUM is the global table part)
             tsq = torch.zeros(1, dtype=torch.float32, device=self.device)
             tparts = [rec.sq for grp in self._groups for rec in grp.pending]
+            if self.dense_reg:
+                # |G + r|^2 over this rank's rows = sum r^2 + sum G^2 + sum 2 G.r (see fx_reg_*)
+                for grp in self._groups:
+                    if grp.table is None:
+                        continue
+                    if not grp.reg_fresh:
+                        ops.reg_stats(grp.table, self.scal, grp.reg_partials)
+                    grp.reg_fresh = False
+                    tparts.append(grp.reg_partials[2 * _lib.FX_REG_BLOCKS:])
+                    for rec in grp.pending:
+                        ops.reg_cross(grp.table, grp.D, rec.dd, rec.G, self.scal, grp.reg_cross)
+                        tparts.append(grp.reg_cross.clone())
             if tparts:
                 ops.sum_parts(tparts, tsq)
             flat = torch.cat([g.reshape(-1) for g in gs] + [tsq])
@@ -283,7 +301,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
             if tsq is None:
                 for rec in grp.pending:
                     parts.append(rec.sq)
-            if self.dense_reg and grp.table is not None:
+            if self.dense_reg and grp.table is not None and tsq is None:
                 if not grp.reg_fresh:
                     ops.reg_stats(grp.table, self.scal, grp.reg_partials)
                 grp.reg_fresh = False

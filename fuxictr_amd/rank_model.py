@@ -335,6 +335,12 @@ class BaseModel(nn.Module):
                                        if self._embedding_regularizer else None)
         self.loss_fn = get_loss(loss)
         layers.link_fusion(self)
+        if self._dist is not None and self._dist.world > 1 and self._use_graph \
+                and any(isinstance(m, layers.Dice) for m in self.modules()):
+            # Dice all-reduces its batch statistics inside the backward pass (autograd thread); the
+            # segmented capture can only be cut from the thread that began it: launch eagerly
+            logging.info("hip_graph disabled: Dice statistics are all-reduced inside the backward")
+            self._use_graph = False
 
     def regularization_loss(self):
         """rank_model.py:95-118.  The embedding part is computed by fx_reg_stats and carries no

@@ -410,7 +410,28 @@ int fx_din_pool_bwd(const float* w, const int32_t* ids, int64_t ids_ld, const fl
                     int64_t k_ldb, int64_t k_ldl, const float* dout, int64_t B, int32_t L,
                     int32_t E, float* dw, float* dK, int64_t dk_ldb, int64_t dk_ldl,
                     fx_stream_t stream);
+/* Row-sharded training (every rank holds a slice of the global batch): the two column reductions are
+ * exposed on their own so that the host can all-reduce them and Dice normalises with the statistics
+ * of the WHOLE batch, as the reference does on one device:
+ *   fx_dice_local_sums     sums[0..H) = sum_rows z, sums[H..2H) = sum_rows z^2 of this rank's rows
+ *   fx_dice_fwd_from_sums  mean / biased variance from (all-reduced) sums and n_total rows, running
+ *                          statistics (momentum, unbiased), then the gate — fx_dice_fwd's apply pass
+ *   fx_dice_bwd_local_sums sums3 = [dalpha | sum dzhat | sum dzhat*zhat] of this rank's rows
+ *   fx_dice_bwd_from_sums  dz from (all-reduced) sums3[H..3H) and n_total (dalpha = sums3[0..H) of
+ *                          each rank is summed with the other dense gradients)
+ * (activations.py:40-51; new functionality: the reference is single-device) */
 int64_t fx_dice_workspace_floats(int32_t H);
+int fx_dice_local_sums(const float* Z, int64_t N, int32_t H, float* sums, float* workspace,
+                       fx_stream_t stream);
+int fx_dice_fwd_from_sums(const float* Z, int64_t N, int32_t H, const float* alpha, float eps,
+                          float momentum, const float* sums, int64_t n_total, float* running_mean,
+                          float* running_var, float* stats, float* Y, fx_stream_t stream);
+int fx_dice_bwd_local_sums(const float* Z, const float* dY, int64_t N, int32_t H, const float* alpha,
+                           float eps, const float* stats, float* sums3, float* workspace,
+                           fx_stream_t stream);
+int fx_dice_bwd_from_sums(const float* Z, const float* dY, int64_t N, int32_t H, const float* alpha,
+                          float eps, const float* stats, const float* sums3, int64_t n_total,
+                          float* dZ, fx_stream_t stream);
 int fx_dice_fwd(const float* Z, int64_t N, int32_t H, const float* alpha, float eps, float momentum,
                 int32_t training, float* running_mean, float* running_var, float* stats, float* Y,
                 float* workspace, fx_stream_t stream);

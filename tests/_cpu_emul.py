@@ -436,6 +436,48 @@ def dice_bwd(Z, dY, alpha, eps, training, stats, dZ, dalpha, workspace):
     dZ.copy_(dY * (p + alpha * (1 - p)) + dzh * rstd)
 
 
+def dice_local_sums(Z, sums, workspace):
+    H = Z.shape[1]
+    sums[:H] = Z.sum(0)
+    sums[H:2 * H] = (Z * Z).sum(0)
+
+
+def dice_fwd_from_sums(Z, alpha, eps, momentum, sums, n_total, running_mean, running_var, stats, Y):
+    H = Z.shape[1]
+    mean = sums[:H].double() / n_total
+    var = (sums[H:2 * H].double() / n_total - mean * mean).clamp(min=0)
+    stats[:H] = mean.float()
+    stats[H:] = var.float()
+    unb = var * n_total / (n_total - 1) if n_total > 1 else var
+    running_mean.copy_(((1 - momentum) * running_mean.double() + momentum * mean).float())
+    running_var.copy_(((1 - momentum) * running_var.double() + momentum * unb).float())
+    zh = (Z - stats[:H]) / torch.sqrt(stats[H:] + eps)
+    p = torch.sigmoid(zh)
+    Y.copy_(p * Z + alpha * (1 - p) * Z)
+    return Y
+
+
+def dice_bwd_local_sums(Z, dY, alpha, eps, stats, sums3, workspace):
+    H = Z.shape[1]
+    rstd = 1.0 / torch.sqrt(stats[H:] + eps)
+    zh = (Z - stats[:H]) * rstd
+    p = torch.sigmoid(zh)
+    dzh = dY * Z * (1 - alpha) * p * (1 - p)
+    sums3[:H] = (dY * (1 - p) * Z).sum(0)
+    sums3[H:2 * H] = dzh.sum(0)
+    sums3[2 * H:] = (dzh * zh).sum(0)
+
+
+def dice_bwd_from_sums(Z, dY, alpha, eps, stats, sums3, n_total, dZ):
+    H = Z.shape[1]
+    rstd = 1.0 / torch.sqrt(stats[H:] + eps)
+    zh = (Z - stats[:H]) * rstd
+    p = torch.sigmoid(zh)
+    dzh = dY * Z * (1 - alpha) * p * (1 - p)
+    dzh = dzh - sums3[H:2 * H] / n_total - zh * (sums3[2 * H:] / n_total)
+    dZ.copy_(dY * (p + alpha * (1 - p)) + dzh * rstd)
+
+
 def dot_interact_fwd(emb, F, D, out):
     e = emb.view(-1, F, D)
     ipm = torch.bmm(e, e.transpose(1, 2))
@@ -649,7 +691,8 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update",
          "shard_plan_workspace_ints", "emb_seq_pool_fwd", "dedup_sorted_runs", "RowState",
          "dedup_catchup", "emb_fm_fwd", "emb_fm_bwd", "sparse_update_multi", "pack_columns_multi",
-         "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats", "adam_catchup_all"]
+         "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats", "adam_catchup_all",
+         "dice_local_sums", "dice_fwd_from_sums", "dice_bwd_local_sums", "dice_bwd_from_sums"]
 
 
 def install_plain():

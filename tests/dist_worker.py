@@ -41,6 +41,7 @@ def run(rank, world, case, port, out_path, use_gpu):
                   learning_rate=m["lr"], optimizer=m["optimizer"], loss="binary_crossentropy",
                   task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
                   model_root="/tmp/fx_dist_%d" % rank, shard="row",
+                  embedding_regularizer=m.get("emb_reg", 0), net_regularizer=m.get("net_reg", 0),
                   hip_graph=os.environ.get("FX_HIP_GRAPH", "0") == "1")
     if m["model"] == "DeepFM":
         model = zoo.DeepFM(fmap, model_id=case, hidden_units=m["hidden"],

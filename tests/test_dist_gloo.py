@@ -44,10 +44,11 @@ def check_against_golden(z, g):
         assert_weights_close(z["state/" + k], ref, g.meta["lr"], g.meta["steps"], k)
 
 
-# (DIN is not in the list: Dice normalises with BATCH statistics, which each rank takes over its own
-# slice — like unsynchronised BatchNorm under DDP — so a 2-rank run is not the 1-rank trajectory)
+# (DIN: Dice normalises with the statistics of the WHOLE batch — its column sums are all-reduced
+# across the ranks, layers._DiceFn — so the 2-rank run is the reference's 1-rank trajectory too)
 @pytest.mark.parametrize("case", ["deepfm_adam", "dcnv2_adam", "deepfm_adam_clip", "dlrm_adam",
-                                  "xdeepfm_adam", "deepfm_seqpool", "dcnv2_mixdim"])
+                                  "xdeepfm_adam", "deepfm_seqpool", "dcnv2_mixdim", "din_adam",
+                                  "din_pairs_softmax", "deepfm_reg", "deepfm_reg_sgd"])
 def test_two_rank_sharded_training_equals_reference(case, tmp_path):
     g = Golden(case)
     z = run_workers(case, tmp_path, use_gpu=False)
