@@ -14,6 +14,57 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
+def run_c5(rank, world, port, out_path):
+    """configs[4] in miniature: the c5 DLRM (bottom [512,256,16], dot, top [1024,1024,512,256],
+    26 tables with the Criteo-skewed split) row-sharded over `world` ranks, each rank on its slice of
+    the GLOBAL batch, against the oracle's single-process run on the full batches (CPU emulation of
+    the kernels; tables scaled down so that dense Adam is affordable)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import _cpu_emul
+    _cpu_emul.install_plain()
+    import baseline_shapes as BS
+    from fuxictr_amd import zoo
+    from oracle import ctr_oracle as O
+    model, features, cfg, spec, cards = BS.build("c5_dlrm", zoo, -1, "/tmp/fx_dist_c5_%d" % rank,
+                                                 vocab_scale=0.0005, shard="row")
+    # identical on every rank (tables all-gathered); cloned: the dense entries are live views
+    state0 = {k: v.detach().clone() for k, v in model.full_state_dict().items()}
+    teacher = BS.Teacher(features)
+    rng = np.random.default_rng(5)
+    B = 256 * world                            # global batch
+    batches = BS.make_batches("c5_dlrm", spec, cards, rng, B, 4, "powerlaw", teacher)
+
+    def part(b):
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        return {k: torch.from_numpy(np.asarray(v)[lo:hi]) for k, v in b.items()}
+    model.train()
+    model._max_gradient_norm = 10.0
+    losses = []
+    for b in batches:
+        loss = model.train_step(part(b)).detach().cpu().reshape(1).clone()
+        dist.all_reduce(loss)
+        losses.append(float(loss) / world)
+    model.optimizer.check_errors()
+    model.eval()
+    with torch.no_grad():
+        p = model.forward(part(batches[-1]))["y_pred"].reshape(-1).cpu()
+    gp = [torch.empty_like(p) for _ in range(world)]
+    dist.all_gather(gp, p)
+    full = model.full_state_dict()
+    if rank == 0:
+        tr = O.OracleTrainer(cfg, state0, features, lr=1e-3, max_norm=10.0)
+        ref_losses = [tr.train_step(BS.tb(b), BS.tb(b)["label"])[0] for b in batches]
+        ref_p = tr.predict(BS.tb(batches[-1])).reshape(-1).numpy()
+        wdiff = max(float((full[k].cpu() - tr.state[k].detach()).abs().max()) for k in full
+                    if full[k].is_floating_point())
+        np.savez(out_path, losses=np.asarray(losses), ref_losses=np.asarray(ref_losses),
+                 pred=torch.cat(gp).numpy(), ref_pred=ref_p, wdiff=np.asarray([wdiff]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def run(rank, world, case, port, out_path, use_gpu):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -145,4 +196,7 @@ def run(rank, world, case, port, out_path, use_gpu):
 
 if __name__ == "__main__":
     rank, world, case, port, out_path, use_gpu = sys.argv[1:7]
-    run(int(rank), int(world), case, int(port), out_path, use_gpu == "1")
+    if case == "c5_dlrm":
+        run_c5(int(rank), int(world), int(port), out_path)
+    else:
+        run(int(rank), int(world), case, int(port), out_path, use_gpu == "1")

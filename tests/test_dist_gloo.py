@@ -90,3 +90,13 @@ def test_fit_takes_the_same_decisions_on_every_rank(tmp_path):
     y = np.asarray(g.batches[-1]["label"], dtype=np.float64)
     assert abs(fit[0, 5] - roc_auc_score(y, z["pred"])) < 1e-9
     assert abs(fit[0, 6] - log_loss(y, z["pred"])) < 1e-6
+
+
+def test_c5_shaped_dlrm_sharded_equals_the_oracle(tmp_path):
+    """BASELINE configs[4] in miniature (SURVEY.md 8e parity test): the c5 DLRM at its real layer
+    widths, tables row-sharded over 2 ranks, each rank on its half of the global batch == the
+    oracle's single-process run on the full batches."""
+    z = run_workers("c5_dlrm", tmp_path, use_gpu=False)
+    np.testing.assert_allclose(z["losses"], z["ref_losses"], atol=1e-5)
+    np.testing.assert_allclose(z["pred"], z["ref_pred"], atol=2e-5)
+    assert float(z["wdiff"][0]) <= 1e-3 * 4 + 2e-5       # (Adam's eps-conditioning, see conftest)
