@@ -36,6 +36,13 @@ static inline hipStream_t fx_hip_stream(fx_stream_t s) { return reinterpret_cast
 
 static inline int64_t fx_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- fx_sort.hip: device-wide stable LSD radix sort of (uint32 key, uint32 value) pairs --------
+size_t fx_sort_temp_bytes(int64_t n);
+size_t fx_sort_zero_words(int64_t n);   // leading words of `temp` that must be 0 before the sort
+int fx_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                      uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n,
+                      unsigned end_bit, void* temp, bool zeroed, hipStream_t s);
+
 // Row-vector geometry: a D-float row is handled by G lanes (power of two) holding VEC floats each.
 struct FxRowGeom {
     int vec;    // 4, 2 or 1

@@ -80,22 +80,13 @@ __global__ __launch_bounds__(256) void k_metric_ranks(const uint32_t* key, const
     if (np) atomicAdd(&cnt[1], np);
 }
 
-static hipError_t fx_metric_sort_bytes(int64_t n, size_t* bytes) {
-    uint32_t* nul = nullptr;
-    return rocprim::radix_sort_pairs(nullptr, *bytes, nul, nul, nul, nul, (size_t)n, 0u, 32u, 0,
-                                     false);
-}
-
 static inline size_t fx_up(size_t x) { return (x + 255) / 256 * 256; }
 
 extern "C" size_t fx_binary_metrics_workspace_bytes(int64_t n) {
     if (n <= 0) return 256;
-    size_t sort_bytes = 0;
-    if (fx_metric_sort_bytes(n, &sort_bytes) != hipSuccess) {
-        fx_set_error("fx_binary_metrics_workspace_bytes: rocprim size query failed");
-        return 0;
-    }
-    return 4 * fx_up((size_t)n * 4) + fx_up(FX_METRIC_BLOCKS * sizeof(double)) + fx_up(sort_bytes) + 256;
+    // key/value in, out and the sort's ping-pong scratch (fx_sort.hip: 4 passes over 32-bit keys)
+    return 6 * fx_up((size_t)n * 4) + fx_up(FX_METRIC_BLOCKS * sizeof(double)) +
+           fx_up(fx_sort_temp_bytes(n)) + 256;
 }
 
 extern "C" int fx_binary_metrics(const float* y_pred, const float* y_true, int64_t n,
@@ -105,26 +96,28 @@ extern "C" int fx_binary_metrics(const float* y_pred, const float* y_true, int64
                  (long long)n);
     FX_CHECK_ARG(y_pred && y_true && workspace && out_logloss_sum && out_counts,
                  "fx_binary_metrics: null pointer");
-    size_t sort_bytes = 0;
-    FX_CHECK_HIP(fx_metric_sort_bytes(n, &sort_bytes));
+    const size_t sort_bytes = fx_sort_temp_bytes(n);
     const size_t arr = fx_up((size_t)n * 4), llb = fx_up(FX_METRIC_BLOCKS * sizeof(double));
-    FX_CHECK_ARG(workspace_bytes >= 4 * arr + llb + fx_up(sort_bytes),
+    FX_CHECK_ARG(workspace_bytes >= 6 * arr + llb + fx_up(sort_bytes),
                  "fx_binary_metrics: workspace too small");
     char* w = reinterpret_cast<char*>(workspace);
     uint32_t* key_in = reinterpret_cast<uint32_t*>(w);
     uint32_t* val_in = reinterpret_cast<uint32_t*>(w + arr);
     uint32_t* key = reinterpret_cast<uint32_t*>(w + 2 * arr);
     uint32_t* val = reinterpret_cast<uint32_t*>(w + 3 * arr);
-    double* llp = reinterpret_cast<double*>(w + 4 * arr);
-    void* temp = w + 4 * arr + llb;
+    uint32_t* key_tmp = reinterpret_cast<uint32_t*>(w + 4 * arr);
+    uint32_t* val_tmp = reinterpret_cast<uint32_t*>(w + 5 * arr);
+    double* llp = reinterpret_cast<double*>(w + 6 * arr);
+    void* temp = w + 6 * arr + llb;
     hipStream_t s = fx_hip_stream(stream);
     hipLaunchKernelGGL(k_metric_keys, dim3(FX_METRIC_BLOCKS), dim3(256), 0, s, y_pred, y_true, n,
                        key_in, val_in, llp);
     hipLaunchKernelGGL(k_metric_finish_ll, dim3(1), dim3(256), 0, s, llp, (int)FX_METRIC_BLOCKS,
                        out_logloss_sum, reinterpret_cast<unsigned long long*>(out_counts));
     FX_CHECK_LAUNCH();
-    size_t tb = fx_up(sort_bytes);
-    FX_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, key_in, key, val_in, val, (size_t)n, 0u, 32u, s));
+    const int rc = fx_sort_pairs_u32(key_in, val_in, key, val, key_tmp, val_tmp, n, 32u, temp, false,
+                                     s);
+    if (rc != FX_OK) return rc;
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_metric_ranks, dim3((unsigned)blocks), dim3(256), 0, s, key, val, n,

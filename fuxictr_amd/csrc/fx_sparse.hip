@@ -30,7 +30,10 @@ __global__ __launch_bounds__(256) void k_build_keys(const int32_t* ids, int64_t 
                                                     const int32_t* col_vocab,
                                                     const int32_t* col_pad, uint32_t sentinel,
                                                     uint32_t n_shards, uint32_t rows_per_shard,
-                                                    uint32_t* keys, uint32_t* pos) {
+                                                    uint32_t* keys, uint32_t* zero, int zero_words) {
+    // (also clears the sort's first counter set, fx_sort_zero_words: saves a launch)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_words; i += gridDim.x * blockDim.x)
+        zero[i] = 0u;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / C;
@@ -42,7 +45,6 @@ __global__ __launch_bounds__(256) void k_build_keys(const int32_t* ids, int64_t 
             key = n_shards > 1 ? (g % n_shards) * rows_per_shard + g / n_shards : g;
         }
         keys[i] = key;
-        pos[i] = (uint32_t)i;
     }
 }
 
@@ -197,13 +199,6 @@ __global__ __launch_bounds__(256) void k_scatter_unique(const uint32_t* key, con
 
 static inline size_t fx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Device-wide sort of the generic path (sequence columns, owner side of the sharded path): Onesweep
-// radix passes over only the key bits in use.  rocPRIM's default picks its merge sort below 1 M
-// items — measured for c4's 262 K lookups: a block sort + 16 merge launches + a 75 us copy-back,
-// ~200 us of the 0.87 ms DIN step (profiles/r02_step_timeline_din_before.txt).
-using FxSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                rocprim::default_config, 0>;
-
 static hipError_t fx_dedup_temp_bytes(int64_t n, size_t* sort_bytes, size_t* scan_bytes) {
     // size queries are host-only but not free; a training loop asks for the same n every step
     static thread_local int64_t c_n = -1;
@@ -214,12 +209,10 @@ static hipError_t fx_dedup_temp_bytes(int64_t n, size_t* sort_bytes, size_t* sca
         return hipSuccess;
     }
     uint32_t* nul = nullptr;
-    hipError_t e = rocprim::radix_sort_pairs<FxSortConfig>(nullptr, *sort_bytes, nul, nul, nul, nul,
-                                                           (size_t)n, 0u, 32u, (hipStream_t)0);
-    if (e != hipSuccess) return e;
+    *sort_bytes = fx_sort_temp_bytes(n);       // the device-wide sort is fx_sort.hip's
     HeadFlag hf{nullptr, 0};
     auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), hf);
-    e = rocprim::inclusive_scan(nullptr, *scan_bytes, in, nul, (size_t)n,
+    hipError_t e = rocprim::inclusive_scan(nullptr, *scan_bytes, in, nul, (size_t)n,
                                 rocprim::plus<uint32_t>(), (hipStream_t)0);
     if (e == hipSuccess) {
         c_n = n;
@@ -276,8 +269,8 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
                  workspace_bytes, 3 * arr + tmp);
     char* w = reinterpret_cast<char*>(workspace);
     uint32_t* keys_in = reinterpret_cast<uint32_t*>(w);
-    uint32_t* pos_in = reinterpret_cast<uint32_t*>(w + arr);
-    uint32_t* scan = reinterpret_cast<uint32_t*>(w + 2 * arr);
+    uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(w + arr);
+    uint32_t* scan = reinterpret_cast<uint32_t*>(w + 2 * arr);   // the sort's value scratch first
     void* temp = w + 3 * arr;
     const uint32_t sentinel = (uint32_t)(n_shards > 1 ? rows_per_shard * n_shards : total_rows);
 
@@ -311,13 +304,16 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
     } else {
         hipLaunchKernelGGL(k_build_keys, dim3((unsigned)blocks), dim3(256), 0, s, ids, ids_ld, n,
                            (int)C, col_row_base, col_vocab, col_pad, sentinel, (uint32_t)n_shards,
-                           (uint32_t)rows_per_shard, keys_in, pos_in);
+                           (uint32_t)rows_per_shard, keys_in, reinterpret_cast<uint32_t*>(temp),
+                           (int)fx_sort_zero_words(n));
         FX_CHECK_LAUNCH();
-        // only the bits the key space needs (keys <= sentinel): c4's 2.8 M rows take 22 of 32 bits
+        // (key, lookup index) pairs, over only the bits the key space needs (keys <= sentinel):
+        // c4's 2.8 M rows take 22 of 32 bits = 3 radix passes
         unsigned end_bit = 1;
         while (end_bit < 32 && (sentinel >> end_bit) != 0u) ++end_bit;
-        FX_CHECK_HIP(rocprim::radix_sort_pairs<FxSortConfig>(temp, tb, keys_in, sorted_key, pos_in,
-                                                             sorted_pos, (size_t)n, 0u, end_bit, s));
+        const int rc = fx_sort_pairs_u32(keys_in, nullptr, sorted_key, sorted_pos, keys_tmp, scan, n,
+                                         end_bit, temp, true, s);
+        if (rc != FX_OK) return rc;
     }
     HeadFlag hf{sorted_key, sentinel};
     auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), hf);

@@ -16,6 +16,7 @@ into libfxctr.so (include/fxctr.h):
 
 torch is used for device memory, streams, nn.Module bookkeeping and the autograd tape only.
 """
+import os
 from collections import OrderedDict
 from functools import partial  # noqa: F401  (used by eval'ed initializer strings)
 
@@ -807,6 +808,7 @@ class FeatureEmbeddingDict(nn.Module):
         self._groups = OrderedDict()   # D -> _TableGroup
         self._feat_group = {}          # feature -> D
         self._torch_feats = set()      # features served by stock torch modules ("embedding" type)
+        self._stock_feats = set()      # id features delegated to the reference's PretrainedEmbedding
         lr_mode = (not (use_pretrain and use_sharing)) and embedding_dim == 1
         for feature, spec in self._feature_map.features.items():
             if not self.is_required(feature):
@@ -823,18 +825,27 @@ class FeatureEmbeddingDict(nn.Module):
                 elif ftype == "embedding":
                     pretrain_dim = spec.get("pretrain_dim", feat_dim)
                     self.feature_encoders[feature] = nn.Linear(pretrain_dim, feat_dim, bias=False)
-            if ftype in ("categorical", "sequence") and use_pretrain and "pretrained_emb" in spec:
-                raise NotImplementedError(
-                    "feature '%s': pretrained_emb tables are outside the native hot path "
-                    "(SURVEY.md §2 row 14); drop `pretrained_emb` or pass use_pretrain=False"
-                    % feature)
+            share = spec.get("share_embedding")
+            if ftype in ("categorical", "sequence") and use_sharing and share in self._stock_feats:
+                # shares the table of a delegated feature: the same stock module serves both
+                self.embedding_layers[feature] = self.embedding_layers[share]
+                self._stock_feats.add(feature)
+                continue
+            if ftype in ("categorical", "sequence") and use_pretrain and "pretrained_emb" in spec \
+                    and not (use_sharing and share in self._feat_group):
+                # pretrained tables are not part of the native hot path: the
+                # reference's own module is instantiated and called, exactly as
+                # feature_embedding.py:156-171 does; its parameters are ordinary dense parameters
+                self.embedding_layers[feature] = self._stock_pretrained(feature, spec, feat_dim,
+                                                                        embedding_initializer)
+                self._stock_feats.add(feature)
+                continue
             width = spec["max_len"] if ftype == "sequence" else 1
             if ftype in ("categorical", "sequence", "numeric"):
                 grp = self._groups.get(feat_dim)
                 if grp is None:
                     grp = self._groups[feat_dim] = _TableGroup(feat_dim, self._device)
                 self._feat_group[feature] = feat_dim
-            share = spec.get("share_embedding")
             if use_sharing and share in self._feat_group and ftype in ("categorical", "sequence"):
                 if self._feat_group[share] != feat_dim:
                     raise NotImplementedError("share_embedding across different embedding dims")
@@ -894,9 +905,26 @@ class FeatureEmbeddingDict(nn.Module):
         self._bind_views()
         for module in self.feature_encoders.values():
             module._apply(fn)
-        for f in self._torch_feats:
+        for f in self._torch_feats | self._stock_feats:
             self.embedding_layers[f]._apply(fn)
         return self
+
+    def _stock_pretrained(self, feature, spec, feat_dim, embedding_initializer):
+        """The reference's PretrainedEmbedding for one feature (pretrained_embedding.py:30-189),
+        built with the arguments feature_embedding.py:157-171 passes."""
+        try:
+            from fuxictr.pytorch.layers.embeddings.pretrained_embedding import PretrainedEmbedding
+        except ImportError as exc:
+            raise NotImplementedError(
+                "feature '%s' has `pretrained_emb`: it is delegated to the reference's "
+                "PretrainedEmbedding module, which needs the `fuxictr` package importable (%s); "
+                "drop `pretrained_emb` or pass use_pretrain=False" % (feature, exc))
+        fmap = self._feature_map
+        return PretrainedEmbedding(feature, spec,
+                                   os.path.join(fmap.data_dir, spec["pretrained_emb"]),
+                                   os.path.join(fmap.data_dir, "feature_vocab.json"),
+                                   feat_dim, spec.get("pretrain_dim", feat_dim),
+                                   spec.get("pretrain_usage", "init"), embedding_initializer)
 
     def _default_init(self):
         """What the stock modules would hold before init_weights(): nn.Embedding ~ N(0,1) with a
@@ -928,6 +956,9 @@ class FeatureEmbeddingDict(nn.Module):
         with torch.no_grad():
             for k, v in self.embedding_layers.items():
                 if "share_embedding" in self._feature_map.features[k]:
+                    continue
+                if k in self._stock_feats:
+                    v.init_weights()                      # feature_embedding.py:210-211
                     continue
                 if isinstance(v, _TableView):
                     grp = self._groups[self._feat_group[k]]
@@ -987,7 +1018,8 @@ class FeatureEmbeddingDict(nn.Module):
                 lr_mod, lr_grp, lr_plan = self._lr_peer_for(plan, feats, inputs)
                 peers = (lr_grp,) if lr_grp is not None else ()
                 dd = grp.prepare_train(plan, ids, inputs, peers) if track else None
-                want_fm = bool(self._fuse_fm) and plan.n_slots == plan.C + plan.Fd
+                want_fm = bool(self._fuse_fm) and plan.n_slots == plan.C + plan.Fd \
+                    and not (self._torch_feats or self._stock_feats)
                 out, lr_out, fm_out, fm_lr = _EmbFMFn.apply(
                     anchor, lr_mod.embedding_layer.embedding_layer._anchor(lr_grp)
                     if lr_grp is not None else None,
@@ -1019,6 +1051,8 @@ class FeatureEmbeddingDict(nn.Module):
         for f in present:
             if f in self._torch_feats:
                 emb[f] = self.embedding_layers[f](inputs[f].float())
+            elif f in self._stock_feats:
+                emb[f] = self.embedding_layers[f](inputs[f].long())   # feature_embedding.py:292-294
         feature_emb_dict = _EmbDict()
         for f in present:  # reference order = order of `inputs`
             e = emb[f]
@@ -1046,7 +1080,7 @@ class FeatureEmbeddingDict(nn.Module):
         groups = layer.table_groups()
         fmap = layer._feature_map.features
         lr_feats = [f for f in fmap if f in inputs and f in layer.embedding_layers]
-        if (len(groups) != 1 or layer._torch_feats or lr_feats != list(feats)
+        if (len(groups) != 1 or layer._torch_feats or layer._stock_feats or lr_feats != list(feats)
                 or groups[0].D != 1 or groups[0].sharded
                 or lr.training != self.training):
             return None, None, None

@@ -2,7 +2,7 @@
 # bench lines of the other BASELINE models (no cpu baseline, no DCNv2 sub-run) + a DIN step timeline
 TAG=$1
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-for M in DIN DLRM xDeepFM; do
+for M in ${MODELS:-DIN DLRM xDeepFM}; do
   timeout 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-dcnv2 --model $M > $OUT/bench_${TAG}_$M.json 2> $OUT/bench_${TAG}_$M.err
   python - $OUT/bench_${TAG}_$M.json $M <<'PY'
 import json, sys

@@ -245,3 +245,142 @@ def test_feature_filters_match_the_reference_layer(kw, flatten, stock_reference,
         got2 = ours.embedding_layer.dict2tensor(ours.embedding_layer(nat.FeatureDict(X)),
                                                 flatten_emb=flatten, feature_list=names)
         np.testing.assert_allclose(got2.numpy(), want2.numpy(), atol=1e-6)
+
+
+def _pretrain_case(tmp_path, usage, freeze):
+    """A schema with one `pretrained_emb` feature + a sequence sharing its table, and the files
+    the reference's loader reads (feature_vocab.json, an .npz of key/value pairs)."""
+    import json
+    rng = np.random.default_rng(11)
+    vocab = {"user": {"__PAD__": 0, "u1": 1},      # (the reference reads the key type off entry 1)
+             "item": {"__PAD__": 0, **{"i%d" % j: j for j in range(1, 39)}, "__OOV__": 39}}
+    with open(os.path.join(str(tmp_path), "feature_vocab.json"), "w") as fd:
+        json.dump(vocab, fd)
+    np.savez(os.path.join(str(tmp_path), "item_emb.npz"),
+             key=np.array(["i%d" % j for j in range(1, 30)]),
+             value=rng.normal(size=(29, 6)).astype(np.float32))
+    item = {"source": "item", "type": "categorical", "padding_idx": 0, "vocab_size": 40,
+            "oov_idx": 39, "freeze_emb": freeze, "pretrained_emb": "item_emb.npz",
+            "pretrain_dim": 6, "pretrain_usage": usage}
+    spec = {"dataset_id": "pre", "labels": ["label"], "features": [
+        {"price": {"source": "item", "type": "numeric"}},
+        {"user": {"source": "user", "type": "categorical", "padding_idx": 0, "vocab_size": 30}},
+        {"item": item},
+        {"hist": {"source": "user", "type": "sequence", "share_embedding": "item",
+                  "feature_encoder": "layers.MaskedAveragePooling()", "padding_idx": 0,
+                  "vocab_size": 40, "max_len": 5}},
+        {"ctx": {"source": "context", "type": "categorical", "vocab_size": 7}}]}
+    B = 64
+    X = {"price": rng.random(B).astype(np.float32), "user": rng.integers(0, 30, B),
+         "item": rng.integers(0, 40, B), "hist": rng.integers(0, 40, (B, 5)),
+         "ctx": rng.integers(0, 7, B)}
+    return spec, X
+
+
+@pytest.mark.parametrize("usage,freeze", [("init", False), ("sum", False), ("concat", True)])
+def test_pretrained_emb_is_delegated_to_the_stock_module(usage, freeze, monkeypatch, tmp_path):
+    """a `pretrained_emb` feature (and a sequence sharing its table) is served
+    by the reference's own PretrainedEmbedding inside the native FeatureEmbedding — same
+    state_dict keys, same forward values and same gradients as the stock FeatureEmbedding
+    (feature_embedding.py:156-171, pretrained_embedding.py:30-189), while the other features stay
+    on the native gather."""
+    for name in ["polars", "h5py", "keras_preprocessing", "keras_preprocessing.sequence"]:
+        if name not in sys.modules:
+            monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    sys.modules["keras_preprocessing.sequence"].pad_sequences = lambda *a, **k: None
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    monkeypatch.syspath_prepend(REF)
+    for k in [k for k in sys.modules if k.startswith(("fuxictr.", "model_zoo")) or k == "fuxictr"]:
+        monkeypatch.delitem(sys.modules, k)
+    try:
+        from fuxictr.pytorch.layers.embeddings.feature_embedding import FeatureEmbedding as StockFE
+        from fuxictr.pytorch.layers.embeddings.pretrained_embedding import PretrainedEmbedding
+        import fuxictr_amd.layers as nat
+        from fuxictr_amd.features import FeatureMap
+        _cpu_emul.install(monkeypatch)
+        spec, X = _pretrain_case(tmp_path, usage, freeze)
+        fmap = FeatureMap("pre", str(tmp_path))
+        fmap.load_dict(spec, {"embedding_dim": 8})
+        torch.manual_seed(3)
+        stock = StockFE(fmap, 8)
+        native = nat.FeatureEmbedding(fmap, 8)
+        layer = native.embedding_layer
+        assert type(layer.embedding_layers["item"]) is PretrainedEmbedding
+        assert layer.embedding_layers["hist"] is layer.embedding_layers["item"]
+        assert "item" not in layer._feat_group and "user" in layer._feat_group
+        sd = stock.state_dict()
+        assert sorted(native.state_dict().keys()) == sorted(sd.keys())
+        native.load_state_dict(sd)
+        Xt = tb(X)
+        w = torch.randn(64, 5, 8, generator=torch.Generator().manual_seed(5))
+        outs = []
+        for mod in (stock, native):
+            mod.train()
+            mod.zero_grad()
+            out = mod(Xt)
+            assert out.shape == (64, 5, 8)
+            (out * w).sum().backward()
+            outs.append(out.detach())
+        np.testing.assert_allclose(outs[1].numpy(), outs[0].numpy(), atol=1e-6)
+        stock_params = dict(stock.named_parameters())
+        checked = 0
+        for name, p in native.named_parameters():
+            if ".item." not in name or not p.requires_grad:
+                continue
+            np.testing.assert_allclose(p.grad.numpy(), stock_params[name].grad.numpy(), atol=1e-6)
+            checked += 1
+        assert checked >= (1 if usage == "init" else 2) - (1 if freeze else 0)
+    finally:
+        for k in [k for k in sys.modules if k.startswith(("fuxictr.", "model_zoo")) or k == "fuxictr"]:
+            sys.modules.pop(k, None)
+
+
+def test_pretrained_emb_without_the_reference_package_says_so(monkeypatch, tmp_path):
+    import fuxictr_amd.layers as nat
+    from fuxictr_amd.features import FeatureMap
+    for k in [k for k in sys.modules if k.startswith("fuxictr.") or k == "fuxictr"]:
+        monkeypatch.delitem(sys.modules, k)
+    monkeypatch.setattr(sys, "path", [p for p in sys.path if os.path.abspath(p) != REF])
+    spec, _ = _pretrain_case(tmp_path, "init", False)
+    fmap = FeatureMap("pre", str(tmp_path))
+    fmap.load_dict(spec, {"embedding_dim": 8})
+    with pytest.raises(NotImplementedError, match="PretrainedEmbedding"):
+        nat.FeatureEmbedding(fmap, 8)
+
+
+@pytest.mark.parametrize("usage,freeze", [("sum", False), ("init", True)])
+def test_model_with_a_delegated_pretrained_feature_trains(usage, freeze, monkeypatch, tmp_path):
+    """The delegated module's parameters are ordinary dense parameters of the native optimizer
+    (frozen ones are left alone), next to the native sparse-row tables of the other features."""
+    for name in ["polars", "h5py", "keras_preprocessing", "keras_preprocessing.sequence"]:
+        if name not in sys.modules:
+            monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    sys.modules["keras_preprocessing.sequence"].pad_sequences = lambda *a, **k: None
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    monkeypatch.syspath_prepend(REF)
+    for k in [k for k in sys.modules if k.startswith(("fuxictr.", "model_zoo")) or k == "fuxictr"]:
+        monkeypatch.delitem(sys.modules, k)
+    try:
+        from fuxictr_amd import optim, zoo
+        from fuxictr_amd.features import FeatureMap
+        _cpu_emul.install(monkeypatch)
+        monkeypatch.setattr(optim._NativeOptimizer, "__init__", _cpu_opt_init(optim))
+        spec, X = _pretrain_case(tmp_path, usage, freeze)
+        fmap = FeatureMap("pre", str(tmp_path))
+        fmap.load_dict(spec, {"embedding_dim": 8})
+        model = zoo.DeepFM(fmap, model_id="pre", gpu=-1, embedding_dim=8, hidden_units=[16, 8],
+                           learning_rate=1e-2, optimizer="adam", loss="binary_crossentropy",
+                           task="binary_classification", metrics=["logloss", "AUC"], verbose=0,
+                           model_root=str(tmp_path))
+        rng = np.random.default_rng(0)
+        X["label"] = (rng.random(64) < 0.3).astype(np.float32)
+        pre = model.embedding_layer.embedding_layer.embedding_layers["item"]
+        w0 = pre.pretrain_embedding.weight.detach().clone()
+        model.train()
+        losses = [float(model.train_step(tb(X)).item()) for _ in range(8)]
+        assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+        moved = float((pre.pretrain_embedding.weight.detach() - w0).abs().max())
+        assert (moved == 0.0) if freeze else (moved > 0.0)
+    finally:
+        for k in [k for k in sys.modules if k.startswith(("fuxictr.", "model_zoo")) or k == "fuxictr"]:
+            sys.modules.pop(k, None)

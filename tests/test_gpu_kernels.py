@@ -658,7 +658,8 @@ def test_embedding_regularizer_dense_step_equals_dense_optimizer(D, adam):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,ties", [(100, False), (4096, True), (300000, True), (65537, False)])
+@pytest.mark.parametrize("n,ties", [(100, False), (4096, True), (300000, True), (65537, False),
+                                     (2100000, False)])
 def test_binary_metrics_match_sklearn(n, ties):
     """fx_binary_metrics == sklearn log_loss / roc_auc_score on the float64 view of the same float32
     predictions (what BaseModel.evaluate feeds them, rank_model.py:369-381), incl. heavy ties and
@@ -857,3 +858,71 @@ def test_dedup_sorted_runs_equals_the_generic_sort_path(R, L, vocab):
     assert torch.equal(a.seg_start[:nu + 1], b.seg_start[:nu + 1])
     ref = np.unique(np.concatenate([r_[r_ != pad] for r_ in runs]))
     assert np.array_equal(a.uniq_row[:nu].cpu().numpy().astype(np.int64), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,vocab,where", [
+    (4096, 64, 2800000, "stream"), (4096, 64, 2800000, "graph"), (2049, 3, 1 << 24, "stream"),
+    (8192, 26, 70000, "graph"), (300, 7, 200, "graph"), (32768, 26, 40000000, "stream")])
+def test_dedup_generic_sort_on_side_stream_and_in_graph(B, C, vocab, where):
+    """The generic path (one table shared by every column: c4's click_sequence + adgroup_id) is
+    fx_sort.hip's LSD radix sort.  It must give numpy's answer — unique rows ascending, runs in
+    ascending lookup position (stable) — on a non-null stream and when replayed from a captured
+    hipGraph with fresh ids, which is how the training step runs it."""
+    rng = np.random.default_rng(B * 31 + C)
+    vocabs, bases = [vocab] * C, np.zeros(C, dtype=np.int64)
+    ids_dev = torch.zeros(B, C, dtype=torch.int32, device=DEV)
+    bases_d, vocab_d = _dev(bases, torch.int64), _dev(vocabs, torch.int32)
+    pad_d = _dev([0] * C, torch.int32)
+    ws = torch.empty(ops.dedup_workspace_bytes(B * C), dtype=torch.uint8, device=DEV)
+    torch.cuda.synchronize()
+
+    def draw():
+        ids = np.minimum((vocab * rng.random((B, C)) ** 3).astype(np.int64), vocab - 1)
+        ids[rng.random(ids.shape) < 0.2] = 0
+        return ids
+
+    def run():
+        return ops.dedup(ids_dev, bases_d, vocab_d, pad_d, vocab, ws, want_uid=True)
+
+    def check(dd, ids):
+        keys = ids.reshape(-1)
+        order = np.argsort(keys, kind="stable")
+        order = order[keys[order] != 0]
+        uniq, counts = np.unique(keys[order], return_counts=True)
+        nu = int(dd.n_unique.item())
+        assert nu == len(uniq)
+        assert np.array_equal(dd.uniq_row[:nu].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, uniq)
+        seg = dd.seg_start[:nu + 1].cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.diff(seg), counts) and seg[0] == 0
+        n_valid = len(order)
+        pos = dd.sorted_pos[:n_valid].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        assert np.array_equal(pos, order)                      # the whole stable permutation
+        uid = dd.sorted_uid.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        assert np.array_equal(uid[:n_valid], np.repeat(np.arange(nu), counts))
+        assert np.all(uid[n_valid:] == 0xFFFFFFFF)
+
+    side = torch.cuda.Stream()
+    if where == "stream":
+        for _ in range(3):
+            ids = draw()
+            with torch.cuda.stream(side):
+                ids_dev.copy_(torch.from_numpy(ids.astype(np.int32)))
+                dd = run()
+            side.synchronize()
+            check(dd, ids)
+        return
+    with torch.cuda.stream(side):
+        ids_dev.copy_(torch.from_numpy(draw().astype(np.int32)))
+        run()
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        dd = run()
+    for _ in range(4):
+        ids = draw()
+        ids_dev.copy_(torch.from_numpy(ids.astype(np.int32)))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        check(dd, ids)
