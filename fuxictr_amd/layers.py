@@ -1753,6 +1753,74 @@ class _DinPoolFn(torch.autograd.Function):
         return dw, dK, None
 
 
+class _DinAttnFn(torch.autograd.Function):
+    """target_attention.py:66-92 with its MLP_Block(4E -> H, Dice, -> 1) as ONE autograd node on the
+    fused kernels of fx_din_attn.hip: neither the [B*L, 4E] concatenation nor the [B*L, H] hidden
+    tensor is written.  Forward = statistics pass, (all-reduce across ranks), Dice statistics, apply
+    pass -> logits a[B, L], masked pooling; backward mirrors it (pool backward, sums pass,
+    (all-reduce), apply pass -> dq, dK, dW1, db1; dalpha, dW2, db2 come out of the sums pass)."""
+
+    @staticmethod
+    def forward(ctx, q, K, mask_i32, W1, b1, alpha, W2, b2, mod):
+        q = q.contiguous()
+        B, L, E = K.shape
+        H = W1.shape[0]
+        dev = q.device
+        training = mod.training
+        dist = _DIST if (training and _DIST is not None and _DIST.world > 1) else None
+        ws = _Workspace.get(dev, ops.din_attn_workspace_floats(B, L, E, H), tag="din_attn")
+        stats = torch.empty(2 * H, dtype=torch.float32, device=dev)
+        n_total = B * L
+        if training:
+            sums = torch.empty(2 * H + 1, dtype=torch.float32, device=dev)
+            ops.din_attn_stats(q, K, W1, b1, sums, ws)
+            if dist is not None:
+                # row-sharded training: the reference normalises with the statistics of the WHOLE
+                # batch (activations.py:40-51) — one small all-reduce ([2H + 1] floats)
+                sums[2 * H] = float(B * L)
+                dist.all_reduce_sum(sums)
+                n_total = int(round(float(sums[2 * H].item())))
+            ops.dice_stats_from_sums(sums, H, n_total, mod.bn.momentum, True, mod.bn.running_mean,
+                                     mod.bn.running_var, stats)
+        else:
+            ops.dice_stats_from_sums(None, H, 1, 0.0, False, mod.bn.running_mean,
+                                     mod.bn.running_var, stats)
+        w2 = W2.reshape(-1)
+        a = torch.empty(B, L, dtype=torch.float32, device=dev)
+        ops.din_attn_fwd(q, K, W1, b1, alpha, mod.bn.eps, stats, w2, b2, a)
+        out = torch.empty(B, E, dtype=torch.float32, device=dev)
+        ops.din_pool_fwd(a, mask_i32, K, out)
+        ctx.save_for_backward(q, K, mask_i32, W1, b1, alpha, W2, stats, a)
+        ctx.training, ctx.eps, ctx.dist, ctx.n_total = training, mod.bn.eps, dist, n_total
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, K, mask_i32, W1, b1, alpha, W2, stats, a = ctx.saved_tensors
+        B, L, E = K.shape
+        H = W1.shape[0]
+        dev = q.device
+        ws = _Workspace.get(dev, ops.din_attn_workspace_floats(B, L, E, H), tag="din_attn")
+        da = torch.empty(B, L, dtype=torch.float32, device=dev)
+        dKp = torch.empty(B, L, E, dtype=torch.float32, device=dev)
+        ops.din_pool_bwd(a, mask_i32, K, dout.contiguous(), da, dKp)
+        w2 = W2.reshape(-1)
+        sums5 = torch.empty(5 * H, dtype=torch.float32, device=dev)
+        ops.din_attn_bwd_sums(q, K, W1, b1, alpha, ctx.eps, stats, w2, da, sums5, ws)
+        if ctx.dist is not None:
+            ctx.dist.all_reduce_sum(sums5[H:3 * H])   # sum dzhat, sum dzhat*zhat: global batch
+        dq = torch.empty(B, E, dtype=torch.float32, device=dev)
+        dK = torch.empty(B, L, E, dtype=torch.float32, device=dev)
+        dW1b1 = torch.empty(H * 4 * E + H, dtype=torch.float32, device=dev)
+        ops.din_attn_bwd(q, K, W1, b1, alpha, ctx.eps, ctx.training, stats, w2, da, sums5,
+                         ctx.n_total, dKp, dq, dK, dW1b1, ws)
+        dW1 = dW1b1[:H * 4 * E].view(H, 4 * E)
+        db1 = dW1b1[H * 4 * E:] if b1 is not None else None
+        dW2 = sums5[3 * H:4 * H].view(W2.shape)
+        db2 = sums5[4 * H:4 * H + 1]
+        return dq, dK, None, dW1, db1, sums5[:H], dW2, db2, None
+
+
 class DIN_Attention(nn.Module):
     """fuxictr/pytorch/layers/attentions/target_attention.py:26-92."""
 
@@ -1769,8 +1837,38 @@ class DIN_Attention(nn.Module):
                                          output_activation=output_activation,
                                          dropout_rates=dropout_rate, batch_norm=batch_norm)
 
+    def _fused_plan(self):
+        """(Linear 4E -> H, Dice, Linear H -> 1) when the attention MLP is exactly that — the
+        reference's DIN configs — and fits fx_din_attn.hip; None otherwise (unfused kernels)."""
+        plan = getattr(self, "_fx_plan", False)
+        if plan is False:
+            plan = None
+            mods = list(self.attention_layer.mlp)
+            if (_os.environ.get("FX_DIN_FUSED", "1") != "0" and not self.use_softmax
+                    and len(mods) == 3 and isinstance(mods[0], FxLinear)
+                    and isinstance(mods[1], Dice) and isinstance(mods[2], FxLinear)
+                    and mods[2].out_features == 1
+                    and mods[0].out_features <= ops.DIN_ATTN_MAX_H
+                    and mods[0].in_features <= 4 * ops.DIN_ATTN_MAX_E):
+                plan = (mods[0], mods[1], mods[2])
+            self._fx_plan = plan
+        return plan
+
     def forward(self, target_item, history_sequence, mask=None):
         seq_len = history_sequence.size(1)
+        plan = self._fused_plan()
+        if plan is not None and 4 * history_sequence.size(2) == plan[0].in_features \
+                and target_item.dim() == 2:
+            lin1, dice, lin2 = plan
+            if mask is None:
+                m = torch.ones(history_sequence.shape[:2], dtype=torch.int32,
+                               device=history_sequence.device)
+            else:
+                m = mask.to(torch.int32).contiguous()
+            if dice.training:
+                dice.bn.num_batches_tracked += 1
+            return _DinAttnFn.apply(target_item, history_sequence, m, lin1.weight, lin1.bias,
+                                    dice.alpha, lin2.weight, lin2.bias, dice)
         attention_input = _DinConcatFn.apply(target_item, history_sequence)   # [B*L, 4E]
         attention_weight = self.attention_layer(attention_input).view(-1, seq_len)
         if self.use_softmax or history_sequence.size(2) > 64:

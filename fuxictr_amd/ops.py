@@ -576,6 +576,69 @@ def dice_bwd_from_sums(Z, dY, alpha, eps, stats, sums3, n_total, dZ):
           "fx_dice_bwd_from_sums")
 
 
+# ---- DIN attention with the attention MLP fused in (fx_din_attn.hip) --------------------------------
+DIN_ATTN_MAX_E, DIN_ATTN_MAX_H = 16, 64
+
+
+def din_attn_workspace_floats(B, L, E, H):
+    return int(_lib.load().fx_din_attn_workspace_floats(B, L, E, H))
+
+
+def _din_attn_head(q, K):
+    K, sb, sl = _k_strides(K)
+    B, L, E = K.shape
+    return K, (ptr(q), q.stride(0), ptr(K), sb, sl, B, L, E)
+
+
+def din_attn_stats(q, K, W1, b1, sums, workspace):
+    """sums[2H] = [sum h | sum h^2] over the B*L positions, h = W1 [q,k,q-k,q*k] + b1."""
+    K, head = _din_attn_head(q, K)
+    H = W1.shape[0]
+    check(_lib.load().fx_din_attn_stats(*head, ptr(W1), ptr(b1) if b1 is not None else None, H,
+                                        ptr(sums), ptr(workspace), stream_ptr(q.device)),
+          "fx_din_attn_stats")
+
+
+def dice_stats_from_sums(sums, H, n_total, momentum, training, running_mean, running_var, stats):
+    check(_lib.load().fx_dice_stats_from_sums(ptr(sums) if sums is not None else None, H, n_total,
+                                              momentum, 1 if training else 0, ptr(running_mean),
+                                              ptr(running_var), ptr(stats),
+                                              stream_ptr(stats.device)), "fx_dice_stats_from_sums")
+
+
+def din_attn_fwd(q, K, W1, b1, alpha, eps, stats, W2, b2, a_out):
+    K, head = _din_attn_head(q, K)
+    H = W1.shape[0]
+    check(_lib.load().fx_din_attn_fwd(*head, ptr(W1), ptr(b1) if b1 is not None else None, H,
+                                      ptr(alpha), eps, ptr(stats), ptr(W2),
+                                      ptr(b2) if b2 is not None else None, ptr(a_out),
+                                      stream_ptr(q.device)), "fx_din_attn_fwd")
+    return a_out
+
+
+def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, da, sums5, workspace):
+    """sums5[5H] = [dalpha | sum dzhat | sum dzhat*zhat | dW2 | db2, 0, ...]."""
+    K, head = _din_attn_head(q, K)
+    H = W1.shape[0]
+    check(_lib.load().fx_din_attn_bwd_sums(*head, ptr(W1), ptr(b1) if b1 is not None else None, H,
+                                           ptr(alpha), eps, ptr(stats), ptr(W2), ptr(da),
+                                           ptr(sums5), ptr(workspace), stream_ptr(q.device)),
+          "fx_din_attn_bwd_sums")
+
+
+def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, da, sums5, n_total, dk_add, dq, dK,
+                 dW1b1, workspace):
+    K, head = _din_attn_head(q, K)
+    H = W1.shape[0]
+    add = (ptr(dk_add), dk_add.stride(0), dk_add.stride(1)) if dk_add is not None else (None, 0, 0)
+    check(_lib.load().fx_din_attn_bwd(*head, ptr(W1), ptr(b1) if b1 is not None else None, H,
+                                      ptr(alpha), eps, 1 if training else 0, ptr(stats), ptr(W2),
+                                      ptr(da), ptr(sums5) if sums5 is not None else None, n_total,
+                                      add[0], add[1], add[2], ptr(dq), dq.stride(0), ptr(dK),
+                                      dK.stride(0), dK.stride(1), ptr(dW1b1), ptr(workspace),
+                                      stream_ptr(q.device)), "fx_din_attn_bwd")
+
+
 def dot_interact_fwd(emb, F, D, out):
     B = emb.shape[0]
     check(_lib.load().fx_dot_interact_fwd(ptr(emb), emb.stride(0), F, D, B, ptr(out),

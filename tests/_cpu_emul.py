@@ -478,6 +478,101 @@ def dice_bwd_from_sums(Z, dY, alpha, eps, stats, sums3, n_total, dZ):
     dZ.copy_(dY * (p + alpha * (1 - p)) + dzh * rstd)
 
 
+# ---- DIN attention with the MLP fused in (fx_din_attn.hip) ----------------------------------------
+DIN_ATTN_MAX_E, DIN_ATTN_MAX_H = 16, 64
+
+
+def din_attn_workspace_floats(B, L, E, H):
+    return 1
+
+
+def _din_attn_h(q, K, W1, b1):
+    B, L, E = K.shape
+    t = q.unsqueeze(1).expand(-1, L, -1)
+    x = torch.cat([t, K, t - K, t * K], dim=-1).reshape(B * L, 4 * E)
+    h = x @ W1.t()
+    if b1 is not None:
+        h = h + b1
+    return x, h
+
+
+def din_attn_stats(q, K, W1, b1, sums, workspace):
+    H = W1.shape[0]
+    _, h = _din_attn_h(q, K, W1, b1)
+    sums[:H] = h.sum(0)
+    sums[H:2 * H] = (h * h).sum(0)
+
+
+def dice_stats_from_sums(sums, H, n_total, momentum, training, running_mean, running_var, stats):
+    if not training:
+        stats[:H] = running_mean
+        stats[H:] = running_var
+        return
+    mean = sums[:H].double() / n_total
+    var = (sums[H:2 * H].double() / n_total - mean * mean).clamp(min=0)
+    stats[:H] = mean.float()
+    stats[H:] = var.float()
+    unb = var * n_total / (n_total - 1) if n_total > 1 else var
+    running_mean.copy_(((1 - momentum) * running_mean.double() + momentum * mean).float())
+    running_var.copy_(((1 - momentum) * running_var.double() + momentum * unb).float())
+
+
+def _din_attn_gate(h, alpha, eps, stats):
+    H = h.shape[1]
+    rstd = 1.0 / torch.sqrt(stats[H:] + eps)
+    zh = (h - stats[:H]) * rstd
+    p = torch.sigmoid(zh)
+    return rstd, zh, p
+
+
+def din_attn_fwd(q, K, W1, b1, alpha, eps, stats, W2, b2, a_out):
+    _, h = _din_attn_h(q, K, W1, b1)
+    _, _, p = _din_attn_gate(h, alpha, eps, stats)
+    y = p * h + alpha * (1 - p) * h
+    a = y @ W2.reshape(-1)
+    if b2 is not None:
+        a = a + b2
+    a_out.copy_(a.view(a_out.shape))
+    return a_out
+
+
+def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, da, sums5, workspace):
+    H = W1.shape[0]
+    _, h = _din_attn_h(q, K, W1, b1)
+    _, zh, p = _din_attn_gate(h, alpha, eps, stats)
+    y = p * h + alpha * (1 - p) * h
+    d = da.reshape(-1, 1)
+    dy = d * W2.reshape(1, -1)
+    dzh = dy * h * (1 - alpha) * p * (1 - p)
+    sums5[:H] = (dy * (1 - p) * h).sum(0)
+    sums5[H:2 * H] = dzh.sum(0)
+    sums5[2 * H:3 * H] = (dzh * zh).sum(0)
+    sums5[3 * H:4 * H] = (d * y).sum(0)
+    sums5[4 * H:] = 0
+    sums5[4 * H] = d.sum()
+
+
+def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, da, sums5, n_total, dk_add, dq, dK,
+                 dW1b1, workspace):
+    B, L, E = K.shape
+    H = W1.shape[0]
+    x, h = _din_attn_h(q, K, W1, b1)
+    rstd, zh, p = _din_attn_gate(h, alpha, eps, stats)
+    dy = da.reshape(-1, 1) * W2.reshape(1, -1)
+    dzh = dy * h * (1 - alpha) * p * (1 - p)
+    if training:
+        dzh = dzh - sums5[H:2 * H] / n_total - zh * (sums5[2 * H:3 * H] / n_total)
+    dh = dy * (p + alpha * (1 - p)) + dzh * rstd
+    dW1b1[:H * 4 * E] = (dh.t() @ x).reshape(-1)
+    dW1b1[H * 4 * E:] = dh.sum(0)
+    d = (dh @ W1).view(B, L, 4, E)
+    dq.copy_((d[:, :, 0] + d[:, :, 2] + d[:, :, 3] * K).sum(1))
+    dk = d[:, :, 1] - d[:, :, 2] + d[:, :, 3] * q.unsqueeze(1)
+    if dk_add is not None:
+        dk = dk + dk_add
+    dK.copy_(dk)
+
+
 def dot_interact_fwd(emb, F, D, out):
     e = emb.view(-1, F, D)
     ipm = torch.bmm(e, e.transpose(1, 2))
@@ -692,7 +787,9 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "shard_plan_workspace_ints", "emb_seq_pool_fwd", "dedup_sorted_runs", "RowState",
          "dedup_catchup", "emb_fm_fwd", "emb_fm_bwd", "sparse_update_multi", "pack_columns_multi",
          "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats", "adam_catchup_all",
-         "dice_local_sums", "dice_fwd_from_sums", "dice_bwd_local_sums", "dice_bwd_from_sums"]
+         "dice_local_sums", "dice_fwd_from_sums", "dice_bwd_local_sums", "dice_bwd_from_sums",
+         "din_attn_workspace_floats", "din_attn_stats", "dice_stats_from_sums", "din_attn_fwd",
+         "din_attn_bwd_sums", "din_attn_bwd"]
 
 
 def install_plain():
