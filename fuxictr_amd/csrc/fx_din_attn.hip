@@ -39,6 +39,8 @@
 // takes the unfused kernels (fx_din.hip) — both are native paths.
 #include "fx_common.h"
 
+#include <stdlib.h>
+
 typedef float da_f32x16 __attribute__((ext_vector_type(16)));
 
 #define DA_LDX 33   // row stride of the per-wave x^T tile [feature][position]; odd -> conflict-free
@@ -82,7 +84,8 @@ struct DaSmem {
     float4 PA[HP];                              // {b1, mean, rstd, alpha}
     float4 PB[HP];                              // {w2, mean(dzhat), mean(dzhat zhat), 0}
     float Xs[WAVES][FP * DA_LDX];               // x^T tile per wave (backward: reused for dx^T)
-    float Hs[BWD ? WAVES : 1][BWD ? 32 * LDH : 1];   // dh tile per wave, [position][hidden]
+    static constexpr int HSZ = 32 * LDH > FP * DA_LDX ? 32 * LDH : FP * DA_LDX;
+    float Hs[BWD ? WAVES : 1][BWD ? HSZ : 1];   // dh tile per wave, [position][hidden]; then dx^T
 };
 
 // W1 and the per-unit parameters into LDS (padding = neutral values); ends with a barrier
@@ -116,55 +119,73 @@ __device__ __forceinline__ void da_load_params(S& sm, const DinAttnArgs& a, int 
     __syncthreads();
 }
 
-// x^T of the wave's 32 positions: lane (l31 = position, half) loads features [8 half, 8 half + 8) of
-// its q and K rows and writes the four blocks [q, k, q - k, q * k]; rows outside the range are 0.
-__device__ __forceinline__ void da_build_x(float* __restrict__ Xs, const DinAttnArgs& a, int64_t row,
-                                           bool valid, int l31, int half, float (&qv)[8],
-                                           float (&kv)[8], int64_t& b, int& l) {
-    b = 0;
-    l = 0;
+// The q / K values of one position as the lanes hold them: lane (l31 = position, half) owns features
+// [8 half, 8 half + 8).  Loading (global) and writing the x^T tile (LDS) are separate steps so that the
+// rows of tile t+1 are requested before the matrix products of tile t (the only HBM latency of a pass).
+struct DaRows {
+    float qv[8], kv[8];
+    int64_t b;
+    int l;
+};
+
+__device__ __forceinline__ void da_load_rows(const DinAttnArgs& a, int64_t row, bool valid, int half,
+                                             DaRows& x) {
+    x.b = 0;
+    x.l = 0;
     if (valid) {
-        b = row / a.L;
-        l = (int)(row - b * a.L);
+        x.b = row / a.L;
+        x.l = (int)(row - x.b * a.L);
     }
     const int E = a.E, e0 = 8 * half;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        qv[u] = 0.f;
-        kv[u] = 0.f;
+        x.qv[u] = 0.f;
+        x.kv[u] = 0.f;
     }
     if (valid && e0 < E) {
-        const float* qp = a.q + b * a.q_ld + e0;
-        const float* kp = a.K + b * a.k_ldb + (int64_t)l * a.k_ldl + e0;
+        const float* qp = a.q + x.b * a.q_ld + e0;
+        const float* kp = a.K + x.b * a.k_ldb + (int64_t)x.l * a.k_ldl + e0;
         if (a.vec) {
             const float4 q0 = *reinterpret_cast<const float4*>(qp);
             const float4 q1 = *reinterpret_cast<const float4*>(qp + 4);
             const float4 k0 = *reinterpret_cast<const float4*>(kp);
             const float4 k1 = *reinterpret_cast<const float4*>(kp + 4);
-            qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w;
-            qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
-            kv[0] = k0.x; kv[1] = k0.y; kv[2] = k0.z; kv[3] = k0.w;
-            kv[4] = k1.x; kv[5] = k1.y; kv[6] = k1.z; kv[7] = k1.w;
+            x.qv[0] = q0.x; x.qv[1] = q0.y; x.qv[2] = q0.z; x.qv[3] = q0.w;
+            x.qv[4] = q1.x; x.qv[5] = q1.y; x.qv[6] = q1.z; x.qv[7] = q1.w;
+            x.kv[0] = k0.x; x.kv[1] = k0.y; x.kv[2] = k0.z; x.kv[3] = k0.w;
+            x.kv[4] = k1.x; x.kv[5] = k1.y; x.kv[6] = k1.z; x.kv[7] = k1.w;
         } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (e0 + u < E) {
-                    qv[u] = qp[u];
-                    kv[u] = kp[u];
+                    x.qv[u] = qp[u];
+                    x.kv[u] = kp[u];
                 }
             }
         }
     }
+}
+
+// x^T[f][position] = [q, k, q - k, q * k] of the tile (rows outside the range were loaded as 0)
+__device__ __forceinline__ void da_store_x(float* Xs, int E, int l31, int half, const DaRows& x) {
+    const int e0 = 8 * half;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int e = e0 + u;
         if (e < E) {
-            Xs[e * DA_LDX + l31] = qv[u];
-            Xs[(E + e) * DA_LDX + l31] = kv[u];
-            Xs[(2 * E + e) * DA_LDX + l31] = qv[u] - kv[u];
-            Xs[(3 * E + e) * DA_LDX + l31] = qv[u] * kv[u];
+            Xs[e * DA_LDX + l31] = x.qv[u];
+            Xs[(E + e) * DA_LDX + l31] = x.kv[u];
+            Xs[(2 * E + e) * DA_LDX + l31] = x.qv[u] - x.kv[u];
+            Xs[(3 * E + e) * DA_LDX + l31] = x.qv[u] * x.kv[u];
         }
     }
+}
+
+// sigmoid on the transcendental unit: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the ~40
+// instructions of expf + IEEE division — the Dice gate is evaluated 32 x per lane and tile, which
+// made the passes VALU-bound (profiles/r02_step_timeline_din_fused_v1.txt); |error| <= 2e-7
+__device__ __forceinline__ float da_sigmoid(float z) {
+    return __builtin_amdgcn_rcpf(1.f + __expf(-z));
 }
 
 // The hidden layer of the wave's 32 positions on the matrix cores, bias not yet added.
@@ -222,12 +243,11 @@ __global__ __launch_bounds__(256) void k_din_attn_stats(DinAttnArgs a) {
         s2[j] = 0.f;
         b1v[j] = sm.PA[32 * j + l31].x;
     }
+    DaRows cur;
+    da_load_rows(a, R0 + l31, R0 + l31 < R1, half, cur);
     for (int64_t rb = R0; rb < R1; rb += 32) {
-        const int64_t row = rb + l31;
-        float qv[8], kv[8];
-        int64_t b;
-        int l;
-        da_build_x(Xs, a, row, row < R1, l31, half, qv, kv, b, l);
+        da_store_x(Xs, a.E, l31, half, cur);
+        da_load_rows(a, rb + 32 + l31, rb + 32 + l31 < R1, half, cur);     // tile t+1 in flight
         da_f32x16 acc[NB];
         da_gemm_h<NB, false>(sm.W1s, S::LDW, Xs, KX, l31, half, acc);
         const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
@@ -277,13 +297,13 @@ __global__ __launch_bounds__(256) void k_din_attn_fwd(DinAttnArgs a) {
     const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
     const int64_t R0 = gw * a.rows_per_wave;
     const int64_t R1 = (R0 + a.rows_per_wave < a.n_rows) ? R0 + a.rows_per_wave : a.n_rows;
+    DaRows cur;
+    da_load_rows(a, R0 + l31, R0 + l31 < R1, half, cur);
     for (int64_t rb = R0; rb < R1; rb += 32) {
         const int64_t row = rb + l31;
         const bool valid = row < R1;
-        float qv[8], kv[8];
-        int64_t b;
-        int l;
-        da_build_x(Xs, a, row, valid, l31, half, qv, kv, b, l);
+        da_store_x(Xs, a.E, l31, half, cur);
+        da_load_rows(a, row + 32, row + 32 < R1, half, cur);               // tile t+1 in flight
         da_f32x16 acc[NB];
         da_gemm_h<NB, true>(sm.W1s, S::LDW, Xs, KX, l31, half, acc);
         float t = 0.f;
@@ -296,7 +316,7 @@ __global__ __launch_bounds__(256) void k_din_attn_fwd(DinAttnArgs a) {
                 const float w2 = sm.PB[n].x;
                 const float z = acc[j][r] + pa.x;
                 const float zh = (z - pa.y) * pa.z;
-                const float p = 1.f / (1.f + expf(-zh));
+                const float p = da_sigmoid(zh);
                 const float y = p * z + pa.w * (1.f - p) * z;
                 t += y * w2;
             }
@@ -336,18 +356,18 @@ __global__ __launch_bounds__(256) void k_din_attn_bwd_sums(DinAttnArgs a) {
         pa[j] = sm.PA[32 * j + l31];
         w2[j] = sm.PB[32 * j + l31].x;
     }
+    DaRows cur;
+    da_load_rows(a, R0 + l31, R0 + l31 < R1, half, cur);
+    float da_i = (R0 + l31 < R1) ? a.da[R0 + l31] : 0.f;
     for (int64_t rb = R0; rb < R1; rb += 32) {
         const int64_t row = rb + l31;
-        const bool valid = row < R1;
-        float qv[8], kv[8];
-        int64_t b;
-        int l;
-        da_build_x(Xs, a, row, valid, l31, half, qv, kv, b, l);
-        const float da_i = valid ? a.da[row] : 0.f;
+        da_store_x(Xs, a.E, l31, half, cur);
         if (half == 0) {
             das[wave][l31] = da_i;
             sb2 += da_i;
         }
+        da_load_rows(a, row + 32, row + 32 < R1, half, cur);               // tile t+1 in flight
+        da_i = (row + 32 < R1) ? a.da[row + 32] : 0.f;
         da_f32x16 acc[NB];
         da_gemm_h<NB, false>(sm.W1s, S::LDW, Xs, KX, l31, half, acc);
 #pragma unroll
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(256) void k_din_attn_bwd_sums(DinAttnArgs a) {
             for (int j = 0; j < NB; ++j) {
                 const float z = acc[j][r] + pa[j].x;
                 const float zh = (z - pa[j].y) * pa[j].z;
-                const float p = 1.f / (1.f + expf(-zh));
+                const float p = da_sigmoid(zh);
                 const float y = p * z + pa[j].w * (1.f - p) * z;
                 const float dy = dar * w2[j];
                 const float dzh = dy * z * (1.f - pa[j].w) * p * (1.f - p);
@@ -405,7 +425,8 @@ __global__ __launch_bounds__(256) void k_din_attn_bwd_sums(DinAttnArgs a) {
 // feature walking the positions in order.
 // ---------------------------------------------------------------------------------------------
 template <int NB, int FB>
-__global__ __launch_bounds__(128) void k_din_attn_bwd(DinAttnArgs a) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_din_attn_bwd(DinAttnArgs a) {
     using S = DaSmem<NB, FB, 2, true>;
     __shared__ S sm;
     da_load_params(sm, a, 128);
@@ -430,14 +451,18 @@ __global__ __launch_bounds__(128) void k_din_attn_bwd(DinAttnArgs a) {
         db1q[j] = 0.f;
     }
     float dq_run = 0.f;
+    DaRows cur;
+    da_load_rows(a, R0 + l31, R0 + l31 < R1, half, cur);
+    float da_n = (R0 + l31 < R1) ? a.da[R0 + l31] : 0.f;
     for (int64_t rb = R0; rb < R1; rb += 32) {
         const int64_t row = rb + l31;
         const bool valid = row < R1;
-        float qv[8], kv[8];
-        int64_t b;
-        int l;
-        da_build_x(Xs, a, row, valid, l31, half, qv, kv, b, l);
-        const float da_i = valid ? a.da[row] : 0.f;
+        const int64_t b = cur.b;
+        const int l = cur.l;
+        const float da_i = da_n;
+        da_store_x(Xs, E, l31, half, cur);
+        da_load_rows(a, row + 32, row + 32 < R1, half, cur);               // tile t+1 in flight
+        da_n = (row + 32 < R1) ? a.da[row + 32] : 0.f;
         {
             da_f32x16 acc[NB];
             da_gemm_h<NB, true>(sm.W1s, S::LDW, Xs, KX, l31, half, acc);
@@ -450,7 +475,7 @@ __global__ __launch_bounds__(128) void k_din_attn_bwd(DinAttnArgs a) {
                     const float4 pb = sm.PB[n];
                     const float z = acc[j][r] + pa.x;
                     const float zh = (z - pa.y) * pa.z;
-                    const float p = 1.f / (1.f + expf(-zh));
+                    const float p = da_sigmoid(zh);
                     const float dy = da_i * pb.x;
                     float dzh = dy * z * (1.f - pa.w) * p * (1.f - p);
                     dzh -= pb.y + zh * pb.z;                 // 0 outside training mode
@@ -492,26 +517,29 @@ __global__ __launch_bounds__(128) void k_din_attn_bwd(DinAttnArgs a) {
                 accD[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bh, accD[jb], 0, 0, 0);
             }
         }
-        // dx^T through LDS (over the x tile, which the dW1 product has finished reading)
+        // dx^T through LDS, over the dh tile (both products have consumed it); the x tile still holds
+        // this tile's q and k rows
 #pragma unroll
         for (int jb = 0; jb < FB; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Xs[(32 * jb + da_rowmap(r, half)) * DA_LDX + l31] = accD[jb][r];
+                Hs[(32 * jb + da_rowmap(r, half)) * DA_LDX + l31] = accD[jb][r];
         // dk = dx_k - dx_(q-k) + dx_(q*k) q ;  this position's share of dq = dx_q + dx_(q-k) + dx_(q*k) k
+        // (written over the (q-k) rows of the x tile, which nobody reads any more)
         float dkv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + u;
             dkv[u] = 0.f;
             if (e < E) {
-                const float dxa = Xs[e * DA_LDX + l31];
-                const float dxb = Xs[(E + e) * DA_LDX + l31];
-                const float dxc = Xs[(2 * E + e) * DA_LDX + l31];
-                const float dxd = Xs[(3 * E + e) * DA_LDX + l31];
-                dkv[u] = dxb - dxc + dxd * qv[u];
-                const float dqc = dxa + dxc + dxd * kv[u];
-                Hs[e * DA_LDX + l31] = valid ? dqc : 0.f;   // over the dh tile (fully consumed)
+                const float qe = Xs[e * DA_LDX + l31], ke = Xs[(E + e) * DA_LDX + l31];
+                const float dxa = Hs[e * DA_LDX + l31];
+                const float dxb = Hs[(E + e) * DA_LDX + l31];
+                const float dxc = Hs[(2 * E + e) * DA_LDX + l31];
+                const float dxd = Hs[(3 * E + e) * DA_LDX + l31];
+                dkv[u] = dxb - dxc + dxd * qe;
+                const float dqc = dxa + dxc + dxd * ke;
+                Xs[(2 * E + e) * DA_LDX + l31] = valid ? dqc : 0.f;
             }
         }
         if (valid && e0 < E) {
@@ -537,7 +565,7 @@ __global__ __launch_bounds__(128) void k_din_attn_bwd(DinAttnArgs a) {
             int lcur = (int)(rb - bcur * L);
             const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
             for (int i = 0; i < nvalid; ++i) {
-                if (lane < E) dq_run += Hs[lane * DA_LDX + i];
+                if (lane < E) dq_run += Xs[(2 * E + lane) * DA_LDX + i];
                 if (++lcur == L) {
                     if (lane < E) a.dq[bcur * a.dq_ld + lane] = dq_run;
                     dq_run = 0.f;
@@ -636,16 +664,27 @@ struct DaGeom {
     int64_t n_rows, rpw13, wgs13, rpw4, wgs4;
 };
 
+static int64_t da_env_cap(const char* name, int64_t dflt) {
+    const char* e = getenv(name);
+    const int64_t v = e ? atoll(e) : 0;
+    return v >= 64 ? v : dflt;
+}
+
 static DaGeom da_geom(int64_t B, int32_t L) {
+    // waves per launch (experiment switches FX_DIN_ATTN_WAVES / FX_DIN_ATTN_BWD_WAVES): the passes are
+    // a serial chain per wave (x tile -> MFMA -> gate -> ...), so what matters is that every SIMD gets
+    // the same number of tiles, not how many waves are resident
+    static const int64_t cap13 = da_env_cap("FX_DIN_ATTN_WAVES", 2048);
+    static const int64_t cap4 = da_env_cap("FX_DIN_ATTN_BWD_WAVES", 1536);
     DaGeom g;
     g.n_rows = B * L;
-    // passes without a per-sample reduction: 32-position tiles dealt to <= 2048 waves (2 per SIMD)
+    // passes without a per-sample reduction: 32-position tiles dealt to <= cap13 waves
     const int64_t nblocks = fx_ceil_div(g.n_rows, 32);
-    const int64_t bpw = fx_ceil_div(nblocks, 2048) > 1 ? fx_ceil_div(nblocks, 2048) : 1;
+    const int64_t bpw = fx_ceil_div(nblocks, cap13) > 1 ? fx_ceil_div(nblocks, cap13) : 1;
     g.rpw13 = bpw * 32;
     g.wgs13 = fx_ceil_div(fx_ceil_div(nblocks, bpw), 4);
-    // backward apply: whole samples per wave, <= 1536 waves (3 workgroups of 2 waves per CU: LDS)
-    const int64_t S = fx_ceil_div(B, 1536) > 1 ? fx_ceil_div(B, 1536) : 1;
+    // backward apply: whole samples per wave, <= cap4 waves (3 workgroups of 2 waves per CU: LDS)
+    const int64_t S = fx_ceil_div(B, cap4) > 1 ? fx_ceil_div(B, cap4) : 1;
     g.rpw4 = S * L;
     g.wgs4 = fx_ceil_div(fx_ceil_div(B, S), 2);
     return g;
