@@ -18,9 +18,11 @@
 // of the whole batch before any row can be finished, so the fused form is two passes that RECOMPUTE
 // the hidden layer from the 2 x 16 floats a position really has (q_b and k_{b,l}, 13 MB in total):
 //   forward : stats pass  (h -> per-workgroup partial sums of h and h^2)          -> [host: finish /
-//             all-reduce across ranks] -> apply pass (h -> Dice -> . W2 -> a[B*L])
-//   backward: sums pass   (h, da -> dalpha, sum dzhat, sum dzhat*zhat, dW2, db2)  -> [all-reduce]
-//             -> apply pass (h -> dh -> dW1 / db1 partials, dx -> dq, dK)
+//             all-reduce across ranks] -> apply pass (h -> Dice -> . W2 -> a[B*L] -> mask -> the
+//             weighted sum over the sequence, out[B,E]: target_attention.py:85-91 rides along)
+//   backward: sums pass   (da = mask (dout . k); h, da -> dalpha, sum dzhat, sum dzhat*zhat, dW2, db2)
+//             -> [all-reduce] -> apply pass (h -> dh -> dW1 / db1 partials, dx -> dq, dK incl. the
+//             pooling's share a mask dout)
 // Every pass is one launch over 32-position tiles, one wave per tile stream:
 //   * the tile's x^T [4E][32] is built in LDS from q / K rows read with 16-byte loads,
 //   * the hidden layer of the tile on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32
@@ -52,9 +54,9 @@ struct DinAttnArgs {
     const float* K;
     int64_t k_ldb, k_ldl;
     int64_t n_rows;          // B * L positions
-    int64_t rows_per_wave;   // contiguous positions a wave owns (bwd apply: whole samples)
+    int64_t rows_per_wave;   // contiguous positions a wave owns (fwd / bwd apply: whole samples)
     int32_t L, E, H;
-    int32_t vec;             // q / K / dK rows may be moved with 16-byte accesses (E % 8 == 0, aligned)
+    int32_t vec;             // q / K / dout / dK rows may be moved with 16-byte accesses
     const float* W1;         // [H, 4E]
     const float* b1;         // [H] or null
     const float* alpha;      // [H]
@@ -62,12 +64,18 @@ struct DinAttnArgs {
     float eps;
     const float* W2;         // [H]
     const float* b2;         // [1] or null
-    const float* da;         // [B*L] gradient of the attention logits
+    const int32_t* mask;     // [B, L] (row stride m_ld), position kept when != 0; null = all kept
+    int64_t m_ld;
+    const float* dout;       // [B, E] gradient of the pooled output
+    int64_t dout_ld;
+    const float* a_in;       // [B*L] attention logits of the forward (bwd apply)
+    const float* da_in;      // [B*L] gradient of the logits (bwd apply; written by the sums pass)
     const float* sums;       // [H + n] = sum dzhat, [2H + n] = sum dzhat * zhat (training mode)
     float inv_n;
-    const float* dk_add;     // optional [B, L, E] addend of dK (the pooling's share)
-    int64_t dka_ldb, dka_ldl;
     float* a_out;            // [B*L]
+    float* out;              // [B, E] pooled output
+    int64_t out_ld;
+    float* da_out;           // [B*L]
     float* dq;
     int64_t dq_ld;
     float* dK;
@@ -77,15 +85,16 @@ struct DinAttnArgs {
 
 __device__ __forceinline__ int da_rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <int NB, int FB, int WAVES, bool BWD>
+template <int NB, int FB, int WAVES, bool BWD, bool POOL>
 struct DaSmem {
     static constexpr int HP = 32 * NB, FP = 32 * FB, LDW = HP + 1, LDH = HP + 1;
     float W1s[FP * LDW];                        // W1^T, [feature][hidden]: W1s[f * LDW + n] = W1[n][f]
     float4 PA[HP];                              // {b1, mean, rstd, alpha}
     float4 PB[HP];                              // {w2, mean(dzhat), mean(dzhat zhat), 0}
-    float Xs[WAVES][FP * DA_LDX];               // x^T tile per wave (backward: reused for dx^T)
+    float Xs[WAVES][FP * DA_LDX];               // x^T tile per wave
     static constexpr int HSZ = 32 * LDH > FP * DA_LDX ? 32 * LDH : FP * DA_LDX;
     float Hs[BWD ? WAVES : 1][BWD ? HSZ : 1];   // dh tile per wave, [position][hidden]; then dx^T
+    float Ps[POOL ? WAVES : 1][POOL ? 16 * DA_LDX : 1];   // a mask k per wave, [feature][position]
 };
 
 // W1 and the per-unit parameters into LDS (padding = neutral values); ends with a barrier
@@ -119,56 +128,62 @@ __device__ __forceinline__ void da_load_params(S& sm, const DinAttnArgs& a, int 
     __syncthreads();
 }
 
-// The q / K values of one position as the lanes hold them: lane (l31 = position, half) owns features
-// [8 half, 8 half + 8).  Loading (global) and writing the x^T tile (LDS) are separate steps so that the
-// rows of tile t+1 are requested before the matrix products of tile t (the only HBM latency of a pass).
+// What one position brings, as the lanes hold it: lane (l31 = position, half) owns features
+// [8 half, 8 half + 8) of its q, K (and dout) rows.  Loading (global) and writing the x^T tile (LDS)
+// are separate steps so that the rows of tile t+1 are requested before the matrix products of tile t
+// (the only HBM latency of a pass).  EC > 0: E is the compile-time constant EC and rows are 16-byte
+// aligned (the BASELINE shape E = 16 and E = 8); EC = 0: any E <= 16, any alignment.
 struct DaRows {
-    float qv[8], kv[8];
-    int64_t b;
+    float qv[8], kv[8], dov[8];
+    uint32_t b;
     int l;
+    float m;      // 1 = position kept, 0 = masked
 };
 
+__device__ __forceinline__ void da_ld8(const float* p, bool vec, int e0, int E, float (&v)[8]) {
+    if (vec) {
+        const float4 t0 = *reinterpret_cast<const float4*>(p);
+        const float4 t1 = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
+        v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u < E) v[u] = p[u];
+    }
+}
+
+template <int EC, bool DOUT, bool MASK>
 __device__ __forceinline__ void da_load_rows(const DinAttnArgs& a, int64_t row, bool valid, int half,
                                              DaRows& x) {
+    const int E = EC ? EC : a.E, e0 = 8 * half;
+    const bool vec = EC ? true : (a.vec != 0);
     x.b = 0;
     x.l = 0;
-    if (valid) {
-        x.b = row / a.L;
-        x.l = (int)(row - x.b * a.L);
-    }
-    const int E = a.E, e0 = 8 * half;
+    x.m = 0.f;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         x.qv[u] = 0.f;
         x.kv[u] = 0.f;
+        x.dov[u] = 0.f;
     }
-    if (valid && e0 < E) {
-        const float* qp = a.q + x.b * a.q_ld + e0;
-        const float* kp = a.K + x.b * a.k_ldb + (int64_t)x.l * a.k_ldl + e0;
-        if (a.vec) {
-            const float4 q0 = *reinterpret_cast<const float4*>(qp);
-            const float4 q1 = *reinterpret_cast<const float4*>(qp + 4);
-            const float4 k0 = *reinterpret_cast<const float4*>(kp);
-            const float4 k1 = *reinterpret_cast<const float4*>(kp + 4);
-            x.qv[0] = q0.x; x.qv[1] = q0.y; x.qv[2] = q0.z; x.qv[3] = q0.w;
-            x.qv[4] = q1.x; x.qv[5] = q1.y; x.qv[6] = q1.z; x.qv[7] = q1.w;
-            x.kv[0] = k0.x; x.kv[1] = k0.y; x.kv[2] = k0.z; x.kv[3] = k0.w;
-            x.kv[4] = k1.x; x.kv[5] = k1.y; x.kv[6] = k1.z; x.kv[7] = k1.w;
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (e0 + u < E) {
-                    x.qv[u] = qp[u];
-                    x.kv[u] = kp[u];
-                }
-            }
+    if (valid) {
+        const uint32_t r32 = (uint32_t)row, L32 = (uint32_t)a.L;     // B * L < 2^31 (checked on the host)
+        x.b = r32 / L32;
+        x.l = (int)(r32 - x.b * L32);
+        if (MASK) x.m = (!a.mask || a.mask[(int64_t)x.b * a.m_ld + x.l] != 0) ? 1.f : 0.f;
+        if (e0 < E) {
+            da_ld8(a.q + (int64_t)x.b * a.q_ld + e0, vec, e0, E, x.qv);
+            da_ld8(a.K + (int64_t)x.b * a.k_ldb + (int64_t)x.l * a.k_ldl + e0, vec, e0, E, x.kv);
+            if (DOUT) da_ld8(a.dout + (int64_t)x.b * a.dout_ld + e0, vec, e0, E, x.dov);
         }
     }
 }
 
 // x^T[f][position] = [q, k, q - k, q * k] of the tile (rows outside the range were loaded as 0)
-__device__ __forceinline__ void da_store_x(float* Xs, int E, int l31, int half, const DaRows& x) {
-    const int e0 = 8 * half;
+template <int EC>
+__device__ __forceinline__ void da_store_x(float* Xs, int Erun, int l31, int half, const DaRows& x) {
+    const int E = EC ? EC : Erun, e0 = 8 * half;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int e = e0 + u;
@@ -195,28 +210,108 @@ __device__ __forceinline__ float da_sigmoid(float z) {
 //   POS_IN_LANE = false: h = x W1^T   -> acc[j][r] = h(position rowmap(r, half), unit 32 j + l31):
 //                        one unit per lane (per-unit statistics are register loops, the unit's
 //                        parameters are lane constants)
-// Same LDS reads either way; only the operand order of the MFMA changes.
-template <int NB, bool POS_IN_LANE>
-__device__ __forceinline__ void da_gemm_h(const float* __restrict__ W1s, int ldw,
-                                          const float* __restrict__ Xs, int KX, int l31, int half,
-                                          da_f32x16 (&acc)[NB]) {
+// Same LDS reads either way; only the operand order of the MFMA changes.  KXC > 0 (= 4 EC): fully
+// unrolled, the fragments of step k+1 are read before the MFMAs of step k are issued — the first
+// version (a rolled loop: read, wait, 2 MFMAs, read, wait ...) exposed the LDS latency 32 x per tile.
+template <int NB, bool POS_IN_LANE, int KXC, int LDW>
+__device__ __forceinline__ void da_gemm_h(const float* __restrict__ W1s, const float* __restrict__ Xs,
+                                          int KX, int l31, int half, da_f32x16 (&acc)[NB]) {
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const float* xb = Xs + half * DA_LDX + l31;
-    const float* wa = W1s + half * ldw + l31;
-    const int nk = KX >> 1;
-#pragma unroll 4
-    for (int kk = 0; kk < nk; ++kk) {
-        const float bx = xb[2 * kk * DA_LDX];
+    const float* wa = W1s + half * LDW + l31;
+    if constexpr (KXC > 0) {
+        constexpr int NK = KXC / 2;
+        float bx[2], aw[2][NB];
+        bx[0] = xb[0];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const float aw = wa[2 * kk * ldw + 32 * j];
-            if constexpr (POS_IN_LANE)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bx, acc[j], 0, 0, 0);
-            else
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bx, aw, acc[j], 0, 0, 0);
+        for (int j = 0; j < NB; ++j) aw[0][j] = wa[32 * j];
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int c = kk & 1, n = c ^ 1;
+            if (kk + 1 < NK) {
+                bx[n] = xb[2 * (kk + 1) * DA_LDX];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) aw[n][j] = wa[2 * (kk + 1) * LDW + 32 * j];
+            }
+            // pin the order "reads of step k+1, then MFMAs of step k": left alone, the scheduler
+            // sinks every read to just before its MFMA (read, wait, 2 MFMAs, read, wait, ...) and
+            // the matrix pipe idles for one LDS latency per step
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if constexpr (POS_IN_LANE)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[c][j], bx[c], acc[j], 0, 0, 0);
+                else
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bx[c], aw[c][j], acc[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        const int nk = KX >> 1;
+#pragma unroll 4
+        for (int kk = 0; kk < nk; ++kk) {
+            const float bx = xb[2 * kk * DA_LDX];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float aw = wa[2 * kk * LDW + 32 * j];
+                if constexpr (POS_IN_LANE)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bx, acc[j], 0, 0, 0);
+                else
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bx, aw, acc[j], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// Per-sample sums over the positions of a tile T[feature][position] (E rows x DA_LDX), carried across
+// the tiles of a wave that owns whole samples: run (+)= the tile's positions of the current sample;
+// when the sample's L-th position lies in the tile, out[b][e] = run and the rest of the tile opens the
+// next sample.  L >= 32 (at most one sample ends inside a tile): lane (e = lane & 15, g = lane >> 4)
+// adds positions [8 g, 8 g + 8), the four groups are combined by two xor-shuffles (every lane of a
+// feature ends with the same bits); smaller L: lane e walks the positions in order.
+__device__ __forceinline__ void da_seg_sum(const float* T, int E, int L, int lane, int nvalid,
+                                           uint32_t& bcur, int& lcur, float& run, float* out,
+                                           int64_t out_ld) {
+    if (L >= 32) {
+        const int e = lane & 15, g = lane >> 4;
+        const int c = (L - lcur < nvalid) ? L - lcur : nvalid;   // positions that belong to sample bcur
+        float v0 = 0.f, v1 = 0.f;
+        if (e < E) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = T[e * DA_LDX + 8 * g + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = 8 * g + u;
+                if (i < c) v0 += t[u];
+                else if (i < nvalid) v1 += t[u];
+            }
+        }
+        v0 += __shfl_xor(v0, 16, 64);
+        v0 += __shfl_xor(v0, 32, 64);
+        v1 += __shfl_xor(v1, 16, 64);
+        v1 += __shfl_xor(v1, 32, 64);
+        run += v0;
+        if (lcur + c == L) {
+            if (lane < E) out[(int64_t)bcur * out_ld + lane] = run;
+            run = v1;
+            ++bcur;
+            lcur = nvalid - c;
+        } else {
+            lcur += c;
+        }
+    } else {
+        for (int i = 0; i < nvalid; ++i) {
+            if (lane < E) run += T[lane * DA_LDX + i];
+            if (++lcur == L) {
+                if (lane < E) out[(int64_t)bcur * out_ld + lane] = run;
+                run = 0.f;
+                lcur = 0;
+                ++bcur;
+            }
         }
     }
 }
@@ -225,9 +320,9 @@ __device__ __forceinline__ void da_gemm_h(const float* __restrict__ W1s, int ldw
 // forward, pass 1: per-workgroup partial sums of h and h^2 over the positions
 //   partial[(wg * 2 + k) * H + n]
 // ---------------------------------------------------------------------------------------------
-template <int NB, int FB>
+template <int NB, int FB, int EC>
 __global__ __launch_bounds__(256) void k_din_attn_stats(DinAttnArgs a) {
-    using S = DaSmem<NB, FB, 4, false>;
+    using S = DaSmem<NB, FB, 4, false, false>;
     __shared__ S sm;
     da_load_params(sm, a, 256);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
@@ -244,12 +339,12 @@ __global__ __launch_bounds__(256) void k_din_attn_stats(DinAttnArgs a) {
         b1v[j] = sm.PA[32 * j + l31].x;
     }
     DaRows cur;
-    da_load_rows(a, R0 + l31, R0 + l31 < R1, half, cur);
+    da_load_rows<EC, false, false>(a, R0 + l31, R0 + l31 < R1, half, cur);
     for (int64_t rb = R0; rb < R1; rb += 32) {
-        da_store_x(Xs, a.E, l31, half, cur);
-        da_load_rows(a, rb + 32 + l31, rb + 32 + l31 < R1, half, cur);     // tile t+1 in flight
+        da_store_x<EC>(Xs, a.E, l31, half, cur);
+        da_load_rows<EC, false, false>(a, rb + 32 + l31, rb + 32 + l31 < R1, half, cur);   // tile t+1
         da_f32x16 acc[NB];
-        da_gemm_h<NB, false>(sm.W1s, S::LDW, Xs, KX, l31, half, acc);
+        da_gemm_h<NB, false, 4 * EC, S::LDW>(sm.W1s, Xs, KX, l31, half, acc);
         const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
 #pragma unroll
         for (int j = 0; j < NB; ++j)
@@ -283,29 +378,35 @@ __global__ __launch_bounds__(256) void k_din_attn_stats(DinAttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward, pass 2: a[b*L + l] = W2 . Dice(W1 x + b1) + b2
+// forward, pass 2: a[b*L + l] = W2 . Dice(W1 x + b1) + b2;  out[b] = sum_l a mask k   (a wave owns
+// whole samples)
 // ---------------------------------------------------------------------------------------------
-template <int NB, int FB>
+template <int NB, int FB, int EC>
 __global__ __launch_bounds__(256) void k_din_attn_fwd(DinAttnArgs a) {
-    using S = DaSmem<NB, FB, 4, false>;
+    using S = DaSmem<NB, FB, 4, false, true>;
     __shared__ S sm;
     da_load_params(sm, a, 256);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
     float* Xs = sm.Xs[wave];
-    const int KX = 4 * a.E;
+    float* Ps = sm.Ps[wave];
+    const int E = EC ? EC : a.E, KX = 4 * E, L = a.L, e0 = 8 * half;
     const float b2 = a.b2 ? a.b2[0] : 0.f;
     const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
     const int64_t R0 = gw * a.rows_per_wave;
     const int64_t R1 = (R0 + a.rows_per_wave < a.n_rows) ? R0 + a.rows_per_wave : a.n_rows;
+    uint32_t bcur = (uint32_t)(R0 / L);
+    int lcur = 0;
+    float run = 0.f;
     DaRows cur;
-    da_load_rows(a, R0 + l31, R0 + l31 < R1, half, cur);
+    da_load_rows<EC, false, true>(a, R0 + l31, R0 + l31 < R1, half, cur);
     for (int64_t rb = R0; rb < R1; rb += 32) {
         const int64_t row = rb + l31;
         const bool valid = row < R1;
-        da_store_x(Xs, a.E, l31, half, cur);
-        da_load_rows(a, row + 32, row + 32 < R1, half, cur);               // tile t+1 in flight
+        const float m = cur.m;
+        da_store_x<EC>(Xs, E, l31, half, cur);
+        da_load_rows<EC, false, true>(a, row + 32, row + 32 < R1, half, cur);              // tile t+1
         da_f32x16 acc[NB];
-        da_gemm_h<NB, true>(sm.W1s, S::LDW, Xs, KX, l31, half, acc);
+        da_gemm_h<NB, true, 4 * EC, S::LDW>(sm.W1s, Xs, KX, l31, half, acc);
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < NB; ++j)
@@ -321,19 +422,30 @@ __global__ __launch_bounds__(256) void k_din_attn_fwd(DinAttnArgs a) {
                 t += y * w2;
             }
         const float o = __shfl_xor(t, 32, 64);
-        const float s = half == 0 ? t + o : o + t;        // units of half 0 first, in both lanes
-        if (half == 0 && valid) a.a_out[row] = s + b2;
+        const float ai = (half == 0 ? t + o : o + t) + b2;   // units of half 0 first, in both lanes
+        if (half == 0 && valid) a.a_out[row] = ai;
+        // pooled output: this position's share a mask k, summed per sample
+        const float wm = valid ? ai * m : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u;
+            if (e < E) Ps[e * DA_LDX + l31] = wm * Xs[(E + e) * DA_LDX + l31];
+        }
+        const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
+        da_seg_sum(Ps, E, L, lane, nvalid, bcur, lcur, run, a.out, a.out_ld);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, pass 1: per-workgroup partial sums over the positions
+// backward, pass 1: da = mask (dout . k) per position (written for pass 2), and the per-workgroup
+// partial sums over the positions
 //   k = 0: dalpha[n]  1: sum dzhat[n]  2: sum dzhat zhat[n]  3: dW2[n]  4: db2 (at n = 0)
 //   partial[(wg * 5 + k) * H + n]
 // ---------------------------------------------------------------------------------------------
-template <int NB, int FB>
-__global__ __launch_bounds__(256) void k_din_attn_bwd_sums(DinAttnArgs a) {
-    using S = DaSmem<NB, FB, 4, false>;
+template <int NB, int FB, int EC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_din_attn_bwd_sums(DinAttnArgs a) {
+    using S = DaSmem<NB, FB, 4, false, false>;
     __shared__ S sm;
     __shared__ float das[4][32];                   // da of the wave's 32 positions
     da_load_params(sm, a, 256);
@@ -357,22 +469,28 @@ __global__ __launch_bounds__(256) void k_din_attn_bwd_sums(DinAttnArgs a) {
         w2[j] = sm.PB[32 * j + l31].x;
     }
     DaRows cur;
-    da_load_rows(a, R0 + l31, R0 + l31 < R1, half, cur);
-    float da_i = (R0 + l31 < R1) ? a.da[R0 + l31] : 0.f;
+    da_load_rows<EC, true, true>(a, R0 + l31, R0 + l31 < R1, half, cur);
     for (int64_t rb = R0; rb < R1; rb += 32) {
         const int64_t row = rb + l31;
-        da_store_x(Xs, a.E, l31, half, cur);
+        const bool valid = row < R1;
+        da_store_x<EC>(Xs, a.E, l31, half, cur);
+        // da = mask * sum_e dout[b][e] k[e]  (fx_din_pool_bwd's dw): 8 features per lane, halves added
+        float d = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d = fmaf(cur.dov[u], cur.kv[u], d);
+        const float od = __shfl_xor(d, 32, 64);
+        const float da_i = (half == 0 ? d + od : od + d) * cur.m;      // 0 past the range (m = 0)
         if (half == 0) {
             das[wave][l31] = da_i;
             sb2 += da_i;
+            if (valid) a.da_out[row] = da_i;
         }
-        da_load_rows(a, row + 32, row + 32 < R1, half, cur);               // tile t+1 in flight
-        da_i = (row + 32 < R1) ? a.da[row + 32] : 0.f;
+        da_load_rows<EC, true, true>(a, row + 32, row + 32 < R1, half, cur);                // tile t+1
         da_f32x16 acc[NB];
-        da_gemm_h<NB, false>(sm.W1s, S::LDW, Xs, KX, l31, half, acc);
+        da_gemm_h<NB, false, 4 * EC, S::LDW>(sm.W1s, Xs, KX, l31, half, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float dar = das[wave][da_rowmap(r, half)];     // 0 for positions past the range
+            const float dar = das[wave][da_rowmap(r, half)];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const float z = acc[j][r] + pa[j].x;
@@ -419,22 +537,23 @@ __global__ __launch_bounds__(256) void k_din_attn_bwd_sums(DinAttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, pass 2: dh -> dW1 / db1 partials (per workgroup), dq, dK
+// backward, pass 2: dh -> dW1 / db1 partials (per workgroup), dq, dK (attention part + the pooling's
+// share a mask dout)
 //   partial[wg * (H * 4E + H) + n * 4E + f]  and  [... + H * 4E + n]
-// A wave owns whole samples (rows_per_wave is a multiple of L), so dq[b] is finished by one lane per
-// feature walking the positions in order.
+// A wave owns whole samples (rows_per_wave is a multiple of L), so dq[b] is finished inside the wave.
 // ---------------------------------------------------------------------------------------------
-template <int NB, int FB>
+template <int NB, int FB, int EC>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_din_attn_bwd(DinAttnArgs a) {
-    using S = DaSmem<NB, FB, 2, true>;
+    using S = DaSmem<NB, FB, 2, true, false>;
     __shared__ S sm;
     da_load_params(sm, a, 128);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
     float* Xs = sm.Xs[wave];
     float* Hs = sm.Hs[wave];
-    const int E = a.E, KX = 4 * E, H = a.H, L = a.L;
+    const int E = EC ? EC : a.E, KX = 4 * E, H = a.H, L = a.L;
     const int e0 = 8 * half;
+    const bool vec = EC ? true : (a.vec != 0);
     const int64_t gw = (int64_t)blockIdx.x * 2 + wave;
     const int64_t R0 = gw * a.rows_per_wave;
     const int64_t R1 = (R0 + a.rows_per_wave < a.n_rows) ? R0 + a.rows_per_wave : a.n_rows;
@@ -450,22 +569,27 @@ void k_din_attn_bwd(DinAttnArgs a) {
             for (int r = 0; r < 16; ++r) accW[j][jb][r] = 0.f;
         db1q[j] = 0.f;
     }
+    uint32_t bcur = (uint32_t)(R0 / L);
+    int lcur = 0;
     float dq_run = 0.f;
     DaRows cur;
-    da_load_rows(a, R0 + l31, R0 + l31 < R1, half, cur);
-    float da_n = (R0 + l31 < R1) ? a.da[R0 + l31] : 0.f;
+    da_load_rows<EC, false, true>(a, R0 + l31, R0 + l31 < R1, half, cur);
+    float da_n = (R0 + l31 < R1) ? a.da_in[R0 + l31] : 0.f;
+    float a_n = (R0 + l31 < R1) ? a.a_in[R0 + l31] : 0.f;
     for (int64_t rb = R0; rb < R1; rb += 32) {
         const int64_t row = rb + l31;
         const bool valid = row < R1;
-        const int64_t b = cur.b;
+        const uint32_t b = cur.b;
         const int l = cur.l;
         const float da_i = da_n;
-        da_store_x(Xs, E, l31, half, cur);
-        da_load_rows(a, row + 32, row + 32 < R1, half, cur);               // tile t+1 in flight
-        da_n = (row + 32 < R1) ? a.da[row + 32] : 0.f;
+        const float wm = a_n * cur.m;                              // a mask (fx_din_pool_bwd's w m)
+        da_store_x<EC>(Xs, E, l31, half, cur);
+        da_load_rows<EC, false, true>(a, row + 32, row + 32 < R1, half, cur);              // tile t+1
+        da_n = (row + 32 < R1) ? a.da_in[row + 32] : 0.f;
+        a_n = (row + 32 < R1) ? a.a_in[row + 32] : 0.f;
         {
             da_f32x16 acc[NB];
-            da_gemm_h<NB, true>(sm.W1s, S::LDW, Xs, KX, l31, half, acc);
+            da_gemm_h<NB, true, 4 * EC, S::LDW>(sm.W1s, Xs, KX, l31, half, acc);
 #pragma unroll
             for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -484,39 +608,58 @@ void k_din_attn_bwd(DinAttnArgs a) {
                     Hs[l31 * S::LDH + n] = dh;
                 }
         }
-        // dW1[n][f] += sum_i dh[i][n] x[i][f]
-#pragma unroll 2
-        for (int kk = 0; kk < 16; ++kk) {
-            float av[NB], bv[FB];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                av[j] = Hs[(2 * kk + half) * S::LDH + 32 * j + l31];
-                db1q[j] += av[j];                  // db1 rides along: the A fragments ARE dh
-            }
-#pragma unroll
-            for (int jb = 0; jb < FB; ++jb) bv[jb] = Xs[(32 * jb + l31) * DA_LDX + 2 * kk + half];
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int jb = 0; jb < FB; ++jb)
-                    accW[j][jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[jb], accW[j][jb],
-                                                                       0, 0, 0);
-        }
-        // dx^T[f][i] = sum_n W1[n][f] dh[i][n]
+        // dW1[n][f] += sum_i dh[i][n] x[i][f]  and  dx^T[f][i] = sum_n W1[n][f] dh[i][n], interleaved
+        // (six independent accumulator chains keep the matrix pipe busy while fragments are read)
         da_f32x16 accD[FB];
 #pragma unroll
         for (int jb = 0; jb < FB; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accD[jb][r] = 0.f;
-#pragma unroll 4
-        for (int kk = 0; kk < S::HP / 2; ++kk) {
-            const float bh = Hs[l31 * S::LDH + 2 * kk + half];
+        {
+            // fragments of step k+1 are read before the MFMAs of step k (order pinned as in da_gemm_h)
+            float av[2][NB], bv[2][FB], bh[2][NB], aw[2][NB][FB];
+            auto rd = [&](int kk, int s_) {
 #pragma unroll
-            for (int jb = 0; jb < FB; ++jb) {
-                const float aw = sm.W1s[(32 * jb + l31) * S::LDW + 2 * kk + half];
-                accD[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bh, accD[jb], 0, 0, 0);
+                for (int j = 0; j < NB; ++j) av[s_][j] = Hs[(2 * kk + half) * S::LDH + 32 * j + l31];
+#pragma unroll
+                for (int jb = 0; jb < FB; ++jb) bv[s_][jb] = Xs[(32 * jb + l31) * DA_LDX + 2 * kk + half];
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const int kd = kk * NB + t;     // HP / 2 = 16 NB steps over the hidden units
+                    bh[s_][t] = Hs[l31 * S::LDH + 2 * kd + half];
+#pragma unroll
+                    for (int jb = 0; jb < FB; ++jb)
+                        aw[s_][t][jb] = sm.W1s[(32 * jb + l31) * S::LDW + 2 * kd + half];
+                }
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int c = kk & 1;
+                if (kk + 1 < 16) rd(kk + 1, c ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    db1q[j] += av[c][j];           // db1 rides along: the A fragments ARE dh
+#pragma unroll
+                    for (int jb = 0; jb < FB; ++jb)
+                        accW[j][jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][j], bv[c][jb],
+                                                                           accW[j][jb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < NB; ++t)
+#pragma unroll
+                    for (int jb = 0; jb < FB; ++jb)
+                        accD[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[c][t][jb], bh[c][t],
+                                                                        accD[jb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // this sample's dout features of the lane (L1 / L2 hits: a tile spans 1-2 samples)
+        float dov[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dov[u] = 0.f;
+        if (valid && e0 < E) da_ld8(a.dout + (int64_t)b * a.dout_ld + e0, vec, e0, E, dov);
         // dx^T through LDS, over the dh tile (both products have consumed it); the x tile still holds
         // this tile's q and k rows
 #pragma unroll
@@ -524,8 +667,9 @@ void k_din_attn_bwd(DinAttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 Hs[(32 * jb + da_rowmap(r, half)) * DA_LDX + l31] = accD[jb][r];
-        // dk = dx_k - dx_(q-k) + dx_(q*k) q ;  this position's share of dq = dx_q + dx_(q-k) + dx_(q*k) k
-        // (written over the (q-k) rows of the x tile, which nobody reads any more)
+        // dk = dx_k - dx_(q-k) + dx_(q*k) q + a mask dout ;  this position's share of
+        // dq = dx_q + dx_(q-k) + dx_(q*k) k  (written over the (q-k) rows of the x tile, which nobody
+        // reads any more)
         float dkv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -537,20 +681,14 @@ void k_din_attn_bwd(DinAttnArgs a) {
                 const float dxb = Hs[(E + e) * DA_LDX + l31];
                 const float dxc = Hs[(2 * E + e) * DA_LDX + l31];
                 const float dxd = Hs[(3 * E + e) * DA_LDX + l31];
-                dkv[u] = dxb - dxc + dxd * qe;
+                dkv[u] = (dxb - dxc + dxd * qe) + wm * dov[u];
                 const float dqc = dxa + dxc + dxd * ke;
                 Xs[(2 * E + e) * DA_LDX + l31] = valid ? dqc : 0.f;
             }
         }
         if (valid && e0 < E) {
-            float* dkp = a.dK + b * a.dk_ldb + (int64_t)l * a.dk_ldl + e0;
-            if (a.dk_add) {
-                const float* ap = a.dk_add + b * a.dka_ldb + (int64_t)l * a.dka_ldl + e0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (e0 + u < E) dkv[u] += ap[u];
-            }
-            if (a.vec) {
+            float* dkp = a.dK + (int64_t)b * a.dk_ldb + (int64_t)l * a.dk_ldl + e0;
+            if (vec) {
                 *reinterpret_cast<float4*>(dkp) = make_float4(dkv[0], dkv[1], dkv[2], dkv[3]);
                 *reinterpret_cast<float4*>(dkp + 4) = make_float4(dkv[4], dkv[5], dkv[6], dkv[7]);
             } else {
@@ -559,21 +697,8 @@ void k_din_attn_bwd(DinAttnArgs a) {
                     if (e0 + u < E) dkp[u] = dkv[u];
             }
         }
-        // dq: lane e walks the tile's positions in order; a sample ends after its L-th position
-        {
-            int64_t bcur = rb / L;
-            int lcur = (int)(rb - bcur * L);
-            const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
-            for (int i = 0; i < nvalid; ++i) {
-                if (lane < E) dq_run += Xs[(2 * E + lane) * DA_LDX + i];
-                if (++lcur == L) {
-                    if (lane < E) a.dq[bcur * a.dq_ld + lane] = dq_run;
-                    dq_run = 0.f;
-                    lcur = 0;
-                    ++bcur;
-                }
-            }
-        }
+        const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
+        da_seg_sum(Xs + 2 * E * DA_LDX, E, L, lane, nvalid, bcur, lcur, dq_run, a.dq, a.dq_ld);
     }
     __syncthreads();                               // both waves have left their tile loops
     float* scratch = &sm.Xs[0][0];                 // wave 1's dW1 accumulators: NB*FB*16*64 floats
@@ -661,7 +786,7 @@ __global__ __launch_bounds__(256) void k_da_stats_from_sums(const float* sums, i
 // host side
 // ---------------------------------------------------------------------------------------------
 struct DaGeom {
-    int64_t n_rows, rpw13, wgs13, rpw4, wgs4;
+    int64_t n_rows, rpw_flat, wgs_flat, rpw_fwd, wgs_fwd, rpw_bwd, wgs_bwd;
 };
 
 static int64_t da_env_cap(const char* name, int64_t dflt) {
@@ -671,29 +796,33 @@ static int64_t da_env_cap(const char* name, int64_t dflt) {
 }
 
 static DaGeom da_geom(int64_t B, int32_t L) {
-    // waves per launch (experiment switches FX_DIN_ATTN_WAVES / FX_DIN_ATTN_BWD_WAVES): the passes are
-    // a serial chain per wave (x tile -> MFMA -> gate -> ...), so what matters is that every SIMD gets
-    // the same number of tiles, not how many waves are resident
-    static const int64_t cap13 = da_env_cap("FX_DIN_ATTN_WAVES", 2048);
-    static const int64_t cap4 = da_env_cap("FX_DIN_ATTN_BWD_WAVES", 1536);
+    // waves per launch (experiment switches FX_DIN_ATTN_WAVES / _FWD_WAVES / _BWD_WAVES): a pass is a
+    // serial chain per wave (x tile -> MFMA -> gate -> ...), so what matters is that every SIMD gets
+    // the same number of tiles (measured: profiles/r02_din_attn_passes.txt)
+    static const int64_t cap_flat = da_env_cap("FX_DIN_ATTN_WAVES", 2048);
+    static const int64_t cap_fwd = da_env_cap("FX_DIN_ATTN_FWD_WAVES", 2048);
+    static const int64_t cap_bwd = da_env_cap("FX_DIN_ATTN_BWD_WAVES", 1536);
     DaGeom g;
     g.n_rows = B * L;
-    // passes without a per-sample reduction: 32-position tiles dealt to <= cap13 waves
+    // statistics passes: 32-position tiles dealt to <= cap_flat waves, no per-sample reduction
     const int64_t nblocks = fx_ceil_div(g.n_rows, 32);
-    const int64_t bpw = fx_ceil_div(nblocks, cap13) > 1 ? fx_ceil_div(nblocks, cap13) : 1;
-    g.rpw13 = bpw * 32;
-    g.wgs13 = fx_ceil_div(fx_ceil_div(nblocks, bpw), 4);
-    // backward apply: whole samples per wave, <= cap4 waves (3 workgroups of 2 waves per CU: LDS)
-    const int64_t S = fx_ceil_div(B, cap4) > 1 ? fx_ceil_div(B, cap4) : 1;
-    g.rpw4 = S * L;
-    g.wgs4 = fx_ceil_div(fx_ceil_div(B, S), 2);
+    const int64_t bpw = fx_ceil_div(nblocks, cap_flat) > 1 ? fx_ceil_div(nblocks, cap_flat) : 1;
+    g.rpw_flat = bpw * 32;
+    g.wgs_flat = fx_ceil_div(fx_ceil_div(nblocks, bpw), 4);
+    // apply passes: whole samples per wave (out[b] / dq[b] are finished inside the wave)
+    const int64_t Sf = fx_ceil_div(B, cap_fwd) > 1 ? fx_ceil_div(B, cap_fwd) : 1;
+    g.rpw_fwd = Sf * L;
+    g.wgs_fwd = fx_ceil_div(fx_ceil_div(B, Sf), 4);
+    const int64_t Sb = fx_ceil_div(B, cap_bwd) > 1 ? fx_ceil_div(B, cap_bwd) : 1;
+    g.rpw_bwd = Sb * L;
+    g.wgs_bwd = fx_ceil_div(fx_ceil_div(B, Sb), 2);      // 2 waves per workgroup: 3 per CU fit (LDS)
     return g;
 }
 
 extern "C" int64_t fx_din_attn_workspace_floats(int64_t B, int32_t L, int32_t E, int32_t H) {
     if (B < 1 || L < 1 || E < 1 || H < 1) return 0;
     const DaGeom g = da_geom(B, L);
-    const int64_t a = g.wgs13 * 5 * H, b = g.wgs4 * ((int64_t)H * 4 * E + H);
+    const int64_t a = g.wgs_flat * 5 * H, b = g.wgs_bwd * ((int64_t)H * 4 * E + H);
     return a > b ? a : b;
 }
 
@@ -706,27 +835,33 @@ static int da_check(const char* who, const float* q, const float* K, int64_t B, 
     return FX_OK;
 }
 
+static bool da_al16(const void* p, int64_t ld0, int64_t ld1 = 0) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld0 % 4 == 0 && ld1 % 4 == 0;
+}
+
 static void da_fill(DinAttnArgs& a, const float* q, int64_t q_ld, const float* K, int64_t k_ldb,
                     int64_t k_ldl, int64_t B, int32_t L, int32_t E, int32_t H, const float* W1,
                     const float* b1) {
     memset(&a, 0, sizeof(a));
     a.q = q; a.q_ld = q_ld; a.K = K; a.k_ldb = k_ldb; a.k_ldl = k_ldl;
     a.n_rows = B * L; a.L = L; a.E = E; a.H = H; a.W1 = W1; a.b1 = b1;
-    a.vec = (E % 8 == 0) && (q_ld % 4 == 0) && (k_ldb % 4 == 0) && (k_ldl % 4 == 0) &&
-            (((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(K)) & 15) == 0);
+    a.vec = (E % 8 == 0) && da_al16(q, q_ld) && da_al16(K, k_ldb, k_ldl);
 }
 
-#define DA_DISPATCH(KERNEL, THREADS, GRID, STREAM, ARGS)                                             \
-    do {                                                                                             \
-        const int nb_ = (ARGS.H + 31) / 32, fb_ = (4 * ARGS.E + 31) / 32;                            \
-        if (nb_ == 1 && fb_ == 1)                                                                    \
-            hipLaunchKernelGGL((KERNEL<1, 1>), dim3((unsigned)(GRID)), dim3(THREADS), 0, STREAM, ARGS); \
-        else if (nb_ == 1)                                                                           \
-            hipLaunchKernelGGL((KERNEL<1, 2>), dim3((unsigned)(GRID)), dim3(THREADS), 0, STREAM, ARGS); \
-        else if (fb_ == 1)                                                                           \
-            hipLaunchKernelGGL((KERNEL<2, 1>), dim3((unsigned)(GRID)), dim3(THREADS), 0, STREAM, ARGS); \
-        else                                                                                         \
-            hipLaunchKernelGGL((KERNEL<2, 2>), dim3((unsigned)(GRID)), dim3(THREADS), 0, STREAM, ARGS); \
+// (NB, FB, EC): hidden blocks, feature blocks, compile-time E (16 / 8 with 16-byte rows, else 0)
+#define DA_LAUNCH(KERNEL, NB_, FB_, EC_, THREADS, GRID, STREAM, ARGS) \
+    hipLaunchKernelGGL((KERNEL<NB_, FB_, EC_>), dim3((unsigned)(GRID)), dim3(THREADS), 0, STREAM, ARGS)
+#define DA_DISPATCH_NB(KERNEL, NB_, THREADS, GRID, STREAM, ARGS)                                  \
+    do {                                                                                          \
+        if (ARGS.vec && ARGS.E == 16) DA_LAUNCH(KERNEL, NB_, 2, 16, THREADS, GRID, STREAM, ARGS); \
+        else if (ARGS.vec && ARGS.E == 8) DA_LAUNCH(KERNEL, NB_, 1, 8, THREADS, GRID, STREAM, ARGS); \
+        else if (4 * ARGS.E <= 32) DA_LAUNCH(KERNEL, NB_, 1, 0, THREADS, GRID, STREAM, ARGS);     \
+        else DA_LAUNCH(KERNEL, NB_, 2, 0, THREADS, GRID, STREAM, ARGS);                           \
+    } while (0)
+#define DA_DISPATCH(KERNEL, THREADS, GRID, STREAM, ARGS)                                          \
+    do {                                                                                          \
+        if (ARGS.H <= 32) DA_DISPATCH_NB(KERNEL, 1, THREADS, GRID, STREAM, ARGS);                 \
+        else DA_DISPATCH_NB(KERNEL, 2, THREADS, GRID, STREAM, ARGS);                              \
     } while (0)
 
 extern "C" int fx_din_attn_stats(const float* q, int64_t q_ld, const float* K, int64_t k_ldb,
@@ -739,12 +874,12 @@ extern "C" int fx_din_attn_stats(const float* q, int64_t q_ld, const float* K, i
     const DaGeom g = da_geom(B, L);
     DinAttnArgs a;
     da_fill(a, q, q_ld, K, k_ldb, k_ldl, B, L, E, H, W1, b1);
-    a.rows_per_wave = g.rpw13;
+    a.rows_per_wave = g.rpw_flat;
     a.partial = workspace;
     hipStream_t s = fx_hip_stream(stream);
-    DA_DISPATCH(k_din_attn_stats, 256, g.wgs13, s, a);
+    DA_DISPATCH(k_din_attn_stats, 256, g.wgs_flat, s, a);
     hipLaunchKernelGGL(k_da_chunks_sum, dim3((unsigned)fx_ceil_div(H, 16), 2), dim3(256), 0, s,
-                       (const float*)workspace, (int)g.wgs13, 2, (int64_t)H, sums);
+                       (const float*)workspace, (int)g.wgs_flat, 2, (int64_t)H, sums);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
@@ -771,18 +906,20 @@ extern "C" int fx_dice_stats_from_sums(const float* sums, int32_t H, int64_t n_t
 extern "C" int fx_din_attn_fwd(const float* q, int64_t q_ld, const float* K, int64_t k_ldb,
                                int64_t k_ldl, int64_t B, int32_t L, int32_t E, const float* W1,
                                const float* b1, int32_t H, const float* alpha, float eps,
-                               const float* stats, const float* W2, const float* b2, float* a_out,
-                               fx_stream_t stream) {
+                               const float* stats, const float* W2, const float* b2,
+                               const int32_t* mask, int64_t mask_ld, float* a_out, float* out,
+                               int64_t out_ld, fx_stream_t stream) {
     int rc = da_check("fx_din_attn_fwd", q, K, B, L, E, H, W1);
     if (rc != FX_OK) return rc;
-    FX_CHECK_ARG(alpha && stats && W2 && a_out, "fx_din_attn_fwd: null pointer");
+    FX_CHECK_ARG(alpha && stats && W2 && a_out && out, "fx_din_attn_fwd: null pointer");
     const DaGeom g = da_geom(B, L);
     DinAttnArgs a;
     da_fill(a, q, q_ld, K, k_ldb, k_ldl, B, L, E, H, W1, b1);
-    a.rows_per_wave = g.rpw13;
-    a.alpha = alpha; a.eps = eps; a.stats = stats; a.W2 = W2; a.b2 = b2; a.a_out = a_out;
+    a.rows_per_wave = g.rpw_fwd;
+    a.alpha = alpha; a.eps = eps; a.stats = stats; a.W2 = W2; a.b2 = b2;
+    a.mask = mask; a.m_ld = mask_ld; a.a_out = a_out; a.out = out; a.out_ld = out_ld;
     hipStream_t s = fx_hip_stream(stream);
-    DA_DISPATCH(k_din_attn_fwd, 256, g.wgs13, s, a);
+    DA_DISPATCH(k_din_attn_fwd, 256, g.wgs_fwd, s, a);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
@@ -790,22 +927,25 @@ extern "C" int fx_din_attn_fwd(const float* q, int64_t q_ld, const float* K, int
 extern "C" int fx_din_attn_bwd_sums(const float* q, int64_t q_ld, const float* K, int64_t k_ldb,
                                     int64_t k_ldl, int64_t B, int32_t L, int32_t E, const float* W1,
                                     const float* b1, int32_t H, const float* alpha, float eps,
-                                    const float* stats, const float* W2, const float* da,
+                                    const float* stats, const float* W2, const int32_t* mask,
+                                    int64_t mask_ld, const float* dout, int64_t dout_ld, float* da,
                                     float* sums5, float* workspace, fx_stream_t stream) {
     int rc = da_check("fx_din_attn_bwd_sums", q, K, B, L, E, H, W1);
     if (rc != FX_OK) return rc;
-    FX_CHECK_ARG(alpha && stats && W2 && da && sums5 && workspace,
+    FX_CHECK_ARG(alpha && stats && W2 && dout && da && sums5 && workspace,
                  "fx_din_attn_bwd_sums: null pointer");
     const DaGeom g = da_geom(B, L);
     DinAttnArgs a;
     da_fill(a, q, q_ld, K, k_ldb, k_ldl, B, L, E, H, W1, b1);
-    a.rows_per_wave = g.rpw13;
-    a.alpha = alpha; a.eps = eps; a.stats = stats; a.W2 = W2; a.da = da;
+    a.vec = a.vec && da_al16(dout, dout_ld);
+    a.rows_per_wave = g.rpw_flat;
+    a.alpha = alpha; a.eps = eps; a.stats = stats; a.W2 = W2;
+    a.mask = mask; a.m_ld = mask_ld; a.dout = dout; a.dout_ld = dout_ld; a.da_out = da;
     a.partial = workspace;
     hipStream_t s = fx_hip_stream(stream);
-    DA_DISPATCH(k_din_attn_bwd_sums, 256, g.wgs13, s, a);
+    DA_DISPATCH(k_din_attn_bwd_sums, 256, g.wgs_flat, s, a);
     hipLaunchKernelGGL(k_da_chunks_sum, dim3((unsigned)fx_ceil_div(H, 16), 5), dim3(256), 0, s,
-                       (const float*)workspace, (int)g.wgs13, 5, (int64_t)H, sums5);
+                       (const float*)workspace, (int)g.wgs_flat, 5, (int64_t)H, sums5);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
@@ -814,33 +954,34 @@ extern "C" int fx_din_attn_bwd(const float* q, int64_t q_ld, const float* K, int
                                int64_t k_ldl, int64_t B, int32_t L, int32_t E, const float* W1,
                                const float* b1, int32_t H, const float* alpha, float eps,
                                int32_t training, const float* stats, const float* W2,
-                               const float* da, const float* sums5, int64_t n_total,
-                               const float* dk_add, int64_t dka_ldb, int64_t dka_ldl, float* dq,
-                               int64_t dq_ld, float* dK, int64_t dk_ldb, int64_t dk_ldl,
-                               float* dW1b1, float* workspace, fx_stream_t stream) {
+                               const int32_t* mask, int64_t mask_ld, const float* a_logit,
+                               const float* dout, int64_t dout_ld, const float* da,
+                               const float* sums5, int64_t n_total, float* dq, int64_t dq_ld,
+                               float* dK, int64_t dk_ldb, int64_t dk_ldl, float* dW1b1,
+                               float* workspace, fx_stream_t stream) {
     int rc = da_check("fx_din_attn_bwd", q, K, B, L, E, H, W1);
     if (rc != FX_OK) return rc;
-    FX_CHECK_ARG(alpha && stats && W2 && da && dq && dK && dW1b1 && workspace,
+    FX_CHECK_ARG(alpha && stats && W2 && a_logit && dout && da && dq && dK && dW1b1 && workspace,
                  "fx_din_attn_bwd: null pointer");
     FX_CHECK_ARG(!training || (sums5 && n_total >= B * (int64_t)L),
                  "fx_din_attn_bwd: training mode needs the backward sums and the global row count");
     const DaGeom g = da_geom(B, L);
     DinAttnArgs a;
     da_fill(a, q, q_ld, K, k_ldb, k_ldl, B, L, E, H, W1, b1);
-    a.rows_per_wave = g.rpw4;
-    a.alpha = alpha; a.eps = eps; a.stats = stats; a.W2 = W2; a.da = da;
+    a.vec = a.vec && da_al16(dout, dout_ld) && da_al16(dK, dk_ldb, dk_ldl);
+    a.rows_per_wave = g.rpw_bwd;
+    a.alpha = alpha; a.eps = eps; a.stats = stats; a.W2 = W2;
+    a.mask = mask; a.m_ld = mask_ld; a.a_in = a_logit; a.dout = dout; a.dout_ld = dout_ld;
+    a.da_in = da;
     a.sums = training ? sums5 : nullptr;
     a.inv_n = training ? 1.f / (float)n_total : 0.f;
-    a.dk_add = dk_add; a.dka_ldb = dka_ldb; a.dka_ldl = dka_ldl;
     a.dq = dq; a.dq_ld = dq_ld; a.dK = dK; a.dk_ldb = dk_ldb; a.dk_ldl = dk_ldl;
-    a.vec = a.vec && (dk_ldb % 4 == 0) && (dk_ldl % 4 == 0) &&
-            ((reinterpret_cast<uintptr_t>(dK) & 15) == 0);
     a.partial = workspace;
     hipStream_t s = fx_hip_stream(stream);
-    DA_DISPATCH(k_din_attn_bwd, 128, g.wgs4, s, a);
+    DA_DISPATCH(k_din_attn_bwd, 128, g.wgs_bwd, s, a);
     const int64_t tot = (int64_t)H * 4 * E + H;
     hipLaunchKernelGGL(k_da_chunks_sum, dim3((unsigned)fx_ceil_div(tot, 16), 1), dim3(256), 0, s,
-                       (const float*)workspace, (int)g.wgs4, 1, tot, dW1b1);
+                       (const float*)workspace, (int)g.wgs_bwd, 1, tot, dW1b1);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

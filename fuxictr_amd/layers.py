@@ -1757,8 +1757,8 @@ class _DinAttnFn(torch.autograd.Function):
     """target_attention.py:66-92 with its MLP_Block(4E -> H, Dice, -> 1) as ONE autograd node on the
     fused kernels of fx_din_attn.hip: neither the [B*L, 4E] concatenation nor the [B*L, H] hidden
     tensor is written.  Forward = statistics pass, (all-reduce across ranks), Dice statistics, apply
-    pass -> logits a[B, L], masked pooling; backward mirrors it (pool backward, sums pass,
-    (all-reduce), apply pass -> dq, dK, dW1, db1; dalpha, dW2, db2 come out of the sums pass)."""
+    pass -> logits a[B, L] and the masked pooled output; backward mirrors it (sums pass -> da,
+    dalpha, dW2, db2; (all-reduce); apply pass -> dq, dK, dW1, db1)."""
 
     @staticmethod
     def forward(ctx, q, K, mask_i32, W1, b1, alpha, W2, b2, mod):
@@ -1787,9 +1787,8 @@ class _DinAttnFn(torch.autograd.Function):
                                      mod.bn.running_var, stats)
         w2 = W2.reshape(-1)
         a = torch.empty(B, L, dtype=torch.float32, device=dev)
-        ops.din_attn_fwd(q, K, W1, b1, alpha, mod.bn.eps, stats, w2, b2, a)
         out = torch.empty(B, E, dtype=torch.float32, device=dev)
-        ops.din_pool_fwd(a, mask_i32, K, out)
+        ops.din_attn_fwd(q, K, W1, b1, alpha, mod.bn.eps, stats, w2, b2, mask_i32, a, out)
         ctx.save_for_backward(q, K, mask_i32, W1, b1, alpha, W2, stats, a)
         ctx.training, ctx.eps, ctx.dist, ctx.n_total = training, mod.bn.eps, dist, n_total
         return out
@@ -1801,19 +1800,18 @@ class _DinAttnFn(torch.autograd.Function):
         H = W1.shape[0]
         dev = q.device
         ws = _Workspace.get(dev, ops.din_attn_workspace_floats(B, L, E, H), tag="din_attn")
-        da = torch.empty(B, L, dtype=torch.float32, device=dev)
-        dKp = torch.empty(B, L, E, dtype=torch.float32, device=dev)
-        ops.din_pool_bwd(a, mask_i32, K, dout.contiguous(), da, dKp)
+        dout = dout.contiguous()
         w2 = W2.reshape(-1)
+        da = torch.empty(B, L, dtype=torch.float32, device=dev)
         sums5 = torch.empty(5 * H, dtype=torch.float32, device=dev)
-        ops.din_attn_bwd_sums(q, K, W1, b1, alpha, ctx.eps, stats, w2, da, sums5, ws)
+        ops.din_attn_bwd_sums(q, K, W1, b1, alpha, ctx.eps, stats, w2, mask_i32, dout, da, sums5, ws)
         if ctx.dist is not None:
             ctx.dist.all_reduce_sum(sums5[H:3 * H])   # sum dzhat, sum dzhat*zhat: global batch
         dq = torch.empty(B, E, dtype=torch.float32, device=dev)
         dK = torch.empty(B, L, E, dtype=torch.float32, device=dev)
         dW1b1 = torch.empty(H * 4 * E + H, dtype=torch.float32, device=dev)
-        ops.din_attn_bwd(q, K, W1, b1, alpha, ctx.eps, ctx.training, stats, w2, da, sums5,
-                         ctx.n_total, dKp, dq, dK, dW1b1, ws)
+        ops.din_attn_bwd(q, K, W1, b1, alpha, ctx.eps, ctx.training, stats, w2, mask_i32, a, dout,
+                         da, sums5, ctx.n_total, dq, dK, dW1b1, ws)
         dW1 = dW1b1[:H * 4 * E].view(H, 4 * E)
         db1 = dW1b1[H * 4 * E:] if b1 is not None else None
         dW2 = sums5[3 * H:4 * H].view(W2.shape)
@@ -1860,11 +1858,7 @@ class DIN_Attention(nn.Module):
         if plan is not None and 4 * history_sequence.size(2) == plan[0].in_features \
                 and target_item.dim() == 2:
             lin1, dice, lin2 = plan
-            if mask is None:
-                m = torch.ones(history_sequence.shape[:2], dtype=torch.int32,
-                               device=history_sequence.device)
-            else:
-                m = mask.to(torch.int32).contiguous()
+            m = None if mask is None else mask.to(torch.int32).contiguous()
             if dice.training:
                 dice.bn.num_batches_tracked += 1
             return _DinAttnFn.apply(target_item, history_sequence, m, lin1.weight, lin1.bias,

@@ -594,7 +594,7 @@ def din_attn_stats(q, K, W1, b1, sums, workspace):
     """sums[2H] = [sum h | sum h^2] over the B*L positions, h = W1 [q,k,q-k,q*k] + b1."""
     K, head = _din_attn_head(q, K)
     H = W1.shape[0]
-    check(_lib.load().fx_din_attn_stats(*head, ptr(W1), ptr(b1) if b1 is not None else None, H,
+    check(_lib.load().fx_din_attn_stats(*head, ptr(W1), ptr(b1), H,
                                         ptr(sums), ptr(workspace), stream_ptr(q.device)),
           "fx_din_attn_stats")
 
@@ -606,37 +606,40 @@ def dice_stats_from_sums(sums, H, n_total, momentum, training, running_mean, run
                                               stream_ptr(stats.device)), "fx_dice_stats_from_sums")
 
 
-def din_attn_fwd(q, K, W1, b1, alpha, eps, stats, W2, b2, a_out):
+def din_attn_fwd(q, K, W1, b1, alpha, eps, stats, W2, b2, mask, a_out, out):
+    """a_out[B, L] = attention logits (before the mask), out[B, E] = sum_l a mask k."""
     K, head = _din_attn_head(q, K)
     H = W1.shape[0]
-    check(_lib.load().fx_din_attn_fwd(*head, ptr(W1), ptr(b1) if b1 is not None else None, H,
-                                      ptr(alpha), eps, ptr(stats), ptr(W2),
-                                      ptr(b2) if b2 is not None else None, ptr(a_out),
-                                      stream_ptr(q.device)), "fx_din_attn_fwd")
-    return a_out
+    check(_lib.load().fx_din_attn_fwd(*head, ptr(W1), ptr(b1), H, ptr(alpha), eps, ptr(stats),
+                                      ptr(W2), ptr(b2), ptr(mask),
+                                      mask.stride(0) if mask is not None else 0, ptr(a_out),
+                                      ptr(out), out.stride(0), stream_ptr(q.device)),
+          "fx_din_attn_fwd")
+    return out
 
 
-def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, da, sums5, workspace):
-    """sums5[5H] = [dalpha | sum dzhat | sum dzhat*zhat | dW2 | db2, 0, ...]."""
+def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, mask, dout, da, sums5, workspace):
+    """da[B, L] = mask (dout . k);  sums5[5H] = [dalpha | sum dzhat | sum dzhat*zhat | dW2 | db2, 0...]."""
     K, head = _din_attn_head(q, K)
     H = W1.shape[0]
-    check(_lib.load().fx_din_attn_bwd_sums(*head, ptr(W1), ptr(b1) if b1 is not None else None, H,
-                                           ptr(alpha), eps, ptr(stats), ptr(W2), ptr(da),
-                                           ptr(sums5), ptr(workspace), stream_ptr(q.device)),
-          "fx_din_attn_bwd_sums")
+    check(_lib.load().fx_din_attn_bwd_sums(*head, ptr(W1), ptr(b1), H, ptr(alpha), eps, ptr(stats),
+                                           ptr(W2), ptr(mask),
+                                           mask.stride(0) if mask is not None else 0, ptr(dout),
+                                           dout.stride(0), ptr(da), ptr(sums5), ptr(workspace),
+                                           stream_ptr(q.device)), "fx_din_attn_bwd_sums")
 
 
-def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, da, sums5, n_total, dk_add, dq, dK,
-                 dW1b1, workspace):
+def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, mask, a_logit, dout, da, sums5,
+                 n_total, dq, dK, dW1b1, workspace):
     K, head = _din_attn_head(q, K)
     H = W1.shape[0]
-    add = (ptr(dk_add), dk_add.stride(0), dk_add.stride(1)) if dk_add is not None else (None, 0, 0)
-    check(_lib.load().fx_din_attn_bwd(*head, ptr(W1), ptr(b1) if b1 is not None else None, H,
-                                      ptr(alpha), eps, 1 if training else 0, ptr(stats), ptr(W2),
-                                      ptr(da), ptr(sums5) if sums5 is not None else None, n_total,
-                                      add[0], add[1], add[2], ptr(dq), dq.stride(0), ptr(dK),
-                                      dK.stride(0), dK.stride(1), ptr(dW1b1), ptr(workspace),
-                                      stream_ptr(q.device)), "fx_din_attn_bwd")
+    check(_lib.load().fx_din_attn_bwd(*head, ptr(W1), ptr(b1), H, ptr(alpha), eps,
+                                      1 if training else 0, ptr(stats), ptr(W2), ptr(mask),
+                                      mask.stride(0) if mask is not None else 0, ptr(a_logit),
+                                      ptr(dout), dout.stride(0), ptr(da), ptr(sums5), n_total,
+                                      ptr(dq), dq.stride(0), ptr(dK), dK.stride(0), dK.stride(1),
+                                      ptr(dW1b1), ptr(workspace), stream_ptr(q.device)),
+          "fx_din_attn_bwd")
 
 
 def dot_interact_fwd(emb, F, D, out):

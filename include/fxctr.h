@@ -442,20 +442,24 @@ int fx_dice_bwd(const float* Z, const float* dY, int64_t N, int32_t H, const flo
 /* ------------------------------------------------------------------------------------------
  * DIN target attention with the attention MLP fused in
  * (fuxictr/pytorch/layers/attentions/target_attention.py:66-92 — concatenation [q, k, q-k, q*k],
- * MLP_Block(4E -> H, Dice, -> 1) — and fuxictr/pytorch/layers/activations.py:40-51, Dice; their
- * autograd at rank_model.py:320).  Neither the [B*L, 4E] concatenation nor the [B*L, H] hidden
- * tensor is written: every pass recomputes the hidden layer on the matrix cores from q [B,E] and
- * K [B,L,E] (addressed like fx_din_concat_fwd).  Limits: E <= 16, H <= 64, one hidden layer.
- * W1: [H, 4E] row-major, b1: [H] or NULL, W2: [H], b2: [1] or NULL, stats: mean[H] | biased var[H].
+ * MLP_Block(4E -> H, Dice, -> 1), mask, weighted sum over the sequence — and
+ * fuxictr/pytorch/layers/activations.py:40-51, Dice; their autograd at rank_model.py:320).
+ * Neither the [B*L, 4E] concatenation nor the [B*L, H] hidden tensor is written: every pass
+ * recomputes the hidden layer on the matrix cores from q [B,E] and K [B,L,E] (addressed like
+ * fx_din_concat_fwd).  Limits: E <= 16, H <= 64, one hidden layer.
+ * W1: [H, 4E] row-major, b1: [H] or NULL, W2: [H], b2: [1] or NULL, stats: mean[H] | biased var[H],
+ * mask: int32 [B, L] (row stride mask_ld; position kept when != 0; NULL = all kept).
  *   fx_din_attn_stats       sums[2H] = [sum h | sum h^2] over this rank's B*L positions
  *   fx_dice_stats_from_sums training != 0: stats from (all-reduced) sums and n_total rows + running
  *                           statistics update (momentum, unbiased variance), like
  *                           nn.BatchNorm1d(affine=False); training == 0: stats = running statistics
- *   fx_din_attn_fwd         a[b*L + l] = W2 . Dice(W1 x_bl + b1) + b2   (before the mask)
- *   fx_din_attn_bwd_sums    sums5[5H] = [dalpha | sum dzhat | sum dzhat*zhat | dW2 | db2, 0...] from
- *                           da[B*L]; the host all-reduces [H, 3H) across ranks in sharded training
- *   fx_din_attn_bwd         dq[B,E], dK[B,L,E] (= attention part + optional addend dk_add, the
- *                           pooling's share), dW1b1 = [dW1 (H*4E) | db1 (H)]
+ *   fx_din_attn_fwd         a[b*L + l] = W2 . Dice(W1 x_bl + b1) + b2 (before the mask) and the
+ *                           pooled output out[b,:] = sum_l a mask k_bl
+ *   fx_din_attn_bwd_sums    from dout[B,E]: da[b*L + l] = mask (dout_b . k_bl) (written) and
+ *                           sums5[5H] = [dalpha | sum dzhat | sum dzhat*zhat | dW2 | db2, 0...];
+ *                           the host all-reduces [H, 3H) across ranks in sharded training
+ *   fx_din_attn_bwd         dq[B,E], dK[B,L,E] (attention part + the pooling's share a mask dout),
+ *                           dW1b1 = [dW1 (H*4E) | db1 (H)]
  * workspace: fx_din_attn_workspace_floats(B, L, E, H) floats.
  * ------------------------------------------------------------------------------------------ */
 int64_t fx_din_attn_workspace_floats(int64_t B, int32_t L, int32_t E, int32_t H);
@@ -468,19 +472,21 @@ int fx_dice_stats_from_sums(const float* sums, int32_t H, int64_t n_total, float
 int fx_din_attn_fwd(const float* q, int64_t q_ld, const float* K, int64_t k_ldb, int64_t k_ldl,
                     int64_t B, int32_t L, int32_t E, const float* W1, const float* b1, int32_t H,
                     const float* alpha, float eps, const float* stats, const float* W2,
-                    const float* b2, float* a_out, fx_stream_t stream);
+                    const float* b2, const int32_t* mask, int64_t mask_ld, float* a_out, float* out,
+                    int64_t out_ld, fx_stream_t stream);
 int fx_din_attn_bwd_sums(const float* q, int64_t q_ld, const float* K, int64_t k_ldb, int64_t k_ldl,
                          int64_t B, int32_t L, int32_t E, const float* W1, const float* b1,
                          int32_t H, const float* alpha, float eps, const float* stats,
-                         const float* W2, const float* da, float* sums5, float* workspace,
+                         const float* W2, const int32_t* mask, int64_t mask_ld, const float* dout,
+                         int64_t dout_ld, float* da, float* sums5, float* workspace,
                          fx_stream_t stream);
 int fx_din_attn_bwd(const float* q, int64_t q_ld, const float* K, int64_t k_ldb, int64_t k_ldl,
                     int64_t B, int32_t L, int32_t E, const float* W1, const float* b1, int32_t H,
                     const float* alpha, float eps, int32_t training, const float* stats,
-                    const float* W2, const float* da, const float* sums5, int64_t n_total,
-                    const float* dk_add, int64_t dka_ldb, int64_t dka_ldl, float* dq, int64_t dq_ld,
-                    float* dK, int64_t dk_ldb, int64_t dk_ldl, float* dW1b1, float* workspace,
-                    fx_stream_t stream);
+                    const float* W2, const int32_t* mask, int64_t mask_ld, const float* a_logit,
+                    const float* dout, int64_t dout_ld, const float* da, const float* sums5,
+                    int64_t n_total, float* dq, int64_t dq_ld, float* dK, int64_t dk_ldb,
+                    int64_t dk_ldl, float* dW1b1, float* workspace, fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * xDeepFM Compressed Interaction Network layer, fused (compressed_interaction_net.py:54-76):

@@ -36,19 +36,18 @@ dout = torch.randn(B, E, generator=g).to(dev)
 steps = [
     ("stats (2 launches)", lambda: ops.din_attn_stats(q, K, W1, b1, sums, ws)),
     ("dice_stats_from_sums", lambda: ops.dice_stats_from_sums(sums, H, B * L, 0.01, True, rm, rv, stats)),
-    ("fwd apply", lambda: ops.din_attn_fwd(q, K, W1, b1, alpha, 1e-9, stats, W2, b2, a)),
-    ("pool fwd", lambda: ops.din_pool_fwd(a, mask, K, out)),
-    ("pool bwd", lambda: ops.din_pool_bwd(a, mask, K, dout, da, dKp)),
-    ("bwd sums (2 launches)", lambda: ops.din_attn_bwd_sums(q, K, W1, b1, alpha, 1e-9, stats, W2, da, sums5, ws)),
-    ("bwd apply (2 launches)", lambda: ops.din_attn_bwd(q, K, W1, b1, alpha, 1e-9, True, stats, W2, da, sums5,
-                                                        B * L, dKp, dq, dK, dW, ws)),
+    ("fwd apply + pooling", lambda: ops.din_attn_fwd(q, K, W1, b1, alpha, 1e-9, stats, W2, b2, mask, a, out)),
+    ("bwd sums (2 launches)", lambda: ops.din_attn_bwd_sums(q, K, W1, b1, alpha, 1e-9, stats, W2, mask, dout, da,
+                                                            sums5, ws)),
+    ("bwd apply (2 launches)", lambda: ops.din_attn_bwd(q, K, W1, b1, alpha, 1e-9, True, stats, W2, mask, a, dout,
+                                                        da, sums5, B * L, dq, dK, dW, ws)),
 ]
 for _, f in steps:
     f()
 torch.cuda.synchronize()
 total = 0.0
 print("B=%d L=%d E=%d H=%d  waves=%s bwd_waves=%s" % (B, L, E, H, os.environ.get("FX_DIN_ATTN_WAVES", "dflt"),
-                                                       os.environ.get("FX_DIN_ATTN_BWD_WAVES", "dflt")))
+                                                       os.environ.get("FX_DIN_ATTN_BWD_WAVES", "dflt")) + " fwd_waves=%s" % os.environ.get("FX_DIN_ATTN_FWD_WAVES", "dflt"))
 for name, f in steps:
     best = 1e9
     for _ in range(3):

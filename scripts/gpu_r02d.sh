@@ -8,8 +8,8 @@ timeout 900 python -m pytest tests/test_gpu_din_attn.py tests/test_gpu_models.py
 echo "pytest exit $?" | tee -a $S
 tail -15 $OUT/pytest_dinattn_$TAG.log | tee -a $S
 echo "== per-pass times, wave-count sweep" | tee -a $S
-for W in 1024 2048 3072; do FX_DIN_ATTN_WAVES=$W timeout 300 python scripts/din_attn_bench.py 2>&1 | grep -v amdgpu.ids | tee -a $S; done
-for W in 1024 1366 2048; do FX_DIN_ATTN_BWD_WAVES=$W timeout 300 python scripts/din_attn_bench.py 2>&1 | grep -E "B=|bwd apply" | tee -a $S; done
+for W in 1024 2048; do FX_DIN_ATTN_WAVES=$W timeout 300 python scripts/din_attn_bench.py 2>&1 | grep -v amdgpu.ids | tee -a $S; done
+for W in 1024 1366; do FX_DIN_ATTN_BWD_WAVES=$W FX_DIN_ATTN_FWD_WAVES=$W timeout 300 python scripts/din_attn_bench.py 2>&1 | grep -E "B=|apply" | tee -a $S; done
 echo "== bench DIN" | tee -a $S
 timeout 600 python bench.py --model DIN --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_din_$TAG.json 2> $OUT/bench_din_$TAG.err
 cut -c1-330 $OUT/bench_din_$TAG.json | tee -a $S

@@ -525,7 +525,12 @@ def _din_attn_gate(h, alpha, eps, stats):
     return rstd, zh, p
 
 
-def din_attn_fwd(q, K, W1, b1, alpha, eps, stats, W2, b2, a_out):
+def _din_attn_mask(mask, B, L):
+    return torch.ones(B, L) if mask is None else (mask != 0).float()
+
+
+def din_attn_fwd(q, K, W1, b1, alpha, eps, stats, W2, b2, mask, a_out, out):
+    B, L, E = K.shape
     _, h = _din_attn_h(q, K, W1, b1)
     _, _, p = _din_attn_gate(h, alpha, eps, stats)
     y = p * h + alpha * (1 - p) * h
@@ -533,11 +538,14 @@ def din_attn_fwd(q, K, W1, b1, alpha, eps, stats, W2, b2, a_out):
     if b2 is not None:
         a = a + b2
     a_out.copy_(a.view(a_out.shape))
-    return a_out
+    out.copy_(((a.view(B, L) * _din_attn_mask(mask, B, L)).unsqueeze(-1) * K).sum(1))
+    return out
 
 
-def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, da, sums5, workspace):
+def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, mask, dout, da, sums5, workspace):
+    B, L, E = K.shape
     H = W1.shape[0]
+    da.copy_((_din_attn_mask(mask, B, L) * (dout.unsqueeze(1) * K).sum(-1)).view(da.shape))
     _, h = _din_attn_h(q, K, W1, b1)
     _, zh, p = _din_attn_gate(h, alpha, eps, stats)
     y = p * h + alpha * (1 - p) * h
@@ -552,8 +560,8 @@ def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, da, sums5, workspace)
     sums5[4 * H] = d.sum()
 
 
-def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, da, sums5, n_total, dk_add, dq, dK,
-                 dW1b1, workspace):
+def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, mask, a_logit, dout, da, sums5,
+                 n_total, dq, dK, dW1b1, workspace):
     B, L, E = K.shape
     H = W1.shape[0]
     x, h = _din_attn_h(q, K, W1, b1)
@@ -567,10 +575,8 @@ def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, da, sums5, n_tot
     dW1b1[H * 4 * E:] = dh.sum(0)
     d = (dh @ W1).view(B, L, 4, E)
     dq.copy_((d[:, :, 0] + d[:, :, 2] + d[:, :, 3] * K).sum(1))
-    dk = d[:, :, 1] - d[:, :, 2] + d[:, :, 3] * q.unsqueeze(1)
-    if dk_add is not None:
-        dk = dk + dk_add
-    dK.copy_(dk)
+    wm = a_logit.view(B, L) * _din_attn_mask(mask, B, L)
+    dK.copy_(d[:, :, 1] - d[:, :, 2] + d[:, :, 3] * q.unsqueeze(1) + wm.unsqueeze(-1) * dout.unsqueeze(1))
 
 
 def dot_interact_fwd(emb, F, D, out):
