@@ -1113,6 +1113,21 @@ class FeatureEmbeddingDict(nn.Module):
             return self.embedding_layers[f].weight
         return self.embedding_layers[grp.numeric[0]].weight
 
+    @staticmethod
+    def packed_ids(inputs, feature):
+        """int32 view [B, width] of `feature`'s id columns in the packed id matrix of this batch (the
+        forward packs it once, FeatureDict.cache), or None.  Lets a model use the raw ids as a
+        padding mask (`X[f].long() != 0`, DIN.py:125) without cast / compare launches."""
+        cache = getattr(inputs, "cache", None) or {}
+        for key, val in cache.items():
+            if isinstance(key, tuple) and key and key[0] == "pack" and val[0] is not None:
+                col = 0
+                for name, width in key[1][0]:
+                    if name == feature:
+                        return val[0][:, col:col + width]
+                    col += width
+        return None
+
     def dict2tensor(self, embedding_dict, flatten_emb=False, feature_list=[], feature_source=[],
                     feature_type=[]):
         """feature_embedding.py:230-259.  When the selection is a contiguous slot range of the
@@ -1762,7 +1777,8 @@ class _DinAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, K, mask_i32, W1, b1, alpha, W2, b2, mod):
-        q = q.contiguous()
+        if q.stride(-1) != 1:
+            q = q.contiguous()       # a row-strided view (a slot of the gather record) is read in place
         B, L, E = K.shape
         H = W1.shape[0]
         dev = q.device
@@ -1858,11 +1874,16 @@ class DIN_Attention(nn.Module):
         if plan is not None and 4 * history_sequence.size(2) == plan[0].in_features \
                 and target_item.dim() == 2:
             lin1, dice, lin2 = plan
-            m = None if mask is None else mask.to(torch.int32).contiguous()
+            if mask is None or (mask.dtype == torch.int32 and mask.stride(-1) == 1):
+                m = mask                     # e.g. the packed id columns: kept when != 0
+            else:
+                m = mask.to(torch.int32).contiguous()
             if dice.training:
                 dice.bn.num_batches_tracked += 1
             return _DinAttnFn.apply(target_item, history_sequence, m, lin1.weight, lin1.bias,
                                     dice.alpha, lin2.weight, lin2.bias, dice)
+        if mask is not None and mask.dtype != torch.bool:
+            mask = mask != 0
         attention_input = _DinConcatFn.apply(target_item, history_sequence)   # [B*L, 4E]
         attention_weight = self.attention_layer(attention_input).view(-1, seq_len)
         if self.use_softmax or history_sequence.size(2) > 64:

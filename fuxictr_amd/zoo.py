@@ -147,7 +147,11 @@ class DIN(_ZooModel):
         for attend, target, sequence in zip(self.attention_layers, self.din_target_field,
                                             self.din_sequence_field):
             seq_names = _fields(sequence)
-            valid = X[seq_names[0]].long() != 0             # padding_idx 0 marks the empty positions
+            # padding_idx 0 marks the empty positions (DIN.py:125: `X[field].long() != 0`); the packed
+            # int32 id columns themselves serve as the mask (kept when != 0): no cast / compare launches
+            valid = self.embedding_layer.packed_ids(X, seq_names[0])
+            if valid is None:
+                valid = X[seq_names[0]].long() != 0
             pooled = attend(self.get_embedding(target, emb), self.get_embedding(sequence, emb),
                             valid)
             # the attended vector replaces each sequence field's [B,L,D] entry by its [B,D] share
