@@ -48,6 +48,13 @@ class GemmEpilogue(C.Structure):
                 ("add", vp), ("ldadd", i64), ("rowsum", vp)]
 
 
+class GemmProblem(C.Structure):
+    """struct fx_gemm_problem"""
+    _fields_ = [("transa", i32), ("transb", i32), ("M", i64), ("N", i64), ("K", i64),
+                ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64),
+                ("epilogue", C.POINTER(GemmEpilogue)), ("split_k", i32), ("workspace", vp)]
+
+
 # name -> (restype, argtypes).  This table is also what tests/test_abi.py checks against the header.
 SIGNATURES = {
     "fx_abi_version": (i32, []),
@@ -90,6 +97,7 @@ SIGNATURES = {
     "fx_dot_interact_fwd": (i32, [vp, i64, i32, i32, i64, vp, vp]),
     "fx_dot_interact_bwd": (i32, [vp, i64, vp, i32, i32, i64, vp, i64, vp]),
     "fx_lr_fwd": (i32, [vp, vp, i64, vp, vp, i32, vp, i64, vp, i32, vp, vp, i64, vp, vp]),
+    "fx_gemm_f32_batch": (i32, [C.POINTER(GemmProblem), i32, vp]),
     "fx_gemm_f32": (i32, [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64,
                           C.POINTER(GemmEpilogue), i32, vp, vp]),
     "fx_colsum": (i32, [vp, i64, i64, i64, vp, vp, vp]),

@@ -396,9 +396,17 @@ __device__ __forceinline__ void fx_static_for(F&& f) {
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int W = 2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
-void k_gemm_f32_pipe(GemmArgs a) {
+template <int BM, int BN, bool A_KC, bool B_KC>
+struct PipeSmem {
+    static constexpr int SA = FX_BK * PipeLoader<BM, A_KC>::LD, SB = FX_BK * PipeLoader<BN, B_KC>::LD;
+    static constexpr int FLOATS = 2 * SA + 2 * SB;
+};
+
+// One output tile (linear tile index L of tiles_m x tiles_n, K slab z) of the pipelined GEMM.  A
+// device function so that one launch can carry tiles of more than one problem (k_gemm_f32_pair).
+template <int BM, int BN, bool A_KC, bool B_KC>
+__device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64_t L, const int z,
+                                                  float* const fx_gemm_smem) {
     using LoaderA = PipeLoader<BM, A_KC>;
     using LoaderB = PipeLoader<BN, B_KC>;
     constexpr int LDA = LoaderA::LD, LDB = LoaderB::LD;
@@ -406,12 +414,10 @@ void k_gemm_f32_pipe(GemmArgs a) {
     constexpr int MI = BM / 64, NJ = BN / 64;
     constexpr int SA = FX_BK * LDA, SB = FX_BK * LDB;
     constexpr int NG = FX_BK / 2;                      // MFMA groups (k-pairs) per tile
-    __shared__ __attribute__((aligned(16))) float fx_gemm_smem[2 * SA + 2 * SB];
     float* const As0 = fx_gemm_smem;
     float* const Bs0 = fx_gemm_smem + 2 * SA;
 
     const int64_t nwg = (int64_t)a.tiles_m * a.tiles_n;
-    const int64_t L = blockIdx.x;
     int64_t T = L;
     if (nwg >= 8) {
         const int64_t q = nwg >> 3, r = nwg & 7, xcd = L & 7;
@@ -419,7 +425,6 @@ void k_gemm_f32_pipe(GemmArgs a) {
     }
     const int64_t m0 = (T / a.tiles_n) * BM;
     const int64_t n0 = (T % a.tiles_n) * BN;
-    const int z = blockIdx.y;
     const int64_t kbeg = (int64_t)z * a.k_chunk;
     const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -594,6 +599,35 @@ void k_gemm_f32_pipe(GemmArgs a) {
                 }
             }
         }
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int W = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
+void k_gemm_f32_pipe(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[PipeSmem<BM, BN, A_KC, B_KC>::FLOATS];
+    fx_gemm_pipe_tile<BM, BN, A_KC, B_KC>(a, blockIdx.x, blockIdx.y, smem);
+}
+
+// Two independent GEMMs in ONE launch (fx_gemm_f32_batch): the weight gradient dW = dZ^T X (problem 1,
+// operands m-/n-contiguous, split-K slabs) and the input gradient dX = dZ W (problem 2) of a layer
+// share dZ and neither depends on the other.  Launched separately each pays its own ramp — all
+// workgroups resident at once, prologue loads and epilogue stores in lock step, ~6 us of idle matrix
+// pipes per launch (K sweep in profiles/r02_gemm_probe.txt); in one grid the second problem's
+// workgroups start as the first one's retire, and the 624-wide CrossNet shapes (640 tiles on 1024
+// slots) no longer leave a third of the CUs one workgroup short.
+template <int BM, int BN, bool A1, bool B1, bool A2, bool B2, int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
+void k_gemm_f32_pair(GemmArgs a1, GemmArgs a2) {
+    constexpr int F1 = PipeSmem<BM, BN, A1, B1>::FLOATS, F2 = PipeSmem<BM, BN, A2, B2>::FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[F1 > F2 ? F1 : F2];
+    const int64_t n1 = (int64_t)a1.tiles_m * a1.tiles_n, w1 = n1 * a1.split_k;
+    const int64_t L = blockIdx.x;
+    if (L < w1) {
+        fx_gemm_pipe_tile<BM, BN, A1, B1>(a1, L % n1, (int)(L / n1), smem);
+    } else {
+        const int64_t n2 = (int64_t)a2.tiles_m * a2.tiles_n, L2 = L - w1;
+        fx_gemm_pipe_tile<BM, BN, A2, B2>(a2, L2 % n2, (int)(L2 / n2), smem);
     }
 }
 
@@ -958,10 +992,13 @@ static void fx_gemm_dispatch_layout(bool a_kc, bool b_kc, bool av, bool bv, dim3
     else fx_gemm_dispatch_vec<BM, BN, false, false>(av, bv, grid, s, a);
 }
 
-extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
+// Validation, K split and tile choice of one GEMM: fills `a`, bm, bn (M == 0 || N == 0: nothing to do,
+// a.M stays 0).
+static int fx_gemm_prepare(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
                            const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                            int64_t ldc, const fx_gemm_epilogue* epi_host, int32_t split_k,
-                           float* workspace, fx_stream_t stream) {
+                           float* workspace, GemmArgs& a, int& bm_out, int& bn_out) {
+    memset(&a, 0, sizeof(a));
     FX_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "fx_gemm_f32: negative dimension");
     if (M == 0 || N == 0) return FX_OK;
     FX_CHECK_ARG(A && B && C, "fx_gemm_f32: null matrix");
@@ -970,8 +1007,6 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
                  (long long)lda, (long long)ldb, (long long)ldc);
     if (split_k < 1) split_k = 1;
     FX_CHECK_ARG(split_k == 1 || workspace, "fx_gemm_f32: split_k > 1 needs a workspace");
-    GemmArgs a;
-    memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K;
     if (epi_host) a.epi = *epi_host;
@@ -1015,6 +1050,35 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     }
     a.tiles_m = (int32_t)fx_ceil_div(M, bm);
     a.tiles_n = (int32_t)fx_ceil_div(N, bn);
+    bm_out = bm;
+    bn_out = bn;
+    return FX_OK;
+}
+
+// operand alignment / offset range the pipelined kernel needs
+static bool fx_gemm_pipe_ok(int32_t transa, int32_t transb, const GemmArgs& a) {
+    const bool a_kc = !transa, b_kc = transb != 0;
+    const bool a_al = (a.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
+    const bool b_al = (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
+    const bool av = a_al && (a_kc ? (a.K % 4 == 0) : (a.M % 4 == 0));
+    const bool bv = b_al && (b_kc ? (a.K % 4 == 0) : (a.N % 4 == 0));
+    const bool small_offsets = (transa ? a.K * a.lda : a.M * a.lda) < (int64_t)0x3FFFFFF0 &&
+                               (transb ? a.N * a.ldb : a.K * a.ldb) < (int64_t)0x3FFFFFF0;
+    return fx_gemm_pipe_mode() && av && bv && small_offsets && a.k_chunk >= 4;
+}
+
+extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
+                           const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                           int64_t ldc, const fx_gemm_epilogue* epi_host, int32_t split_k,
+                           float* workspace, fx_stream_t stream) {
+    GemmArgs a;
+    int bm = 0, bn = 0;
+    const int rc0 = fx_gemm_prepare(transa, transb, M, N, K, A, lda, B, ldb, C, ldc, epi_host, split_k,
+                                    workspace, a, bm, bn);
+    if (rc0 != FX_OK) return rc0;
+    if (M == 0 || N == 0) return FX_OK;
+    split_k = a.split_k;
+    const int64_t kc = a.k_chunk;
     hipStream_t s = fx_hip_stream(stream);
     const bool want_rowsum = a.epi.rowsum != nullptr;
     FX_CHECK_ARG(!want_rowsum || (K > 8 && !(N <= 4 && !transa)),
@@ -1113,6 +1177,57 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     if (split_k > 1) {
         fx_launch_splitk_reduce(a, s);
         FX_CHECK_LAUNCH();
+    }
+    return FX_OK;
+}
+
+// Several independent GEMMs.  Two problems that both take the pipelined 64x64 kernel, the first with
+// m-/n-contiguous operands (transa = 1, transb = 0: a weight gradient) and the second with a
+// k-contiguous A (transa = 0, transb = 0: an input gradient) — the dW / dX pair of a Linear or
+// CrossNet layer — go out as ONE launch (k_gemm_f32_pair); anything else runs problem by problem.
+extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_t stream) {
+    FX_CHECK_ARG(n >= 0 && (n == 0 || p), "fx_gemm_f32_batch: bad problem list");
+    static const bool pair_on = []() {   // FX_GEMM_PAIR=0: always problem by problem (A/B runs)
+        const char* e = getenv("FX_GEMM_PAIR");
+        return !(e && atoi(e) == 0);
+    }();
+    static const bool w64_default = []() { return getenv("FX_GEMM_W64") == nullptr; }();
+    if (n == 2 && pair_on && w64_default && p[0].transa && !p[0].transb && !p[1].transa &&
+        !p[1].transb) {
+        GemmArgs a[2];
+        int bm[2], bn[2];
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; ++i) {
+            const fx_gemm_problem& q = p[i];
+            const int rc = fx_gemm_prepare(q.transa, q.transb, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb,
+                                           q.C, q.ldc, q.epilogue, q.split_k, q.workspace, a[i],
+                                           bm[i], bn[i]);
+            if (rc != FX_OK) return rc;
+            const bool skinny = q.K <= 8 || (q.N <= 4 && !q.transa) ||
+                                (q.M <= 4 && q.transa && !q.transb && q.workspace);
+            ok = q.M > 0 && q.N > 0 && !skinny && bm[i] == 64 && bn[i] == 64 &&
+                 fx_gemm_pipe_ok(q.transa, q.transb, a[i]);
+        }
+        if (ok) {
+            hipStream_t s = fx_hip_stream(stream);
+            const int64_t wgs = (int64_t)a[0].tiles_m * a[0].tiles_n * a[0].split_k +
+                                (int64_t)a[1].tiles_m * a[1].tiles_n * a[1].split_k;
+            hipLaunchKernelGGL((k_gemm_f32_pair<64, 64, false, false, true, false, 4>),
+                               dim3((unsigned)wgs), dim3(256), 0, s, a[0], a[1]);
+            FX_CHECK_LAUNCH();
+            for (int i = 0; i < 2; ++i)
+                if (a[i].split_k > 1) {
+                    fx_launch_splitk_reduce(a[i], s);
+                    FX_CHECK_LAUNCH();
+                }
+            return FX_OK;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const fx_gemm_problem& q = p[i];
+        const int rc = fx_gemm_f32(q.transa, q.transb, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C,
+                                   q.ldc, q.epilogue, q.split_k, q.workspace, stream);
+        if (rc != FX_OK) return rc;
     }
     return FX_OK;
 }

@@ -1490,6 +1490,20 @@ class _Workspace(object):
         return buf
 
 
+def linear_grads(dz, x, W, need_bias, mask=None, add=None):
+    """dW, db (as linear_weight_grads) and dx = dz W (+ the ReLU `mask` of the layer below / the
+    residual `add` in the epilogue), the two products in one launch."""
+    Bsz, N_out = dz.shape
+    K_in = x.shape[1]
+    dW = torch.empty(N_out, K_in, dtype=torch.float32, device=dz.device)
+    dx = torch.empty(Bsz, K_in, dtype=torch.float32, device=dz.device)
+    sk = _split_k_for(N_out, K_in, Bsz)
+    ws = _Workspace.get(dz.device, sk * N_out * (K_in + 1))
+    db = torch.empty(N_out, dtype=torch.float32, device=dz.device) if need_bias else None
+    ops.gemm_dw_dx(dz, x, W, dW, dx, split_k=sk, workspace=ws, rowsum=db, mask=mask, add=add)
+    return dW, db, dx
+
+
 def linear_weight_grads(dz, x, W_shape, need_bias):
     """dW[N_out, K_in] = dz^T x (split-K), db[N_out] = colsum(dz)."""
     Bsz, N_out = dz.shape
@@ -1538,16 +1552,16 @@ class _MLPFn(torch.autograd.Function):
         for i in range(n - 1, -1, -1):
             W, b = wb[2 * i], wb[2 * i + 1]
             h_in = hs[i]
-            dW, db = linear_weight_grads(dz, h_in, W.shape, b is not None)
-            grads[2 * i], grads[2 * i + 1] = dW, db
             if i > 0 or ctx.need_dx:
-                dh = torch.empty_like(h_in)
                 mask = h_in if (i > 0 and acts[i - 1]) else None
-                ops.gemm(dz, W, dh, transa=False, transb=False, mask=mask)
+                dW, db, dh = linear_grads(dz, h_in, W, b is not None, mask=mask)
                 if i > 0:
                     dz = dh
                 else:
                     dx = dh
+            else:
+                dW, db = linear_weight_grads(dz, h_in, W.shape, b is not None)
+            grads[2 * i], grads[2 * i + 1] = dW, db
         return (dx, None) + tuple(grads)
 
 
@@ -2020,11 +2034,8 @@ class _CrossNetV2Fn(torch.autograd.Function):
             # t = dxn * x0 (grad of W x_i + b); dx0 (+)= dxn * z_i; at the first layer x_i IS x_0,
             # so its residual gradient dxn joins dx0 and the last GEMM adds dx0 in its epilogue.
             ops.cross_bwd_prep(dxn, x0, zs[i], t, dx0, init=(i == n - 1), add_dxn=(i == 0))
-            dW, db = linear_weight_grads(t, xs[i], W.shape, b is not None)
+            dW, db, dxn = linear_grads(t, xs[i], W, b is not None, add=(dx0 if i == 0 else dxn))
             grads[2 * i], grads[2 * i + 1] = dW, db
-            dxi = torch.empty_like(x0)
-            ops.gemm(t, W, dxi, transa=False, transb=False, add=(dx0 if i == 0 else dxn))
-            dxn = dxi
         return (dxn,) + tuple(grads)
 
 

@@ -441,10 +441,7 @@ def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul
                  rowsum)
 
 
-def _gemm(A, B_, C_, transa, transb, bias, act, zout, mul, mask, add, split_k, workspace, rowsum):
-    lib = _lib.load()
-    M, N = C_.shape
-    K = A.shape[0] if transa else A.shape[1]
+def _epilogue(bias=None, act=0, zout=None, mul=None, mask=None, add=None, rowsum=None):
     epi = _lib.GemmEpilogue()
     epi.bias = bias.data_ptr() if bias is not None else None
     epi.act = act
@@ -458,6 +455,38 @@ def _gemm(A, B_, C_, transa, transb, bias, act, zout, mul, mask, add, split_k, w
         epi.add, epi.ldadd = add.data_ptr(), add.stride(0)
     if rowsum is not None:
         epi.rowsum = rowsum.data_ptr()
+    return epi
+
+
+def gemm_dw_dx(dz, x, W, dW, dx, split_k=1, workspace=None, rowsum=None, mask=None, add=None):
+    """The two gradient GEMMs of a Linear / CrossNet layer in ONE launch (fx_gemm_f32_batch):
+    dW[N, K] = dz^T x (split-K, `rowsum` = column sums of dz = bias gradient) and
+    dx[M, K] = dz W with the `mask` / `add` epilogue.  Same results as the two gemm() calls."""
+    if KernelTimer.recording:
+        M_, N_ = dz.shape
+        K_ = x.shape[1]
+        KernelTimer.note("k_gemm_f32", "gemm dW+dX %dx%dx%d" % (M_, N_, K_), 4.0 * M_ * N_ * K_,
+                         _gemm_dw_dx, (dz, x, W, dW, dx, split_k, workspace, rowsum, mask, add), {})
+    return _gemm_dw_dx(dz, x, W, dW, dx, split_k, workspace, rowsum, mask, add)
+
+
+def _gemm_dw_dx(dz, x, W, dW, dx, split_k, workspace, rowsum, mask, add):
+    M, N = dz.shape
+    K = x.shape[1]
+    e1, e2 = _epilogue(rowsum=rowsum), _epilogue(mask=mask, add=add)
+    probs = (_lib.GemmProblem * 2)()
+    probs[0] = _lib.GemmProblem(1, 0, N, K, M, ptr(dz), dz.stride(0), ptr(x), x.stride(0), ptr(dW),
+                                dW.stride(0), C.pointer(e1), split_k, ptr(workspace))
+    probs[1] = _lib.GemmProblem(0, 0, M, K, N, ptr(dz), dz.stride(0), ptr(W), W.stride(0), ptr(dx),
+                                dx.stride(0), C.pointer(e2), 1, None)
+    check(_lib.load().fx_gemm_f32_batch(probs, 2, stream_ptr(dz.device)), "fx_gemm_f32_batch")
+
+
+def _gemm(A, B_, C_, transa, transb, bias, act, zout, mul, mask, add, split_k, workspace, rowsum):
+    lib = _lib.load()
+    M, N = C_.shape
+    K = A.shape[0] if transa else A.shape[1]
+    epi = _epilogue(bias, act, zout, mul, mask, add, rowsum)
     check(lib.fx_gemm_f32(1 if transa else 0, 1 if transb else 0, M, N, K, ptr(A), A.stride(0),
                           ptr(B_), B_.stride(0), ptr(C_), C_.stride(0), C.byref(epi), split_k,
                           ptr(workspace), stream_ptr(C_.device)), "fx_gemm_f32")

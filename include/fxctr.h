@@ -353,6 +353,27 @@ int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
                 const fx_gemm_epilogue* epi_host, int32_t split_k, float* workspace,
                 fx_stream_t stream);
 
+/* Several independent GEMMs in as few launches as possible (same semantics as calling fx_gemm_f32 on
+ * each problem, in order; the outputs must not overlap each other or any input).  The weight gradient
+ * dW = dZ^T X (transa = 1, transb = 0) followed by the input gradient dX = dZ W (transa = 0,
+ * transb = 0) of one Linear / CrossNet layer — the two `aten::mm` of its autograd (mlp_block.py:96,
+ * cross_net.py:128 at rank_model.py:320), which share dZ and are independent — go out as ONE grid, so
+ * the second one's workgroups fill the CUs as the first one's retire.  problems_host is a HOST array. */
+typedef struct fx_gemm_problem {
+    int32_t transa, transb;
+    int64_t M, N, K;
+    const float* A;
+    int64_t lda;
+    const float* B;
+    int64_t ldb;
+    float* C;
+    int64_t ldc;
+    const fx_gemm_epilogue* epilogue; /* host pointer or NULL */
+    int32_t split_k;
+    float* workspace;
+} fx_gemm_problem;
+int fx_gemm_f32_batch(const fx_gemm_problem* problems_host, int32_t n, fx_stream_t stream);
+
 /* Column sums (bias gradients): out[n] = sum_m X[m,n].
  * Two-stage deterministic reduction; workspace >= FX_COLSUM_CHUNKS * N floats. */
 #define FX_COLSUM_CHUNKS 64

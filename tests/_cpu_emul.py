@@ -342,6 +342,11 @@ def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul
     return C_
 
 
+def gemm_dw_dx(dz, x, W, dW, dx, split_k=1, workspace=None, rowsum=None, mask=None, add=None):
+    gemm(dz, x, dW, transa=True, transb=False, split_k=split_k, workspace=workspace, rowsum=rowsum)
+    gemm(dz, W, dx, transa=False, transb=False, mask=mask, add=add)
+
+
 def colsum(X, out, workspace):
     out.copy_(X.sum(0))
     return out
@@ -795,7 +800,7 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats", "adam_catchup_all",
          "dice_local_sums", "dice_fwd_from_sums", "dice_bwd_local_sums", "dice_bwd_from_sums",
          "din_attn_workspace_floats", "din_attn_stats", "dice_stats_from_sums", "din_attn_fwd",
-         "din_attn_bwd_sums", "din_attn_bwd"]
+         "din_attn_bwd_sums", "din_attn_bwd", "gemm_dw_dx"]
 
 
 def install_plain():

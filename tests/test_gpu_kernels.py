@@ -377,6 +377,39 @@ def test_gemm_all_layouts(M, N, K, ta, tb):
     assert err <= 2e-6 * bound, (err, bound)             # fp32 accumulate over K terms
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 1024), (4096, 1024, 624), (4096, 624, 624),
+                                   (2048, 512, 128), (300, 70, 52), (257, 33, 9)])
+def test_gemm_dw_dx_pair_is_bit_identical_to_the_two_gemms(M, N, K):
+    """fx_gemm_f32_batch: the weight- and input-gradient products of a layer as ONE grid (the aligned
+    tower shapes) or problem by problem (ragged shapes) — the same bits as two fx_gemm_f32 calls, with
+    the fused bias gradient, the ReLU mask and the residual add; and both equal fp64 within bound."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dz, x = _dev(torch.randn(M, N, generator=g)), _dev(torch.randn(M, K, generator=g))
+    W = _dev(torch.randn(N, K, generator=g) * 0.1)
+    mask, add = _dev(torch.randn(M, K, generator=g)), _dev(torch.randn(M, K, generator=g))
+    sk = 4 if M >= 2048 else 2
+    ws = torch.empty(sk * N * (K + 1) + 64, device=DEV)
+    out = []
+    for pair in (True, False):
+        dW = torch.full((N, K), float("nan"), device=DEV)
+        dx = torch.full((M, K), float("nan"), device=DEV)
+        db = torch.full((N,), float("nan"), device=DEV)
+        if pair:
+            ops.gemm_dw_dx(dz, x, W, dW, dx, split_k=sk, workspace=ws, rowsum=db, mask=mask, add=add)
+        else:
+            ops.gemm(dz, x, dW, transa=True, transb=False, split_k=sk, workspace=ws, rowsum=db)
+            ops.gemm(dz, W, dx, transa=False, transb=False, mask=mask, add=add)
+        out.append((dW, dx, db))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    dW, dx, db = out[0]
+    ref_w = dz.double().t() @ x.double()
+    assert (dW.double() - ref_w).abs().max().item() <= 3e-6 * (dz.abs().double().t() @ x.abs().double()).max().item()
+    ref_x = torch.where(mask > 0, dz.double() @ W.double(), torch.zeros((), dtype=torch.float64, device=DEV)) + add.double()
+    assert (dx.double() - ref_x).abs().max().item() <= 3e-6 * (dz.abs().double() @ W.abs().double()).max().item() + 1e-6
+    assert (db.double() - dz.double().sum(0)).abs().max().item() <= 1e-5 * dz.abs().double().sum(0).max().item()
+
+
 def test_gemm_mfma_layout_is_not_transposed():
     """A = I with an ASYMMETRIC B catches a swapped C/D fragment mapping."""
     n = 128
