@@ -365,10 +365,13 @@ class _TableGroup(object):
                 and plan.C <= 256 and _lib.row_lanes(self.D) <= 64)
 
     def fused_front(self, plan):
-        """The fused gather(+LR+FM) / balanced backward kernels apply: any unsharded plan whose id
-        columns each fill one slot of the record (categorical columns and the positions of RAW
-        sequences alike; pooled sequences keep the pooling kernels)."""
-        return not self.sharded and plan.n_seq == 0 and _lib.row_lanes(self.D) <= 64
+        """The fused gather(+LR+FM) / balanced backward kernels apply: any plan whose id columns each
+        fill one slot of the record (categorical columns and the positions of RAW sequences alike;
+        pooled sequences keep the pooling kernels).  Row-sharded groups run the same kernels over the
+        rows received from their owners (slot matrix instead of ids)."""
+        if self.sharded and self.table is not None and self.table.dtype != torch.float32:
+            return False
+        return plan.n_seq == 0 and _lib.row_lanes(self.D) <= 64
 
     def dedup(self, plan, ids, inputs):
         cache = getattr(inputs, "cache", None)
@@ -572,10 +575,15 @@ class _TableGroup(object):
                          device=self.device)
         ops.emb_grad_reduce(dout, dout_ld, col_off, plan.C, D, dd, G_loc, sq,
                             self.reduce_scratch(dd.n_max), col_denom, denom)
+        self.shard_send_grads(sx, G_loc)
+
+    def shard_send_grads(self, sx, G_loc):
+        """Requester: per-unique-key gradients G_loc [n_max, D] into their bucket slots; the exchange
+        itself runs after autograd returns (finish_backward, called by the optimizer on the main
+        thread): collectives stay in one fixed program order on every rank."""
+        N, cap, D, dd = self.n_shards, sx.cap, self.D, sx.dd
         gsend = torch.zeros(N * cap + 1, D, dtype=torch.float32, device=self.device)
         ops.scatter_rows(G_loc, sx.uniq_slot, dd.n_unique, dd.n_max, D, gsend)
-        # the exchange itself runs after autograd returns (finish_backward, called by the
-        # optimizer on the main thread): collectives stay in one fixed program order on every rank
         self._await_exchange.append((sx, gsend))
 
     def finish_backward(self):
@@ -684,25 +692,41 @@ class _EmbFMFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, lr_anchor, lr_bias, group, plan, lr_group, lr_plan, ids, dense, dd,
-                inputs, want_fm):
+                inputs, want_fm, track=True):
         ctx.set_materialize_grads(False)
         B = (ids if ids is not None else dense).shape[0]
         D = group.D
         dev = group.device
         out = torch.empty(B, plan.n_slots * D, dtype=torch.float32, device=dev)
         want_lr = lr_group is not None
+        sx = None
+        table, table1 = group.table, (lr_group.table if want_lr else None)
+        g_ids, g_base, g_vocab = ids, plan.col_row_base, plan.col_vocab
+        if group.sharded and plan.C:
+            # row-sharded tables: ids -> owners, rows back (ONE all-to-all for the D-float and the
+            # D=1 rows), then the same kernel reads the received rows through the slot matrix
+            sx = group.shard_exchange_ids(plan, ids, inputs)
+            if want_lr:
+                lr_group.shard_exchange_ids(lr_plan, ids, inputs)     # joins the row exchange
+            table = group.shard_fetch_rows(sx, track)
+            table1 = lr_group.shard_fetch_rows(sx, track) if want_lr else None
+            g_ids, g_base, g_vocab = sx.lookup_slot, sx.slot_base, sx.slot_vocab
+            if os.environ.get("FX_DEBUG_FUSED_SHARD") == "1":
+                print("[fx] fused front end on row-sharded tables (lr=%s fm=%s)" % (want_lr, want_fm),
+                      flush=True)
         lr_out = torch.empty(B, 1, dtype=torch.float32, device=dev) if want_lr else None
         fm_out = torch.empty(B, 1, dtype=torch.float32, device=dev) if want_fm else None
         fm_lr = torch.empty(B, 1, dtype=torch.float32, device=dev) if (want_fm and want_lr) else None
         S = torch.empty(B, D, dtype=torch.float32, device=dev) if want_fm else None
-        ops.emb_fm_fwd(group.table, D, ids, plan.col_row_base, plan.col_vocab, plan.col_out_off,
+        ops.emb_fm_fwd(table, D, g_ids, g_base, g_vocab, plan.col_out_off,
                        dense, group.select_num_w(plan), plan.num_out_off, out, group.ensure_scal(),
-                       table1=lr_group.table if want_lr else None,
+                       table1=table1,
                        num_w1=lr_group.select_num_w(lr_plan) if want_lr else None,
                        bias1=lr_bias if want_lr else None, lr_out=lr_out, fm_out=fm_out,
                        fm_lr_out=fm_lr, S=S)
         ctx.group, ctx.plan, ctx.lr_group, ctx.lr_plan = group, plan, lr_group, lr_plan
         ctx.ids, ctx.dense, ctx.dd, ctx.out, ctx.S = ids, dense, dd, out, S
+        ctx.sx = sx
         ctx.inputs = inputs if hasattr(inputs, "cache") else None
         ctx.has_bias = lr_bias is not None
         return out, lr_out, fm_out, fm_lr
@@ -716,7 +740,7 @@ class _EmbFMFn(torch.autograd.Function):
                 return b
             return a if b is None else a + b
         g_fm, g_lr = both(d_fm, d_fm_lr), both(d_lr, d_fm_lr)
-        none = (None,) * 12
+        none = (None,) * 13
         if d_out is None and g_fm is None and g_lr is None:
             return none
         D, dev = group.D, group.device
@@ -724,7 +748,7 @@ class _EmbFMFn(torch.autograd.Function):
         d_out = d_out.contiguous() if d_out is not None else None
         g_fm = g_fm.contiguous() if g_fm is not None else None
         g_lr = g_lr.contiguous() if g_lr is not None else None
-        dd = ctx.dd
+        dd = ctx.sx.dd if ctx.sx is not None else ctx.dd
         if plan.C and (dd is None or dd.sorted_uid is None):
             dd = group.dedup(plan, ctx.ids, ctx.inputs)      # (no optimizer attached)
         G = sq = G1 = sq1 = None
@@ -744,7 +768,12 @@ class _EmbFMFn(torch.autograd.Function):
                                                                  plan.Fd), tag="emb_fm_bwd")
         ops.emb_fm_bwd(d_out, ctx.out, ctx.S, g_fm, g_lr, plan.col_out_off, plan.C, D, dd, G, sq,
                        G1, sq1, ctx.dense, plan.num_out_off, B, dnum, dnum1, dbias, ws)
-        if plan.C:
+        if plan.C and ctx.sx is not None:
+            # sharded: G / G1 are this rank's per-unique-key sums; their owners reduce across ranks
+            group.shard_send_grads(ctx.sx, G)
+            if G1 is not None:
+                lr_group.shard_send_grads(ctx.sx, G1)
+        elif plan.C:
             group.pending.append(_PendingGrad(dd, G, sq))
             if G1 is not None:
                 lr_group.pending.append(_PendingGrad(dd, G1, sq1))
@@ -752,7 +781,7 @@ class _EmbFMFn(torch.autograd.Function):
             group.add_num_grad(plan, dnum)
         if dnum1 is not None:
             lr_group.add_num_grad(lr_plan, dnum1)
-        return (None, None, dbias) + (None,) * 9
+        return (None, None, dbias) + (None,) * 10
 
 
 class _SplitRecordFn(torch.autograd.Function):
@@ -1017,14 +1046,15 @@ class FeatureEmbeddingDict(nn.Module):
                 # the fused front end: gather (+ first-order term + FM term), one launch
                 lr_mod, lr_grp, lr_plan = self._lr_peer_for(plan, feats, inputs)
                 peers = (lr_grp,) if lr_grp is not None else ()
-                dd = grp.prepare_train(plan, ids, inputs, peers) if track else None
+                dd = grp.prepare_train(plan, ids, inputs, peers) \
+                    if (track and not grp.sharded) else None
                 want_fm = bool(self._fuse_fm) and plan.n_slots == plan.C + plan.Fd \
                     and not (self._torch_feats or self._stock_feats)
                 out, lr_out, fm_out, fm_lr = _EmbFMFn.apply(
                     anchor, lr_mod.embedding_layer.embedding_layer._anchor(lr_grp)
                     if lr_grp is not None else None,
                     lr_mod.bias if lr_grp is not None else None, grp, plan, lr_grp, lr_plan, ids,
-                    dense, dd, inputs, want_fm)
+                    dense, dd, inputs, want_fm, track)
                 front = {"lr_mod": lr_mod, "lr": lr_out, "fm": fm_out, "fm_lr": fm_lr}
                 if lr_grp is not None and hasattr(inputs, "cache"):
                     inputs.cache[("lr_out", id(lr_mod))] = lr_out
