@@ -1111,7 +1111,8 @@ class FeatureEmbeddingDict(nn.Module):
         fmap = layer._feature_map.features
         lr_feats = [f for f in fmap if f in inputs and f in layer.embedding_layers]
         if (len(groups) != 1 or layer._torch_feats or layer._stock_feats or lr_feats != list(feats)
-                or groups[0].D != 1 or groups[0].sharded
+                or groups[0].D != 1
+                or groups[0].sharded != next(iter(self._groups.values())).sharded
                 or lr.training != self.training):
             return None, None, None
         lr_grp = groups[0]
