@@ -72,7 +72,8 @@ SIGNATURES = {
                                    vp]),
     "fx_shard_plan_workspace_ints": (i64, [i64, i32]),
     "fx_shard_plan": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp]),
-    "fx_scatter_rows": (i32, [vp, vp, vp, i64, i32, vp, vp]),
+    "fx_scatter_rows": (i32, [vp, vp, vp, i64, i32, vp, i64, vp]),
+    "fx_split_rows": (i32, [vp, i64, i64, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), i32, vp]),
     "fx_sum_parts": (i32, [C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
     "fx_emb_grad_reduce_partials": (i64, [i64, i32]),
     "fx_emb_grad_reduce_scratch_ints": (i64, [i64]),

@@ -884,11 +884,12 @@ extern "C" int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique,
     return FX_OK;
 }
 
-// dst[row_map[u], :] = src[u, :] for u < *n_rows (row gradients into their all-to-all slots)
+// dst[row_map[u] * dst_ld + 0..D) = src[u, :] for u < *n_rows (row gradients into their all-to-all
+// slots; dst_ld > D when several table groups share one exchange block, each in its own columns)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_scatter_rows(const float* src, const int32_t* row_map,
                                                       const int32_t* n_rows, int D, int lanes_log2,
-                                                      float* dst) {
+                                                      float* dst, int64_t dst_ld) {
     const int lanes = 1 << lanes_log2;
     const int d0 = (threadIdx.x & (lanes - 1)) * VEC;
     const int64_t rpb = 256 >> lanes_log2;
@@ -898,25 +899,82 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const float* src, const in
         if (d0 >= D) continue;
         float v[VEC];
         fx_load<VEC>(src + u * D + d0, v);
-        fx_store<VEC>(dst + (int64_t)row_map[u] * D + d0, v);
+        fx_store<VEC>(dst + (int64_t)row_map[u] * dst_ld + d0, v);
     }
 }
 
 extern "C" int fx_scatter_rows(const float* src, const int32_t* row_map, const int32_t* n_rows,
-                               int64_t n_max, int32_t D, float* dst, fx_stream_t stream) {
+                               int64_t n_max, int32_t D, float* dst, int64_t dst_ld,
+                               fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256, "fx_scatter_rows: D=%d not in [1,256]", D);
+    FX_CHECK_ARG(dst_ld >= D, "fx_scatter_rows: dst_ld < D");
     if (n_max <= 0) return FX_OK;
     FX_CHECK_ARG(src && row_map && n_rows && dst, "fx_scatter_rows: null pointer");
-    const FxRowGeom g = fx_row_geom(D);
+    FxRowGeom g = fx_row_geom(D);
+    // vector stores need every destination row 16- / 8-byte aligned
+    while (g.vec > 1 && (dst_ld % g.vec != 0 ||
+                         (reinterpret_cast<uintptr_t>(dst) & (sizeof(float) * g.vec - 1)) != 0)) {
+        g.vec >>= 1;
+        g.lanes <<= 1;
+    }
+    FX_CHECK_ARG(g.lanes <= 256, "fx_scatter_rows: D=%d too wide for an unaligned destination", D);
     int ll = 0;
     while ((1 << ll) < g.lanes) ++ll;
     int64_t blocks = fx_ceil_div(n_max, 256 / g.lanes);
     if (blocks > 256 * 32) blocks = 256 * 32;
     dim3 grid((unsigned)blocks);
     hipStream_t s = fx_hip_stream(stream);
-    if (g.vec == 4) hipLaunchKernelGGL(k_scatter_rows<4>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst);
-    else if (g.vec == 2) hipLaunchKernelGGL(k_scatter_rows<2>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst);
-    else hipLaunchKernelGGL(k_scatter_rows<1>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst);
+    if (g.vec == 4) hipLaunchKernelGGL(k_scatter_rows<4>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst, dst_ld);
+    else if (g.vec == 2) hipLaunchKernelGGL(k_scatter_rows<2>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst, dst_ld);
+    else hipLaunchKernelGGL(k_scatter_rows<1>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst, dst_ld);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// The block of rows an all-to-all delivered, [n_rows, src_ld] with one column range per table group,
+// into one contiguous [n_rows + zero_tail_rows, width_p] buffer per group (the gather kernels read
+// rows of exactly D floats); the tail rows — the pad slot padding lookups point at — are zeroed.
+#define FX_SPLIT_MAX_PARTS 4
+struct SplitArgs {
+    const float* src;
+    int64_t src_ld, n_rows;
+    int32_t n_parts, tail, total_w;
+    float* dst[FX_SPLIT_MAX_PARTS];
+    int32_t off[FX_SPLIT_MAX_PARTS], w[FX_SPLIT_MAX_PARTS];
+};
+
+__global__ __launch_bounds__(256) void k_split_rows(SplitArgs a) {
+    const int64_t n = a.n_rows * a.total_w, nt = (int64_t)a.tail * a.total_w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n + nt;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / a.total_w;
+        int c = (int)(i - r * a.total_w);
+        int p = 0;
+        while (c >= a.w[p]) c -= a.w[p++];                 // part p, column c of it
+        a.dst[p][r * a.w[p] + c] = r < a.n_rows ? a.src[r * a.src_ld + a.off[p] + c] : 0.f;
+    }
+}
+
+extern "C" int fx_split_rows(const float* src, int64_t src_ld, int64_t n_rows, int32_t n_parts,
+                             float* const* dst_host, const int32_t* off_host,
+                             const int32_t* width_host, int32_t zero_tail_rows, fx_stream_t stream) {
+    FX_CHECK_ARG(n_parts >= 1 && n_parts <= FX_SPLIT_MAX_PARTS && n_rows >= 0 && zero_tail_rows >= 0,
+                 "fx_split_rows: bad sizes (1..%d parts)", FX_SPLIT_MAX_PARTS);
+    FX_CHECK_ARG(src && dst_host && off_host && width_host, "fx_split_rows: null pointer");
+    SplitArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = src; a.src_ld = src_ld; a.n_rows = n_rows; a.n_parts = n_parts; a.tail = zero_tail_rows;
+    for (int p = 0; p < n_parts; ++p) {
+        FX_CHECK_ARG(dst_host[p] && width_host[p] >= 1 && off_host[p] >= 0 &&
+                     off_host[p] + width_host[p] <= src_ld, "fx_split_rows: bad part %d", p);
+        a.dst[p] = dst_host[p]; a.off[p] = off_host[p]; a.w[p] = width_host[p];
+        a.total_w += width_host[p];
+    }
+    const int64_t total = (n_rows + zero_tail_rows) * a.total_w;
+    if (total == 0) return FX_OK;
+    int64_t blocks = fx_ceil_div(total, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_split_rows, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), a);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

@@ -144,7 +144,7 @@ class _Plan(object):
 
 class _ShardExchange(object):
     """Per-batch routing state of the row-sharded path (see _TableGroup.shard_exchange_ids)."""
-    pass
+    gblock = None        # backward: the shared gradient block [N*cap + 1, width] (shard_send_grads)
 
 
 # table groups that route with the same id plan (a model's D=16 tables and its D=1 LR tables):
@@ -543,28 +543,39 @@ class _TableGroup(object):
         got = sx.rows.pop(id(self), None)
         if got is not None:
             return got                                # fetched together with a peer group
-        peers = [p for p in _SHARD_PEERS.get(sx.key, []) if p.table is not None]
-        if not any(p is self for p in peers):
-            peers = [self]
-        sends = []
-        for p in peers:
+        layout, width = self.shard_layout(sx)
+        # every group routed by this id plan gathers straight into its columns of ONE send block
+        # ([N*cap, 16 + 1 (+3 pad)]: no concatenation pass), one all-to-all, one launch that splits
+        # what arrived into the per-group row buffers the lookups read (+ their zero pad row)
+        send = torch.empty(N * cap, width, dtype=torch.float32, device=self.device)
+        for p, off in layout:
             if track and p.exact and p.opt_kind == "adam":
                 ops.adam_catchup(p.table, p.m, p.v, p.last_step, p.D, sx.owner_dd,
                                  p.rows_per_shard + 1, -1, p.scal)
-            rs = torch.empty(N * cap, p.D, dtype=torch.float32, device=self.device)
             ops.emb_gather_fwd(p.table, p.D, sx.recv_idx, sx.own_base, sx.own_vocab, sx.own_base,
-                               None, None, None, rs, p.ensure_scal())
-            sends.append(rs)
-        # one all-to-all for every group routed by this id plan (e.g. [N*cap, 16 + 1])
-        recv = self.dist.all_to_all(sends[0] if len(sends) == 1 else torch.cat(sends, dim=1))
-        off = 0
-        for p in peers:
+                               None, None, None, send[:, off:off + p.D], p.ensure_scal())
+        recv = self.dist.all_to_all(send)
+        parts = []
+        for p, off in layout:
             rows = torch.empty(N * cap + 1, p.D, dtype=torch.float32, device=self.device)
-            rows[:N * cap] = recv[:, off:off + p.D]
-            rows[N * cap].zero_()                     # the pad slot reads as a zero row
-            off += p.D
+            parts.append((off, rows))
             sx.rows[id(p)] = rows
+        ops.split_rows(recv, N * cap, parts, zero_tail_rows=1)     # the pad slot reads as a zero row
         return sx.rows.pop(id(self))
+
+    def shard_layout(self, sx):
+        """-> ([(group, column offset)], block width): the table groups that share this exchange,
+        float4-wide groups first so their columns stay 16-byte aligned, row stride a multiple of 4
+        floats (vector loads / stores on the rows of the block).  Identical on every rank."""
+        peers = [p for p in _SHARD_PEERS.get(sx.key, []) if p.table is not None]
+        if not any(p is self for p in peers):
+            peers = [self]
+        peers = sorted(peers, key=lambda p: 0 if p.D % 4 == 0 else 1)
+        layout, off = [], 0
+        for p in peers:
+            layout.append((p, off))
+            off += p.D
+        return layout, (off if len(peers) == 1 else -(-off // 4) * 4)
 
     def shard_backward(self, plan, sx, dout, dout_ld, col_off, col_denom=None, denom=None):
         """Requester: reduce to local unique keys, ship to owners; owner: reduce across ranks."""
@@ -582,9 +593,12 @@ class _TableGroup(object):
         itself runs after autograd returns (finish_backward, called by the optimizer on the main
         thread): collectives stay in one fixed program order on every rank."""
         N, cap, D, dd = self.n_shards, sx.cap, self.D, sx.dd
-        gsend = torch.zeros(N * cap + 1, D, dtype=torch.float32, device=self.device)
-        ops.scatter_rows(G_loc, sx.uniq_slot, dd.n_unique, dd.n_max, D, gsend)
-        self._await_exchange.append((sx, gsend))
+        layout, width = self.shard_layout(sx)
+        if sx.gblock is None:      # one zero-filled block for every group of this exchange
+            sx.gblock = torch.zeros(N * cap + 1, width, dtype=torch.float32, device=self.device)
+        off = next(o for p, o in layout if p is self)
+        ops.scatter_rows(G_loc, sx.uniq_slot, dd.n_unique, dd.n_max, D, sx.gblock[:, off:off + D])
+        self._await_exchange.append((sx, off))
 
     def finish_backward(self):
         """Owner side of the sharded backward: ship row gradients to their owners, reduce the
@@ -616,30 +630,19 @@ class _TableGroup(object):
 
 def finish_shard_backward(groups):
     """Row-gradient exchange of every table group that has one waiting: groups that were routed by
-    the same _ShardExchange send their blocks side by side in ONE all-to-all ([N*cap, sum D])."""
+    the same _ShardExchange scattered their rows side by side into ONE block ([N*cap, sum D]), which
+    goes out in one all-to-all; each owner then reduces its columns in place (row stride = width)."""
     by_sx = OrderedDict()
     for grp in groups:
         waiting, grp._await_exchange = grp._await_exchange, []
-        for sx, gsend in waiting:
-            by_sx.setdefault(id(sx), (sx, []))[1].append((grp, gsend))
+        for sx, off in waiting:
+            by_sx.setdefault(id(sx), (sx, []))[1].append((grp, off))
     for sx, items in by_sx.values():
         n = items[0][0].n_shards * sx.cap
-        if len(items) == 1:
-            grp, gsend = items[0]
-            grp._finish_one(sx, grp.dist.all_to_all(gsend[:n]), grp.D)
-            continue
-        # float4-wide groups first so their column offsets stay 16-byte aligned; row stride padded
-        # to a multiple of 4 floats (the reduce kernel reads rows with vector loads)
-        items.sort(key=lambda it: 0 if it[0].D % 4 == 0 else 1)
-        parts = [gsend[:n] for _, gsend in items]
-        width = sum(g.D for g, _ in items)
-        if width % 4:
-            parts.append(torch.zeros(n, 4 - width % 4, dtype=torch.float32, device=parts[0].device))
-        recv = items[0][0].dist.all_to_all(torch.cat(parts, dim=1))
-        off = 0
-        for grp, _ in items:
+        block, sx.gblock = sx.gblock, None
+        recv = items[0][0].dist.all_to_all(block[:n])
+        for grp, off in items:
             grp._finish_one(sx, recv[:, off:off + grp.D], recv.shape[1])
-            off += grp.D
 
 
 class _EmbGatherFn(torch.autograd.Function):

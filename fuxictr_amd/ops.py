@@ -260,8 +260,19 @@ def shard_plan(dd, n_shards, total_rows, cap, send_idx, uniq_slot, lookup_slot, 
 
 
 def scatter_rows(src, row_map, n_rows, n_max, D, dst):
+    """dst: [*, >= D] (a column range of a wider block is fine: its row stride is used)."""
     check(_lib.load().fx_scatter_rows(ptr(src), ptr(row_map), ptr(n_rows), n_max, D, ptr(dst),
-                                      stream_ptr(dst.device)), "fx_scatter_rows")
+                                      dst.stride(0), stream_ptr(dst.device)), "fx_scatter_rows")
+
+
+def split_rows(src, n_rows, parts, zero_tail_rows=0):
+    """parts: [(column offset, dst [n_rows + zero_tail_rows, width] contiguous)], one launch."""
+    n = len(parts)
+    dsts = _lib.ptr_array([d for _, d in parts])
+    offs = (C.c_int32 * n)(*[o for o, _ in parts])
+    widths = (C.c_int32 * n)(*[d.shape[1] for _, d in parts])
+    check(_lib.load().fx_split_rows(ptr(src), src.stride(0), n_rows, n, dsts, offs, widths,
+                                    zero_tail_rows, stream_ptr(src.device)), "fx_split_rows")
 
 
 def sum_parts(parts, out):

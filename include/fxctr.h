@@ -162,7 +162,8 @@ int fx_dedup_sorted_runs(const int32_t* ids, int32_t n_runs, int64_t run_len, in
  *     lookup_slot[b*C + c]  slot of lookup (b,c): the id matrix to gather from the received rows
  *                           (n_shards*cap = pad slot for padding_idx lookups)
  * A bucket larger than cap sets FX_FLAG_A2A_OVERFLOW.  sorted_uid is fx_dedup's optional output
- * (unique index of every sorted lookup).  fx_scatter_rows moves reduced gradient rows into their
+ * (unique index of every sorted lookup).  fx_scatter_rows moves reduced gradient rows (row stride
+ * dst_ld: several table groups may share one exchange block) into their
  * all-to-all slots; fx_sum_parts reduces partial squared norms to one device scalar (the
  * rank-local table term of the global clip norm, summed across ranks by the host's all-reduce).
  * ------------------------------------------------------------------------------------------ */
@@ -178,7 +179,13 @@ int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique, const uint3
                   int32_t* lookup_slot, fx_scalars* scal, int32_t global_keys, int32_t* workspace,
                   fx_stream_t stream);
 int fx_scatter_rows(const float* src, const int32_t* row_map, const int32_t* n_rows, int64_t n_max,
-                    int32_t D, float* dst, fx_stream_t stream);
+                    int32_t D, float* dst, int64_t dst_ld, fx_stream_t stream);
+/* The received row block of an exchange, [n_rows, src_ld] with one column range (off, width) per
+ * table group, into one contiguous [n_rows + zero_tail_rows, width] buffer per group; the tail rows
+ * (the pad slot) are zeroed.  dst_host / off_host / width_host are HOST arrays (<= 4 parts). */
+int fx_split_rows(const float* src, int64_t src_ld, int64_t n_rows, int32_t n_parts,
+                  float* const* dst_host, const int32_t* off_host, const int32_t* width_host,
+                  int32_t zero_tail_rows, fx_stream_t stream);
 int fx_sum_parts(const float* const* parts_host, const int64_t* counts_host, int32_t n_parts,
                  float* out, fx_stream_t stream);
 

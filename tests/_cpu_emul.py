@@ -139,6 +139,12 @@ def scatter_rows(src, row_map, n_rows, n_max, D, dst):
     dst[row_map[:n].long()] = src[:n]
 
 
+def split_rows(src, n_rows, parts, zero_tail_rows=0):
+    for off, dst in parts:
+        dst[:n_rows] = src[:n_rows, off:off + dst.shape[1]]
+        dst[n_rows:n_rows + zero_tail_rows] = 0
+
+
 def sum_parts(parts, out):
     out[0] = sum(float(p.double().sum()) for p in parts)
 
@@ -800,7 +806,7 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats", "adam_catchup_all",
          "dice_local_sums", "dice_fwd_from_sums", "dice_bwd_local_sums", "dice_bwd_from_sums",
          "din_attn_workspace_floats", "din_attn_stats", "dice_stats_from_sums", "din_attn_fwd",
-         "din_attn_bwd_sums", "din_attn_bwd", "gemm_dw_dx"]
+         "din_attn_bwd_sums", "din_attn_bwd", "gemm_dw_dx", "split_rows"]
 
 
 def install_plain():

@@ -410,6 +410,35 @@ def test_gemm_dw_dx_pair_is_bit_identical_to_the_two_gemms(M, N, K):
     assert (db.double() - dz.double().sum(0)).abs().max().item() <= 1e-5 * dz.abs().double().sum(0).max().item()
 
 
+@pytest.mark.parametrize("widths", [(16, 1), (16,), (8, 4, 1), (3,)])
+def test_exchange_block_scatter_and_split(widths):
+    """fx_scatter_rows into the column range of a shared block (row stride > D, 16-byte aligned or
+    not) and fx_split_rows back into per-group row buffers with a zero pad row: bit-exact moves."""
+    g = torch.Generator().manual_seed(sum(widths))
+    n_slots, n_max = 5000, 3000
+    W = sum(widths) if len(widths) == 1 else -(-sum(widths) // 4) * 4
+    block = torch.zeros(n_slots + 1, W, device=DEV)
+    ref = torch.zeros(n_slots + 1, W)
+    n_rows = torch.tensor([2777], dtype=torch.int32)
+    off = 0
+    for D in widths:
+        src = torch.randn(n_max, D, generator=g)
+        row_map = torch.randperm(n_slots, generator=g)[:n_max].int()
+        ops.scatter_rows(_dev(src), _dev(row_map), _dev(n_rows), n_max, D, block[:, off:off + D])
+        ref[row_map[:2777].long(), off:off + D] = src[:2777]
+        off += D
+    assert torch.equal(block.cpu(), ref)
+    parts, off = [], 0
+    for D in widths:
+        parts.append((off, torch.full((n_slots + 1, D), float("nan"), device=DEV)))
+        off += D
+    ops.split_rows(block, n_slots, parts, zero_tail_rows=1)
+    for o, dst in parts:
+        D = dst.shape[1]
+        assert torch.equal(dst[:n_slots].cpu(), ref[:n_slots, o:o + D])
+        assert float(dst[n_slots].abs().max()) == 0.0
+
+
 def test_gemm_mfma_layout_is_not_transposed():
     """A = I with an ASYMMETRIC B catches a swapped C/D fragment mapping."""
     n = 128
