@@ -278,13 +278,22 @@ class _NativeOptimizer(torch.optim.Optimizer):
                         tparts.append(grp.reg_cross.clone())
             if tparts:
                 ops.sum_parts(tparts, tsq)
-            flat = torch.cat([g.reshape(-1) for g in gs] + [tsq])
-            self.dist.all_reduce_sum(flat)
-            out, off = [], 0
+            # every gradient starts on a 16-byte boundary of the flat buffer (a 1-element bias in the
+            # middle would otherwise push everything after it onto the scalar path of the
+            # multi-tensor norm / update kernels: 36 us instead of 19 us for k_mt_adam)
+            if getattr(self, "_flat_pad", None) is None:
+                self._flat_pad = torch.zeros(3, dtype=torch.float32, device=self.device)
+            pieces, offs, off = [], [], 0
             for g in gs:
-                out.append(flat[off:off + g.numel()].view_as(g))
+                pieces.append(g.reshape(-1))
+                offs.append(off)
                 off += g.numel()
-            gs = out
+                if off % 4:
+                    pieces.append(self._flat_pad[:4 - off % 4])
+                    off += 4 - off % 4
+            flat = torch.cat(pieces + [tsq])
+            self.dist.all_reduce_sum(flat)
+            gs = [flat[o:o + g.numel()].view_as(g) for o, g in zip(offs, gs)]
             tsq = flat[off:off + 1]
         parts = []
         if ps:
