@@ -385,8 +385,10 @@ def rooflines(m, args, world):
     n_inst = 1                         # the record is ONE step
     # the MFMA kernel's launches: every GEMM shape with all three extents >= 64 (the 1-wide head
     # of the tower and its two gradients run on the skinny HBM-bound kernels, not on k_gemm_f32_pipe)
-    mf = [v for k, v in kt.items() if k.startswith("gemm ")
-          and min(int(x) for x in k[5:].split("x")) >= 64]
+    # ("gemm MxNxK": one product; "gemm2 MxNxK": the dW + dX pair of a layer as one launch, 4 M N K flops)
+    def dims(k):
+        return [int(x) for x in k.split(" ", 1)[1].split("x")]
+    mf = [v for k, v in kt.items() if k.startswith(("gemm ", "gemm2 ")) and min(dims(k)) >= 64]
     g = None
     if mf:
         g = {"launches": sum(v["launches"] for v in mf), "total_ms": sum(v["total_ms"] for v in mf),
@@ -395,7 +397,8 @@ def rooflines(m, args, world):
     if g and g["total_ms"] > 0:
         ach = g["work"] / (g["total_ms"] * 1e-3) / 1e12
         traffic, src = _traffic(args.model, args.batch, world)
-        out["roofline"] = {"kernel": "k_gemm_f32_pipe (fp32 MFMA GEMM, MLP/CrossNet fwd+bwd)",
+        out["roofline"] = {"kernel": "k_gemm_f32_pipe / k_gemm_f32_pair (fp32 MFMA GEMM, MLP/CrossNet "
+                                     "fwd; dW+dX pairs bwd)",
                            "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                            "traffic": traffic,
@@ -406,9 +409,11 @@ def rooflines(m, args, world):
                            "timing": m["timing_mode"]}
         shapes = {}
         for k, v in kt.items():
-            if k.startswith("gemm ") and v["total_ms"] > 0:
+            if k.startswith(("gemm ", "gemm2 ")) and v["total_ms"] > 0:
                 tf = v["work"] / (v["total_ms"] * 1e-3) / 1e12
-                shapes[k[5:]] = {"launches_per_step": v["launches"] / n_inst,
+                label = k.split(" ", 1)[1] + (" (dW+dX pair, incl. slab reduce)"
+                                              if k.startswith("gemm2 ") else "")
+                shapes[label] = {"launches_per_step": v["launches"] / n_inst,
                                  "avg_launch_us": round(v["avg_us"], 2),
                                  "tflops": round(tf, 1),
                                  "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 3)}

@@ -476,7 +476,7 @@ def gemm_dw_dx(dz, x, W, dW, dx, split_k=1, workspace=None, rowsum=None, mask=No
     if KernelTimer.recording:
         M_, N_ = dz.shape
         K_ = x.shape[1]
-        KernelTimer.note("k_gemm_f32", "gemm dW+dX %dx%dx%d" % (M_, N_, K_), 4.0 * M_ * N_ * K_,
+        KernelTimer.note("k_gemm_f32", "gemm2 %dx%dx%d" % (M_, N_, K_), 4.0 * M_ * N_ * K_,
                          _gemm_dw_dx, (dz, x, W, dW, dx, split_k, workspace, rowsum, mask, add), {})
     return _gemm_dw_dx(dz, x, W, dW, dx, split_k, workspace, rowsum, mask, add)
 
