@@ -54,6 +54,7 @@ struct DinAttnArgs {
     const float* K;
     int64_t k_ldb, k_ldl;
     int64_t n_rows;          // B * L positions
+    int32_t nb;              // B
     int64_t rows_per_wave;   // contiguous positions a wave owns (fwd / bwd apply: whole samples)
     int32_t L, E, H;
     int32_t vec;             // q / K / dout / dK rows may be moved with 16-byte accesses
@@ -274,7 +275,7 @@ __device__ __forceinline__ void da_gemm_h(const float* __restrict__ W1s, const f
 // feature ends with the same bits); smaller L: lane e walks the positions in order.
 __device__ __forceinline__ void da_seg_sum(const float* T, int E, int L, int lane, int nvalid,
                                            uint32_t& bcur, int& lcur, float& run, float* out,
-                                           int64_t out_ld) {
+                                           int64_t out_ld, float extra = 0.f) {
     if (L >= 32) {
         const int e = lane & 15, g = lane >> 4;
         const int c = (L - lcur < nvalid) ? L - lcur : nvalid;   // positions that belong to sample bcur
@@ -296,7 +297,7 @@ __device__ __forceinline__ void da_seg_sum(const float* T, int E, int L, int lan
         v1 += __shfl_xor(v1, 32, 64);
         run += v0;
         if (lcur + c == L) {
-            if (lane < E) out[(int64_t)bcur * out_ld + lane] = run;
+            if (lane < E) out[(int64_t)bcur * out_ld + lane] = run + extra;   // extra: per-sample term
             run = v1;
             ++bcur;
             lcur = nvalid - c;
@@ -735,6 +736,571 @@ void k_din_attn_bwd(DinAttnArgs a) {
     }
 }
 
+// =============================================================================================
+// Second formulation ("q split") of the same four passes, used for the BASELINE shape (E = 8 / 16 with
+// 16-byte rows, L >= 32).  With x = (q, k, q - k, q * k) and W1 = (Wa | Wb | Wc | Wd):
+//     W1 x = (Wa + Wc) q  +  (Wb - Wc) k + Wd (q * k)
+// The first term is the same for all L positions of a sample: hq[b] = (Wa + Wc) q_b + b1 costs 16 FMAs
+// per hidden unit and SAMPLE, and what is left per POSITION is a 2E-wide product — half the MFMA
+// work of every pass, half the x tile, half the LDS copy of W1 (so twice the waves fit a CU: the
+// passes are serial chains per wave and live on having a second wave to switch to).  Backward:
+//     dWa = sum_b dhs_b q_b^T,  dWb = sum dh k^T,  dWc = dWa - dWb,  dWd = sum dh (q*k)^T
+//     dk  = (Wb - Wc)^T dh + (Wd^T dh) * q (+ the pooling's share),
+//     dq_b = (Wa + Wc)^T dhs_b + sum_l (Wd^T dh_l) * k_l,      dhs_b = sum_l dh_{b,l}
+// (dhs rides along on the A fragments of the dW product, like db1).  The sums are re-associated with
+// respect to the reference's fp32 order (W1 x as one 4E-long dot product): differences ~1e-7
+// relative, inside the parity bounds of tests/test_gpu_din_attn.py.  L >= 32 guarantees that a
+// 32-position tile touches at most two samples.
+// =============================================================================================
+template <int NB, int WAVES, bool BWD, bool POOL>
+struct Da2Smem {
+    static constexpr int HP = 32 * NB, LDW = HP + 1, LDH = HP + 1;
+    float Ws[32 * LDW];                  // rows e < E: (Wb - Wc)[n][e]; rows E + e: Wd[n][e]; then 0
+    float Wqs[16 * LDW];                 // (Wa + Wc)^T: Wqs[e * LDW + n]
+    float4 PA[HP];
+    float4 PB[HP];
+    float Xs[WAVES][32 * DA_LDX];        // x'^T tile per wave: rows e: k, rows E + e: q * k, then 0
+    float Hq[WAVES][2 * HP];             // hq of the (at most) two samples of the current tile
+    static constexpr int HSZ = 32 * LDH > HP * DA_LDX ? 32 * LDH : HP * DA_LDX;
+    float Hs[BWD ? WAVES : 1][BWD ? HSZ : 1];
+    float Ps[POOL ? WAVES : 1][POOL ? 16 * DA_LDX : 1];
+};
+
+template <class S, int EC>
+__device__ __forceinline__ void da2_load_params(S& sm, const DinAttnArgs& a, int nthreads) {
+    const int H = a.H;
+    for (int i = threadIdx.x; i < 32 * S::LDW; i += nthreads) sm.Ws[i] = 0.f;
+    for (int i = threadIdx.x; i < 16 * S::LDW; i += nthreads) sm.Wqs[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < H * EC; i += nthreads) {
+        const int n = i / EC, e = i - n * EC;
+        const float* w = a.W1 + (int64_t)n * 4 * EC + e;
+        const float wa = w[0], wb = w[EC], wc = w[2 * EC], wd = w[3 * EC];
+        sm.Ws[e * S::LDW + n] = wb - wc;
+        sm.Ws[(EC + e) * S::LDW + n] = wd;
+        sm.Wqs[e * S::LDW + n] = wa + wc;
+    }
+    for (int n = threadIdx.x; n < S::HP; n += nthreads) {
+        float4 pa = make_float4(0.f, 0.f, 1.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < H) {
+            pa.x = a.b1 ? a.b1[n] : 0.f;
+            if (a.stats) {
+                pa.y = a.stats[n];
+                pa.z = rsqrtf(a.stats[H + n] + a.eps);
+            }
+            pa.w = a.alpha ? a.alpha[n] : 0.f;
+            pb.x = a.W2 ? a.W2[n] : 0.f;
+            if (a.sums) {
+                pb.y = a.sums[H + n] * a.inv_n;
+                pb.z = a.sums[2 * H + n] * a.inv_n;
+            }
+        }
+        sm.PA[n] = pa;
+        sm.PB[n] = pb;
+    }
+    __syncthreads();
+}
+
+template <int EC>
+__device__ __forceinline__ void da2_store_x(float* Xs, int l31, int half, const DaRows& x) {
+    const int e0 = 8 * half;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u;
+        if (e < EC) {
+            Xs[e * DA_LDX + l31] = x.kv[u];
+            Xs[(EC + e) * DA_LDX + l31] = x.qv[u] * x.kv[u];
+        }
+    }
+}
+
+// hq[s][j] = b1[n] + sum_e (Wa + Wc)[n][e] q[b0 + s][e] for the lane's units n = 32 j + l31, s = 0, 1
+template <int NB, int EC, class S>
+__device__ __forceinline__ void da2_hq(const S& sm, const DinAttnArgs& a, uint32_t b0, int l31,
+                                       float (&hq)[2][NB]) {
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+        const uint32_t b = b0 + s_;
+        const bool ok = b < (uint32_t)a.nb;
+        const float* qp = a.q + (int64_t)(ok ? b : 0) * a.q_ld;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) hq[s_][j] = sm.PA[32 * j + l31].x;
+#pragma unroll
+        for (int e = 0; e < EC; ++e) {
+            const float qe = ok ? qp[e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                hq[s_][j] = fmaf(sm.Wqs[e * S::LDW + 32 * j + l31], qe, hq[s_][j]);
+        }
+    }
+}
+
+// sample bookkeeping of a wave that owns whole samples, L >= 32: c = positions of the tile that
+// belong to sample bcur (the rest opens bcur + 1)
+__device__ __forceinline__ int da2_cut(int nvalid, int L, int lcur) {
+    return (L - lcur < nvalid) ? L - lcur : nvalid;
+}
+__device__ __forceinline__ void da2_advance(int nvalid, int L, int c, uint32_t& bcur, int& lcur) {
+    if (lcur + c == L) {
+        ++bcur;
+        lcur = nvalid - c;
+    } else {
+        lcur += c;
+    }
+}
+
+template <int NB, int EC>
+__global__ __launch_bounds__(256) void k_din_attn2_stats(DinAttnArgs a) {
+    using S = Da2Smem<NB, 4, false, false>;
+    __shared__ S sm;
+    da2_load_params<S, EC>(sm, a, 256);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    float* Xs = sm.Xs[wave];
+    const int H = a.H, L = a.L;
+    for (int i = lane; i < (32 - 2 * EC) * DA_LDX; i += 64) Xs[2 * EC * DA_LDX + i] = 0.f;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t R0 = gw * a.rows_per_wave;
+    const int64_t R1 = (R0 + a.rows_per_wave < a.n_rows) ? R0 + a.rows_per_wave : a.n_rows;
+    uint32_t bcur = (uint32_t)(R0 / L);
+    int lcur = 0;
+    float s1[NB], s2[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        s1[j] = 0.f;
+        s2[j] = 0.f;
+    }
+    DaRows cur;
+    da_load_rows<EC, false, false>(a, R0 + l31, R0 + l31 < R1, half, cur);
+    for (int64_t rb = R0; rb < R1; rb += 32) {
+        const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
+        const int c = da2_cut(nvalid, L, lcur);
+        float hq[2][NB];
+        da2_hq<NB, EC>(sm, a, bcur, l31, hq);
+        da2_store_x<EC>(Xs, l31, half, cur);
+        da_load_rows<EC, false, false>(a, rb + 32 + l31, rb + 32 + l31 < R1, half, cur);   // tile t+1
+        da_f32x16 acc[NB];
+        da_gemm_h<NB, false, 2 * EC, S::LDW>(sm.Ws, Xs, 2 * EC, l31, half, acc);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = da_rowmap(r, half);
+                const float z = acc[j][r] + (i < c ? hq[0][j] : hq[1][j]);
+                if (i < nvalid) {
+                    s1[j] += z;
+                    s2[j] = fmaf(z, z, s2[j]);
+                }
+            }
+        da2_advance(nvalid, L, c, bcur, lcur);
+    }
+    __syncthreads();
+    float* red = &sm.Xs[0][0];                     // [4 waves][2][HP]
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const float o1 = __shfl_xor(s1[j], 32, 64), o2 = __shfl_xor(s2[j], 32, 64);
+        if (half == 0) {
+            red[(wave * 2 + 0) * S::HP + 32 * j + l31] = s1[j] + o1;
+            red[(wave * 2 + 1) * S::HP + 32 * j + l31] = s2[j] + o2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * S::HP) {
+        const int k = threadIdx.x / S::HP, n = threadIdx.x % S::HP;
+        if (n < H)
+            a.partial[((int64_t)blockIdx.x * 2 + k) * H + n] =
+                (red[(0 * 2 + k) * S::HP + n] + red[(1 * 2 + k) * S::HP + n]) +
+                (red[(2 * 2 + k) * S::HP + n] + red[(3 * 2 + k) * S::HP + n]);
+    }
+}
+
+template <int NB, int EC>
+__global__ __launch_bounds__(256) void k_din_attn2_fwd(DinAttnArgs a) {
+    using S = Da2Smem<NB, 4, false, true>;
+    __shared__ S sm;
+    da2_load_params<S, EC>(sm, a, 256);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    float* Xs = sm.Xs[wave];
+    float* Ps = sm.Ps[wave];
+    float* Hq = sm.Hq[wave];
+    const int L = a.L, e0 = 8 * half;
+    for (int i = lane; i < (32 - 2 * EC) * DA_LDX; i += 64) Xs[2 * EC * DA_LDX + i] = 0.f;
+    const float b2 = a.b2 ? a.b2[0] : 0.f;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t R0 = gw * a.rows_per_wave;
+    const int64_t R1 = (R0 + a.rows_per_wave < a.n_rows) ? R0 + a.rows_per_wave : a.n_rows;
+    uint32_t bcur = (uint32_t)(R0 / L);
+    int lcur = 0;
+    float run = 0.f;
+    DaRows cur;
+    da_load_rows<EC, false, true>(a, R0 + l31, R0 + l31 < R1, half, cur);
+    for (int64_t rb = R0; rb < R1; rb += 32) {
+        const int64_t row = rb + l31;
+        const bool valid = row < R1;
+        const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
+        const int c = da2_cut(nvalid, L, lcur);
+        const float m = cur.m;
+        {
+            float hq[2][NB];
+            da2_hq<NB, EC>(sm, a, bcur, l31, hq);
+            if (half < NB) {
+                Hq[32 * half + l31] = hq[0][half < NB ? half : 0];
+                Hq[S::HP + 32 * half + l31] = hq[1][half < NB ? half : 0];
+            }
+        }
+        da2_store_x<EC>(Xs, l31, half, cur);
+        da_load_rows<EC, false, true>(a, row + 32, row + 32 < R1, half, cur);              // tile t+1
+        da_f32x16 acc[NB];
+        da_gemm_h<NB, true, 2 * EC, S::LDW>(sm.Ws, Xs, 2 * EC, l31, half, acc);
+        const float* hqi = Hq + (l31 < c ? 0 : S::HP);
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = 32 * j + da_rowmap(r, half);
+                const float4 pa = sm.PA[n];
+                const float w2 = sm.PB[n].x;
+                const float z = acc[j][r] + hqi[n];
+                const float zh = (z - pa.y) * pa.z;
+                const float p = da_sigmoid(zh);
+                const float y = p * z + pa.w * (1.f - p) * z;
+                t += y * w2;
+            }
+        const float o = __shfl_xor(t, 32, 64);
+        const float ai = (half == 0 ? t + o : o + t) + b2;
+        if (half == 0 && valid) a.a_out[row] = ai;
+        const float wm = valid ? ai * m : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u;
+            if (e < EC) Ps[e * DA_LDX + l31] = wm * Xs[e * DA_LDX + l31];
+        }
+        da_seg_sum(Ps, EC, L, lane, nvalid, bcur, lcur, run, a.out, a.out_ld);
+    }
+}
+
+template <int NB, int EC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_din_attn2_bwd_sums(DinAttnArgs a) {
+    using S = Da2Smem<NB, 4, false, false>;
+    __shared__ S sm;
+    __shared__ float das[4][32];
+    da2_load_params<S, EC>(sm, a, 256);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    float* Xs = sm.Xs[wave];
+    const int H = a.H, L = a.L;
+    for (int i = lane; i < (32 - 2 * EC) * DA_LDX; i += 64) Xs[2 * EC * DA_LDX + i] = 0.f;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t R0 = gw * a.rows_per_wave;
+    const int64_t R1 = (R0 + a.rows_per_wave < a.n_rows) ? R0 + a.rows_per_wave : a.n_rows;
+    uint32_t bcur = (uint32_t)(R0 / L);
+    int lcur = 0;
+    float sa[NB], sd[NB], sz[NB], sw[NB];
+    float4 pa[NB];
+    float w2[NB];
+    float sb2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        sa[j] = 0.f;
+        sd[j] = 0.f;
+        sz[j] = 0.f;
+        sw[j] = 0.f;
+        pa[j] = sm.PA[32 * j + l31];
+        w2[j] = sm.PB[32 * j + l31].x;
+    }
+    DaRows cur;
+    da_load_rows<EC, true, true>(a, R0 + l31, R0 + l31 < R1, half, cur);
+    for (int64_t rb = R0; rb < R1; rb += 32) {
+        const int64_t row = rb + l31;
+        const bool valid = row < R1;
+        const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
+        const int c = da2_cut(nvalid, L, lcur);
+        float hq[2][NB];
+        da2_hq<NB, EC>(sm, a, bcur, l31, hq);
+        da2_store_x<EC>(Xs, l31, half, cur);
+        float d = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d = fmaf(cur.dov[u], cur.kv[u], d);
+        const float od = __shfl_xor(d, 32, 64);
+        const float da_i = (half == 0 ? d + od : od + d) * cur.m;
+        if (half == 0) {
+            das[wave][l31] = da_i;
+            sb2 += da_i;
+            if (valid) a.da_out[row] = da_i;
+        }
+        da_load_rows<EC, true, true>(a, row + 32, row + 32 < R1, half, cur);                // tile t+1
+        da_f32x16 acc[NB];
+        da_gemm_h<NB, false, 2 * EC, S::LDW>(sm.Ws, Xs, 2 * EC, l31, half, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = da_rowmap(r, half);
+            const float dar = das[wave][i];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float z = acc[j][r] + (i < c ? hq[0][j] : hq[1][j]);
+                const float zh = (z - pa[j].y) * pa[j].z;
+                const float p = da_sigmoid(zh);
+                const float y = p * z + pa[j].w * (1.f - p) * z;
+                const float dy = dar * w2[j];
+                const float dzh = dy * z * (1.f - pa[j].w) * p * (1.f - p);
+                sa[j] = fmaf(dy * (1.f - p), z, sa[j]);
+                sd[j] += dzh;
+                sz[j] = fmaf(dzh, zh, sz[j]);
+                sw[j] = fmaf(dar, y, sw[j]);
+            }
+        }
+        da2_advance(nvalid, L, c, bcur, lcur);
+    }
+    sb2 = fx_wave_sum(sb2);
+    __syncthreads();
+    float* red = &sm.Xs[0][0];                     // [4 waves][4][HP] + [4] for db2 (4 * 1056 floats)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const float oa = __shfl_xor(sa[j], 32, 64), od = __shfl_xor(sd[j], 32, 64);
+        const float oz = __shfl_xor(sz[j], 32, 64), ow = __shfl_xor(sw[j], 32, 64);
+        if (half == 0) {
+            red[(wave * 4 + 0) * S::HP + 32 * j + l31] = sa[j] + oa;
+            red[(wave * 4 + 1) * S::HP + 32 * j + l31] = sd[j] + od;
+            red[(wave * 4 + 2) * S::HP + 32 * j + l31] = sz[j] + oz;
+            red[(wave * 4 + 3) * S::HP + 32 * j + l31] = sw[j] + ow;
+        }
+    }
+    if (lane == 0) red[16 * S::HP + wave] = sb2;
+    __syncthreads();
+    for (int t = threadIdx.x; t < 4 * S::HP; t += 256) {
+        const int k = t / S::HP, n = t % S::HP;
+        if (n < H)
+            a.partial[((int64_t)blockIdx.x * 5 + k) * H + n] =
+                (red[(0 * 4 + k) * S::HP + n] + red[(1 * 4 + k) * S::HP + n]) +
+                (red[(2 * 4 + k) * S::HP + n] + red[(3 * 4 + k) * S::HP + n]);
+    }
+    for (int n = threadIdx.x; n < H; n += 256)
+        a.partial[((int64_t)blockIdx.x * 5 + 4) * H + n] =
+            n == 0 ? (red[16 * S::HP + 0] + red[16 * S::HP + 1]) +
+                         (red[16 * S::HP + 2] + red[16 * S::HP + 3])
+                   : 0.f;
+}
+
+template <int NB, int EC>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_din_attn2_bwd(DinAttnArgs a) {
+    using S = Da2Smem<NB, 2, true, false>;
+    __shared__ S sm;
+    da2_load_params<S, EC>(sm, a, 128);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    float* Xs = sm.Xs[wave];
+    float* Hs = sm.Hs[wave];
+    float* Hq = sm.Hq[wave];
+    const int H = a.H, L = a.L, KX = 4 * EC;
+    const int e0 = 8 * half;
+    for (int i = lane; i < (32 - 2 * EC) * DA_LDX; i += 64) Xs[2 * EC * DA_LDX + i] = 0.f;
+    const int64_t gw = (int64_t)blockIdx.x * 2 + wave;
+    const int64_t R0 = gw * a.rows_per_wave;
+    const int64_t R1 = (R0 + a.rows_per_wave < a.n_rows) ? R0 + a.rows_per_wave : a.n_rows;
+    da_f32x16 accW[NB];                            // dW'[n][f], f < E: dWb - (c part), f >= E: dWd
+    float dWq[NB][EC];                             // unit 32 j + l31 (both halves hold the same)
+    float db1q[NB], dhs_run[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[j][r] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EC; ++e) dWq[j][e] = 0.f;
+        db1q[j] = 0.f;
+        dhs_run[j] = 0.f;
+    }
+    uint32_t bcur = (uint32_t)(R0 / L);
+    int lcur = 0;
+    float dq_run = 0.f;
+    DaRows cur;
+    da_load_rows<EC, false, true>(a, R0 + l31, R0 + l31 < R1, half, cur);
+    float da_n = (R0 + l31 < R1) ? a.da_in[R0 + l31] : 0.f;
+    float a_n = (R0 + l31 < R1) ? a.a_in[R0 + l31] : 0.f;
+    for (int64_t rb = R0; rb < R1; rb += 32) {
+        const int64_t row = rb + l31;
+        const bool valid = row < R1;
+        const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
+        const int c = da2_cut(nvalid, L, lcur);
+        const uint32_t b = cur.b;
+        const int l = cur.l;
+        const float da_i = da_n;
+        const float wm = a_n * cur.m;
+        float qv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) qv[u] = cur.qv[u];
+        {
+            float hq[2][NB];
+            da2_hq<NB, EC>(sm, a, bcur, l31, hq);
+            if (half < NB) {
+                Hq[32 * half + l31] = hq[0][half < NB ? half : 0];
+                Hq[S::HP + 32 * half + l31] = hq[1][half < NB ? half : 0];
+            }
+        }
+        da2_store_x<EC>(Xs, l31, half, cur);
+        da_load_rows<EC, false, true>(a, row + 32, row + 32 < R1, half, cur);              // tile t+1
+        da_n = (row + 32 < R1) ? a.da_in[row + 32] : 0.f;
+        a_n = (row + 32 < R1) ? a.a_in[row + 32] : 0.f;
+        {
+            da_f32x16 acc[NB];
+            da_gemm_h<NB, true, 2 * EC, S::LDW>(sm.Ws, Xs, 2 * EC, l31, half, acc);
+            const float* hqi = Hq + (l31 < c ? 0 : S::HP);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = 32 * j + da_rowmap(r, half);
+                    const float4 pa = sm.PA[n];
+                    const float4 pb = sm.PB[n];
+                    const float z = acc[j][r] + hqi[n];
+                    const float zh = (z - pa.y) * pa.z;
+                    const float p = da_sigmoid(zh);
+                    const float dy = da_i * pb.x;
+                    float dzh = dy * z * (1.f - pa.w) * p * (1.f - p);
+                    dzh -= pb.y + zh * pb.z;                 // 0 outside training mode
+                    float dh = dy * (p + pa.w * (1.f - p)) + dzh * pa.z;
+                    if (!valid) dh = 0.f;
+                    Hs[l31 * S::LDH + n] = dh;
+                }
+        }
+        // dW'[n][f] += sum_i dh[i][n] x'[i][f]  and  dx'^T[f][i] = sum_n W'[n][f] dh[i][n], interleaved;
+        // db1 and the per-sample sums dhs ride along on the A fragments (= dh)
+        da_f32x16 accD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accD[r] = 0.f;
+        float dhs0[NB], dhs1[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            dhs0[j] = 0.f;
+            dhs1[j] = 0.f;
+        }
+        {
+            float av[2][NB], bv[2], bh[2][NB], aw[2][NB];
+            auto rd = [&](int kk, int s_) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) av[s_][j] = Hs[(2 * kk + half) * S::LDH + 32 * j + l31];
+                bv[s_] = Xs[l31 * DA_LDX + 2 * kk + half];
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const int kd = kk * NB + t;
+                    bh[s_][t] = Hs[l31 * S::LDH + 2 * kd + half];
+                    aw[s_][t] = sm.Ws[l31 * S::LDW + 2 * kd + half];
+                }
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int cs = kk & 1;
+                if (kk + 1 < 16) rd(kk + 1, cs ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const bool first = 2 * kk + half < c;      // this fragment's position: sample bcur?
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    db1q[j] += av[cs][j];
+                    if (first) dhs0[j] += av[cs][j];
+                    else dhs1[j] += av[cs][j];
+                    accW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cs][j], bv[cs], accW[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < NB; ++t)
+                    accD = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cs][t], bh[cs][t], accD, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float dov[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dov[u] = 0.f;
+        if (valid && e0 < EC) da_ld8(a.dout + (int64_t)b * a.dout_ld + e0, true, e0, EC, dov);
+        // dx'^T through LDS (over the dh tile); rows e: (Wb - Wc)^T dh, rows E + e: Wd^T dh
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Hs[da_rowmap(r, half) * DA_LDX + l31] = accD[r];
+        float dkv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u;
+            dkv[u] = 0.f;
+            if (e < EC) {
+                const float ke = Xs[e * DA_LDX + l31];
+                const float dxk = Hs[e * DA_LDX + l31];
+                const float dxp = Hs[(EC + e) * DA_LDX + l31];
+                dkv[u] = (dxk + dxp * qv[u]) + wm * dov[u];
+                Xs[(EC + e) * DA_LDX + l31] = valid ? dxp * ke : 0.f;   // share of dq (over q*k rows)
+            }
+        }
+        if (valid && e0 < EC) {
+            float* dkp = a.dK + (int64_t)b * a.dk_ldb + (int64_t)l * a.dk_ldl + e0;
+            *reinterpret_cast<float4*>(dkp) = make_float4(dkv[0], dkv[1], dkv[2], dkv[3]);
+            *reinterpret_cast<float4*>(dkp + 4) = make_float4(dkv[4], dkv[5], dkv[6], dkv[7]);
+        }
+        // a sample ends inside this tile: its dhs is complete -> dWa += dhs q^T, dq gets (Wa+Wc)^T dhs
+        float extra = 0.f;
+        if (lcur + c == L) {
+            float dfin[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float t = dhs_run[j] + dhs0[j];
+                const float o = __shfl_xor(t, 32, 64);
+                dfin[j] = half == 0 ? t + o : o + t;
+                dhs_run[j] = dhs1[j];
+            }
+            const float* qp = a.q + (int64_t)bcur * a.q_ld;
+#pragma unroll
+            for (int e = 0; e < EC; ++e) {
+                const float qe = qp[e];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) dWq[j][e] = fmaf(dfin[j], qe, dWq[j][e]);
+            }
+            if (half < NB) Hq[32 * half + l31] = dfin[half < NB ? half : 0];   // hq is consumed
+            const int e = lane & 15;
+            if (e < EC) {
+#pragma unroll 8
+                for (int n = 0; n < S::HP; ++n) extra = fmaf(sm.Wqs[e * S::LDW + n], Hq[n], extra);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) dhs_run[j] += dhs0[j];
+        }
+        da_seg_sum(Xs + EC * DA_LDX, EC, L, lane, nvalid, bcur, lcur, dq_run, a.dq, a.dq_ld, extra);
+    }
+    // ---- per-workgroup partial of dW1 (assembled from dWq, dW') and db1
+    __syncthreads();
+    float* Wt = sm.Hs[wave];                       // this wave's dW' as [n][DA_LDX] (f < 2E)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Wt[(32 * j + da_rowmap(r, half)) * DA_LDX + l31] = accW[j][r];
+    float* Q1 = &sm.Xs[1][0];                      // wave 1's dWq as [n][EC] (HP * EC <= 32 * 33 floats)
+    float* bsc = &sm.Hq[0][0];                     // [2 waves][HP] (Hq[0] and Hq[1] are adjacent)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const float o = __shfl_xor(db1q[j], 32, 64);
+        if (half == 0) bsc[wave * 2 * S::HP + 32 * j + l31] = db1q[j] + o;
+    }
+    if (wave == 1 && half < NB) {
+#pragma unroll
+        for (int e = 0; e < EC; ++e) Q1[(32 * half + l31) * EC + e] = dWq[half < NB ? half : 0][e];
+    }
+    __syncthreads();
+    if (wave == 0 && half < NB) {
+        const int n = 32 * half + l31;
+        if (n < H) {
+            float* P = a.partial + (int64_t)blockIdx.x * ((int64_t)H * KX + H);
+            const float* W0 = sm.Hs[0] + n * DA_LDX;
+            const float* W1t = sm.Hs[1] + n * DA_LDX;
+#pragma unroll
+            for (int e = 0; e < EC; ++e) {
+                const float qa = dWq[half < NB ? half : 0][e] + Q1[n * EC + e];
+                const float kb = W0[e] + W1t[e];
+                const float pd = W0[EC + e] + W1t[EC + e];
+                P[(int64_t)n * KX + e] = qa;
+                P[(int64_t)n * KX + EC + e] = kb;
+                P[(int64_t)n * KX + 2 * EC + e] = qa - kb;
+                P[(int64_t)n * KX + 3 * EC + e] = pd;
+            }
+            P[(int64_t)H * KX + n] = bsc[n] + bsc[2 * S::HP + n];
+        }
+    }
+}
+
 // out[k * H + h] = sum over chunks c (fixed order) of partial[(c * nt + k) * H + h]
 __global__ __launch_bounds__(256) void k_da_chunks_sum(const float* partial, int chunks, int nt,
                                                        int64_t H, float* out) {
@@ -795,13 +1361,14 @@ static int64_t da_env_cap(const char* name, int64_t dflt) {
     return v >= 64 ? v : dflt;
 }
 
-static DaGeom da_geom(int64_t B, int32_t L) {
+static DaGeom da_geom(int64_t B, int32_t L, bool qsplit = false) {
     // waves per launch (experiment switches FX_DIN_ATTN_WAVES / _FWD_WAVES / _BWD_WAVES): a pass is a
     // serial chain per wave (x tile -> MFMA -> gate -> ...), so what matters is that every SIMD gets
     // the same number of tiles (measured: profiles/r02_din_attn_passes.txt)
     static const int64_t cap_flat = da_env_cap("FX_DIN_ATTN_WAVES", 2048);
     static const int64_t cap_fwd = da_env_cap("FX_DIN_ATTN_FWD_WAVES", 2048);
     static const int64_t cap_bwd = da_env_cap("FX_DIN_ATTN_BWD_WAVES", 1536);
+    static const int64_t cap_bwd2 = da_env_cap("FX_DIN_ATTN_BWD_WAVES", 2048);   // q split: 4 WGs per CU
     DaGeom g;
     g.n_rows = B * L;
     // statistics passes: 32-position tiles dealt to <= cap_flat waves, no per-sample reduction
@@ -813,17 +1380,27 @@ static DaGeom da_geom(int64_t B, int32_t L) {
     const int64_t Sf = fx_ceil_div(B, cap_fwd) > 1 ? fx_ceil_div(B, cap_fwd) : 1;
     g.rpw_fwd = Sf * L;
     g.wgs_fwd = fx_ceil_div(fx_ceil_div(B, Sf), 4);
-    const int64_t Sb = fx_ceil_div(B, cap_bwd) > 1 ? fx_ceil_div(B, cap_bwd) : 1;
+    const int64_t cb = qsplit ? cap_bwd2 : cap_bwd;
+    const int64_t Sb = fx_ceil_div(B, cb) > 1 ? fx_ceil_div(B, cb) : 1;
     g.rpw_bwd = Sb * L;
-    g.wgs_bwd = fx_ceil_div(fx_ceil_div(B, Sb), 2);      // 2 waves per workgroup: 3 per CU fit (LDS)
+    g.wgs_bwd = fx_ceil_div(fx_ceil_div(B, Sb), 2);      // 2 waves per workgroup (LDS)
+    if (qsplit) {                                        // every pass owns whole samples
+        g.rpw_flat = g.rpw_fwd;
+        g.wgs_flat = g.wgs_fwd;
+    }
     return g;
 }
 
 extern "C" int64_t fx_din_attn_workspace_floats(int64_t B, int32_t L, int32_t E, int32_t H) {
     if (B < 1 || L < 1 || E < 1 || H < 1) return 0;
-    const DaGeom g = da_geom(B, L);
-    const int64_t a = g.wgs_flat * 5 * H, b = g.wgs_bwd * ((int64_t)H * 4 * E + H);
-    return a > b ? a : b;
+    int64_t need = 0;
+    for (int q = 0; q < 2; ++q) {                       // either formulation may be dispatched
+        const DaGeom g = da_geom(B, L, q != 0);
+        const int64_t a = g.wgs_flat * 5 * H, b = g.wgs_bwd * ((int64_t)H * 4 * E + H);
+        need = a > need ? a : need;
+        need = b > need ? b : need;
+    }
+    return need;
 }
 
 static int da_check(const char* who, const float* q, const float* K, int64_t B, int32_t L, int32_t E,
@@ -844,7 +1421,7 @@ static void da_fill(DinAttnArgs& a, const float* q, int64_t q_ld, const float* K
                     const float* b1) {
     memset(&a, 0, sizeof(a));
     a.q = q; a.q_ld = q_ld; a.K = K; a.k_ldb = k_ldb; a.k_ldl = k_ldl;
-    a.n_rows = B * L; a.L = L; a.E = E; a.H = H; a.W1 = W1; a.b1 = b1;
+    a.n_rows = B * L; a.nb = (int32_t)B; a.L = L; a.E = E; a.H = H; a.W1 = W1; a.b1 = b1;
     a.vec = (E % 8 == 0) && da_al16(q, q_ld) && da_al16(K, k_ldb, k_ldl);
 }
 
@@ -864,6 +1441,26 @@ static void da_fill(DinAttnArgs& a, const float* q, int64_t q_ld, const float* K
         else DA_DISPATCH_NB(KERNEL, 2, THREADS, GRID, STREAM, ARGS);                              \
     } while (0)
 
+// the q-split formulation: E = 8 / 16 with 16-byte rows, L >= 32 (FX_DIN_ATTN_QSPLIT=0: never)
+static bool da2_ok(const DinAttnArgs& a) {
+    static const bool on = []() {
+        const char* e = getenv("FX_DIN_ATTN_QSPLIT");
+        return !(e && atoi(e) == 0);
+    }();
+    return on && a.vec && (a.E == 16 || a.E == 8) && a.L >= 32;
+}
+#define DA2_LAUNCH(KERNEL, THREADS, GRID, STREAM, ARGS)                                            \
+    do {                                                                                           \
+        if (ARGS.H <= 32 && ARGS.E == 16)                                                          \
+            hipLaunchKernelGGL((KERNEL<1, 16>), dim3((unsigned)(GRID)), dim3(THREADS), 0, STREAM, ARGS); \
+        else if (ARGS.H <= 32)                                                                     \
+            hipLaunchKernelGGL((KERNEL<1, 8>), dim3((unsigned)(GRID)), dim3(THREADS), 0, STREAM, ARGS); \
+        else if (ARGS.E == 16)                                                                     \
+            hipLaunchKernelGGL((KERNEL<2, 16>), dim3((unsigned)(GRID)), dim3(THREADS), 0, STREAM, ARGS); \
+        else                                                                                       \
+            hipLaunchKernelGGL((KERNEL<2, 8>), dim3((unsigned)(GRID)), dim3(THREADS), 0, STREAM, ARGS); \
+    } while (0)
+
 extern "C" int fx_din_attn_stats(const float* q, int64_t q_ld, const float* K, int64_t k_ldb,
                                  int64_t k_ldl, int64_t B, int32_t L, int32_t E, const float* W1,
                                  const float* b1, int32_t H, float* sums, float* workspace,
@@ -871,13 +1468,15 @@ extern "C" int fx_din_attn_stats(const float* q, int64_t q_ld, const float* K, i
     int rc = da_check("fx_din_attn_stats", q, K, B, L, E, H, W1);
     if (rc != FX_OK) return rc;
     FX_CHECK_ARG(sums && workspace, "fx_din_attn_stats: null pointer");
-    const DaGeom g = da_geom(B, L);
     DinAttnArgs a;
     da_fill(a, q, q_ld, K, k_ldb, k_ldl, B, L, E, H, W1, b1);
+    const bool q2 = da2_ok(a);
+    const DaGeom g = da_geom(B, L, q2);
     a.rows_per_wave = g.rpw_flat;
     a.partial = workspace;
     hipStream_t s = fx_hip_stream(stream);
-    DA_DISPATCH(k_din_attn_stats, 256, g.wgs_flat, s, a);
+    if (q2) DA2_LAUNCH(k_din_attn2_stats, 256, g.wgs_flat, s, a);
+    else DA_DISPATCH(k_din_attn_stats, 256, g.wgs_flat, s, a);
     hipLaunchKernelGGL(k_da_chunks_sum, dim3((unsigned)fx_ceil_div(H, 16), 2), dim3(256), 0, s,
                        (const float*)workspace, (int)g.wgs_flat, 2, (int64_t)H, sums);
     FX_CHECK_LAUNCH();
@@ -912,14 +1511,16 @@ extern "C" int fx_din_attn_fwd(const float* q, int64_t q_ld, const float* K, int
     int rc = da_check("fx_din_attn_fwd", q, K, B, L, E, H, W1);
     if (rc != FX_OK) return rc;
     FX_CHECK_ARG(alpha && stats && W2 && a_out && out, "fx_din_attn_fwd: null pointer");
-    const DaGeom g = da_geom(B, L);
     DinAttnArgs a;
     da_fill(a, q, q_ld, K, k_ldb, k_ldl, B, L, E, H, W1, b1);
+    const bool q2 = da2_ok(a);
+    const DaGeom g = da_geom(B, L, q2);
     a.rows_per_wave = g.rpw_fwd;
     a.alpha = alpha; a.eps = eps; a.stats = stats; a.W2 = W2; a.b2 = b2;
     a.mask = mask; a.m_ld = mask_ld; a.a_out = a_out; a.out = out; a.out_ld = out_ld;
     hipStream_t s = fx_hip_stream(stream);
-    DA_DISPATCH(k_din_attn_fwd, 256, g.wgs_fwd, s, a);
+    if (q2) DA2_LAUNCH(k_din_attn2_fwd, 256, g.wgs_fwd, s, a);
+    else DA_DISPATCH(k_din_attn_fwd, 256, g.wgs_fwd, s, a);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
@@ -934,16 +1535,18 @@ extern "C" int fx_din_attn_bwd_sums(const float* q, int64_t q_ld, const float* K
     if (rc != FX_OK) return rc;
     FX_CHECK_ARG(alpha && stats && W2 && dout && da && sums5 && workspace,
                  "fx_din_attn_bwd_sums: null pointer");
-    const DaGeom g = da_geom(B, L);
     DinAttnArgs a;
     da_fill(a, q, q_ld, K, k_ldb, k_ldl, B, L, E, H, W1, b1);
     a.vec = a.vec && da_al16(dout, dout_ld);
+    const bool q2 = da2_ok(a);
+    const DaGeom g = da_geom(B, L, q2);
     a.rows_per_wave = g.rpw_flat;
     a.alpha = alpha; a.eps = eps; a.stats = stats; a.W2 = W2;
     a.mask = mask; a.m_ld = mask_ld; a.dout = dout; a.dout_ld = dout_ld; a.da_out = da;
     a.partial = workspace;
     hipStream_t s = fx_hip_stream(stream);
-    DA_DISPATCH(k_din_attn_bwd_sums, 256, g.wgs_flat, s, a);
+    if (q2) DA2_LAUNCH(k_din_attn2_bwd_sums, 256, g.wgs_flat, s, a);
+    else DA_DISPATCH(k_din_attn_bwd_sums, 256, g.wgs_flat, s, a);
     hipLaunchKernelGGL(k_da_chunks_sum, dim3((unsigned)fx_ceil_div(H, 16), 5), dim3(256), 0, s,
                        (const float*)workspace, (int)g.wgs_flat, 5, (int64_t)H, sums5);
     FX_CHECK_LAUNCH();
@@ -965,10 +1568,11 @@ extern "C" int fx_din_attn_bwd(const float* q, int64_t q_ld, const float* K, int
                  "fx_din_attn_bwd: null pointer");
     FX_CHECK_ARG(!training || (sums5 && n_total >= B * (int64_t)L),
                  "fx_din_attn_bwd: training mode needs the backward sums and the global row count");
-    const DaGeom g = da_geom(B, L);
     DinAttnArgs a;
     da_fill(a, q, q_ld, K, k_ldb, k_ldl, B, L, E, H, W1, b1);
     a.vec = a.vec && da_al16(dout, dout_ld) && da_al16(dK, dk_ldb, dk_ldl);
+    const bool q2 = da2_ok(a);
+    const DaGeom g = da_geom(B, L, q2);
     a.rows_per_wave = g.rpw_bwd;
     a.alpha = alpha; a.eps = eps; a.stats = stats; a.W2 = W2;
     a.mask = mask; a.m_ld = mask_ld; a.a_in = a_logit; a.dout = dout; a.dout_ld = dout_ld;
@@ -978,7 +1582,8 @@ extern "C" int fx_din_attn_bwd(const float* q, int64_t q_ld, const float* K, int
     a.dq = dq; a.dq_ld = dq_ld; a.dK = dK; a.dk_ldb = dk_ldb; a.dk_ldl = dk_ldl;
     a.partial = workspace;
     hipStream_t s = fx_hip_stream(stream);
-    DA_DISPATCH(k_din_attn_bwd, 128, g.wgs_bwd, s, a);
+    if (q2) DA2_LAUNCH(k_din_attn2_bwd, 128, g.wgs_bwd, s, a);
+    else DA_DISPATCH(k_din_attn_bwd, 128, g.wgs_bwd, s, a);
     const int64_t tot = (int64_t)H * 4 * E + H;
     hipLaunchKernelGGL(k_da_chunks_sum, dim3((unsigned)fx_ceil_div(tot, 16), 1), dim3(256), 0, s,
                        (const float*)workspace, (int)g.wgs_bwd, 1, tot, dW1b1);

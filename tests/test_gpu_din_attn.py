@@ -95,6 +95,7 @@ def _close(got, ref, tol, what):
 
 
 SHAPES = [(64, 50, 16, 64), (7, 3, 4, 16), (33, 50, 8, 36), (5, 1, 10, 64), (300, 20, 16, 32),
+          (50, 32, 16, 32), (41, 97, 8, 64), (19, 33, 16, 64),
           (129, 7, 12, 64), (4096, 50, 16, 64)]
 
 
@@ -128,8 +129,9 @@ def test_fused_and_unfused_native_paths_agree(B, L, E, H):
         _close(a[3][name], b[3][name].cpu(), 1e-4, "d " + name)
 
 
-def test_fused_din_attention_on_a_record_view_without_mask_and_biases():
-    B, L, E, H = 200, 11, 16, 64
+@pytest.mark.parametrize("L", [11, 40])       # 40: the q-split formulation (L >= 32)
+def test_fused_din_attention_on_a_record_view_without_mask_and_biases(L):
+    B, E, H = 200, 16, 64
     q, K, _, state, dout = _case(B, L, E, H, seed=5)
     state[PFX + "attention_layer.mlp.0.bias"].zero_()
     state[PFX + "attention_layer.mlp.2.bias"].zero_()
