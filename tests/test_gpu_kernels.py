@@ -358,7 +358,11 @@ def test_lr_forward():
 
 
 GEMM_SHAPES = [(4096, 1024, 624), (4096, 1024, 1024), (4096, 1, 1024), (100, 70, 50), (257, 129, 17),
-               (1, 1, 1), (64, 624, 4096), (130, 1648, 33)]
+               (1, 1, 1), (64, 624, 4096), (130, 1648, 33),
+               # rows only 4-byte aligned (DLRM: 367 = 27*26/2 + 16 inputs of the top MLP): the
+               # pipelined kernel's UA loaders — straddling float4 at the end of K / of the rows
+               (4096, 1024, 367), (4096, 367, 1024), (367, 1024, 4096), (333, 65, 37), (66, 67, 9),
+               (5, 7, 11), (4099, 130, 131)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -437,6 +441,39 @@ def test_exchange_block_scatter_and_split(widths):
         D = dst.shape[1]
         assert torch.equal(dst[:n_slots].cpu(), ref[:n_slots, o:o + D])
         assert float(dst[n_slots].abs().max()) == 0.0
+
+
+def test_gemm_unaligned_rows_with_epilogues_split_k_and_views():
+    """The UA path with everything on: operands that are column slices of wider buffers (4-byte
+    aligned base pointers and odd leading dimensions), split-K with the fused row sums, bias + ReLU +
+    mask + add epilogues."""
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 1030, 367, 1501
+    big = torch.randn(M, K + 5, generator=g)
+    Wb = torch.randn(N, K + 3, generator=g)
+    A, W = _dev(big)[:, 3:3 + K], _dev(Wb)[:, 1:1 + K]
+    bias, add, msk = _dev(torch.randn(N, generator=g)), _dev(torch.randn(M, N, generator=g)), _dev(torch.randn(M, N, generator=g))
+    ref = A.double() @ W.double().t() + bias.double()
+    tol = 3e-6 * (A.abs().double() @ W.abs().double().t()).max().item()
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(A, W, C, transb=True, bias=bias, act=1, mask=msk, add=add)
+    want = torch.where(msk > 0, ref.clamp(min=0), torch.zeros((), dtype=torch.float64, device=DEV)) + add.double()
+    assert (C.double() - want).abs().max().item() <= tol
+    # weight-gradient layout: dW[N, K] = dz^T x with dz [M, N] and x a strided [M, K] view, split-K 3
+    dz = _dev(torch.randn(M, N, generator=g))
+    dW = torch.empty(N, K, device=DEV)
+    db = torch.empty(N, device=DEV)
+    ws = torch.empty(3 * N * (K + 1) + 64, device=DEV)
+    ops.gemm(dz, A, dW, transa=True, transb=False, split_k=3, workspace=ws, rowsum=db)
+    refw = dz.double().t() @ A.double()
+    assert (dW.double() - refw).abs().max().item() <= 3e-6 * (dz.abs().double().t() @ A.abs().double()).max().item()
+    assert (db.double() - dz.double().sum(0)).abs().max().item() <= 1e-5 * dz.abs().double().sum(0).max().item()
+    # input-gradient layout: dx[M, K] = dz W into a strided view
+    out = torch.zeros(M, K + 2, device=DEV)
+    ops.gemm(dz, W, out[:, 1:1 + K], transa=False, transb=False)
+    refx = dz.double() @ W.double()
+    assert (out[:, 1:1 + K].double() - refx).abs().max().item() <= 3e-6 * (dz.abs().double() @ W.abs().double()).max().item()
+    assert float(out[:, 0].abs().max()) == 0.0 and float(out[:, K + 1].abs().max()) == 0.0
 
 
 def test_gemm_mfma_layout_is_not_transposed():
