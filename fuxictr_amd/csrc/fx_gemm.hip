@@ -262,35 +262,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
 //     copied all 64 of them in and out around the loop's branches.
 // Out-of-range rows / the K tail are clamped addresses + zero selects (no exec-mask branches).
 // ---------------------------------------------------------------------------------------------
-// UA ("unaligned") = the operand's rows are only 4-byte aligned (leading dimension or extent not a
-// multiple of 4 floats, e.g. DLRM's 367-wide interaction output): the same 16-byte loads with an
-// alignment-4 vector type (the compiler picks what the target's unaligned-access mode allows), and
-// the ONE float4 that straddles the end of the contiguous extent — v = extent mod 4 of its elements
-// are inside — is fetched from [end - 4, end) instead and rotated into place, so nothing is read
-// past the matrix.  Validity then has two bits per float4: full (bit p) and partial (bit 8 + p).
-typedef float fx_f4u __attribute__((ext_vector_type(4), aligned(4)));
-
-template <bool UA>
-__device__ __forceinline__ float4 fx_ld4(const float* p) {
-    if constexpr (UA) {
-        const fx_f4u v = *reinterpret_cast<const fx_f4u*>(p);
-        return make_float4(v.x, v.y, v.z, v.w);
-    } else {
-        return *reinterpret_cast<const float4*>(p);
-    }
-}
-
-// component `comp` of a float4 that was fetched from [end - 4, end) while its own window starts
-// 4 - v elements later (v in 1..3 elements inside): element comp of the window = loaded[comp + 4 - v]
-template <int comp>
-__device__ __forceinline__ float fx_rot(const float4& s, int v) {
-    if constexpr (comp == 0) return v == 3 ? s.y : (v == 2 ? s.z : s.w);
-    else if constexpr (comp == 1) return v == 3 ? s.z : (v == 2 ? s.w : 0.f);
-    else if constexpr (comp == 2) return v == 3 ? s.w : 0.f;
-    else return 0.f;
-}
-
-template <int R, bool KC, bool UA = false>
+template <int R, bool KC>
 struct PipeLoader {
     static constexpr int NST = R / 32;
     static constexpr int LD = KC ? R + 1 : R + 4;
@@ -298,10 +270,9 @@ struct PipeLoader {
     int32_t ld;
     int32_t rc[NST];       // KC: clamped row * ld ; else: clamped first row of the float4
     int32_t kl[NST];       // k of this thread's float4 inside a tile
-    uint32_t rok;          // bit p: the row(s) of float4 p exist (UA, !KC: bit 8 + p: partially)
+    uint32_t rok;          // bit p: the row(s) of float4 p exist
     uint32_t voff[NST];    // byte offset of float4 p in tile 0 (valid when the rows exist)
     int32_t kbeg, kend;
-    int32_t vtail;         // UA: elements of the straddling float4 that lie inside (extent mod 4)
 
     __device__ __forceinline__ void init(const float* P_, int64_t ld_, int64_t r0, int64_t Rext,
                                          int64_t kbeg_, int64_t kend_) {
@@ -310,7 +281,6 @@ struct PipeLoader {
         kbeg = (int32_t)kbeg_;
         kend = (int32_t)kend_;
         rok = 0;
-        vtail = KC ? ((kend - kbeg) & 3) : ((int32_t)Rext & 3);
 #pragma unroll
         for (int p = 0; p < NST; ++p) {
             const int q = threadIdx.x + 256 * p;
@@ -323,39 +293,10 @@ struct PipeLoader {
             } else {
                 const int32_t r = (int32_t)r0 + ((q % (R / 4)) << 2);
                 kl[p] = q / (R / 4);
-                if constexpr (UA) {
-                    if (r + 4 <= (int32_t)Rext) rok |= 1u << p;
-                    else if (r < (int32_t)Rext) rok |= 1u << (8 + p);
-                    rc[p] = r + 4 <= (int32_t)Rext ? r : (int32_t)Rext - 4;
-                } else {
-                    if (r < (int32_t)Rext) rok |= 1u << p;
-                    rc[p] = r < (int32_t)Rext ? r : (int32_t)Rext - 4;
-                }
+                if (r < (int32_t)Rext) rok |= 1u << p;
+                rc[p] = r < (int32_t)Rext ? r : (int32_t)Rext - 4;
                 voff[p] = (uint32_t)((kbeg + kl[p]) * ld + rc[p]) * 4u;
             }
-        }
-    }
-
-    // validity bits + clamped address of float4 p of tile t
-    __device__ __forceinline__ const float* addr(int p, int64_t t, uint32_t& okm) const {
-        const int32_t k = kbeg + (int32_t)t * FX_BK + kl[p];
-        okm &= ~((1u << p) | (1u << (8 + p)));
-        if constexpr (KC) {
-            if constexpr (UA) {
-                const bool row = (rok >> p) & 1u;
-                if (row && k + 4 <= kend) okm |= 1u << p;
-                else if (row && k < kend) okm |= 1u << (8 + p);
-                const int32_t kc = k + 4 <= kend ? k : kend - 4;
-                return P + (rc[p] + kc);
-            } else {
-                if ((k < kend) && ((rok >> p) & 1u)) okm |= 1u << p;
-                const int32_t kc = k < kend ? k : kend - 4;
-                return P + (rc[p] + kc);
-            }
-        } else {
-            if (k < kend) okm |= rok & ((1u << p) | (1u << (8 + p)));
-            const int32_t kc = k < kend ? k : kend - 1;
-            return P + (kc * ld + rc[p]);
         }
     }
 
@@ -365,7 +306,17 @@ struct PipeLoader {
     __device__ __forceinline__ uint32_t load(int64_t t, float4 (&st)[NST]) const {
         uint32_t okm = 0;
 #pragma unroll
-        for (int p = 0; p < NST; ++p) st[p] = fx_ld4<UA>(addr(p, t, okm));
+        for (int p = 0; p < NST; ++p) {
+            const int32_t k = kbeg + (int32_t)t * FX_BK + kl[p];
+            if ((k < kend) && ((rok >> p) & 1u)) okm |= 1u << p;
+            if constexpr (KC) {
+                const int32_t kc = k < kend ? k : kend - 4;
+                st[p] = *reinterpret_cast<const float4*>(P + (rc[p] + kc));
+            } else {
+                const int32_t kc = k < kend ? k : kend - 1;
+                st[p] = *reinterpret_cast<const float4*>(P + (kc * ld + rc[p]));
+            }
+        }
         return okm;
     }
 
@@ -375,24 +326,22 @@ struct PipeLoader {
     __device__ __forceinline__ void load_plain(int64_t t, float4 (&st)[NST], uint32_t& okm) const {
         const int64_t tile_off = KC ? t * (FX_BK * 4) : t * (FX_BK * 4) * (int64_t)ld;
         const char* base = reinterpret_cast<const char*>(P) + tile_off;
-        st[p] = fx_ld4<UA>(reinterpret_cast<const float*>(base + voff[p]));
+        st[p] = *reinterpret_cast<const float4*>(base + voff[p]);
         okm = (1u << NST) - 1u;
     }
 
     template <int p>
     __device__ __forceinline__ void load_one(int64_t t, float4 (&st)[NST], uint32_t& okm) const {
-        st[p] = fx_ld4<UA>(addr(p, t, okm));
-    }
-
-    // element `comp` of float4 p as it goes to LDS: itself, rotated (UA, straddling float4) or 0
-    template <int p, int comp>
-    __device__ __forceinline__ float piece(const float4 (&st)[NST], uint32_t okm) const {
-        const float x = comp == 0 ? st[p].x : comp == 1 ? st[p].y : comp == 2 ? st[p].z : st[p].w;
-        float y = ((okm >> p) & 1u) ? x : 0.f;
-        if constexpr (UA) {
-            if ((okm >> (8 + p)) & 1u) y = fx_rot<comp>(st[p], vtail);
+        const int32_t k = kbeg + (int32_t)t * FX_BK + kl[p];
+        if ((k < kend) && ((rok >> p) & 1u)) okm |= 1u << p;
+        else okm &= ~(1u << p);
+        if constexpr (KC) {
+            const int32_t kc = k < kend ? k : kend - 4;
+            st[p] = *reinterpret_cast<const float4*>(P + (rc[p] + kc));
+        } else {
+            const int32_t kc = k < kend ? k : kend - 1;
+            st[p] = *reinterpret_cast<const float4*>(P + (kc * ld + rc[p]));
         }
-        return y;
     }
 
     // one LDS write instruction: component `comp` of float4 p (KC, transposing) or the whole float4
@@ -400,16 +349,18 @@ struct PipeLoader {
     __device__ __forceinline__ void store_piece(float* __restrict__ T, const float4 (&st)[NST],
                                                 uint32_t okm) const {
         const int q = threadIdx.x + 256 * p;
+        const bool ok = MASK ? ((okm >> p) & 1u) : true;
         if constexpr (KC) {
             const int r = q >> 3, kq = (q & 7) << 2;
             const float x = comp == 0 ? st[p].x : comp == 1 ? st[p].y : comp == 2 ? st[p].z : st[p].w;
-            T[(kq + comp) * LD + r] = MASK ? piece<p, comp>(st, okm) : x;
+            T[(kq + comp) * LD + r] = ok ? x : 0.f;
         } else {
             const int k = q / (R / 4), r = (q % (R / 4)) << 2;
-            float4 v = st[p];
-            if constexpr (MASK)
-                v = make_float4(piece<p, 0>(st, okm), piece<p, 1>(st, okm), piece<p, 2>(st, okm),
-                                piece<p, 3>(st, okm));
+            float4 v;
+            v.x = ok ? st[p].x : 0.f;
+            v.y = ok ? st[p].y : 0.f;
+            v.z = ok ? st[p].z : 0.f;
+            v.w = ok ? st[p].w : 0.f;
             *reinterpret_cast<float4*>(T + k * LD + r) = v;
         }
     }
@@ -418,8 +369,12 @@ struct PipeLoader {
     __device__ __forceinline__ void store_one(float* __restrict__ T, const float4 (&st)[NST],
                                               uint32_t okm) const {
         const int q = threadIdx.x + 256 * p;
-        const float4 v = make_float4(piece<p, 0>(st, okm), piece<p, 1>(st, okm), piece<p, 2>(st, okm),
-                                     piece<p, 3>(st, okm));
+        const bool ok = (okm >> p) & 1u;
+        float4 v;
+        v.x = ok ? st[p].x : 0.f;
+        v.y = ok ? st[p].y : 0.f;
+        v.z = ok ? st[p].z : 0.f;
+        v.w = ok ? st[p].w : 0.f;
         if constexpr (KC) {
             const int r = q >> 3, kq = (q & 7) << 2;
             T[(kq + 0) * LD + r] = v.x;
@@ -449,11 +404,11 @@ struct PipeSmem {
 
 // One output tile (linear tile index L of tiles_m x tiles_n, K slab z) of the pipelined GEMM.  A
 // device function so that one launch can carry tiles of more than one problem (k_gemm_f32_pair).
-template <int BM, int BN, bool A_KC, bool B_KC, bool UA = false>
+template <int BM, int BN, bool A_KC, bool B_KC>
 __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64_t L, const int z,
                                                   float* const fx_gemm_smem) {
-    using LoaderA = PipeLoader<BM, A_KC, UA>;
-    using LoaderB = PipeLoader<BN, B_KC, UA>;
+    using LoaderA = PipeLoader<BM, A_KC>;
+    using LoaderB = PipeLoader<BN, B_KC>;
     constexpr int LDA = LoaderA::LD, LDB = LoaderB::LD;
     constexpr int NSA = LoaderA::NST, NSB = LoaderB::NST, NS = NSA + NSB;
     constexpr int MI = BM / 64, NJ = BN / 64;
@@ -647,11 +602,11 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int W = 2, bool UA = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int W = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
 void k_gemm_f32_pipe(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[PipeSmem<BM, BN, A_KC, B_KC>::FLOATS];
-    fx_gemm_pipe_tile<BM, BN, A_KC, B_KC, UA>(a, blockIdx.x, blockIdx.y, smem);
+    fx_gemm_pipe_tile<BM, BN, A_KC, B_KC>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 // Two independent GEMMs in ONE launch (fx_gemm_f32_batch): the weight gradient dW = dZ^T X (problem 1,
@@ -689,13 +644,9 @@ static int fx_gemm_pipe_mode() {   // FX_GEMM_PIPE=0 falls back to the unpipelin
     return mode;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool UA>
+template <int BM, int BN, bool A_KC, bool B_KC>
 static int fx_gemm_launch_pipe(dim3 grid, hipStream_t s, const GemmArgs& a) {
-    if constexpr (UA) {
-        // rows that are only 4-byte aligned: one build per tile (the default occupancy)
-        constexpr int W = BM * BN <= 64 * 64 ? 4 : 2;
-        hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, W, true>), grid, dim3(256), 0, s, a);
-    } else if constexpr (BM * BN <= 64 * 64) {
+    if constexpr (BM * BN <= 64 * 64) {
         // 64x64 tiles need ~110 VGPRs: 4 waves/SIMD = 4 workgroups per CU (LDS 4 x 34 KB), so the
         // 1024 tiles of a 4096 x 1024 layer are all resident in ONE round (2 per CU took two)
         static const int w = []() {   // FX_GEMM_W64=2|3|4 (experiments)
@@ -714,12 +665,12 @@ static int fx_gemm_launch_pipe(dim3 grid, hipStream_t s, const GemmArgs& a) {
     return FX_OK;
 }
 
-template <int BM, int BN, bool UA = false>
+template <int BM, int BN>
 static int fx_gemm_dispatch_pipe(bool a_kc, bool b_kc, dim3 grid, hipStream_t s, const GemmArgs& a) {
-    if (a_kc && b_kc) return fx_gemm_launch_pipe<BM, BN, true, true, UA>(grid, s, a);
-    if (a_kc) return fx_gemm_launch_pipe<BM, BN, true, false, UA>(grid, s, a);
-    if (b_kc) return fx_gemm_launch_pipe<BM, BN, false, true, UA>(grid, s, a);
-    return fx_gemm_launch_pipe<BM, BN, false, false, UA>(grid, s, a);
+    if (a_kc && b_kc) return fx_gemm_launch_pipe<BM, BN, true, true>(grid, s, a);
+    if (a_kc) return fx_gemm_launch_pipe<BM, BN, true, false>(grid, s, a);
+    if (b_kc) return fx_gemm_launch_pipe<BM, BN, false, true>(grid, s, a);
+    return fx_gemm_launch_pipe<BM, BN, false, false>(grid, s, a);
 }
 
 __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a) {
@@ -1213,22 +1164,11 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     const int pipe_mode = fx_gemm_pipe_mode();
     const bool small_offsets = (transa ? K * lda : M * lda) < (int64_t)0x3FFFFFF0 &&
                                (transb ? N * ldb : K * ldb) < (int64_t)0x3FFFFFF0;   // 32-bit byte offsets
-    static const bool ua_on = []() {   // FX_GEMM_UA=0: unaligned operands on the unpipelined kernel (A/B)
-        const char* e = getenv("FX_GEMM_UA");
-        return !(e && atoi(e) == 0);
-    }();
     if (pipe_mode && av && bv && small_offsets && kc >= 4) {
         int rc;
         if (bm == 128 && bn == 128) rc = fx_gemm_dispatch_pipe<128, 128>(a_kc, b_kc, grid, s, a);
         else if (bm == 128) rc = fx_gemm_dispatch_pipe<128, 64>(a_kc, b_kc, grid, s, a);
         else rc = fx_gemm_dispatch_pipe<64, 64>(a_kc, b_kc, grid, s, a);
-        if (rc != FX_OK) return rc;
-    } else if (pipe_mode && ua_on && small_offsets && kc >= 4 && M >= 4 && N >= 4 && K >= 4) {
-        // rows only 4-byte aligned (ld or extent not a multiple of 4 floats): same pipeline, UA loaders
-        int rc;
-        if (bm == 128 && bn == 128) rc = fx_gemm_dispatch_pipe<128, 128, true>(a_kc, b_kc, grid, s, a);
-        else if (bm == 128) rc = fx_gemm_dispatch_pipe<128, 64, true>(a_kc, b_kc, grid, s, a);
-        else rc = fx_gemm_dispatch_pipe<64, 64, true>(a_kc, b_kc, grid, s, a);
         if (rc != FX_OK) return rc;
     } else if (bm == 128 && bn == 128) fx_gemm_dispatch_layout<128, 128>(a_kc, b_kc, av, bv, grid, s, a);
     else if (bm == 128) fx_gemm_dispatch_layout<128, 64>(a_kc, b_kc, av, bv, grid, s, a);
