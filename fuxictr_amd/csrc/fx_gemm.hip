@@ -797,6 +797,87 @@ __global__ __launch_bounds__(256) void k_gemm_small_k(GemmArgs a, int ta, int tb
     }
 }
 
+// K <= 8 with 4 | N (the input gradient of a Linear(hidden -> 1) head: an outer product that writes
+// M x N floats and reads the same amount of ReLU mask): one thread per 4 output columns, 16-byte stores,
+// no 64-bit division per element.  Pure HBM stream.
+__global__ __launch_bounds__(256) void k_gemm_small_k_v4(GemmArgs a, int ta, int tb) {
+    const uint32_t n4 = (uint32_t)(a.N >> 2);
+    const uint32_t total = (uint32_t)(a.M * n4);              // < 2^31 (checked by the launcher)
+    const fx_gemm_epilogue& e = a.epi;
+    // the tower case: nothing but the ReLU mask of the layer below -> one 16-byte mask load
+    const bool mask_only = e.mask && !e.bias && !e.zout && e.act == 0 && !e.mul && !e.add &&
+                           (e.ldmask & 3) == 0 && (reinterpret_cast<uintptr_t>(e.mask) & 15) == 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t mi = i / n4;
+        const int64_t m = mi, n = (int64_t)(i - mi * n4) << 2;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t k = 0; k < a.K; ++k) {
+            const float x = fx_a_at(a, ta, m, k);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = fmaf(x, fx_b_at(a, tb, k, n + c), acc[c]);
+        }
+        float4 o;
+        if (mask_only) {
+            const float4 mk = *reinterpret_cast<const float4*>(e.mask + m * e.ldmask + n);
+            o.x = mk.x > 0.f ? acc[0] : 0.f;
+            o.y = mk.y > 0.f ? acc[1] : 0.f;
+            o.z = mk.z > 0.f ? acc[2] : 0.f;
+            o.w = mk.w > 0.f ? acc[3] : 0.f;
+        } else {
+            o.x = fx_epilogue(e, acc[0], m, n);
+            o.y = fx_epilogue(e, acc[1], m, n + 1);
+            o.z = fx_epilogue(e, acc[2], m, n + 2);
+            o.w = fx_epilogue(e, acc[3], m, n + 3);
+        }
+        *reinterpret_cast<float4*>(a.C + m * a.ldc + n) = o;
+    }
+}
+
+// N <= 4, A [M,K] and B [N,K] k-contiguous, 4 | K, any K: one wave per output row, a lane takes a float4
+// every 256 floats, four loads in flight per lane (the scalar kernel below issues one dependent 4-byte
+// load per iteration: 1.7 TB/s on the 4096 x 1024 head of the towers)
+__global__ __launch_bounds__(256) void k_gemm_small_n_wide(GemmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < a.M; m += waves) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = a.A + m * a.lda;
+        int64_t k = (int64_t)lane * 4;
+        for (; k + 768 < a.K; k += 1024) {
+            float4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4*>(arow + k + 256 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (n < a.N) {
+                        const float4 w = *reinterpret_cast<const float4*>(a.B + n * a.ldb + k + 256 * u);
+                        acc[n] = fmaf(x[u].x, w.x, acc[n]);
+                        acc[n] = fmaf(x[u].y, w.y, acc[n]);
+                        acc[n] = fmaf(x[u].z, w.z, acc[n]);
+                        acc[n] = fmaf(x[u].w, w.w, acc[n]);
+                    }
+        }
+        for (; k < a.K; k += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(arow + k);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < a.N) {
+                    const float4 w = *reinterpret_cast<const float4*>(a.B + n * a.ldb + k);
+                    acc[n] = fmaf(x.x, w.x, acc[n]);
+                    acc[n] = fmaf(x.y, w.y, acc[n]);
+                    acc[n] = fmaf(x.z, w.z, acc[n]);
+                    acc[n] = fmaf(x.w, w.w, acc[n]);
+                }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = fx_wave_sum(acc[n]);
+        if (lane == 0)
+            for (int n = 0; n < a.N; ++n) a.C[m * a.ldc + n] = fx_epilogue(a.epi, acc[n], m, n);
+    }
+}
+
 // N <= 4, A stored [M,K]: one wave per output row, lanes stride k (coalesced), xor reduction
 __global__ __launch_bounds__(256) void k_gemm_small_n(GemmArgs a, int tb) {
     const int lane = threadIdx.x & 63;
@@ -1085,6 +1166,15 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
                  "fx_gemm_f32: epilogue.rowsum is not available on the K<=8 / N<=4 skinny paths");
     if (K <= 8) {
         a.split_k = 1;
+        if (N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+            M * (N / 4) < ((int64_t)1 << 31)) {
+            int64_t blocks = fx_ceil_div(M * (N / 4), 256);
+            if (blocks > 16384) blocks = 16384;
+            hipLaunchKernelGGL(k_gemm_small_k_v4, dim3((unsigned)blocks), dim3(256), 0, s, a,
+                               (int)(transa != 0), (int)(transb != 0));
+            FX_CHECK_LAUNCH();
+            return FX_OK;
+        }
         int64_t blocks = fx_ceil_div(M * N, 256);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(k_gemm_small_k, dim3((unsigned)blocks), dim3(256), 0, s, a,
@@ -1118,6 +1208,12 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
         }
         int64_t blocks = fx_ceil_div(M, 4);
         if (blocks > 8192) blocks = 8192;
+        if (transb && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+            ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0) {
+            hipLaunchKernelGGL(k_gemm_small_n_wide, dim3((unsigned)blocks), dim3(256), 0, s, a);
+            FX_CHECK_LAUNCH();
+            return FX_OK;
+        }
         hipLaunchKernelGGL(k_gemm_small_n, dim3((unsigned)blocks), dim3(256), 0, s, a,
                            (int)(transb != 0));
         FX_CHECK_LAUNCH();

@@ -362,7 +362,10 @@ GEMM_SHAPES = [(4096, 1024, 624), (4096, 1024, 1024), (4096, 1, 1024), (100, 70,
                # rows only 4-byte aligned (DLRM: 367 = 27*26/2 + 16 inputs of the top MLP): the
                # pipelined kernel's UA loaders — straddling float4 at the end of K / of the rows
                (4096, 1024, 367), (4096, 367, 1024), (367, 1024, 4096), (333, 65, 37), (66, 67, 9),
-               (5, 7, 11), (4099, 130, 131)]
+               (5, 7, 11), (4099, 130, 131),
+               # the Linear(hidden -> 1) head of a tower: forward N = 1 (row dots), input gradient K = 1
+               # (outer product, 16-byte stores), also with small odd extents
+               (4096, 1024, 1), (300, 64, 3), (77, 1648, 1), (4096, 2, 2048), (513, 3, 40)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -474,6 +477,18 @@ def test_gemm_unaligned_rows_with_epilogues_split_k_and_views():
     refx = dz.double() @ W.double()
     assert (out[:, 1:1 + K].double() - refx).abs().max().item() <= 3e-6 * (dz.abs().double() @ W.abs().double()).max().item()
     assert float(out[:, 0].abs().max()) == 0.0 and float(out[:, K + 1].abs().max()) == 0.0
+
+
+def test_gemm_head_layer_input_gradient_with_relu_mask():
+    """dX of the head: dz [M,1] x W [1,N] with the ReLU mask of the layer below in the epilogue."""
+    g = torch.Generator().manual_seed(3)
+    M, N = 4096, 1024
+    dz, W = _dev(torch.randn(M, 1, generator=g)), _dev(torch.randn(1, N, generator=g))
+    h = _dev(torch.randn(M, N, generator=g))
+    dx = torch.empty(M, N, device=DEV)
+    ops.gemm(dz, W, dx, transa=False, transb=False, mask=h)
+    ref = torch.where(h > 0, dz * W, torch.zeros((), device=DEV))
+    assert torch.equal(dx, ref)
 
 
 def test_gemm_mfma_layout_is_not_transposed():
