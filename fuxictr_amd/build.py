@@ -33,8 +33,7 @@ def _digest(paths):
 def build(force=False, verbose=True):
     """Compile every HIP translation unit for gfx950 and link libfxctr.so. Returns the path."""
     os.makedirs(OBJ_DIR, exist_ok=True)
-    objs = []
-    rebuilt = False
+    objs, todo = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(OBJ_DIR, src.rsplit(".", 1)[0] + ".o")
@@ -43,14 +42,24 @@ def build(force=False, verbose=True):
         fresh = (not force and os.path.exists(obj) and os.path.exists(stamp)
                  and open(stamp).read() == dig)
         if not fresh:
-            cmd = [HIPCC] + CXXFLAGS + ["-x", "hip", "-c", sp, "-o", obj]
-            if verbose:
-                print("[fuxictr_amd.build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-            with open(stamp, "w") as f:
-                f.write(dig)
-            rebuilt = True
+            todo.append((sp, obj, stamp, dig))
         objs.append(obj)
+
+    def compile_one(job):
+        sp, obj, stamp, dig = job
+        cmd = [HIPCC] + CXXFLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+        if verbose:
+            print("[fuxictr_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(dig)
+
+    if todo:
+        # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1, 8)) as pool:
+            list(pool.map(compile_one, todo))
+    rebuilt = bool(todo)
     if rebuilt or force or not os.path.exists(LIB_PATH):
         cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB_PATH] + objs
         if verbose:
