@@ -9,6 +9,8 @@
 //   fuxictr/pytorch/layers/interactions/inner_product.py:55-62.
 #include "fx_common.h"
 
+#include <stdlib.h>
+
 // ---------------------------------------------------------------------------------------------
 // fx_pack_columns
 // ---------------------------------------------------------------------------------------------
@@ -608,12 +610,115 @@ __global__ __launch_bounds__(256) void k_dot_interact_bwd(const float* emb, int6
     }
 }
 
+// The same two kernels on the matrix cores for F <= 32 fields of even D <= 32 (DLRM: 27 x 16): per
+// sample the work is a 27 x 27 x 16 product — far too little for a workgroup with two barriers per
+// sample (the kernels above: 17.7 / 46.2 us of the 0.93 ms DLRM step).  Here ONE WAVE owns a sample:
+// E goes to a wave-private LDS tile, E E^T is D/2 MFMAs (v_mfma_f32_32x32x2_f32, A and B fragments
+// are the same LDS read), the backward (G + G^T) E is 16 MFMAs on the symmetrised gradient tile.
+typedef float fx_dot_f32x16 __attribute__((ext_vector_type(16)));
+#define FX_DOT_LD 33
+
+__global__ __launch_bounds__(256) void k_dot_interact_fwd_mfma(const float* emb, int64_t emb_ld,
+                                                               int F, int D, int64_t B, float* out) {
+    __shared__ float Es_[4][32 * FX_DOT_LD];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    float* Es = Es_[wave];
+    for (int t = lane; t < 32 * FX_DOT_LD; t += 64) Es[t] = 0.f;
+    const int P = F * (F - 1) / 2;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < B; b += (int64_t)gridDim.x * 4) {
+        for (int t = lane; t < F * D; t += 64) {
+            const int i = t / D;
+            Es[i * FX_DOT_LD + (t - i * D)] = emb[b * emb_ld + t];
+        }
+        fx_dot_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int kk = 0; kk < (D >> 1); ++kk) {
+            const float a = Es[l31 * FX_DOT_LD + 2 * kk + half];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0);
+        }
+        const int j = l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (i < j && j < F) out[b * P + fx_pair_index(i, j, F)] = acc[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dot_interact_bwd_mfma(const float* emb, int64_t emb_ld,
+                                                               const float* g, int F, int D,
+                                                               int64_t B, float* demb,
+                                                               int64_t demb_ld) {
+    __shared__ float Es_[4][32 * FX_DOT_LD];
+    __shared__ float Gs_[4][32 * FX_DOT_LD];
+    __shared__ unsigned char pi_[512], pj_[512];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    float* Es = Es_[wave];
+    float* Gs = Gs_[wave];
+    const int P = F * (F - 1) / 2;
+    for (int t = lane; t < 32 * FX_DOT_LD; t += 64) {
+        Es[t] = 0.f;
+        Gs[t] = 0.f;
+    }
+    for (int p = threadIdx.x; p < P; p += 256) {       // p -> (i, j), i < j, row-major upper triangle
+        int i = 0, rem = p;
+        while (rem >= F - 1 - i) { rem -= F - 1 - i; ++i; }
+        pi_[p] = (unsigned char)i;
+        pj_[p] = (unsigned char)(i + 1 + rem);
+    }
+    __syncthreads();
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < B; b += (int64_t)gridDim.x * 4) {
+        for (int t = lane; t < F * D; t += 64) {
+            const int i = t / D;
+            Es[i * FX_DOT_LD + (t - i * D)] = emb[b * emb_ld + t];
+        }
+        for (int p = lane; p < P; p += 64) {
+            const float v = g[b * P + p];
+            const int i = pi_[p], j = pj_[p];
+            Gs[i * FX_DOT_LD + j] = v;
+            Gs[j * FX_DOT_LD + i] = v;
+        }
+        fx_dot_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int nk = (F + 1) >> 1;
+        for (int kk = 0; kk < nk; ++kk) {
+            const float a = Gs[l31 * FX_DOT_LD + 2 * kk + half];
+            const float e = Es[(2 * kk + half) * FX_DOT_LD + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, e, acc, 0, 0, 0);
+        }
+        const int d = l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (i < F && d < D) demb[b * demb_ld + i * D + d] = acc[r];
+        }
+    }
+}
+
+static bool fx_dot_mfma_ok(int F, int D) {
+    static const bool on = []() {   // FX_DOT_MFMA=0: the workgroup-per-sample kernels (A/B runs)
+        const char* e = getenv("FX_DOT_MFMA");
+        return !(e && atoi(e) == 0);
+    }();
+    return on && F <= 32 && D <= 32 && D % 2 == 0;
+}
+
 extern "C" int fx_dot_interact_fwd(const float* emb, int64_t emb_ld, int32_t F, int32_t D,
                                    int64_t B, float* out, fx_stream_t stream) {
     FX_CHECK_ARG(F >= 2 && D >= 1 && F * D <= FX_DOT_MAX_FD && F * (F - 1) / 2 <= FX_DOT_MAX_FD,
                  "fx_dot_interact_fwd: F=%d D=%d outside the supported range", F, D);
     if (B <= 0) return FX_OK;
     FX_CHECK_ARG(emb && out, "fx_dot_interact_fwd: null pointer");
+    if (fx_dot_mfma_ok(F, D)) {
+        int64_t wgs = fx_ceil_div(B, 4);
+        if (wgs > 2048) wgs = 2048;
+        hipLaunchKernelGGL(k_dot_interact_fwd_mfma, dim3((unsigned)wgs), dim3(256), 0,
+                           fx_hip_stream(stream), emb, emb_ld, (int)F, (int)D, B, out);
+        FX_CHECK_LAUNCH();
+        return FX_OK;
+    }
     int64_t blocks = B < 8192 ? B : 8192;
     hipLaunchKernelGGL(k_dot_interact_fwd, dim3((unsigned)blocks), dim3(256), 0,
                        fx_hip_stream(stream), emb, emb_ld, (int)F, (int)D, B, out);
@@ -628,6 +733,14 @@ extern "C" int fx_dot_interact_bwd(const float* emb, int64_t emb_ld, const float
                  "fx_dot_interact_bwd: F=%d D=%d outside the supported range", F, D);
     if (B <= 0) return FX_OK;
     FX_CHECK_ARG(emb && g && demb, "fx_dot_interact_bwd: null pointer");
+    if (fx_dot_mfma_ok(F, D)) {
+        int64_t wgs = fx_ceil_div(B, 4);
+        if (wgs > 2048) wgs = 2048;
+        hipLaunchKernelGGL(k_dot_interact_bwd_mfma, dim3((unsigned)wgs), dim3(256), 0,
+                           fx_hip_stream(stream), emb, emb_ld, g, (int)F, (int)D, B, demb, demb_ld);
+        FX_CHECK_LAUNCH();
+        return FX_OK;
+    }
     int64_t blocks = B < 8192 ? B : 8192;
     hipLaunchKernelGGL(k_dot_interact_bwd, dim3((unsigned)blocks), dim3(256), 0,
                        fx_hip_stream(stream), emb, emb_ld, g, (int)F, (int)D, B, demb, demb_ld);

@@ -659,7 +659,7 @@ def test_dice_matches_reference_batchnorm_gate(training, N, H):
     assert (da.cpu() - state["p.alpha"].grad).abs().max().item() <= 2e-4 * max(1.0, state["p.alpha"].grad.abs().max().item())
 
 
-@pytest.mark.parametrize("F,D", [(27, 16), (15, 8), (2, 3), (40, 40)])
+@pytest.mark.parametrize("F,D", [(27, 16), (15, 8), (2, 3), (40, 40), (32, 32), (31, 2), (3, 4), (2, 16)])
 def test_dot_interaction_matches_bmm_triu(F, D):
     g = torch.Generator().manual_seed(F * D)
     B = 300
