@@ -1551,6 +1551,17 @@ def linear_weight_grads(dz, x, W_shape, need_bias):
     return dW, db
 
 
+_ZERO_COLS = {}
+
+
+def _zero_cols(rows, cols, device):
+    key = (rows, cols, device)
+    z = _ZERO_COLS.get(key)
+    if z is None:
+        z = _ZERO_COLS[key] = torch.zeros(rows, cols, dtype=torch.float32, device=device)
+    return z
+
+
 class _MLPFn(torch.autograd.Function):
     """Whole Linear(+ReLU) stack as ONE autograd node: forward = one GEMM per layer with
     bias+ReLU in the epilogue; backward = dX GEMM with the ReLU mask of the layer below in its
@@ -1569,8 +1580,8 @@ class _MLPFn(torch.autograd.Function):
         pad = (-K0) % 4 if K0 >= 64 else 0
         W0p = None
         if pad:
-            x = torch.nn.functional.pad(x, (0, pad))
-            W0p = torch.nn.functional.pad(wb[0], (0, pad))
+            x = torch.cat([x, _zero_cols(x.shape[0], pad, x.device)], dim=1)          # one launch each
+            W0p = torch.cat([wb[0], _zero_cols(wb[0].shape[0], pad, x.device)], dim=1)
         hs = [x]
         h = x
         for i in range(n):
