@@ -1415,20 +1415,28 @@ extern "C" int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, floa
 // ---------------------------------------------------------------------------------------------
 // relu backward mask (only for a tower whose last layer is activated)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mask_mul(const float* dy, const float* y, float* out,
-                                                  int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        out[i] = y[i] > 0.f ? dy[i] : 0.f;
+// (the incoming gradient may be a column slice of a wider tensor — the backward of the torch.cat that
+// joins the towers' outputs hands out strided views: read in place through its row stride instead of
+// a .contiguous() copy first)
+__global__ __launch_bounds__(256) void k_mask_mul(const float* dy, int64_t dy_ld, const float* y,
+                                                  float* out, uint32_t n, uint32_t cols) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t r = i / cols;
+        const float d = dy[(int64_t)r * dy_ld + (i - r * cols)];
+        out[i] = y[i] > 0.f ? d : 0.f;
+    }
 }
 
-extern "C" int fx_mask_mul(const float* dy, const float* y, float* out, int64_t n,
-                           fx_stream_t stream) {
+extern "C" int fx_mask_mul(const float* dy, int64_t dy_ld, const float* y, float* out, int64_t rows,
+                           int64_t cols, fx_stream_t stream) {
+    const int64_t n = rows * cols;
     if (n <= 0) return FX_OK;
-    FX_CHECK_ARG(dy && y && out, "fx_mask_mul: null pointer");
+    FX_CHECK_ARG(dy && y && out && dy_ld >= cols, "fx_mask_mul: bad arguments");
+    FX_CHECK_ARG(n < ((int64_t)1 << 32), "fx_mask_mul: more than 2^32 elements");
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_mask_mul, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), dy,
-                       y, out, n);
+                       dy_ld, y, out, (uint32_t)n, (uint32_t)cols);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
@@ -1436,12 +1444,13 @@ extern "C" int fx_mask_mul(const float* dy, const float* y, float* out, int64_t 
 // ---------------------------------------------------------------------------------------------
 // CrossNetV2 backward glue
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cross_bwd_prep(const float* dxn, const float* x0,
-                                                        const float* z, float* t, float* dx0,
-                                                        int64_t n, int init, int add_dxn) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * 256) {
-        const float d = dxn[i];
+__global__ __launch_bounds__(256) void k_cross_bwd_prep(const float* dxn, int64_t dxn_ld,
+                                                        const float* x0, const float* z, float* t,
+                                                        float* dx0, uint32_t n, uint32_t cols,
+                                                        int init, int add_dxn) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t r = i / cols;
+        const float d = dxn[(int64_t)r * dxn_ld + (i - r * cols)];
         t[i] = d * x0[i];
         float term = d * z[i];
         if (add_dxn) term += d;
@@ -1449,15 +1458,18 @@ __global__ __launch_bounds__(256) void k_cross_bwd_prep(const float* dxn, const 
     }
 }
 
-extern "C" int fx_cross_bwd_prep(const float* dxn, const float* x0, const float* z, float* t,
-                                 float* dx0, int64_t n, int32_t init, int32_t add_dxn,
-                                 fx_stream_t stream) {
+extern "C" int fx_cross_bwd_prep(const float* dxn, int64_t dxn_ld, const float* x0, const float* z,
+                                 float* t, float* dx0, int64_t rows, int64_t cols, int32_t init,
+                                 int32_t add_dxn, fx_stream_t stream) {
+    const int64_t n = rows * cols;
     if (n <= 0) return FX_OK;
-    FX_CHECK_ARG(dxn && x0 && z && t && dx0, "fx_cross_bwd_prep: null pointer");
+    FX_CHECK_ARG(dxn && x0 && z && t && dx0 && dxn_ld >= cols, "fx_cross_bwd_prep: bad arguments");
+    FX_CHECK_ARG(n < ((int64_t)1 << 32), "fx_cross_bwd_prep: more than 2^32 elements");
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_cross_bwd_prep, dim3((unsigned)blocks), dim3(256), 0,
-                       fx_hip_stream(stream), dxn, x0, z, t, dx0, n, (int)init, (int)add_dxn);
+                       fx_hip_stream(stream), dxn, dxn_ld, x0, z, t, dx0, (uint32_t)n,
+                       (uint32_t)cols, (int)init, (int)add_dxn);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

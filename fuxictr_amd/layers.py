@@ -1603,9 +1603,12 @@ class _MLPFn(torch.autograd.Function):
     def backward(ctx, dy):
         acts, wb, hs = ctx.acts, ctx.wb, ctx.hs
         n = len(acts)
-        dz = dy.contiguous()
         if acts[n - 1]:
-            dz = ops.mask_mul(dz, hs[n], torch.empty_like(dz))
+            # (a column slice of the gradient of the torch.cat that joins the towers is read in place)
+            dz = ops.mask_mul(dy if dy.stride(-1) == 1 else dy.contiguous(), hs[n],
+                              torch.empty_like(hs[n]))
+        else:
+            dz = dy.contiguous()
         grads = [None] * (2 * n)
         dx = None
         for i in range(n - 1, -1, -1):
@@ -2089,7 +2092,8 @@ class _CrossNetV2Fn(torch.autograd.Function):
         wb, xs, zs = ctx.wb, ctx.xs, ctx.zs
         n = len(wb) // 2
         x0 = xs[0]
-        dxn = dxn.contiguous()
+        if dxn.stride(-1) != 1:
+            dxn = dxn.contiguous()         # (a row-strided slice of a cat's gradient is read in place)
         dx0 = torch.empty_like(x0)
         t = torch.empty_like(x0)
         grads = [None] * (2 * n)

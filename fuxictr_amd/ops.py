@@ -512,14 +512,17 @@ def colsum(X, out, workspace):
 
 
 def mask_mul(dy, y, out):
-    check(_lib.load().fx_mask_mul(ptr(dy), ptr(y), ptr(out), dy.numel(), stream_ptr(dy.device)),
-          "fx_mask_mul")
+    """dy: [rows, cols] with unit inner stride (a column slice of a wider tensor is read in place)."""
+    rows, cols = dy.shape
+    check(_lib.load().fx_mask_mul(ptr(dy), dy.stride(0), ptr(y), ptr(out), rows, cols,
+                                  stream_ptr(dy.device)), "fx_mask_mul")
     return out
 
 
 def cross_bwd_prep(dxn, x0, z, t, dx0, init, add_dxn):
-    check(_lib.load().fx_cross_bwd_prep(ptr(dxn), ptr(x0), ptr(z), ptr(t), ptr(dx0), dxn.numel(),
-                                        1 if init else 0, 1 if add_dxn else 0,
+    rows, cols = dxn.shape
+    check(_lib.load().fx_cross_bwd_prep(ptr(dxn), dxn.stride(0), ptr(x0), ptr(z), ptr(t), ptr(dx0),
+                                        rows, cols, 1 if init else 0, 1 if add_dxn else 0,
                                         stream_ptr(dxn.device)), "fx_cross_bwd_prep")
 
 

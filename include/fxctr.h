@@ -389,15 +389,19 @@ int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, flo
 
 /* ReLU backward for a tower whose LAST layer is activated (e.g. DCNv2 parallel_dnn,
  * mlp_block.py:80-81 with output_dim=None): out[i] = y[i] > 0 ? dy[i] : 0.  (Inner layers get
- * this mask for free in the dX GEMM epilogue.) */
-int fx_mask_mul(const float* dy, const float* y, float* out, int64_t n, fx_stream_t stream);
+ * this mask for free in the dX GEMM epilogue.)  dy is [rows, cols] with row stride dy_ld (it may be a
+ * column slice of the gradient of a torch.cat); y and out are contiguous. */
+int fx_mask_mul(const float* dy, int64_t dy_ld, const float* y, float* out, int64_t rows,
+                int64_t cols, fx_stream_t stream);
 
 /* CrossNetV2 backward glue (autograd of cross_net.py:128), one pass over [n] elements:
  *     t[i]   = dxn[i] * x0[i]                         (gradient of W x_i + b)
  *     term   = dxn[i] * z[i] (+ dxn[i] if add_dxn)    (gradient reaching x_0 through the Hadamard)
- *     dx0[i] = init ? term : dx0[i] + term */
-int fx_cross_bwd_prep(const float* dxn, const float* x0, const float* z, float* t, float* dx0,
-                      int64_t n, int32_t init, int32_t add_dxn, fx_stream_t stream);
+ *     dx0[i] = init ? term : dx0[i] + term
+ * dxn is [rows, cols] with row stride dxn_ld; the other operands are contiguous. */
+int fx_cross_bwd_prep(const float* dxn, int64_t dxn_ld, const float* x0, const float* z, float* t,
+                      float* dx0, int64_t rows, int64_t cols, int32_t init, int32_t add_dxn,
+                      fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Output activation + loss, fused: p = sigmoid(logit); loss = mean BCE(p, y) with torch's

@@ -562,6 +562,14 @@ def test_colsum_mask_cross_prep_bce():
     assert (dx0.cpu() - (1 + X * Z + X)).abs().max().item() <= 1e-5
     ops.cross_bwd_prep(_dev(X), _dev(Y), _dev(Z), t, dx0, init=True, add_dxn=False)
     assert torch.equal(dx0.cpu(), X * Z)
+    # the incoming gradient as a column slice of a wider tensor (backward of a torch.cat): read in place
+    wide = torch.randn(M, N + 24, generator=g)
+    dw = _dev(wide)[:, 17:17 + N]
+    o = ops.mask_mul(dw, _dev(Y), torch.empty(M, N, device=DEV))
+    assert torch.equal(o.cpu(), torch.where(Y > 0, wide[:, 17:17 + N], torch.zeros(())))
+    ops.cross_bwd_prep(dw, _dev(Y), _dev(Z), t, dx0, init=True, add_dxn=True)
+    assert torch.equal(t.cpu(), wide[:, 17:17 + N] * Y)
+    assert (dx0.cpu() - (wide[:, 17:17 + N] * Z + wide[:, 17:17 + N])).abs().max().item() <= 1e-6
     # sigmoid + BCE: value and gradient against torch autograd on the reference's two ops
     B = 4096
     logit = (torch.randn(B, 1, generator=g) * 4).requires_grad_(True)
