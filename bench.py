@@ -434,6 +434,19 @@ def rooflines(m, args, world):
             "frac": ach / PEAK_HBM_GBS, "traffic": None,
             "algorithmic_bytes_per_sample": per_sample, "us_per_step": us_step,
             "launches_per_step": sp["launches"] / n_inst}
+    da = kt.get("din_attention")
+    if da and da["total_ms"] > 0:
+        # the fused DIN attention passes (fx_din_attn.hip).  Algorithmic flops = what the reference's
+        # graph needs: the hidden-layer product 2 (B L) 4E H once forward, twice backward (dW1, dX) —
+        # the statistics passes and the recomputation the fused form adds are NOT counted as work
+        ach = da["work"] / (da["total_ms"] * 1e-3) / 1e12
+        out["roofline_attention"] = {
+            "kernels": "k_din_attn(2)_{stats,fwd,bwd_sums,bwd} + their partial-sum launches",
+            "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "us_per_step": 1e3 * da["total_ms"] / n_inst, "launches_per_step": da["launches"] / n_inst,
+            "note": "serial chain per wave (x tile -> MFMA -> Dice gate -> ...), 4 passes around the "
+                    "batch statistics; see DESIGN.md section 4"}
     e = kt.get("k_emb_gather_fwd")
     if e and e["total_ms"] > 0:
         ach = e["work"] / (e["total_ms"] * 1e-3) / 1e9

@@ -623,6 +623,13 @@ def dice_bwd_from_sums(Z, dY, alpha, eps, stats, sums3, n_total, dZ):
 DIN_ATTN_MAX_E, DIN_ATTN_MAX_H = 16, 64
 
 
+def _din_attn_flops(n_eval):
+    def work(q, K, W1, *a, **kw):
+        B, L, E = K.shape
+        return 2.0 * n_eval * B * L * 4 * E * W1.shape[0]
+    return work
+
+
 def din_attn_workspace_floats(B, L, E, H):
     return int(_lib.load().fx_din_attn_workspace_floats(B, L, E, H))
 
@@ -633,6 +640,7 @@ def _din_attn_head(q, K):
     return K, (ptr(q), q.stride(0), ptr(K), sb, sl, B, L, E)
 
 
+@_timed("din_attn_stats", "din_attention", _din_attn_flops(0))
 def din_attn_stats(q, K, W1, b1, sums, workspace):
     """sums[2H] = [sum h | sum h^2] over the B*L positions, h = W1 [q,k,q-k,q*k] + b1."""
     K, head = _din_attn_head(q, K)
@@ -649,6 +657,7 @@ def dice_stats_from_sums(sums, H, n_total, momentum, training, running_mean, run
                                               stream_ptr(stats.device)), "fx_dice_stats_from_sums")
 
 
+@_timed("din_attn_fwd", "din_attention", _din_attn_flops(1))
 def din_attn_fwd(q, K, W1, b1, alpha, eps, stats, W2, b2, mask, a_out, out):
     """a_out[B, L] = attention logits (before the mask), out[B, E] = sum_l a mask k."""
     K, head = _din_attn_head(q, K)
@@ -661,6 +670,7 @@ def din_attn_fwd(q, K, W1, b1, alpha, eps, stats, W2, b2, mask, a_out, out):
     return out
 
 
+@_timed("din_attn_bwd_sums", "din_attention", _din_attn_flops(0))
 def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, mask, dout, da, sums5, workspace):
     """da[B, L] = mask (dout . k);  sums5[5H] = [dalpha | sum dzhat | sum dzhat*zhat | dW2 | db2, 0...]."""
     K, head = _din_attn_head(q, K)
@@ -672,6 +682,7 @@ def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, mask, dout, da, sums5
                                            stream_ptr(q.device)), "fx_din_attn_bwd_sums")
 
 
+@_timed("din_attn_bwd", "din_attention", _din_attn_flops(2))
 def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, mask, a_logit, dout, da, sums5,
                  n_total, dq, dK, dW1b1, workspace):
     K, head = _din_attn_head(q, K)
