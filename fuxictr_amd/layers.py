@@ -1641,6 +1641,16 @@ class FxLinear(nn.Linear):
         return y.reshape(*lead, self.out_features)
 
 
+def _global_rows(count, n_local, dist):
+    """Rows of the global batch behind an all-reduced statistic.  Eagerly the all-reduced count is read
+    back (ranks may hold batches of different size, e.g. the last one of an epoch); while a hipGraph is
+    being captured there is no host round trip and no ragged batch either (the captured step has static
+    shapes on every rank): world x the local count."""
+    if n_local and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return n_local * dist.world
+    return int(round(float(count.item())))
+
+
 class _DiceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, alpha, mod):
@@ -1659,7 +1669,7 @@ class _DiceFn(torch.autograd.Function):
             ops.dice_local_sums(z, sums, ws)
             sums[2 * H] = float(N)
             dist.all_reduce_sum(sums)
-            n_total = int(round(float(sums[2 * H].item())))
+            n_total = _global_rows(sums[2 * H], N, dist)
             ops.dice_fwd_from_sums(z, alpha, mod.bn.eps, mod.bn.momentum, sums, n_total,
                                    mod.bn.running_mean, mod.bn.running_var, stats, y)
         else:
@@ -1876,7 +1886,7 @@ class _DinAttnFn(torch.autograd.Function):
                 # batch (activations.py:40-51) — one small all-reduce ([2H + 1] floats)
                 sums[2 * H] = float(B * L)
                 dist.all_reduce_sum(sums)
-                n_total = int(round(float(sums[2 * H].item())))
+                n_total = _global_rows(sums[2 * H], B * L, dist)
             ops.dice_stats_from_sums(sums, H, n_total, mod.bn.momentum, True, mod.bn.running_mean,
                                      mod.bn.running_var, stats)
         else:
