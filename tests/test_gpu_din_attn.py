@@ -95,7 +95,8 @@ def _close(got, ref, tol, what):
 
 
 SHAPES = [(64, 50, 16, 64), (7, 3, 4, 16), (33, 50, 8, 36), (5, 1, 10, 64), (300, 20, 16, 32),
-          (50, 32, 16, 32), (41, 97, 8, 64), (19, 33, 16, 64),
+          (50, 32, 16, 32), (41, 97, 8, 64), (19, 33, 16, 64), (1, 1, 16, 64), (2, 64, 16, 64),
+          (3, 32, 8, 7),
           (129, 7, 12, 64), (4096, 50, 16, 64)]
 
 
@@ -139,6 +140,25 @@ def test_fused_din_attention_on_a_record_view_without_mask_and_biases(L):
     ro, rdq, rdK, rg, _ = _oracle(q, K, ones, state, dout, True)
     mod = _module(E, H, state, fused=True)
     out, dq, dK, grads = _run(mod, q, K, None, dout, True, record_view=True)
+    _close(out, ro, 2e-5, "out")
+    _close(dq, rdq, 1e-4, "dq")
+    _close(dK, rdK, 1e-4, "dK")
+    _close(grads["mlp.0.weight"], rg["mlp.0.weight"], 2e-4, "dW1")
+
+
+@pytest.mark.parametrize("L", [9, 50])
+def test_fully_masked_and_fully_kept_histories(L):
+    """A sample whose history is all padding pools to zero and sends no pooling gradient into K; the
+    attention MLP still sees its positions (Dice statistics run over ALL B*L rows, as in the reference)."""
+    B, E, H = 37, 16, 64
+    q, K, mask, state, dout = _case(B, L, E, H, seed=21)
+    mask[0] = False
+    mask[1] = True
+    mask[B - 1] = False
+    ro, rdq, rdK, rg, _ = _oracle(q, K, mask, state, dout, True)
+    mod = _module(E, H, state, fused=True)
+    out, dq, dK, grads = _run(mod, q, K, mask, dout, True)
+    assert float(out[0].abs().max()) == 0.0 and float(out[B - 1].abs().max()) == 0.0
     _close(out, ro, 2e-5, "out")
     _close(dq, rdq, 1e-4, "dq")
     _close(dK, rdK, 1e-4, "dK")
