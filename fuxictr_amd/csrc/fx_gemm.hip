@@ -36,15 +36,7 @@ struct GemmArgs {
     float* ws;
     int32_t split_k;
     int32_t tiles_m, tiles_n;
-    int32_t* tickets;   // split_k > 1: per-tile arrival counters (0 on entry, 0 again on exit) -> the
-                        // last-arriving workgroup of a tile reduces the slabs itself; null: separate launch
 };
-
-// arrival counters of the in-kernel split-K reduce: zero-initialised with the module, every tile's
-// counter is reset by the workgroup that finishes it, so launches that follow each other in stream
-// order can share it (GEMMs of this library are never issued concurrently on two streams)
-#define FX_GEMM_MAX_TICKETS 8192
-__device__ int32_t fx_gemm_tickets[FX_GEMM_MAX_TICKETS];
 
 __device__ __forceinline__ float fx_epilogue(const fx_gemm_epilogue& e, float z, int64_t m,
                                              int64_t n) {
@@ -608,47 +600,6 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
             }
         }
     }
-    // In-kernel slab reduce (split_k > 1 with arrival counters): the workgroup that arrives LAST at a
-    // tile sums the split_k slabs of its elements in slab order — the order of the separate reduce
-    // kernel, so the bits are the same — applies the epilogue and re-arms the counter.  Saves the
-    // k_splitk_reduce launch (8 us per weight gradient); in the dW + dX pair the tail hides under dX's tiles.
-    if (a.split_k > 1 && a.tickets != nullptr) {
-        __shared__ int fx_last_arrival;
-        __threadfence();                                   // this workgroup's slab: visible device-wide
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int old = atomicAdd(&a.tickets[T], 1);
-            fx_last_arrival = (old == a.split_k - 1);
-            if (old == a.split_k - 1) a.tickets[T] = 0;    // everybody has arrived: re-arm
-        }
-        __syncthreads();
-        if (fx_last_arrival) {
-            __threadfence();                               // the other workgroups' slabs: acquire
-            const int64_t total = a.M * a.N;
-            if (do_rowsum && threadIdx.x < BM && m0 + threadIdx.x < a.M) {
-                const float* rs = a.ws + (int64_t)a.split_k * total;
-                float sr = 0.f;
-                for (int zz = 0; zz < a.split_k; ++zz) sr += rs[(int64_t)zz * a.M + m0 + threadIdx.x];
-                a.epi.rowsum[m0 + threadIdx.x] = sr;
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int64_t n = n0 + wn * (BN / 2) + j * 32 + l31;
-                    if (n >= a.N) continue;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (m >= a.M) continue;
-                        float sum = 0.f;
-                        for (int zz = 0; zz < a.split_k; ++zz) sum += a.ws[(int64_t)zz * total + m * a.N + n];
-                        a.C[m * a.ldc + n] = fx_epilogue(a.epi, sum, m, n);
-                    }
-                }
-            }
-        }
-    }
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int W = 2>
@@ -1197,21 +1148,6 @@ static bool fx_gemm_pipe_ok(int32_t transa, int32_t transb, const GemmArgs& a) {
     return fx_gemm_pipe_mode() && av && bv && small_offsets && a.k_chunk >= 4;
 }
 
-// arrival counters for the in-kernel slab reduce, or null (FX_GEMM_TICKETS=0; too many tiles)
-static int32_t* fx_gemm_ticket_ptr(const GemmArgs& a) {
-    static const bool on = []() {
-        const char* e = getenv("FX_GEMM_TICKETS");
-        return !(e && atoi(e) == 0);
-    }();
-    if (!on || a.split_k <= 1 || (int64_t)a.tiles_m * a.tiles_n > FX_GEMM_MAX_TICKETS) return nullptr;
-    static int32_t* dev = []() {
-        void* p = nullptr;
-        return hipGetSymbolAddress(&p, HIP_SYMBOL(fx_gemm_tickets)) == hipSuccess
-                   ? static_cast<int32_t*>(p) : nullptr;
-    }();
-    return dev;
-}
-
 extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
                            const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                            int64_t ldc, const fx_gemm_epilogue* epi_host, int32_t split_k,
@@ -1326,7 +1262,6 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
                                (transb ? N * ldb : K * ldb) < (int64_t)0x3FFFFFF0;   // 32-bit byte offsets
     if (pipe_mode && av && bv && small_offsets && kc >= 4) {
         int rc;
-        a.tickets = fx_gemm_ticket_ptr(a);      // split-K: the last workgroup of a tile reduces the slabs
         if (bm == 128 && bn == 128) rc = fx_gemm_dispatch_pipe<128, 128>(a_kc, b_kc, grid, s, a);
         else if (bm == 128) rc = fx_gemm_dispatch_pipe<128, 64>(a_kc, b_kc, grid, s, a);
         else rc = fx_gemm_dispatch_pipe<64, 64>(a_kc, b_kc, grid, s, a);
@@ -1335,7 +1270,7 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     else if (bm == 128) fx_gemm_dispatch_layout<128, 64>(a_kc, b_kc, av, bv, grid, s, a);
     else fx_gemm_dispatch_layout<64, 64>(a_kc, b_kc, av, bv, grid, s, a);
     FX_CHECK_LAUNCH();
-    if (split_k > 1 && a.tickets == nullptr) {
+    if (split_k > 1) {
         fx_launch_splitk_reduce(a, s);
         FX_CHECK_LAUNCH();
     }
@@ -1373,19 +1308,11 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
             hipStream_t s = fx_hip_stream(stream);
             const int64_t wgs = (int64_t)a[0].tiles_m * a[0].tiles_n * a[0].split_k +
                                 (int64_t)a[1].tiles_m * a[1].tiles_n * a[1].split_k;
-            a[0].tickets = fx_gemm_ticket_ptr(a[0]);
-            a[1].tickets = nullptr;
-            if (a[1].split_k > 1 && a[0].tickets != nullptr) {
-                // both problems split K: give the second one the counters after the first one's
-                const int64_t t0 = (int64_t)a[0].tiles_m * a[0].tiles_n;
-                if (t0 + (int64_t)a[1].tiles_m * a[1].tiles_n <= FX_GEMM_MAX_TICKETS)
-                    a[1].tickets = a[0].tickets + t0;
-            }
             hipLaunchKernelGGL((k_gemm_f32_pair<64, 64, false, false, true, false, 4>),
                                dim3((unsigned)wgs), dim3(256), 0, s, a[0], a[1]);
             FX_CHECK_LAUNCH();
             for (int i = 0; i < 2; ++i)
-                if (a[i].split_k > 1 && a[i].tickets == nullptr) {
+                if (a[i].split_k > 1) {
                     fx_launch_splitk_reduce(a[i], s);
                     FX_CHECK_LAUNCH();
                 }
