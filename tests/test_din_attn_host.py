@@ -30,3 +30,26 @@ def test_fused_and_unfused_host_paths_agree(emulated):
 
 def test_record_view_no_mask(emulated):
     G.test_fused_din_attention_on_a_record_view_without_mask_and_biases(11)
+
+
+def test_mlp_tower_pads_an_unaligned_input_width(emulated):
+    """layers._MLPFn: an input width that is not a multiple of 4 floats (DLRM: 367) is zero-padded for
+    the first layer's GEMMs; outputs and every gradient equal the plain torch stack."""
+    import fuxictr_amd.layers as nat
+    g = torch.Generator().manual_seed(0)
+    B, K, H1, H2 = 33, 367, 40, 8
+    x = torch.randn(B, K, generator=g).requires_grad_(True)
+    W0, b0 = torch.randn(H1, K, generator=g) * 0.1, torch.randn(H1, generator=g)
+    W1, b1 = torch.randn(H2, H1, generator=g) * 0.1, torch.randn(H2, generator=g)
+    ps = [t.clone().requires_grad_(True) for t in (W0, b0, W1, b1)]
+    y = nat._MLPFn.apply(x, (True, False), *ps)
+    gy = torch.randn(B, H2, generator=g)
+    y.backward(gy)
+    xr = x.detach().clone().requires_grad_(True)
+    pr = [t.clone().requires_grad_(True) for t in (W0, b0, W1, b1)]
+    yr = torch.relu(xr @ pr[0].t() + pr[1]) @ pr[2].t() + pr[3]
+    yr.backward(gy)
+    assert torch.allclose(y, yr, atol=1e-5)
+    assert x.grad.shape == (B, K) and torch.allclose(x.grad, xr.grad, atol=1e-5)
+    for a, b in zip(ps, pr):
+        assert a.grad.shape == b.grad.shape and torch.allclose(a.grad, b.grad, atol=1e-4)
