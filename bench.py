@@ -348,7 +348,9 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
                        "shape (of the sparse path) are captured in step order into a hipGraph that "
                        "is replayed 20x between one HIP-event pair on the launch stream (the timed "
                        "region itself replays a hipGraph); average = kernel + dependent-launch "
-                       "boundary")
+                       "boundary; a split-K GEMM call includes its k_splitk_reduce launch, so the GEMM "
+                       "figure is a few per cent below the k_gemm_f32_* rows of the rocprofv3 summary "
+                       "(profiles/r02_kernel_stats_deepfm_final.csv: 0.73 of peak)")
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
