@@ -85,12 +85,16 @@ class KernelTimer(object):
         cls.calls = []
 
 
-def _timed(name, group=None, work=None):
-    """Decorator: when KernelTimer is recording, note this C-ABI call (it still runs normally)."""
+def _timed(name, group=None, work=None, alone=False):
+    """Decorator: when KernelTimer is recording, note this C-ABI call (it still runs normally).
+    alone: besides its group, time the call on its own under `name` (idempotent calls only)."""
     def deco(fn):
         def wrapper(*a, **kw):
             if KernelTimer.recording:
-                KernelTimer.note(name, group, work(*a, **kw) if work else 0, fn, a, kw)
+                w = work(*a, **kw) if work else 0
+                KernelTimer.note(name, group, w, fn, a, kw)
+                if alone and group:
+                    KernelTimer.note(name, None, w, fn, a, kw)
             return fn(*a, **kw)
         wrapper.__name__ = fn.__name__
         wrapper.__doc__ = fn.__doc__
@@ -812,7 +816,7 @@ def _emb_fm_bytes(table, D, ids, col_row_base, col_vocab, col_out_off, dense, nu
                 + (C_ + Fd) * 4 * D)
 
 
-@_timed("k_emb_fm_fwd", "sparse_path", _emb_fm_bytes)
+@_timed("k_emb_fm_fwd", "sparse_path", _emb_fm_bytes, alone=True)
 def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w, num_out_off, out,
                scal, table1=None, num_w1=None, bias1=None, lr_out=None, fm_out=None, fm_lr_out=None,
                S=None):
