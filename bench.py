@@ -449,7 +449,7 @@ def rooflines(m, args, world):
             "us_per_step": 1e3 * da["total_ms"] / n_inst, "launches_per_step": da["launches"] / n_inst,
             "note": "serial chain per wave (x tile -> MFMA -> Dice gate -> ...), 4 passes around the "
                     "batch statistics; see DESIGN.md section 4"}
-    e, ename = kt.get("k_emb_fm_fwd"), "k_emb_fm_fwd (gather + numeric expansion + LR + FM, one launch)"
+    e, ename = kt.get("k_emb_fm_fwd@alone"), "k_emb_fm_fwd (gather + numeric expansion + LR + FM, one launch)"
     if not (e and e["total_ms"] > 0):
         e, ename = kt.get("k_emb_gather_fwd"), "k_emb_gather_fwd"
     if e and e["total_ms"] > 0:
@@ -458,7 +458,7 @@ def rooflines(m, args, world):
                                   "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                   "frac": ach / PEAK_HBM_GBS, "traffic": None,
                                   "launches": e["launches"], "avg_launch_us": e["avg_us"],
-                                  "note": "the recorded launch replayed 20x on ONE batch: its rows stay "
+                                  "note": "the recorded launch replayed back to back on ONE batch: its rows stay "
                                           "in the Infinity Cache; inside the step, where every batch "
                                           "brings new rows, rocprofv3 times this kernel at 10.8 us "
                                           "(profiles/r02_step_timeline_deepfm_final.txt: 18.1 MB -> "

@@ -51,10 +51,14 @@ class KernelTimer(object):
                 for _, _, _, fn, args, kwargs in calls:              # warm (allocations, caches)
                     fn(*args, **kwargs)
                 torch.cuda.synchronize()
+                # a group of ONE launch: ten copies of it in the graph, so that the graph launch itself
+                # (several us) does not sit in a 10-us kernel's figure
+                copies = 10 if len(calls) == 1 else 1
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
-                    for _, _, _, fn, args, kwargs in calls:
-                        fn(*args, **kwargs)
+                    for _ in range(copies):
+                        for _, _, _, fn, args, kwargs in calls:
+                            fn(*args, **kwargs)
                 g.replay()
                 torch.cuda.synchronize()
                 e0 = torch.cuda.Event(enable_timing=True)
@@ -64,7 +68,7 @@ class KernelTimer(object):
                     g.replay()
                 e1.record()
                 torch.cuda.synchronize()
-                per_call_ms = e0.elapsed_time(e1) / reps / len(calls)
+                per_call_ms = e0.elapsed_time(e1) / reps / (len(calls) * copies)
                 for name, group, work, _, _, _ in calls:
                     for k in (name, group):
                         if k is None:
@@ -94,7 +98,7 @@ def _timed(name, group=None, work=None, alone=False):
                 w = work(*a, **kw) if work else 0
                 KernelTimer.note(name, group, w, fn, a, kw)
                 if alone and group:
-                    KernelTimer.note(name, None, w, fn, a, kw)
+                    KernelTimer.note(name + "@alone", None, w, fn, a, kw)
             return fn(*a, **kw)
         wrapper.__name__ = fn.__name__
         wrapper.__doc__ = fn.__doc__
