@@ -404,6 +404,8 @@ class _TableGroup(object):
         tables of LogisticRegression): their rows are caught up in the same launch."""
         if plan.C == 0 or self.opt_kind is None:
             return None
+        if self.opt is not None:
+            self.opt.ensure_begun()     # forward; backward; step(); zero_grad() loops: see optim.py
         cache = getattr(inputs, "cache", None)
         ckey = ("dedup", plan.sig, self.total_rows)
         todo = [g for g in (self,) + tuple(peers)
@@ -476,7 +478,7 @@ class _TableGroup(object):
         per_peer = -(-n_lookups // self.n_shards)
         return int(-(-int(per_peer * self.a2a_factor) // 64) * 64 + 64)
 
-    def shard_exchange_ids(self, plan, ids, inputs):
+    def shard_exchange_ids(self, plan, ids, inputs, track=False):
         """De-dup the local lookups owner-major, route the unique keys to their owners (one
         all-to-all) and de-dup what this rank received as an owner.  Shared by table groups with
         the same id columns / row bases (the D=16 and the D=1 LR tables)."""
@@ -487,6 +489,8 @@ class _TableGroup(object):
             peers.append(self)
         if cache is not None and ckey in cache:
             return cache[ckey]
+        if self.opt is not None and track:
+            self.opt.ensure_begun()
         dev, N = self.device, self.n_shards
         n = ids.shape[0] * ids.shape[1]
         if self.dedup_ws is None or self.dedup_ws[0] != n:
@@ -658,7 +662,7 @@ class _EmbGatherFn(torch.autograd.Function):
         if group.sharded and plan.C:
             # row-sharded: ids -> owners, rows <- owners, then the same kernels read the received
             # rows through the per-lookup slot matrix
-            sx = group.shard_exchange_ids(plan, ids, inputs)
+            sx = group.shard_exchange_ids(plan, ids, inputs, track)
             table = group.shard_fetch_rows(sx, track)
             src, base, vocab = sx.lookup_slot, sx.slot_base, sx.slot_vocab
         else:
@@ -708,9 +712,9 @@ class _EmbFMFn(torch.autograd.Function):
         if group.sharded and plan.C:
             # row-sharded tables: ids -> owners, rows back (ONE all-to-all for the D-float and the
             # D=1 rows), then the same kernel reads the received rows through the slot matrix
-            sx = group.shard_exchange_ids(plan, ids, inputs)
+            sx = group.shard_exchange_ids(plan, ids, inputs, track)
             if want_lr:
-                lr_group.shard_exchange_ids(lr_plan, ids, inputs)     # joins the row exchange
+                lr_group.shard_exchange_ids(lr_plan, ids, inputs, track)     # joins the row exchange
             table = group.shard_fetch_rows(sx, track)
             table1 = lr_group.shard_fetch_rows(sx, track) if want_lr else None
             g_ids, g_base, g_vocab = sx.lookup_slot, sx.slot_base, sx.slot_vocab
@@ -1320,7 +1324,7 @@ class _LRFn(torch.autograd.Function):
         num_w1 = group.select_num_w(plan)
         sx = None
         if group.sharded and plan.C:
-            sx = group.shard_exchange_ids(plan, ids, inputs)
+            sx = group.shard_exchange_ids(plan, ids, inputs, track)
             rows = group.shard_fetch_rows(sx, track)
             ops.lr_fwd(rows, sx.lookup_slot, sx.slot_base, sx.slot_vocab, dense, num_w1, bias,
                        out, group.ensure_scal())
@@ -1485,6 +1489,7 @@ class FactorizationMachine(nn.Module):
 # ------------------------------------------------------------------------------------------------
 import os as _os
 _FORCE_SPLITK = int(_os.environ.get("FX_DW_SPLITK", "0"))
+_MLP_PAD = _os.environ.get("FX_MLP_PAD", "1") != "0"      # A/B switch of the 4-float input padding
 
 
 def _split_k_for(M, N, K):
@@ -1577,7 +1582,7 @@ class _MLPFn(torch.autograd.Function):
         # kernel (55 us instead of 28 for 4096 x 1024 x 367, and no dW + dX pair).  One zero column
         # more on both operands changes no sum and keeps every row 16-byte aligned.
         K0 = x.shape[1]
-        pad = (-K0) % 4 if K0 >= 64 else 0
+        pad = (-K0) % 4 if (K0 >= 64 and _MLP_PAD) else 0
         W0p = None
         if pad:
             x = torch.cat([x, _zero_cols(x.shape[0], pad, x.device)], dim=1)          # one launch each

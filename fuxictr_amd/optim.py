@@ -51,7 +51,8 @@ class _NativeOptimizer(torch.optim.Optimizer):
         self.scal = ops.new_scalars(self.device, lr=lr, beta1=betas[0], beta2=betas[1], eps=eps)
         self._lr_dev = float(lr)
         self._max_norm = 0.0
-        self._begun = False      # zero_grad() opened a step that step() has not closed yet
+        self._max_norm_explicit = False   # set_max_norm() was called by the user of the optimizer
+        self._begun = False      # a step is open (zero_grad() or the first training forward opened it)
         self._begin_pending = False   # ... and its device-side part has not been launched yet
         self._model = model
         self._state_dense = {}   # id(tensor) -> (m, v)
@@ -99,7 +100,12 @@ class _NativeOptimizer(torch.optim.Optimizer):
                                         device=grp.device)
             grp.reg_fresh = False
 
-    def set_max_norm(self, max_norm):
+    def set_max_norm(self, max_norm, _from_model=False):
+        """Global-norm clip applied inside the update kernels (0 / None: no clipping).  An explicit call
+        wins over the model's `_max_gradient_norm` (which step() only adopts while nobody has set one:
+        a train_step override that deliberately does not clip calls set_max_norm(0))."""
+        if not _from_model:
+            self._max_norm_explicit = True
         max_norm = float(max_norm) if max_norm else 0.0
         if max_norm != self._max_norm:
             self.scal[_lib.SC_MAX_NORM:_lib.SC_MAX_NORM + 1].fill_(max_norm)
@@ -117,9 +123,11 @@ class _NativeOptimizer(torch.optim.Optimizer):
     def begin_step(self):
         """Opens a training step BEFORE its forward: t += 1 and the Adam bias corrections on the
         device (exact mode replays a row's missed steps up to t - 1 when the forward reads it).
-        Idempotent until step() closes the step; zero_grad() calls it, so any training loop of the
-        reference's shape — optimizer.zero_grad(); forward; backward; optimizer.step()
-        (rank_model.py:307-323 and the LongCTR models' own train_step) — advances t correctly."""
+        Idempotent until step() closes the step.  Three callers, so that both loop shapes of the
+        reference advance t correctly: zero_grad() (BaseModel.train_step: zero_grad; forward; backward;
+        step — rank_model.py:307-323), the first training forward of a step (`ensure_begun`, for the
+        LongCTR models' forward; backward; step; zero_grad order, model_zoo/LongCTR/DCNv2/DCNv2.py:209-217,
+        whose first step has no zero_grad before it) and step() itself (a model without table lookups)."""
         if self._begun:
             return
         self.sync_lr()
@@ -127,6 +135,15 @@ class _NativeOptimizer(torch.optim.Optimizer):
         # the step (fx_dedup_catchup); whoever needs it earlier calls flush_begin()
         self._begin_pending = True
         self._begun = True
+
+    def ensure_begun(self):
+        """Called by the embedding layers at the top of a training forward: opens the step if nobody
+        has, and re-reads the host-side lr while the device-side opening is still pending (zero_grad()
+        at the END of the previous step opened this one before an lr_decay between epochs)."""
+        if not self._begun:
+            self.begin_step()
+        elif self._begin_pending:
+            self.sync_lr()
 
     def take_begin(self):
         """-> the scalar block if the step's device-side opening is still due (the caller's kernel
@@ -239,18 +256,16 @@ class _NativeOptimizer(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError("closure is not supported by the native optimizer")
         if not self._begun:
-            raise RuntimeError(
-                "native optimizer: step() without a preceding zero_grad() — the step counter and "
-                "the Adam bias corrections are advanced by zero_grad() before the forward pass "
-                "(call optimizer.zero_grad() at the top of every training step, as "
-                "BaseModel.train_step does)")
+            self.begin_step()      # no training forward opened the step (no table lookups)
         self._begun = False
         self.flush_begin()
-        if self._model is not None and hasattr(self._model, "_max_gradient_norm"):
+        if (not self._max_norm_explicit and self._model is not None
+                and hasattr(self._model, "_max_gradient_norm")):
             # the global-norm clip (rank_model.py:321) lives inside the update kernels: a train_step
             # override that reaches step() directly still gets fit()'s max_gradient_norm, table
-            # gradients included (they are invisible to a clip_grad_norm_ over .grad attributes)
-            self.set_max_norm(self._model._max_gradient_norm)
+            # gradients included (they are invisible to a clip_grad_norm_ over .grad attributes);
+            # an explicit optimizer.set_max_norm() is never overridden
+            self.set_max_norm(self._model._max_gradient_norm, _from_model=True)
         if self.dist is not None:           # row-gradient all-to-all(s) + owner-side reduction
             finish_shard_backward([grp for grp in self._groups if grp.dist is not None])
         ps, gs = self._dense_lists()

@@ -598,7 +598,8 @@ class BaseModel(nn.Module):
         (about 60 launches) is captured once into a hipGraph and replayed: every per-step scalar
         (step counter, lr, clip coefficient, unique-row count) already lives in device memory."""
         opt = self.optimizer
-        opt.set_max_norm(self._max_gradient_norm)
+        if not getattr(opt, "_max_norm_explicit", False):
+            opt.set_max_norm(self._max_gradient_norm, _from_model=True)
         opt.sync_lr()
         if self._use_graph:
             return self._train_step_graph(batch_data)

@@ -25,17 +25,30 @@ class Golden(object):
         self.meta = json.loads(bytes(z["meta"]).decode())
         self.spec = self.meta["spec"]
         self.state0, self.state1, self.expect, batches = {}, {}, {}, {}
+        self.state1_rows = {}       # big matrices of a slim fixture: every 8th row of the trained copy
         for k in z.files:
             if k.startswith("state0/"):
                 self.state0[k[7:]] = z[k]
             elif k.startswith("state1/"):
                 self.state1[k[7:]] = z[k]
+            elif k.startswith("state1s/"):
+                self.state1_rows[k[8:]] = z[k]
             elif k.startswith("expect/"):
                 self.expect[k[7:]] = z[k]
             elif k.startswith("batch"):
                 i, f = k.split("/", 1)
                 batches.setdefault(int(i[5:]), {})[f] = z[k]
         self.batches = [batches[i] for i in sorted(batches)]
+
+    def final_weights(self, sd):
+        """-> [(name, got, reference)] over the trained weights the fixture holds; `sd` maps names to
+        numpy-convertible arrays (a state_dict moved to the host)."""
+        out = [(k, np.asarray(sd[k]), ref) for k, ref in self.state1.items()]
+        for k, ref in self.state1_rows.items():
+            got = np.asarray(sd[k])
+            stride = -(-got.shape[0] // ref.shape[0])
+            out.append((k + "[::%d]" % stride, got[::stride], ref))
+        return out
 
     @property
     def features(self):

@@ -239,6 +239,8 @@ def run_case(case):
           out["expect/pred1"][:3], "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+SLIM_ROW_STRIDE = 8
+
 DEMOS = {
     # BASELINE.json configs[0]: demo/example3_DeepFM_with_npz_input.py, its own config and data
     "c1_tiny_npz": dict(module="model_zoo.DeepFM.DeepFM_torch.src", cls="DeepFM",
@@ -250,7 +252,7 @@ DEMOS = {
     "demo_din_tiny_seq": dict(module="model_zoo", cls="DIN", config="model_zoo/DIN/config",
                               expid="DIN_test", data="tiny_seq"),
     "demo_dcnv2_tiny_npz": dict(module="model_zoo", cls="DCNv2", config="model_zoo/DCNv2/config",
-                                expid="DCNv2_test", data="tiny_npz", swap_data=True),
+                                expid="DCNv2_test", data="tiny_npz", swap_data=True, slim=True),
     "demo_xdeepfm_tiny_npz": dict(module="model_zoo", cls="xDeepFM",
                                   config="model_zoo/xDeepFM/config", expid="xDeepFM_test",
                                   data="tiny_npz", swap_data=True),
@@ -381,7 +383,14 @@ def run_demo(name):
     out["expect/valid_logloss"] = np.asarray([res["logloss"]], dtype=np.float64)
     out["expect/valid_auc"] = np.asarray([res["AUC"]], dtype=np.float64)
     for k, v in model.state_dict().items():
-        out["state1/" + k] = v.detach().cpu().numpy().copy()
+        v = v.detach().cpu().numpy().copy()
+        if d.get("slim") and v.ndim == 2 and v.size > 65536:
+            # the trained copy of a big matrix: every 8th row (state0 holds the full random init —
+            # incompressible — and the update of a matrix is checked as well on a row sample; keeps
+            # the fixture small enough to be committed)
+            out["state1s/" + k] = v[::SLIM_ROW_STRIDE].copy()
+        else:
+            out["state1/" + k] = v
     for i, b in enumerate(seen + [valid]):
         for k, v in b.items():
             out["batch%d/%s" % (i, k)] = v.numpy()

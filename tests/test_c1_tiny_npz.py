@@ -22,7 +22,7 @@ class Gen(list):
 
 
 DEMOS = ["c1_tiny_npz", "demo_din_tiny_seq", "demo_xdeepfm_tiny_npz", "demo_dlrm_tiny_npz",
-         "demo_dcnv2_tiny_npz"]      # (the DCNv2 fixture, 7 MB of 560x560 cross weights, is not committed)
+         "demo_dcnv2_tiny_npz"]      # (slim fixture: the trained 560x560 cross weights as a row sample)
 
 
 def _golden(name):
@@ -88,9 +88,9 @@ def _fit_and_check(model, g):
         assert round(logs["AUC"], 4) == round(float(g.expect["valid_auc"][0]), 4)
     else:
         assert abs(logs["AUC"] - float(g.expect["valid_auc"][0])) <= slack + 1e-9, (logs, slack)
-    sd = model.state_dict()
-    for k, ref in g.state1.items():
-        assert_weights_close(sd[k].cpu().numpy(), ref, m["lr"], m["steps"], k, tol=1e-6)
+    sd = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+    for k, got, ref in g.final_weights(sd):
+        assert_weights_close(got, ref, m["lr"], m["steps"], k, tol=1e-6)
 
 
 @pytest.mark.parametrize("demo", DEMOS)
@@ -112,8 +112,8 @@ def test_oracle_reproduces_the_reference_demo_run(demo):
     y = g.batches[-1][label]
     assert abs(log_loss(y, p.astype(np.float64)) - float(g.expect["valid_logloss"][0])) <= 1e-6
     assert round(roc_auc_score(y, p), 4) == round(float(g.expect["valid_auc"][0]), 4)
-    for k, ref in g.state1.items():
-        assert_weights_close(tr.state[k].detach().numpy(), ref, m["lr"], m["steps"], k, tol=1e-6)
+    for k, got, ref in g.final_weights({k: v.detach().numpy() for k, v in tr.state.items()}):
+        assert_weights_close(got, ref, m["lr"], m["steps"], k, tol=1e-6)
 
 
 @pytest.mark.parametrize("demo", DEMOS)

@@ -273,17 +273,21 @@ def test_entrywise_reads_of_the_record_share_one_autograd_node(tmp_path, monkeyp
 
 
 def test_optimizer_step_protocol_of_a_train_step_override(tmp_path, monkeypatch):
-    """A train_step override of the reference's shape (LongCTR models: optimizer.zero_grad();
-    forward; loss.backward(); optimizer.step()) drives the native optimizer correctly: zero_grad()
-    opens the step (t += 1, bias corrections), step() closes it and picks up fit()'s
-    max_gradient_norm; step() without zero_grad() raises instead of silently applying 0-size
-    updates."""
+    """Both loop shapes of the reference drive the native optimizer correctly:
+      b: optimizer.zero_grad(); forward; backward; optimizer.step()      (rank_model.py:307-323)
+      c: forward; backward; optimizer.step(); optimizer.zero_grad()      (the LongCTR models' own
+         train_step, model_zoo/LongCTR/DCNv2/DCNv2.py:209-217 — no zero_grad before the FIRST step)
+    In both the step counter / bias corrections advance before the forward reads a row (the first
+    training forward opens the step when zero_grad has not), step() picks up fit()'s
+    max_gradient_norm, and an explicit optimizer.set_max_norm() is not overridden by the model's."""
     g = Golden("deepfm_adam_clip")
     a = _build(g, tmp_path, monkeypatch)
     b = _build(g, tmp_path, monkeypatch)
-    a.train()
-    b.train()
+    c = _build(g, tmp_path, monkeypatch)
+    for m_ in (a, b, c):
+        m_.train()
     b._max_gradient_norm = g.meta["max_norm"]
+    c._max_gradient_norm = g.meta["max_norm"]
     for i in range(g.meta["steps"]):
         batch = tb(g.batches[i])
         la = float(a.train_step(batch).item())
@@ -294,8 +298,36 @@ def test_optimizer_step_protocol_of_a_train_step_override(tmp_path, monkeypatch)
         b.optimizer.step()
         assert abs(float(loss.item()) - la) <= 1e-6, (i, float(loss.item()), la)
         assert abs(la - float(g.expect["loss"][i])) <= 1e-4
-    with pytest.raises(RuntimeError, match="zero_grad"):
-        b.optimizer.step()
+        out = c.forward(batch)                        # LongCTR order: zero_grad comes last
+        loss_c = c.compute_loss(out, c.get_labels(batch))
+        loss_c.backward()
+        c.optimizer.step()
+        c.optimizer.zero_grad()
+        assert abs(float(loss_c.item()) - la) <= 1e-6, (i, float(loss_c.item()), la)
+    sa, sc_ = a.state_dict(), c.state_dict()
+    for k in sa:
+        assert torch.allclose(sa[k].float(), sc_[k].float(), atol=1e-7, rtol=0), k
+    # an lr change between two steps of the LongCTR order (zero_grad already opened the next step)
+    # still reaches the step it precedes
+    for m_ in (a, c):
+        for grp in m_.optimizer.param_groups:
+            grp["lr"] = grp["lr"] * 0.1
+    batch = tb(g.batches[0])
+    la = float(a.train_step(batch).item())
+    out = c.forward(batch)
+    loss_c = c.compute_loss(out, c.get_labels(batch))
+    loss_c.backward()
+    c.optimizer.step()
+    c.optimizer.zero_grad()
+    sa, sc_ = a.state_dict(), c.state_dict()
+    for k in sa:
+        assert torch.allclose(sa[k].float(), sc_[k].float(), atol=1e-7, rtol=0), k
+    # explicit clip setting wins over the model attribute
+    c.optimizer.set_max_norm(0.0)
+    out = c.forward(batch)
+    c.compute_loss(out, c.get_labels(batch)).backward()
+    c.optimizer.step()
+    assert c.optimizer._max_norm == 0.0
 
 
 def test_bf16_table_storage_wiring(tmp_path, monkeypatch):
