@@ -144,6 +144,7 @@ SIGNATURES = {
     "fx_sparse_adam_multi": (i32, [C.POINTER(RowState), i32, vp, vp, i64, vp, vp]),
     "fx_sparse_sgd_multi": (i32, [C.POINTER(RowState), i32, vp, vp, i64, vp, vp]),
     "fx_adam_catchup_all": (i32, [C.POINTER(RowState), i64, i32, vp, vp]),
+    "fx_adam_catchup_rows": (i32, [C.POINTER(RowState), i32, vp, vp, i64, i32, vp, vp]),
     "fx_pack_columns_multi": (i32, [C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp),
                                     C.POINTER(i32), C.POINTER(i64), i32, i64, vp]),
 }

@@ -104,6 +104,28 @@ __device__ __forceinline__ void fx_catchup_row(const FxTableDev& t, int64_t row,
     fx_catchup_finish<VEC>(t, row, sub, r, sc, upto, lb1, lb2);
 }
 
+// one unique row of a de-dup result, in every table group that shares the id plan
+__device__ __forceinline__ void fx_catchup_tables(const FxTableDev* t, int n_tables, int64_t row,
+                                                  int sub, const fx_scalars& sc, int upto, double lb1,
+                                                  double lb2) {
+    if (n_tables == 2 && t[0].vec == 4 && t[1].vec == 1) {
+        // the D-float tables + the D=1 tables of LogisticRegression: all eight loads in flight
+        FxRowRegs<4> r0;
+        FxRowRegs<1> r1;
+        fx_row_load<4>(t[0], row, sub, r0);
+        fx_row_load<1>(t[1], row, sub, r1);
+        fx_catchup_finish<4>(t[0], row, sub, r0, sc, upto, lb1, lb2);
+        fx_catchup_finish<1>(t[1], row, sub, r1, sc, upto, lb1, lb2);
+        return;
+    }
+    for (int i = 0; i < n_tables; ++i) {
+        const FxTableDev& tb = t[i];
+        if (tb.vec == 4) fx_catchup_row<4>(tb, row, sub, sc, upto, lb1, lb2);
+        else if (tb.vec == 2) fx_catchup_row<2>(tb, row, sub, sc, upto, lb1, lb2);
+        else fx_catchup_row<1>(tb, row, sub, sc, upto, lb1, lb2);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fx_dedup_catchup, launch 1: one workgroup sorts one id column in LDS (as k_sort_columns of
 // fx_sparse.hip); block 0 also opens the optimizer step (fx_opt_begin_step fused).
@@ -238,22 +260,7 @@ __global__ __launch_bounds__(256) void k_finish_catchup(FinishArgs a) {
             }
         }
         if (!head) continue;
-        if (a.n_tables == 2 && a.t[0].vec == 4 && a.t[1].vec == 1) {
-            // the D-float tables + the D=1 tables of LogisticRegression: all eight loads in flight
-            FxRowRegs<4> r0;
-            FxRowRegs<1> r1;
-            fx_row_load<4>(a.t[0], (int64_t)k, sub, r0);
-            fx_row_load<1>(a.t[1], (int64_t)k, sub, r1);
-            fx_catchup_finish<4>(a.t[0], (int64_t)k, sub, r0, sc, upto, lb1, lb2);
-            fx_catchup_finish<1>(a.t[1], (int64_t)k, sub, r1, sc, upto, lb1, lb2);
-            continue;
-        }
-        for (int t = 0; t < a.n_tables; ++t) {
-            const FxTableDev& tb = a.t[t];
-            if (tb.vec == 4) fx_catchup_row<4>(tb, (int64_t)k, sub, sc, upto, lb1, lb2);
-            else if (tb.vec == 2) fx_catchup_row<2>(tb, (int64_t)k, sub, sc, upto, lb1, lb2);
-            else fx_catchup_row<1>(tb, (int64_t)k, sub, sc, upto, lb1, lb2);
-        }
+        fx_catchup_tables(a.t, a.n_tables, (int64_t)k, sub, sc, upto, lb1, lb2);
     }
 }
 
@@ -1186,6 +1193,59 @@ extern "C" int fx_adam_catchup_all(const fx_row_state* table_host, int64_t total
     if (t.vec == 4) hipLaunchKernelGGL(k_catchup_all<4>, grid, dim3(256), 0, s, t, total_rows, scal, (int)upto_offset);
     else if (t.vec == 2) hipLaunchKernelGGL(k_catchup_all<2>, grid, dim3(256), 0, s, t, total_rows, scal, (int)upto_offset);
     else hipLaunchKernelGGL(k_catchup_all<1>, grid, dim3(256), 0, s, t, total_rows, scal, (int)upto_offset);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fx_adam_catchup_rows: the exact-mode catch-up of the unique rows of ANY de-dup result (the generic
+// sort path: sequence columns that alias a table, batches beyond the column fast path), for fp32 or
+// bf16 tables, every table group that shares the id plan in ONE launch.  (fx_adam_catchup is the
+// fp32-only, one-table kernel of round 1; it must never see a bf16 table.)
+// ---------------------------------------------------------------------------------------------
+struct CatchRowsArgs {
+    FxTableDev t[FX_MAX_TABLES];
+    const uint32_t* uniq_row;
+    const int32_t* n_unique;
+    const fx_scalars* scal;
+    int32_t n_tables, group_log2, upto_offset;
+};
+
+__global__ __launch_bounds__(256) void k_catchup_rows(CatchRowsArgs a) {
+    const int glanes = 1 << a.group_log2;
+    const int sub = threadIdx.x & (glanes - 1);
+    const int64_t rpb = 256 >> a.group_log2;
+    const int nu = *a.n_unique;
+    const fx_scalars sc = *a.scal;
+    const int upto = sc.step + a.upto_offset;
+    const double lb1 = log2((double)sc.beta1), lb2 = log2((double)sc.beta2);
+    for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.group_log2); u < nu;
+         u += (int64_t)gridDim.x * rpb)
+        fx_catchup_tables(a.t, a.n_tables, (int64_t)a.uniq_row[u], sub, sc, upto, lb1, lb2);
+}
+
+extern "C" int fx_adam_catchup_rows(const fx_row_state* tables_host, int32_t n_tables,
+                                    const uint32_t* uniq_row, const int32_t* n_unique,
+                                    int64_t n_max, int32_t upto_offset, const fx_scalars* scal,
+                                    fx_stream_t stream) {
+    FX_CHECK_ARG(n_tables >= 1 && n_tables <= FX_MAX_TABLES,
+                 "fx_adam_catchup_rows: n_tables=%d not in [1,%d]", n_tables, FX_MAX_TABLES);
+    if (n_max <= 0) return FX_OK;
+    FX_CHECK_ARG(tables_host && uniq_row && n_unique && scal, "fx_adam_catchup_rows: null pointer");
+    CatchRowsArgs a;
+    memset(&a, 0, sizeof(a));
+    int gl = 0;
+    const int st = fx_fill_tables(tables_host, n_tables, a.t, &gl, "fx_adam_catchup_rows", true);
+    if (st != FX_OK) return st;
+    a.uniq_row = uniq_row;
+    a.n_unique = n_unique;
+    a.scal = scal;
+    a.n_tables = n_tables;
+    a.group_log2 = gl;
+    a.upto_offset = upto_offset;
+    int64_t blocks = fx_ceil_div(n_max, 256 >> gl);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_catchup_rows, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), a);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

@@ -428,10 +428,13 @@ class _TableGroup(object):
             return dd
         if dd is None:
             dd = self.dedup(plan, ids, inputs)
-        for g in todo:
-            ops.adam_catchup(g.table, g.m, g.v, g.last_step, g.D, dd, g.total_rows, -1, g.scal)
+        if todo:
+            # generic de-dup (sequence columns that alias a table, B > 8192): one dtype-aware launch
+            # for every table group of the id plan (fx_adam_catchup is fp32-only)
+            ops.adam_catchup_rows([g.row_state() for g in todo], dd, -1, self.scal)
             if cache is not None:
-                cache[("caughtup", id(g), ckey)] = True
+                for g in todo:
+                    cache[("caughtup", id(g), ckey)] = True
         return dd
 
     def backward(self, plan, ids, dense, dout, dout_ld, col_off, num_off, dd, inputs_cache,

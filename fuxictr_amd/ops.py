@@ -337,8 +337,16 @@ def clip_coef(parts, scal):
                            len(parts), ptr(scal), stream_ptr(scal.device)), "fx_clip_coef")
 
 
+def _need_fp32_table(table, who):
+    if table.dtype != torch.float32:
+        raise _lib.FxError("%s is the fp32-only kernel of round 1 and got a %s table; bf16 tables go "
+                           "through the RowState entry points (adam_catchup_rows / "
+                           "sparse_update_multi)" % (who, table.dtype))
+
+
 @_timed("sparse_adam", "sparse_path")
 def sparse_adam(table, m, v, last_step, D, dd, G, scal):
+    _need_fp32_table(table, "fx_sparse_adam")
     check(_lib.load().fx_sparse_adam(ptr(table), ptr(m), ptr(v), ptr(last_step), D,
                                      ptr(dd.uniq_row), ptr(dd.n_unique), dd.n_max, ptr(G),
                                      ptr(scal), stream_ptr(table.device)), "fx_sparse_adam")
@@ -347,6 +355,7 @@ def sparse_adam(table, m, v, last_step, D, dd, G, scal):
 @_timed("adam_catchup", "sparse_path")
 def adam_catchup(table, m, v, last_step, D, dd, total_rows, upto_offset, scal):
     """dd=None: every row of the table (flush); else only the unique rows of dd."""
+    _need_fp32_table(table, "fx_adam_catchup")
     lib = _lib.load()
     if dd is None:
         check(lib.fx_adam_catchup(ptr(table), ptr(m), ptr(v), ptr(last_step), D, vp(0), vp(0), 0,
@@ -361,6 +370,7 @@ def adam_catchup(table, m, v, last_step, D, dd, total_rows, upto_offset, scal):
 
 @_timed("sparse_sgd", "sparse_path")
 def sparse_sgd(table, D, dd, G, scal, last_step=None):
+    _need_fp32_table(table, "fx_sparse_sgd")
     check(_lib.load().fx_sparse_sgd(ptr(table), ptr(last_step), D, ptr(dd.uniq_row),
                                     ptr(dd.n_unique), dd.n_max, ptr(G), ptr(scal),
                                     stream_ptr(table.device)), "fx_sparse_sgd")
@@ -869,6 +879,18 @@ def adam_catchup_all(state, total_rows, upto_offset, scal):
     """Exact-mode flush of one table (fp32 or bf16): every row up to step + upto_offset."""
     check(_lib.load().fx_adam_catchup_all(_row_states([state]), total_rows, upto_offset, ptr(scal),
                                           stream_ptr(scal.device)), "fx_adam_catchup_all")
+
+
+@_timed("adam_catchup_rows", "sparse_path")
+def adam_catchup_rows(states, dd, upto_offset, scal):
+    """Exact-mode catch-up of the unique rows of `dd` in every table group of `states` (RowState; fp32
+    or bf16 tables), FX_MAX_TABLES groups per launch."""
+    lib = _lib.load()
+    for i in range(0, len(states), _lib.FX_MAX_TABLES):
+        part = states[i:i + _lib.FX_MAX_TABLES]
+        check(lib.fx_adam_catchup_rows(_row_states(part), len(part), ptr(dd.uniq_row),
+                                       ptr(dd.n_unique), dd.n_max, upto_offset, ptr(scal),
+                                       stream_ptr(scal.device)), "fx_adam_catchup_rows")
 
 
 @_timed("sparse_update_multi", "sparse_path")

@@ -347,13 +347,15 @@ class _NativeOptimizer(torch.optim.Optimizer):
             for rec in grp.pending:
                 buckets.setdefault(id(rec.dd), []).append((grp, rec))
         for items in buckets.values():
-            if len(items) <= _lib.FX_MAX_TABLES and (
-                    len(items) > 1 or items[0][0].table.dtype != torch.float32):
-                ops.sparse_update_multi(self.kind, [g.row_state(G=r.G) for g, r in items],
-                                        items[0][1].dd, self.scal)
-            else:
-                for grp, rec in items:
-                    self._sparse_update(grp, rec)
+            if len(items) == 1 and items[0][0].table.dtype == torch.float32:
+                self._sparse_update(*items[0])
+                continue
+            # dtype-aware multi-table kernel, FX_MAX_TABLES groups per launch (a bf16 table must never
+            # reach the fp32-only single-table kernels)
+            for i in range(0, len(items), _lib.FX_MAX_TABLES):
+                part = items[i:i + _lib.FX_MAX_TABLES]
+                ops.sparse_update_multi(self.kind, [g.row_state(G=r.G) for g, r in part],
+                                        part[0][1].dd, self.scal)
         for grp in self._groups:
             if self.dense_reg and grp.table is not None:
                 ops.reg_dense_update(grp.table, grp.m, grp.v, grp.last_step, grp.D,

@@ -612,6 +612,12 @@ int fx_binary_metrics(const float* y_pred, const float* y_true, int64_t n, void*
  * fx_adam_catchup_all: fx_adam_catchup over EVERY row of one table (uniq_row = NULL there), for fp32
  *   or bf16 tables: the flush of the exact mode before evaluate / save / a learning-rate change.
  *
+ * fx_adam_catchup_rows: fx_adam_catchup over the unique rows of ANY de-dup result, for fp32 or bf16
+ *   tables and for every table group that shares the id plan (<= 4) in ONE launch: the catch-up of the
+ *   generic de-dup path (sequence columns that alias a table, batches beyond fx_dedup_catchup's
+ *   limits).  Replaces what dense torch.optim.Adam does to untouched rows (torch_utils.py:76,
+ *   rank_model.py:322), like fx_adam_catchup.
+ *
  * fx_pack_columns_multi: fx_pack_columns with one destination per column (outs_host[c] = address of
  *   out[0, first column], out_lds_host[c] its row stride, out_dtypes_host[c] FX_I32 | FX_F32), so the
  *   id block, the numeric block and the label of a batch (rank_model.py:169-204, feature_embedding.py
@@ -659,6 +665,9 @@ int fx_sparse_sgd_multi(const fx_row_state* tables_host, int32_t n_tables, const
                         fx_stream_t stream);
 int fx_adam_catchup_all(const fx_row_state* table_host, int64_t total_rows, int32_t upto_offset,
                         const fx_scalars* scal, fx_stream_t stream);
+int fx_adam_catchup_rows(const fx_row_state* tables_host, int32_t n_tables, const uint32_t* uniq_row,
+                         const int32_t* n_unique, int64_t n_max, int32_t upto_offset,
+                         const fx_scalars* scal, fx_stream_t stream);
 int fx_pack_columns_multi(const void* const* cols_host, const int32_t* dtypes_host,
                           const int32_t* widths_host, void* const* outs_host,
                           const int32_t* out_dtypes_host, const int64_t* out_lds_host, int32_t ncols,

@@ -775,6 +775,12 @@ def adam_catchup_all(state, total_rows, upto_offset, scal):
                  upto_offset, scal)
 
 
+def adam_catchup_rows(states, dd, upto_offset, scal):
+    for st in states:
+        adam_catchup(st.table, st.m, st.v, st.last_step, st.D, dd, st.table.shape[0], upto_offset,
+                     scal)
+
+
 def sparse_update_multi(kind, states, dd, scal):
     for st in states:
         if kind == "adam":
@@ -803,7 +809,7 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update",
          "shard_plan_workspace_ints", "emb_seq_pool_fwd", "dedup_sorted_runs", "RowState",
          "dedup_catchup", "emb_fm_fwd", "emb_fm_bwd", "sparse_update_multi", "pack_columns_multi",
-         "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats", "adam_catchup_all",
+         "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats", "adam_catchup_all", "adam_catchup_rows",
          "dice_local_sums", "dice_fwd_from_sums", "dice_bwd_local_sums", "dice_bwd_from_sums",
          "din_attn_workspace_floats", "din_attn_stats", "dice_stats_from_sums", "din_attn_fwd",
          "din_attn_bwd_sums", "din_attn_bwd", "gemm_dw_dx", "split_rows"]

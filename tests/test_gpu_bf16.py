@@ -137,3 +137,39 @@ def test_bf16_model_error_report_at_c2_shapes(tmp_path):
             f.write(json.dumps({"case": "c2_deepfm_bf16_tables", **rep}) + "\n")
     assert rep["loss_max_diff"] < 5e-3 and abs(rep["auc"][0] - rep["auc"][1]) < 5e-3
     model.optimizer.check_errors()
+
+
+@pytest.mark.parametrize("case,B", [("c2_deepfm", 8448), ("c4_din", 2048)])
+def test_bf16_tables_on_the_generic_dedup_path(case, B, tmp_path):
+    """outside the column fast path — B > 8192, or sequence columns that alias a
+    table (DIN) — the exact-mode catch-up and the row update of a bf16 table must go through the
+    dtype-aware kernels (fx_adam_catchup_rows / fx_sparse_adam_multi); the fp32-only round-1 kernels
+    would write 4-byte floats into the 2-byte table.  Checked: rows no batch touched are bit-identical
+    to their initial value after training (a stray fp32 write lands in other rows), the losses follow
+    the fp32 oracle within the bf16 storage error, nothing is flagged."""
+    dist = "powerlaw"
+    model, features, cfg, spec, cards = BS.build(case, zoo, 0, tmp_path, emb_dtype="bf16")
+    groups = model.embedding_layer.embedding_layer.table_groups()
+    main = [g for g in groups if g.table is not None and g.D > 1]
+    assert main and all(g.table.dtype == torch.bfloat16 for g in main)
+    before = [g.table.clone() for g in main]
+    state0 = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    tr = O.OracleTrainer(cfg, state0, features, lr=1e-3, max_norm=10.0)
+    teacher = BS.Teacher(features)
+    rng = np.random.default_rng(3)
+    train = BS.make_batches(case, spec, cards, rng, B, 4, dist, teacher)
+    model.train()
+    model._max_gradient_norm = 10.0
+    ln, lo = [], []
+    for b in train:
+        t = BS.tb(b)
+        ln.append(float(model.train_step(t).item()))
+        lo.append(tr.train_step(t, t["label"])[0])
+    torch.cuda.synchronize()
+    model.optimizer.check_errors()
+    assert np.abs(np.asarray(ln) - np.asarray(lo)).max() < 5e-3, (ln, lo)
+    for g, b0 in zip(main, before):
+        never = g.last_step == 0                               # never read by any batch
+        assert int(never.sum()) > 0
+        assert torch.equal(g.table[never].view(torch.int16), b0[never].view(torch.int16))
+        assert torch.isfinite(g.table.float()).all()
