@@ -245,6 +245,43 @@ def make_pool(args, rank, cards, spec, dev, n_pool):
     return pool
 
 
+SPARSE_RECORD_STEPS = 32
+C5_BATCH = 32768
+
+
+def gather_at_c5_batch(args, model, cards, dev, n_batches=12):
+    """The fused gather (k_emb_fm_fwd / k_emb_gather_fwd) at configs[4]'s batch of 32 768 on this GPU's
+    full tables: the forward of `n_batches` distinct batches is recorded and the gather launches are
+    replayed round-robin (12 x ~55 MB of looked-up rows, 82 MB record each).  At B = 4096 the kernel is
+    latency-bound (one HBM latency of data in flight); this is the size at which it shows bandwidth
+    (north_star: "achieved HBM-bandwidth fraction on the embedding gather")."""
+    from fuxictr_amd import ops, synthetic
+    rng = np.random.default_rng(4242)
+    big = []
+    for _ in range(n_batches):
+        b = synthetic.criteo_batch(rng, C5_BATCH, cards=cards, dist=args.dist)
+        big.append({k: torch.from_numpy(v).to(dev) for k, v in b.items()})
+    was_training = model.training
+    model.eval()
+    ops.KernelTimer.reset()
+    ops.KernelTimer.recording = True
+    with torch.no_grad():
+        for b in big:
+            model.forward(b)
+            ops.KernelTimer.next_step()
+    ops.KernelTimer.recording = False
+    torch.cuda.synchronize(dev)
+    kt = ops.KernelTimer.replay(reps=10)
+    ops.KernelTimer.reset()
+    model.train(was_training)
+    for key in ("k_emb_fm_fwd@alone", "k_emb_gather_fwd@alone"):
+        if key in kt and kt[key]["total_ms"] > 0:
+            out = dict(kt[key])
+            out["kernel"] = key.split("@")[0]
+            return out
+    return None
+
+
 def measure(args, rank, local_rank, world, world1, dev, dist):
     """Build args.model, warm up, time exactly args.steps steps, then the instrumented pass.
     -> dict(dt, ktimes, launch, parallelism, cards, timing_mode, rows)."""
@@ -263,7 +300,7 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         if world > 1:
             parallelism = "%d independent replicas (--replicas; no data-path collective)" % world
     model.train()
-    n_pool = min(args.pool, max(8, args.warmup + args.steps + 24))
+    n_pool = min(args.pool, max(8, args.warmup + args.steps + 40))
     pool = make_pool(args, rank, cards, spec, dev, n_pool)
 
     loader_iter = None
@@ -337,20 +374,31 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         sync()
         ops.KernelTimer.reset()
         ops.KernelTimer.recording = True
-        model.train_step(pool[step_i % n_pool])
-        step_i += 1
+        n_rec = min(SPARSE_RECORD_STEPS, n_pool)
+        for j in range(n_rec):
+            # one eager step per DISTINCT batch; the HBM-bound groups are replayed round-robin over all
+            # of them (32 x ~10 MB of rows + Adam state > the 256 MB Infinity Cache, as in the timed
+            # region), the GEMM groups over the first one
+            model.train_step(pool[step_i % n_pool])
+            step_i += 1
+            ops.KernelTimer.next_step()
         ops.KernelTimer.recording = False
         sync()
         ktimes = ops.KernelTimer.replay(reps=20)
         ops.KernelTimer.reset()
+        if (args.model != "DIN" and world == 1 and not world1 and not args.host_inputs
+                and not args.loader):
+            ktimes["gather_b32768"] = gather_at_c5_batch(args, model, cards, dev)
         model._use_graph = use_graph
-        timing_mode = ("every native launch of one eager step recorded; the launches of one GEMM "
-                       "shape (of the sparse path) are captured in step order into a hipGraph that "
-                       "is replayed 20x between one HIP-event pair on the launch stream (the timed "
-                       "region itself replays a hipGraph); average = kernel + dependent-launch "
-                       "boundary; a split-K GEMM call includes its k_splitk_reduce launch, so the GEMM "
-                       "figure is a few per cent below the k_gemm_f32_* rows of the rocprofv3 summary "
-                       "(profiles/r02_kernel_stats_deepfm_final.csv: 0.73 of peak)")
+        timing_mode = ("every native launch of %d eager steps over %d distinct batches recorded; the "
+                       "launches of one GEMM shape (first recorded step) / of the sparse path (ALL "
+                       "recorded steps, round-robin, so every launch meets rows it has not seen for %d "
+                       "batches - more than the 256 MB Infinity Cache holds) are captured in step order "
+                       "into a hipGraph that is replayed 20x between one HIP-event pair on the launch "
+                       "stream (the timed region itself replays a hipGraph); average = kernel + "
+                       "dependent-launch boundary; a split-K GEMM call includes its k_splitk_reduce "
+                       "launch, so the GEMM figure is a few per cent below the k_gemm_f32_* rows of the "
+                       "rocprofv3 summary under profiles/" % (n_rec, n_rec, n_rec - 1))
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -371,13 +419,37 @@ def _traffic(model, batch, world):
     if model != "DeepFM" or batch != 4096 or world != 1:
         return None, None
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(here, name)) as f:
                 return json.load(f)["traffic_bytes_per_launch"], name
         except (OSError, ValueError, KeyError):
             continue
     return None, None
+
+
+SPARSE_LAUNCH_NAMES = ("dedup_catchup", "k_emb_fm_fwd", "emb_fm_bwd", "sparse_update_multi", "sparse_adam",
+                       "adam_catchup", "adam_catchup_rows", "sparse_sgd", "lr_fwd")
+
+
+def _sparse_traffic(model, batch, world, kernel=None):
+    """Fabric-side bytes of the sparse-path kernels from the committed PMC passes (per step, or of one
+    kernel per launch); only valid for the exact workload it was collected on."""
+    if model != "DeepFM" or batch != 4096 or world != 1:
+        return None
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in ("r03_pmc_traffic.json",):
+        try:
+            with open(os.path.join(here, name)) as f:
+                d = json.load(f)
+            unit = ("bytes (L2 fabric requests incl. Infinity-Cache hits, FETCH x2 + WRITE; profiles/%s)"
+                    % name)
+            if kernel is None:
+                return d["sparse_traffic_bytes_per_step"], unit + " per step"
+            return d["per_kernel_bytes_per_launch"][kernel], unit + " per launch"
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def rooflines(m, args, world):
@@ -435,7 +507,14 @@ def rooflines(m, args, world):
             "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": ach / PEAK_HBM_GBS, "traffic": None,
             "algorithmic_bytes_per_sample": per_sample, "us_per_step": us_step,
-            "launches_per_step": sp["launches"] / n_inst}
+            "launches_per_step": sp["launches"] / n_inst,
+            "distinct_batches_replayed": sp.get("steps", 1),
+            "by_launch_us": {k: round(v["avg_us"] * v["launches"], 2) for k, v in kt.items()
+                             if k in SPARSE_LAUNCH_NAMES and v["total_ms"] > 0}}
+        tr = _sparse_traffic(args.model, args.batch, world)
+        if tr is not None:
+            out["roofline_sparse"]["traffic"] = tr[0]
+            out["roofline_sparse"]["traffic_unit"] = tr[1]
     da = kt.get("din_attention")
     if da and da["total_ms"] > 0:
         # the fused DIN attention passes (fx_din_attn.hip).  Algorithmic flops = what the reference's
@@ -458,12 +537,24 @@ def rooflines(m, args, world):
                                   "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                   "frac": ach / PEAK_HBM_GBS, "traffic": None,
                                   "launches": e["launches"], "avg_launch_us": e["avg_us"],
-                                  "note": "the recorded launch replayed back to back on ONE batch: its rows stay "
-                                          "in the Infinity Cache; inside the step, where every batch "
-                                          "brings new rows, rocprofv3 times this kernel at 10.8 us "
-                                          "(profiles/r02_step_timeline_deepfm_final.txt: 18.1 MB -> "
-                                          "1.68 TB/s = 0.21 of 8 TB/s, one HBM latency of data in "
-                                          "flight — latency-bound at B = 4096)"}
+                                  "distinct_batches_replayed": e.get("steps", 1),
+                                  "note": "B = %d: the recorded gather launches of %d distinct batches "
+                                          "replayed round-robin (rows not cache-resident, as in the "
+                                          "step); about one HBM latency of data in flight - latency-"
+                                          "bound at this batch size" % (args.batch, e.get("steps", 1))}
+        tr = _sparse_traffic(args.model, args.batch, world, kernel="k_emb_fm_fwd")
+        if tr is not None:
+            out["roofline_gather"]["traffic"] = tr[0]
+            out["roofline_gather"]["traffic_unit"] = tr[1]
+    gb = kt.get("gather_b32768")
+    if gb and gb.get("total_ms", 0) > 0:
+        ach = gb["work"] / (gb["total_ms"] * 1e-3) / 1e9
+        out["roofline_gather_b32768"] = {
+            "kernel": gb["kernel"] + " at configs[4]'s batch (32 768 samples) on this GPU's full tables",
+            "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": ach / PEAK_HBM_GBS, "traffic": None, "launches": gb["launches"],
+            "avg_launch_us": gb["avg_us"], "distinct_batches_replayed": gb.get("steps", 1),
+            "algorithmic_bytes_per_launch": gb["work"] / max(gb["launches"], 1e-9)}
     return out
 
 

@@ -36,7 +36,21 @@ struct GemmArgs {
     float* ws;
     int32_t split_k;
     int32_t tiles_m, tiles_n;
+#ifdef FX_GEMM_LAB
+    unsigned long long* trace;   // scripts/ubench/gemm_lab.hip: 8 words per workgroup (timestamps)
+#endif
 };
+
+#ifdef FX_GEMM_LAB
+unsigned long long* fx_gemm_lab_trace = nullptr;   // set by the lab before a traced launch
+#define FX_LAB_STAMP(slot)                                                                    \
+    do {                                                                                      \
+        if (a.trace && threadIdx.x == 0)                                                      \
+            a.trace[((int64_t)z * a.tiles_m * a.tiles_n + L) * 8 + (slot)] = wall_clock64();  \
+    } while (0)
+#else
+#define FX_LAB_STAMP(slot) do {} while (0)
+#endif
 
 __device__ __forceinline__ float fx_epilogue(const fx_gemm_epilogue& e, float z, int64_t m,
                                              int64_t n) {
@@ -46,6 +60,34 @@ __device__ __forceinline__ float fx_epilogue(const fx_gemm_epilogue& e, float z,
     if (e.mul) z *= e.mul[m * e.ldmul + n];
     if (e.mask) z = e.mask[m * e.ldmask + n] > 0.f ? z : 0.f;
     if (e.add) z += e.add[m * e.ldadd + n];
+    return z;
+}
+
+// The same epilogue for 4 adjacent columns n .. n+3 of one row (every operand 16-byte aligned: checked
+// by the launcher).  Element for element the operation order of fx_epilogue.
+__device__ __forceinline__ float4 fx_epilogue4(const fx_gemm_epilogue& e, float4 z, int64_t m,
+                                               int64_t n) {
+    if (e.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
+        z.x += b.x; z.y += b.y; z.z += b.z; z.w += b.w;
+    }
+    if (e.zout) *reinterpret_cast<float4*>(e.zout + m * e.ldz + n) = z;
+    if (e.act == 1) {
+        z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f);
+    }
+    if (e.mul) {
+        const float4 q = *reinterpret_cast<const float4*>(e.mul + m * e.ldmul + n);
+        z.x *= q.x; z.y *= q.y; z.z *= q.z; z.w *= q.w;
+    }
+    if (e.mask) {
+        const float4 q = *reinterpret_cast<const float4*>(e.mask + m * e.ldmask + n);
+        z.x = q.x > 0.f ? z.x : 0.f; z.y = q.y > 0.f ? z.y : 0.f;
+        z.z = q.z > 0.f ? z.z : 0.f; z.w = q.w > 0.f ? z.w : 0.f;
+    }
+    if (e.add) {
+        const float4 q = *reinterpret_cast<const float4*>(e.add + m * e.ldadd + n);
+        z.x += q.x; z.y += q.y; z.z += q.z; z.w += q.w;
+    }
     return z;
 }
 
@@ -404,9 +446,16 @@ struct PipeSmem {
 
 // One output tile (linear tile index L of tiles_m x tiles_n, K slab z) of the pipelined GEMM.  A
 // device function so that one launch can carry tiles of more than one problem (k_gemm_f32_pair).
-template <int BM, int BN, bool A_KC, bool B_KC>
+// TR: the MFMA is issued with its operands swapped, so the accumulators hold the TRANSPOSED 32x32
+// tile — a lane owns ONE row m of C and, per group of four registers, four ADJACENT columns — and the
+// epilogue reads its operands and writes C as 16-byte vectors: 4 store instructions per 32x32 tile
+// instead of 16 (the drain of a launch is store-issue bound: all workgroups of a launch reach their
+// epilogue together).  a*b commutes, the k order is unchanged: bit-identical results.  Needs N % 4 == 0
+// and 16-byte aligned C / epilogue operands (fx_gemm_tr_ok).
+template <int BM, int BN, bool A_KC, bool B_KC, bool TR = false>
 __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64_t L, const int z,
                                                   float* const fx_gemm_smem) {
+    FX_LAB_STAMP(0);
     using LoaderA = PipeLoader<BM, A_KC>;
     using LoaderB = PipeLoader<BN, B_KC>;
     constexpr int LDA = LoaderA::LD, LDB = LoaderB::LD;
@@ -456,6 +505,7 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
         fx_static_for<0, NSA>([&](auto p) { la.template store_one<p.value>(As0, ra[0], oka[0]); });
         fx_static_for<0, NSB>([&](auto p) { lb.template store_one<p.value>(Bs0, rb[0], okb[0]); });
         __syncthreads();
+        FX_LAB_STAMP(1);
         const int foff_a = half * LDA + wm * (BM / 2) + l31;
         const int foff_b = half * LDB + wn * (BN / 2) + l31;
         float fa[2][MI], fb[2][NJ];
@@ -509,8 +559,12 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
                 fx_static_for<0, S>([&](auto mm) {
                     constexpr int m = decltype(mm)::value;
                     constexpr int i = m / NJ, j = m % NJ;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j],
-                                                                     0, 0, 0);
+                    if constexpr (TR)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c][j], fa[c][i], acc[i][j],
+                                                                         0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j],
+                                                                         0, 0, 0);
                     fx_static_for<0, NOPS>([&](auto oo) {
                         constexpr int o = decltype(oo)::value;
                         if constexpr (o % S == m) {
@@ -577,36 +631,72 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
         }
         if (t < nk) body(t, P0{}, std::true_type{});
     }
+    FX_LAB_STAMP(2);
 
     if (do_rowsum && threadIdx.x < BM && m0 + threadIdx.x < a.M) {
         if (a.split_k > 1) a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + m0 + threadIdx.x] = rsum;
         else a.epi.rowsum[m0 + threadIdx.x] = rsum;
     }
+    if constexpr (TR) {
+        // lane: row m = l31 of the wave tile; registers 4q .. 4q+3: columns 8q + 4*half + 0..3
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < MI; ++i) {
+            const int64_t m = m0 + wm * (BM / 2) + i * 32 + l31;
+            if (m >= a.M) continue;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int64_t n = n0 + wn * (BN / 2) + j * 32 + l31;
-            if (n >= a.N) continue;
+            for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= a.M) continue;
-                if (a.split_k > 1) {
-                    a.ws[((int64_t)z * a.M + m) * a.N + n] = acc[i][j][r];
-                } else {
-                    a.C[m * a.ldc + n] = fx_epilogue(a.epi, acc[i][j][r], m, n);
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t n = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * half;
+                    if (n >= a.N) continue;
+                    float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                                           acc[i][j][4 * q + 3]);
+                    if (a.split_k > 1) {
+                        *reinterpret_cast<float4*>(a.ws + ((int64_t)z * a.M + m) * a.N + n) = v;
+                    } else {
+                        *reinterpret_cast<float4*>(a.C + m * a.ldc + n) = fx_epilogue4(a.epi, v, m, n);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int64_t n = n0 + wn * (BN / 2) + j * 32 + l31;
+                if (n >= a.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m >= a.M) continue;
+                    if (a.split_k > 1) {
+                        a.ws[((int64_t)z * a.M + m) * a.N + n] = acc[i][j][r];
+                    } else {
+                        a.C[m * a.ldc + n] = fx_epilogue(a.epi, acc[i][j][r], m, n);
+                    }
                 }
             }
         }
     }
+#ifdef FX_GEMM_LAB
+    if (a.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FX_LAB_STAMP(3);
+        if (threadIdx.x == 0) {
+            const int64_t w = ((int64_t)z * a.tiles_m * a.tiles_n + L) * 8;
+            a.trace[w + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+            a.trace[w + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+        }
+    }
+#endif
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int W = 2>
+template <int BM, int BN, bool A_KC, bool B_KC, int W = 2, bool TR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
 void k_gemm_f32_pipe(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[PipeSmem<BM, BN, A_KC, B_KC>::FLOATS];
-    fx_gemm_pipe_tile<BM, BN, A_KC, B_KC>(a, blockIdx.x, blockIdx.y, smem);
+    fx_gemm_pipe_tile<BM, BN, A_KC, B_KC, TR>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 // Two independent GEMMs in ONE launch (fx_gemm_f32_batch): the weight gradient dW = dZ^T X (problem 1,
@@ -616,7 +706,7 @@ void k_gemm_f32_pipe(GemmArgs a) {
 // pipes per launch (K sweep in profiles/r02_gemm_probe.txt); in one grid the second problem's
 // workgroups start as the first one's retire, and the 624-wide CrossNet shapes (640 tiles on 1024
 // slots) no longer leave a third of the CUs one workgroup short.
-template <int BM, int BN, bool A1, bool B1, bool A2, bool B2, int W>
+template <int BM, int BN, bool A1, bool B1, bool A2, bool B2, int W, bool TR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
 void k_gemm_f32_pair(GemmArgs a1, GemmArgs a2) {
     constexpr int F1 = PipeSmem<BM, BN, A1, B1>::FLOATS, F2 = PipeSmem<BM, BN, A2, B2>::FLOATS;
@@ -624,10 +714,10 @@ void k_gemm_f32_pair(GemmArgs a1, GemmArgs a2) {
     const int64_t n1 = (int64_t)a1.tiles_m * a1.tiles_n, w1 = n1 * a1.split_k;
     const int64_t L = blockIdx.x;
     if (L < w1) {
-        fx_gemm_pipe_tile<BM, BN, A1, B1>(a1, L % n1, (int)(L / n1), smem);
+        fx_gemm_pipe_tile<BM, BN, A1, B1, TR>(a1, L % n1, (int)(L / n1), smem);
     } else {
         const int64_t n2 = (int64_t)a2.tiles_m * a2.tiles_n, L2 = L - w1;
-        fx_gemm_pipe_tile<BM, BN, A2, B2>(a2, L2 % n2, (int)(L2 / n2), smem);
+        fx_gemm_pipe_tile<BM, BN, A2, B2, TR>(a2, L2 % n2, (int)(L2 / n2), smem);
     }
 }
 
@@ -644,25 +734,43 @@ static int fx_gemm_pipe_mode() {   // FX_GEMM_PIPE=0 falls back to the unpipelin
     return mode;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-static int fx_gemm_launch_pipe(dim3 grid, hipStream_t s, const GemmArgs& a) {
+static int fx_gemm_tr_mode() {     // FX_GEMM_TR=0: 4-byte epilogue stores everywhere (A/B runs)
+    static const int mode = []() {
+        const char* e = getenv("FX_GEMM_TR");
+        return e ? atoi(e) : 1;
+    }();
+    return mode;
+}
+
+static bool fx_al16(const void* p, int64_t ld) {
+    return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0);
+}
+
+// the 16-byte epilogue (TR) applies: every vector access of fx_epilogue4 / the slab stores is aligned
+static bool fx_gemm_tr_ok(const GemmArgs& a) {
+    const fx_gemm_epilogue& e = a.epi;
+    return fx_gemm_tr_mode() && (a.N & 3) == 0 && fx_al16(a.C, a.ldc) && fx_al16(e.bias, 0) &&
+           fx_al16(e.zout, e.ldz) && fx_al16(e.mul, e.ldmul) && fx_al16(e.mask, e.ldmask) &&
+           fx_al16(e.add, e.ldadd) && (a.split_k == 1 || fx_al16(a.ws, 0));
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, bool TR>
+static int fx_gemm_launch_pipe_tr(dim3 grid, hipStream_t s, const GemmArgs& a) {
     if constexpr (BM * BN <= 64 * 64) {
         // 64x64 tiles need ~110 VGPRs: 4 waves/SIMD = 4 workgroups per CU (LDS 4 x 34 KB), so the
-        // 1024 tiles of a 4096 x 1024 layer are all resident in ONE round (2 per CU took two)
-        static const int w = []() {   // FX_GEMM_W64=2|3|4 (experiments)
-            const char* e = getenv("FX_GEMM_W64");
-            return e ? atoi(e) : 4;
-        }();
-        if (w == 2)
-            hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, 2>), grid, dim3(256), 0, s, a);
-        else if (w == 3)
-            hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, 3>), grid, dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, 4>), grid, dim3(256), 0, s, a);
+        // 1024 tiles of a 4096 x 1024 layer are all resident in ONE round (2 per CU took two; the
+        // 2- and 3-wave builds of round 2, FX_GEMM_W64, measured slower and are gone)
+        hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, 4, TR>), grid, dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, 2>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_gemm_f32_pipe<BM, BN, A_KC, B_KC, 2, TR>), grid, dim3(256), 0, s, a);
     }
     return FX_OK;
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+static int fx_gemm_launch_pipe(dim3 grid, hipStream_t s, const GemmArgs& a) {
+    if (fx_gemm_tr_ok(a)) return fx_gemm_launch_pipe_tr<BM, BN, A_KC, B_KC, true>(grid, s, a);
+    return fx_gemm_launch_pipe_tr<BM, BN, A_KC, B_KC, false>(grid, s, a);
 }
 
 template <int BM, int BN>
@@ -1131,6 +1239,9 @@ static int fx_gemm_prepare(int32_t transa, int32_t transb, int64_t M, int64_t N,
     }
     a.tiles_m = (int32_t)fx_ceil_div(M, bm);
     a.tiles_n = (int32_t)fx_ceil_div(N, bn);
+#ifdef FX_GEMM_LAB
+    a.trace = fx_gemm_lab_trace;
+#endif
     bm_out = bm;
     bn_out = bn;
     return FX_OK;
@@ -1287,8 +1398,7 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
         const char* e = getenv("FX_GEMM_PAIR");
         return !(e && atoi(e) == 0);
     }();
-    static const bool w64_default = []() { return getenv("FX_GEMM_W64") == nullptr; }();
-    if (n == 2 && pair_on && w64_default && p[0].transa && !p[0].transb && !p[1].transa &&
+    if (n == 2 && pair_on && p[0].transa && !p[0].transb && !p[1].transa &&
         !p[1].transb) {
         GemmArgs a[2];
         int bm[2], bn[2];
@@ -1308,8 +1418,12 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
             hipStream_t s = fx_hip_stream(stream);
             const int64_t wgs = (int64_t)a[0].tiles_m * a[0].tiles_n * a[0].split_k +
                                 (int64_t)a[1].tiles_m * a[1].tiles_n * a[1].split_k;
-            hipLaunchKernelGGL((k_gemm_f32_pair<64, 64, false, false, true, false, 4>),
-                               dim3((unsigned)wgs), dim3(256), 0, s, a[0], a[1]);
+            if (fx_gemm_tr_ok(a[0]) && fx_gemm_tr_ok(a[1]))
+                hipLaunchKernelGGL((k_gemm_f32_pair<64, 64, false, false, true, false, 4, true>),
+                                   dim3((unsigned)wgs), dim3(256), 0, s, a[0], a[1]);
+            else
+                hipLaunchKernelGGL((k_gemm_f32_pair<64, 64, false, false, true, false, 4, false>),
+                                   dim3((unsigned)wgs), dim3(256), 0, s, a[0], a[1]);
             FX_CHECK_LAUNCH();
             for (int i = 0; i < 2; ++i)
                 if (a[i].split_k > 1) {
@@ -1432,7 +1546,8 @@ extern "C" int fx_mask_mul(const float* dy, int64_t dy_ld, const float* y, float
     const int64_t n = rows * cols;
     if (n <= 0) return FX_OK;
     FX_CHECK_ARG(dy && y && out && dy_ld >= cols, "fx_mask_mul: bad arguments");
-    FX_CHECK_ARG(n < ((int64_t)1 << 32), "fx_mask_mul: more than 2^32 elements");
+    // (32-bit grid-stride counter: i += gridDim.x * 256 must not wrap)
+    FX_CHECK_ARG(n < ((int64_t)1 << 31), "fx_mask_mul: more than 2^31 elements");
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_mask_mul, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), dy,
@@ -1464,7 +1579,7 @@ extern "C" int fx_cross_bwd_prep(const float* dxn, int64_t dxn_ld, const float* 
     const int64_t n = rows * cols;
     if (n <= 0) return FX_OK;
     FX_CHECK_ARG(dxn && x0 && z && t && dx0 && dxn_ld >= cols, "fx_cross_bwd_prep: bad arguments");
-    FX_CHECK_ARG(n < ((int64_t)1 << 32), "fx_cross_bwd_prep: more than 2^32 elements");
+    FX_CHECK_ARG(n < ((int64_t)1 << 31), "fx_cross_bwd_prep: more than 2^31 elements");
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_cross_bwd_prep, dim3((unsigned)blocks), dim3(256), 0,

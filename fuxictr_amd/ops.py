@@ -20,21 +20,39 @@ class KernelTimer(object):
 
     Per-launch HIP events are useless at this kernel size on this platform: an event pair around
     one launch adds ~10 us (measured: 87.7 us for a GEMM rocprofv3 times at 75 us, 12.5 us for the
-    8.5 us gather, even with the stream kept busy).  So the launches of ONE eager training step are
-    RECORDED (entry point + its live arguments) and then each recorded launch is REPLAYED `reps`
-    times back to back between one event pair, the host running ahead behind a queued spin kernel:
+    8.5 us gather, even with the stream kept busy).  So the launches of eager training steps are
+    RECORDED (entry point + its live arguments, tagged with the step they belong to) and then each
+    recorded launch group is REPLAYED `reps` times back to back between one event pair:
     average = kernel duration + the ~1.3 us dependent-launch boundary — what rocprofv3's kernel
-    trace reports, within a few per cent."""
+    trace reports, within a few per cent.
+
+    HBM-bound groups (`multi_step`: the sparse path, the gather on its own) are replayed ROUND-ROBIN over
+    ALL recorded steps — each step holds its own batch, ids, de-dup result and gradients — so that a
+    launch meets rows it has not seen for (steps - 1) other batches, as inside the training step; a
+    single batch replayed back to back would find its rows in the 256 MB Infinity Cache.
+    MFMA-bound groups (one GEMM shape) use the first recorded step only.
+
+    The replay RE-EXECUTES the recorded launches with their live arguments: the optimizer step counter
+    advances, row updates are applied again, outputs are overwritten.  The model / optimizer state is
+    no longer the trained trajectory afterwards — bench.py discards the model after this pass."""
     recording = False
-    calls = []       # (name, group, work, fn, args, kwargs)
+    calls = []       # (name, group, work, fn, args, kwargs, step)
+    step = 0
+    multi_step = ("sparse_path",)
 
     @classmethod
     def note(cls, name, group, work, fn, args, kwargs):
-        cls.calls.append((name, group, work, fn, args, kwargs))
+        if cls.step > 0 and not ((group or name) in cls.multi_step or name.endswith("@alone")):
+            return                     # MFMA-bound groups: the first recorded step is enough
+        cls.calls.append((name, group, work, fn, args, kwargs, cls.step))
+
+    @classmethod
+    def next_step(cls):
+        cls.step += 1
 
     @classmethod
     def replay(cls, reps=20):
-        """-> name/group -> dict(launches, total_ms, avg_us, work) per recorded step.
+        """-> name/group -> dict(launches, total_ms, avg_us, work) PER RECORDED STEP.
         The recorded launches of one group (a GEMM shape, the sparse path) are captured, in step
         order, into ONE hipGraph; the graph is replayed `reps` times between one event pair.  That
         is how the timed region itself executes them (graph launch, dependent boundaries, the same
@@ -48,8 +66,12 @@ class KernelTimer(object):
         try:
             side = torch.cuda.Stream()
             for key, calls in groups.items():
-                for _, _, _, fn, args, kwargs in calls:              # warm (allocations, caches)
-                    fn(*args, **kwargs)
+                steps = sorted(set(c[6] for c in calls))
+                if not (key in cls.multi_step or key.endswith("@alone")):
+                    calls = [c for c in calls if c[6] == steps[0]]
+                    steps = steps[:1]
+                for c in calls:                                      # warm (allocations, caches)
+                    c[3](*c[4], **c[5])
                 torch.cuda.synchronize()
                 # a group of ONE launch: ten copies of it in the graph, so that the graph launch itself
                 # (several us) does not sit in a 10-us kernel's figure
@@ -57,8 +79,8 @@ class KernelTimer(object):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
                     for _ in range(copies):
-                        for _, _, _, fn, args, kwargs in calls:
-                            fn(*args, **kwargs)
+                        for c in calls:
+                            c[3](*c[4], **c[5])
                 g.replay()
                 torch.cuda.synchronize()
                 e0 = torch.cuda.Event(enable_timing=True)
@@ -69,24 +91,26 @@ class KernelTimer(object):
                 e1.record()
                 torch.cuda.synchronize()
                 per_call_ms = e0.elapsed_time(e1) / reps / (len(calls) * copies)
-                for name, group, work, _, _, _ in calls:
-                    for k in (name, group):
+                for c in calls:
+                    for k in (c[0], c[1]):
                         if k is None:
                             continue
-                        o = out.setdefault(k, {"launches": 0, "total_ms": 0.0, "work": 0.0})
-                        o["launches"] += 1
-                        o["total_ms"] += per_call_ms
-                        o["work"] += float(work)
+                        o = out.setdefault(k, {"launches": 0.0, "total_ms": 0.0, "work": 0.0,
+                                               "steps": len(steps)})
+                        o["launches"] += 1.0 / len(steps)
+                        o["total_ms"] += per_call_ms / len(steps)
+                        o["work"] += float(c[2]) / len(steps)
                 del g
         finally:
             cls.recording = was
         for o in out.values():
-            o["avg_us"] = 1e3 * o["total_ms"] / max(o["launches"], 1)
+            o["avg_us"] = 1e3 * o["total_ms"] / max(o["launches"], 1e-9)
         return out
 
     @classmethod
     def reset(cls):
         cls.calls = []
+        cls.step = 0
 
 
 def _timed(name, group=None, work=None, alone=False):

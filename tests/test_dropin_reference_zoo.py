@@ -15,7 +15,7 @@ import _cpu_emul
 from conftest import Golden, assert_weights_close, _din_fields
 from test_host_wiring import _cpu_opt_init, tb
 
-REF = "/root/reference"
+REF = os.environ.get("FX_REFERENCE_ROOT", "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "fuxictr")),
                                 reason="reference checkout not present")
 
