@@ -149,7 +149,9 @@ def test_bf16_tables_on_the_generic_dedup_path(case, B, tmp_path):
     the fp32 oracle within the bf16 storage error, nothing is flagged."""
     dist = "powerlaw"
     model, features, cfg, spec, cards = BS.build(case, zoo, 0, tmp_path, emb_dtype="bf16")
-    groups = model.embedding_layer.embedding_layer.table_groups()
+    from fuxictr_amd.layers import FeatureEmbeddingDict
+    groups = [g for mod in model.modules() if isinstance(mod, FeatureEmbeddingDict)
+              for g in mod.table_groups()]
     main = [g for g in groups if g.table is not None and g.D > 1]
     assert main and all(g.table.dtype == torch.bfloat16 for g in main)
     before = [g.table.clone() for g in main]
