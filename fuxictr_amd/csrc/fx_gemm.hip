@@ -64,30 +64,36 @@ __device__ __forceinline__ float fx_epilogue(const fx_gemm_epilogue& e, float z,
 }
 
 // The same epilogue for 4 adjacent columns n .. n+3 of one row (every operand 16-byte aligned: checked
-// by the launcher).  Element for element the operation order of fx_epilogue.
-__device__ __forceinline__ float4 fx_epilogue4(const fx_gemm_epilogue& e, float4 z, int64_t m,
-                                               int64_t n) {
-    if (e.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
-        z.x += b.x; z.y += b.y; z.z += b.z; z.w += b.w;
-    }
+// by the launcher), in two halves: the operand LOADS of a 32x32 accumulator tile are issued together,
+// one tile ahead of the arithmetic and the stores.  (Written as load -> use -> store per vector, each
+// of a lane's 16 vectors paid its own memory round trip — the compiler may not move a load above a
+// store to memory it cannot prove distinct: +6.7 us on a 128x128 tile with bias + ReLU.)  Element for
+// element the operation order of fx_epilogue.
+struct FxEpiOps4 {
+    float4 bias, mul, mask, add;
+};
+
+__device__ __forceinline__ void fx_epi_load4(const fx_gemm_epilogue& e, int64_t m, int64_t n,
+                                             FxEpiOps4& o) {
+    if (e.bias) o.bias = *reinterpret_cast<const float4*>(e.bias + n);
+    if (e.mul) o.mul = *reinterpret_cast<const float4*>(e.mul + m * e.ldmul + n);
+    if (e.mask) o.mask = *reinterpret_cast<const float4*>(e.mask + m * e.ldmask + n);
+    if (e.add) o.add = *reinterpret_cast<const float4*>(e.add + m * e.ldadd + n);
+}
+
+__device__ __forceinline__ float4 fx_epi_apply4(const fx_gemm_epilogue& e, float4 z, int64_t m,
+                                                int64_t n, const FxEpiOps4& o) {
+    if (e.bias) { z.x += o.bias.x; z.y += o.bias.y; z.z += o.bias.z; z.w += o.bias.w; }
     if (e.zout) *reinterpret_cast<float4*>(e.zout + m * e.ldz + n) = z;
     if (e.act == 1) {
         z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f);
     }
-    if (e.mul) {
-        const float4 q = *reinterpret_cast<const float4*>(e.mul + m * e.ldmul + n);
-        z.x *= q.x; z.y *= q.y; z.z *= q.z; z.w *= q.w;
-    }
+    if (e.mul) { z.x *= o.mul.x; z.y *= o.mul.y; z.z *= o.mul.z; z.w *= o.mul.w; }
     if (e.mask) {
-        const float4 q = *reinterpret_cast<const float4*>(e.mask + m * e.ldmask + n);
-        z.x = q.x > 0.f ? z.x : 0.f; z.y = q.y > 0.f ? z.y : 0.f;
-        z.z = q.z > 0.f ? z.z : 0.f; z.w = q.w > 0.f ? z.w : 0.f;
+        z.x = o.mask.x > 0.f ? z.x : 0.f; z.y = o.mask.y > 0.f ? z.y : 0.f;
+        z.z = o.mask.z > 0.f ? z.z : 0.f; z.w = o.mask.w > 0.f ? z.w : 0.f;
     }
-    if (e.add) {
-        const float4 q = *reinterpret_cast<const float4*>(e.add + m * e.ldadd + n);
-        z.x += q.x; z.y += q.y; z.z += q.z; z.w += q.w;
-    }
+    if (e.add) { z.x += o.add.x; z.y += o.add.y; z.z += o.add.z; z.w += o.add.w; }
     return z;
 }
 
@@ -639,25 +645,49 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
     }
     if constexpr (TR) {
         // lane: row m = l31 of the wave tile; registers 4q .. 4q+3: columns 8q + 4*half + 0..3
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int64_t m = m0 + wm * (BM / 2) + i * 32 + l31;
-            if (m >= a.M) continue;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
+        constexpr int NT = MI * NJ;
+        const int64_t mb = m0 + wm * (BM / 2) + l31, nb = n0 + wn * (BN / 2) + 4 * half;
+        if (a.split_k > 1) {
+            fx_static_for<0, NT>([&](auto tt) {
+                constexpr int i = decltype(tt)::value / NJ, j = decltype(tt)::value % NJ;
+                const int64_t m = mb + i * 32;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int64_t n = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * half;
-                    if (n >= a.N) continue;
-                    float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
-                                           acc[i][j][4 * q + 3]);
-                    if (a.split_k > 1) {
-                        *reinterpret_cast<float4*>(a.ws + ((int64_t)z * a.M + m) * a.N + n) = v;
-                    } else {
-                        *reinterpret_cast<float4*>(a.C + m * a.ldc + n) = fx_epilogue4(a.epi, v, m, n);
+                    const int64_t n = nb + j * 32 + 8 * q;
+                    if (m < a.M && n < a.N)
+                        *reinterpret_cast<float4*>(a.ws + ((int64_t)z * a.M + m) * a.N + n) =
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                                        acc[i][j][4 * q + 3]);
+                }
+            });
+        } else {
+            FxEpiOps4 ops[2][4];
+            auto load_tile = [&](auto tt, FxEpiOps4 (&o)[4]) {
+                constexpr int i = decltype(tt)::value / NJ, j = decltype(tt)::value % NJ;
+                const int64_t m = mb + i * 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t n = nb + j * 32 + 8 * q;
+                    if (m < a.M && n < a.N) fx_epi_load4(a.epi, m, n, o[q]);
+                }
+            };
+            load_tile(std::integral_constant<int, 0>{}, ops[0]);
+            fx_static_for<0, NT>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                constexpr int i = t / NJ, j = t % NJ;
+                if constexpr (t + 1 < NT) load_tile(std::integral_constant<int, t + 1>{}, ops[(t + 1) & 1]);
+                const int64_t m = mb + i * 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t n = nb + j * 32 + 8 * q;
+                    if (m < a.M && n < a.N) {
+                        const float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1],
+                                                     acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                        *reinterpret_cast<float4*>(a.C + m * a.ldc + n) =
+                            fx_epi_apply4(a.epi, v, m, n, ops[t & 1][q]);
                     }
                 }
-            }
+            });
         }
     } else {
 #pragma unroll
@@ -718,6 +748,48 @@ void k_gemm_f32_pair(GemmArgs a1, GemmArgs a2) {
     } else {
         const int64_t n2 = (int64_t)a2.tiles_m * a2.tiles_n, L2 = L - w1;
         fx_gemm_pipe_tile<BM, BN, A2, B2, TR>(a2, L2 % n2, (int)(L2 / n2), smem);
+    }
+}
+
+// Up to FX_MULTI_MAX independent GEMMs in ONE launch on 128-row tiles, two workgroups per CU
+// (fx_gemm_f32_batch).  Round 3 timelines (profiles/r03_gemm_lab_a.txt): a 128x128 workgroup — one wave per
+// SIMD with four accumulators — streams its K loop at 0.91-0.95 of the matrix-pipe peak on its own, while
+// the four 64x64 workgroups of a CU (one accumulator per wave) finish between 50 and 81 us of an 81-us
+// launch: the SIMD arbitrates oldest-first, the early finishers leave the late ones alone on the pipe at
+// a third of its rate.  So: big tiles, and a SECOND problem's workgroup as the co-resident instead of
+// three more of the same — the dW and dX products of a layer (and, for DCNv2's parallel structure, the
+// cross and the deep layer of the same depth) fill each other's prologue / epilogue gaps.
+// cfg bit 0: A k-contiguous, bit 1: B k-contiguous, bit 2: 128x64 tile (else 128x128).
+#define FX_MULTI_MAX 4
+struct MultiArgs {
+    GemmArgs p[FX_MULTI_MAX];
+    int32_t start[FX_MULTI_MAX + 1];     // first workgroup of each problem
+    int32_t cfg[FX_MULTI_MAX];
+    int32_t n;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_gemm_f32_multi(MultiArgs a) {
+    constexpr int F0 = PipeSmem<128, 128, false, false>::FLOATS, F1 = PipeSmem<128, 128, true, true>::FLOATS,
+                  F2 = PipeSmem<128, 128, true, false>::FLOATS;
+    constexpr int FM = F0 > F1 ? (F0 > F2 ? F0 : F2) : (F1 > F2 ? F1 : F2);
+    __shared__ __attribute__((aligned(16))) float smem[FM];
+    int i = 0;
+    while (i + 1 < a.n && (int32_t)blockIdx.x >= a.start[i + 1]) ++i;
+    const GemmArgs& g = a.p[i];
+    int64_t L = (int64_t)blockIdx.x - a.start[i];
+    const int64_t nt = (int64_t)g.tiles_m * g.tiles_n;
+    const int z = (int)(L / nt);
+    L -= (int64_t)z * nt;
+    switch (a.cfg[i]) {
+        case 0: fx_gemm_pipe_tile<128, 128, false, false, true>(g, L, z, smem); break;
+        case 1: fx_gemm_pipe_tile<128, 128, true, false, true>(g, L, z, smem); break;
+        case 2: fx_gemm_pipe_tile<128, 128, false, true, true>(g, L, z, smem); break;
+        case 3: fx_gemm_pipe_tile<128, 128, true, true, true>(g, L, z, smem); break;
+        case 4: fx_gemm_pipe_tile<128, 64, false, false, true>(g, L, z, smem); break;
+        case 5: fx_gemm_pipe_tile<128, 64, true, false, true>(g, L, z, smem); break;
+        case 6: fx_gemm_pipe_tile<128, 64, false, true, true>(g, L, z, smem); break;
+        default: fx_gemm_pipe_tile<128, 64, true, true, true>(g, L, z, smem); break;
     }
 }
 
@@ -1232,6 +1304,11 @@ static int fx_gemm_prepare(int32_t transa, int32_t transb, int64_t M, int64_t N,
             bn = 64;   // e.g. the DIN attention MLP: 204800 x 64 x 64 — do not pad N to 128
         } else if (forced == 0 && !fx_gemm_pipe_mode()) {
             if (t128 < 448) { bm = 64; bn = 64; }      // the unpipelined kernel's rule
+        } else if (forced == 0 && t128 >= 224 && t128 <= 256) {
+            // one 128x128 workgroup per CU: with the 16-byte epilogue (round 3) its K loop streams at
+            // 0.91-0.95 of the matrix-pipe peak and the launch beats four 64x64 workgroups per CU, which
+            // drift apart under the SIMD's oldest-first arbitration (profiles/r03_gemm_lab_a.txt:
+            // 4096x1024x1024 plain 68.0 vs 73.7 us)
         } else if (forced == 0 && t128 < 1024) {
             if (t12864 >= 2048) bn = 64;
             else { bm = 64; bn = 64; }
@@ -1388,16 +1465,303 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
     return FX_OK;
 }
 
-// Several independent GEMMs.  Two problems that both take the pipelined 64x64 kernel, the first with
-// m-/n-contiguous operands (transa = 1, transb = 0: a weight gradient) and the second with a
-// k-contiguous A (transa = 0, transb = 0: an input gradient) — the dW / dX pair of a Linear or
-// CrossNet layer — go out as ONE launch (k_gemm_f32_pair); anything else runs problem by problem.
+// ---------------------------------------------------------------------------------------------
+// fx_gemm_f32_batch: several independent GEMMs in as few launches as possible.
+//   multi path  (default for <= FX_MULTI_MAX aligned, non-skinny problems): ONE k_gemm_f32_multi grid on
+//               128-row tiles, two workgroups per CU; per problem the tile (128x128 | 128x64) and — where
+//               the caller allows a K split (split_k > 1) — the number of K slabs are chosen by a small
+//               list-scheduling model of the launch (256 CUs x 2 slots, workgroups handed out in index
+//               order, longest problem first), cached per shape signature;
+//   pair path   (FX_GEMM_MULTI=0): the dW / dX pair of round 2 on 64x64 tiles;
+//   else        problem by problem.
+// ---------------------------------------------------------------------------------------------
+struct MultiPlanItem {
+    int tile;      // 0: 128x128, 1: 128x64
+    int sk;
+};
+
+// time of one launch under the model: each workgroup carries `w` us of matrix-pipe work (at full rate) +
+// a fixed prologue / epilogue cost; a CU with two resident workgroups shares its pipes evenly at
+// FX_E2 efficiency, a workgroup alone runs at FX_E1[tile]
+static double fx_multi_simulate(const double* w, const int* tile, int nwg) {
+    constexpr int CUS = 256;
+    static const double E1[2] = {0.90, 0.84};
+    constexpr double E2 = 0.96, FIXED = 2.5;
+    double rem[CUS][2];
+    int til[CUS][2], cnt[CUS];
+    double now[CUS];
+    for (int c = 0; c < CUS; ++c) { cnt[c] = 0; now[c] = 0.0; }
+    int next = 0;
+    // initial placement: round-robin, one per CU, then the second slot
+    for (int slot = 0; slot < 2; ++slot)
+        for (int c = 0; c < CUS && next < nwg; ++c) {
+            rem[c][cnt[c]] = w[next] + FIXED;
+            til[c][cnt[c]] = tile[next];
+            ++cnt[c];
+            ++next;
+        }
+    double makespan = 0.0;
+    // event loop: repeatedly take the CU whose next completion is earliest
+    while (true) {
+        int best = -1;
+        double bt = 1e300;
+        for (int c = 0; c < CUS; ++c) {
+            if (cnt[c] == 0) continue;
+            double t;
+            if (cnt[c] == 1) t = now[c] + rem[c][0] / E1[til[c][0]];
+            else {
+                const double r = rem[c][0] < rem[c][1] ? rem[c][0] : rem[c][1];
+                t = now[c] + r / (0.5 * E2);
+            }
+            if (t < bt) { bt = t; best = c; }
+        }
+        if (best < 0) break;
+        const int c = best;
+        const double dt = bt - now[c];
+        if (cnt[c] == 1) {
+            cnt[c] = 0;
+        } else {
+            const int f = rem[c][0] < rem[c][1] ? 0 : 1;
+            const double done = dt * 0.5 * E2;
+            rem[c][1 - f] -= done;
+            if (f == 0) { rem[c][0] = rem[c][1]; til[c][0] = til[c][1]; }
+            cnt[c] = 1;
+        }
+        now[c] = bt;
+        makespan = bt;
+        if (next < nwg) {
+            rem[c][cnt[c]] = w[next] + FIXED;
+            til[c][cnt[c]] = tile[next];
+            ++cnt[c];
+            ++next;
+        }
+    }
+    return makespan;
+}
+
+struct MultiShape {
+    int64_t M, N, K;
+    int splittable;      // 0: no K split; else the LARGEST number of slabs the caller's workspace holds
+};
+
+static double fx_multi_cost(const MultiShape* sh, int n, const MultiPlanItem* plan, const int* order,
+                            double* wbuf, int* tbuf, int cap) {
+    int nwg = 0;
+    double extra = 0.0;
+    for (int oi = 0; oi < n; ++oi) {
+        const int i = order[oi];
+        const int bn = plan[i].tile ? 64 : 128;
+        const int64_t tiles = fx_ceil_div(sh[i].M, 128) * fx_ceil_div(sh[i].N, bn);
+        const int64_t kc = fx_ceil_div(fx_ceil_div(sh[i].K, plan[i].sk), FX_BK) * FX_BK;
+        const int sk = (int)fx_ceil_div(sh[i].K, kc);
+        const double w = (double)kc * 128.0 * bn / 307200.0;      // us at the full matrix-pipe rate
+        for (int z = 0; z < sk; ++z) {
+            const int64_t klen = (z + 1) * kc <= sh[i].K ? kc : sh[i].K - z * kc;
+            for (int64_t t = 0; t < tiles; ++t) {
+                if (nwg >= cap) return 1e300;
+                wbuf[nwg] = w * (double)klen / (double)kc;
+                tbuf[nwg] = plan[i].tile;
+                ++nwg;
+            }
+        }
+        if (sk > 1)     // slab reduce: (sk reads + 1 write) of the output at ~3.5 TB/s + a launch
+            extra += 2.0 + (double)(sk + 1) * sh[i].M * sh[i].N * 4.0 / 3.5e6;
+    }
+    return fx_multi_simulate(wbuf, tbuf, nwg) + extra;
+}
+
+// -> plan[i] for every problem (cached per shape signature; FX_MULTI_CFG="tile,sk;tile,sk;..." overrides)
+static void fx_multi_plan(const MultiShape* sh, int n, MultiPlanItem* plan) {
+    static const char* forced = getenv("FX_MULTI_CFG");
+    if (forced) {
+        const char* q = forced;
+        for (int i = 0; i < n; ++i) {
+            plan[i].tile = 0;
+            plan[i].sk = sh[i].splittable >= 4 ? 4 : (sh[i].splittable ? sh[i].splittable : 1);
+            if (*q) {
+                plan[i].tile = atoi(q);
+                while (*q && *q != ',' && *q != ';') ++q;
+                if (*q == ',') {
+                    ++q;
+                    const int sk = atoi(q);
+                    if (sk >= 1 && sk <= (sh[i].splittable ? sh[i].splittable : 1)) plan[i].sk = sk;
+                    while (*q && *q != ';') ++q;
+                }
+                if (*q == ';') ++q;
+            }
+            if (sh[i].N <= 64) plan[i].tile = 1;
+        }
+        return;
+    }
+    struct Entry {
+        MultiShape sh[FX_MULTI_MAX];
+        int n;
+        MultiPlanItem plan[FX_MULTI_MAX];
+    };
+    static Entry cache[64];
+    static int ncache = 0;
+    for (int e = 0; e < ncache; ++e) {
+        if (cache[e].n != n) continue;
+        bool same = true;
+        for (int i = 0; i < n && same; ++i)
+            same = cache[e].sh[i].M == sh[i].M && cache[e].sh[i].N == sh[i].N &&
+                   cache[e].sh[i].K == sh[i].K && cache[e].sh[i].splittable == sh[i].splittable;
+        if (same) {
+            for (int i = 0; i < n; ++i) plan[i] = cache[e].plan[i];
+            return;
+        }
+    }
+    static const int SKS[] = {1, 2, 3, 4, 5, 6, 8};
+    constexpr int CAP = 16384;
+    static double wbuf[CAP];
+    static int tbuf[CAP];
+    int order[FX_MULTI_MAX];
+    MultiPlanItem cur[FX_MULTI_MAX], best[FX_MULTI_MAX];
+    double best_t = 1e300;
+    int ncand[FX_MULTI_MAX];
+    MultiPlanItem cand[FX_MULTI_MAX][16];
+    for (int i = 0; i < n; ++i) {
+        ncand[i] = 0;
+        for (int tile = 0; tile < 2; ++tile) {
+            if (tile == 0 && sh[i].N <= 64) continue;
+            for (int s = 0; s < 7; ++s) {
+                const int sk = SKS[s];
+                if (sk > 1 && (sk > sh[i].splittable || sh[i].K / sk < 256)) continue;
+                cand[i][ncand[i]].tile = tile;
+                cand[i][ncand[i]].sk = sk;
+                ++ncand[i];
+            }
+        }
+    }
+    int idx[FX_MULTI_MAX] = {0, 0, 0, 0};
+    while (true) {
+        for (int i = 0; i < n; ++i) cur[i] = cand[i][idx[i]];
+        // longest workgroups first
+        double wl[FX_MULTI_MAX];
+        for (int i = 0; i < n; ++i) {
+            order[i] = i;
+            wl[i] = (double)fx_ceil_div(sh[i].K, cur[i].sk) * (cur[i].tile ? 64 : 128);
+        }
+        for (int a2 = 0; a2 < n; ++a2)
+            for (int b2 = a2 + 1; b2 < n; ++b2)
+                if (wl[order[b2]] > wl[order[a2]]) { const int t = order[a2]; order[a2] = order[b2]; order[b2] = t; }
+        const double t = fx_multi_cost(sh, n, cur, order, wbuf, tbuf, CAP);
+        if (t < best_t) {
+            best_t = t;
+            for (int i = 0; i < n; ++i) best[i] = cur[i];
+        }
+        int d = 0;
+        while (d < n && ++idx[d] == ncand[d]) { idx[d] = 0; ++d; }
+        if (d == n) break;
+    }
+    for (int i = 0; i < n; ++i) plan[i] = best[i];
+    if (ncache < 64) {
+        Entry& e = cache[ncache++];
+        e.n = n;
+        for (int i = 0; i < n; ++i) { e.sh[i] = sh[i]; e.plan[i] = best[i]; }
+    }
+}
+
+// split_k of a problem is the LARGEST slab count its workspace holds; the 64x64 paths use the rule of
+// round 2 below that cap: about 1024 workgroups, a power of two, K slabs of >= 256
+static int32_t fx_splitk_rule64(int64_t M, int64_t N, int64_t K, int32_t cap) {
+    if (cap <= 1) return 1;
+    const int64_t tiles = fx_ceil_div(M, 64) * fx_ceil_div(N, 64);
+    int64_t s = 1;
+    if (tiles >= 768) s = 1;
+    else if (tiles <= 4) { s = fx_ceil_div(512, tiles); if (s > 256) s = 256; }
+    else {
+        const double want = 1024.0 / (double)tiles;
+        while ((double)s * 1.5 < want) s *= 2;
+        if (s > 16) s = 16;
+    }
+    if (s > K / 256) s = K / 256;
+    if (s > cap) s = cap;
+    return (int32_t)(s < 1 ? 1 : s);
+}
+
+static bool fx_gemm_skinny(const fx_gemm_problem& q) {
+    return q.K <= 8 || (q.N <= 4 && !q.transa) || (q.M <= 4 && q.transa && !q.transb && q.workspace);
+}
+
+static int fx_gemm_multi_mode() {     // FX_GEMM_MULTI=0: the 64x64 pair / per-problem paths of round 2
+    static const int mode = []() {
+        const char* e = getenv("FX_GEMM_MULTI");
+        return e ? atoi(e) : 1;
+    }();
+    return mode;
+}
+
+// -> FX_OK and *launched = true when the problems went out as one k_gemm_f32_multi grid
+static int fx_gemm_try_multi(const fx_gemm_problem* p, int32_t n, fx_stream_t stream, bool* launched) {
+    *launched = false;
+    if (n < 1 || n > FX_MULTI_MAX || !fx_gemm_multi_mode()) return FX_OK;
+    MultiShape sh[FX_MULTI_MAX];
+    for (int i = 0; i < n; ++i) {
+        const fx_gemm_problem& q = p[i];
+        if (q.M < 64 || q.N < 16 || q.K < 64 || fx_gemm_skinny(q) || !q.A || !q.B || !q.C) return FX_OK;
+        sh[i].M = q.M; sh[i].N = q.N; sh[i].K = q.K;
+        sh[i].splittable = (q.split_k > 1 && q.workspace) ? q.split_k : 0;
+    }
+    MultiPlanItem plan[FX_MULTI_MAX];
+    fx_multi_plan(sh, n, plan);
+    MultiArgs ma;
+    memset(&ma, 0, sizeof(ma));
+    // longest workgroups first
+    int order[FX_MULTI_MAX];
+    double wl[FX_MULTI_MAX];
+    for (int i = 0; i < n; ++i) {
+        order[i] = i;
+        wl[i] = (double)fx_ceil_div(p[i].K, plan[i].sk) * (plan[i].tile ? 64 : 128);
+    }
+    for (int a2 = 0; a2 < n; ++a2)
+        for (int b2 = a2 + 1; b2 < n; ++b2)
+            if (wl[order[b2]] > wl[order[a2]]) { const int t = order[a2]; order[a2] = order[b2]; order[b2] = t; }
+    int64_t wgs = 0;
+    for (int oi = 0; oi < n; ++oi) {
+        const fx_gemm_problem& q = p[order[oi]];
+        const MultiPlanItem& pl = plan[order[oi]];
+        GemmArgs& a = ma.p[oi];
+        int bm = 0, bn = 0;
+        const int rc = fx_gemm_prepare(q.transa, q.transb, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C,
+                                       q.ldc, q.epilogue, pl.sk, q.workspace, a, bm, bn);
+        if (rc != FX_OK) return rc;
+        bn = pl.tile ? 64 : 128;
+        a.tiles_m = (int32_t)fx_ceil_div(q.M, 128);
+        a.tiles_n = (int32_t)fx_ceil_div(q.N, bn);
+        if (!fx_gemm_pipe_ok(q.transa, q.transb, a) || !fx_gemm_tr_ok(a)) return FX_OK;
+        ma.cfg[oi] = (q.transa ? 0 : 1) | (q.transb ? 2 : 0) | (pl.tile ? 4 : 0);
+        ma.start[oi] = (int32_t)wgs;
+        wgs += (int64_t)a.tiles_m * a.tiles_n * a.split_k;
+    }
+    ma.start[n] = (int32_t)wgs;
+    for (int oi = n + 1; oi <= FX_MULTI_MAX; ++oi) ma.start[oi] = (int32_t)wgs;
+    ma.n = n;
+    if (wgs <= 0 || wgs > 0x3FFFFFFF) return FX_OK;
+    hipStream_t s = fx_hip_stream(stream);
+    hipLaunchKernelGGL(k_gemm_f32_multi, dim3((unsigned)wgs), dim3(256), 0, s, ma);
+    FX_CHECK_LAUNCH();
+    for (int oi = 0; oi < n; ++oi)
+        if (ma.p[oi].split_k > 1) {
+            fx_launch_splitk_reduce(ma.p[oi], s);
+            FX_CHECK_LAUNCH();
+        }
+    *launched = true;
+    return FX_OK;
+}
+
 extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_t stream) {
     FX_CHECK_ARG(n >= 0 && (n == 0 || p), "fx_gemm_f32_batch: bad problem list");
     static const bool pair_on = []() {   // FX_GEMM_PAIR=0: always problem by problem (A/B runs)
         const char* e = getenv("FX_GEMM_PAIR");
         return !(e && atoi(e) == 0);
     }();
+    if (pair_on) {
+        bool launched = false;
+        const int rc = fx_gemm_try_multi(p, n, stream, &launched);
+        if (rc != FX_OK) return rc;
+        if (launched) return FX_OK;
+    }
     if (n == 2 && pair_on && p[0].transa && !p[0].transb && !p[1].transa &&
         !p[1].transb) {
         GemmArgs a[2];
@@ -1406,13 +1770,15 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
         for (int i = 0; i < 2 && ok; ++i) {
             const fx_gemm_problem& q = p[i];
             const int rc = fx_gemm_prepare(q.transa, q.transb, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb,
-                                           q.C, q.ldc, q.epilogue, q.split_k, q.workspace, a[i],
-                                           bm[i], bn[i]);
+                                           q.C, q.ldc, q.epilogue,
+                                           fx_gemm_skinny(q) ? q.split_k
+                                                             : fx_splitk_rule64(q.M, q.N, q.K, q.split_k),
+                                           q.workspace, a[i], bm[i], bn[i]);
             if (rc != FX_OK) return rc;
-            const bool skinny = q.K <= 8 || (q.N <= 4 && !q.transa) ||
-                                (q.M <= 4 && q.transa && !q.transb && q.workspace);
-            ok = q.M > 0 && q.N > 0 && !skinny && bm[i] == 64 && bn[i] == 64 &&
-                 fx_gemm_pipe_ok(q.transa, q.transb, a[i]);
+            // (the pair kernel is the 64x64 build: force that tile whatever the single-GEMM rule says)
+            a[i].tiles_m = (int32_t)fx_ceil_div(q.M, 64);
+            a[i].tiles_n = (int32_t)fx_ceil_div(q.N, 64);
+            ok = q.M > 0 && q.N > 0 && !fx_gemm_skinny(q) && fx_gemm_pipe_ok(q.transa, q.transb, a[i]);
         }
         if (ok) {
             hipStream_t s = fx_hip_stream(stream);
@@ -1436,7 +1802,10 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
     for (int i = 0; i < n; ++i) {
         const fx_gemm_problem& q = p[i];
         const int rc = fx_gemm_f32(q.transa, q.transb, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C,
-                                   q.ldc, q.epilogue, q.split_k, q.workspace, stream);
+                                   q.ldc, q.epilogue,
+                                   fx_gemm_skinny(q) ? q.split_k
+                                                     : fx_splitk_rule64(q.M, q.N, q.K, q.split_k),
+                                   q.workspace, stream);
         if (rc != FX_OK) return rc;
     }
     return FX_OK;

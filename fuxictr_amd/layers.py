@@ -1539,7 +1539,13 @@ def linear_grads(dz, x, W, need_bias, mask=None, add=None):
     K_in = x.shape[1]
     dW = torch.empty(N_out, K_in, dtype=torch.float32, device=dz.device)
     dx = torch.empty(Bsz, K_in, dtype=torch.float32, device=dz.device)
+    # split_k is the LARGEST slab count the workspace holds: the library picks the actual K split of
+    # the launch it builds (fx_gemm_f32_batch: one grid for both products, tiles and slabs chosen
+    # together), never more than this
     sk = _split_k_for(N_out, K_in, Bsz)
+    if N_out > 4 and K_in > 8 and not _FORCE_SPLITK:
+        sk = max(sk, min(8, Bsz // 256))
+    sk = max(sk, 1)
     ws = _Workspace.get(dz.device, sk * N_out * (K_in + 1))
     db = torch.empty(N_out, dtype=torch.float32, device=dz.device) if need_bias else None
     ops.gemm_dw_dx(dz, x, W, dW, dx, split_k=sk, workspace=ws, rowsum=db, mask=mask, add=add)

@@ -523,6 +523,48 @@ def gemm_dw_dx(dz, x, W, dW, dx, split_k=1, workspace=None, rowsum=None, mask=No
     return _gemm_dw_dx(dz, x, W, dW, dx, split_k, workspace, rowsum, mask, add)
 
 
+class _GemmProblem(object):
+    """One GEMM of a batch: keeps the tensors (and the epilogue struct the C struct points at) alive."""
+
+    def __init__(self, A, B_, C_, transa, transb, split_k, workspace, epi, keep):
+        M, N = C_.shape
+        K = A.shape[0] if transa else A.shape[1]
+        self.M, self.N, self.K = M, N, K
+        self.epi, self.keep = epi, keep
+        self.struct = _lib.GemmProblem(1 if transa else 0, 1 if transb else 0, M, N, K, ptr(A),
+                                       A.stride(0), ptr(B_), B_.stride(0), ptr(C_), C_.stride(0),
+                                       C.pointer(epi), split_k, ptr(workspace))
+        self.device = C_.device
+
+
+def gemm_problem(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul=None,
+                 mask=None, add=None, split_k=1, workspace=None, rowsum=None):
+    """-> one entry for gemm_batch(); same arguments as gemm().  split_k is the LARGEST number of K slabs
+    `workspace` holds (split_k * M * (N + 1) floats); the library chooses the actual split."""
+    epi = _epilogue(bias, act, zout, mul, mask, add, rowsum)
+    return _GemmProblem(A, B_, C_, transa, transb, split_k, workspace, epi,
+                        (A, B_, C_, bias, zout, mul, mask, add, workspace, rowsum))
+
+
+def gemm_batch(problems):
+    """Independent GEMMs in as few launches as possible (fx_gemm_f32_batch): up to four aligned problems
+    leave as ONE grid on 128-row tiles, two workgroups per CU."""
+    if not problems:
+        return
+    if KernelTimer.recording:
+        KernelTimer.note("k_gemm_f32", "gemmN " + "+".join("%dx%dx%d" % (p.M, p.N, p.K) for p in problems),
+                         sum(2.0 * p.M * p.N * p.K for p in problems), _gemm_batch, (problems,), {})
+    return _gemm_batch(problems)
+
+
+def _gemm_batch(problems):
+    arr = (_lib.GemmProblem * len(problems))()
+    for i, p in enumerate(problems):
+        arr[i] = p.struct
+    check(_lib.load().fx_gemm_f32_batch(arr, len(problems), stream_ptr(problems[0].device)),
+          "fx_gemm_f32_batch")
+
+
 def _gemm_dw_dx(dz, x, W, dW, dx, split_k, workspace, rowsum, mask, add):
     M, N = dz.shape
     K = x.shape[1]

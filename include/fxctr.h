@@ -361,11 +361,15 @@ int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
                 fx_stream_t stream);
 
 /* Several independent GEMMs in as few launches as possible (same semantics as calling fx_gemm_f32 on
- * each problem, in order; the outputs must not overlap each other or any input).  The weight gradient
- * dW = dZ^T X (transa = 1, transb = 0) followed by the input gradient dX = dZ W (transa = 0,
- * transb = 0) of one Linear / CrossNet layer — the two `aten::mm` of its autograd (mlp_block.py:96,
- * cross_net.py:128 at rank_model.py:320), which share dZ and are independent — go out as ONE grid, so
- * the second one's workgroups fill the CUs as the first one's retire.  problems_host is a HOST array. */
+ * each problem, in order; the outputs must not overlap each other or any input).  Up to four aligned,
+ * non-skinny problems — the weight gradient dW = dZ^T X (transa = 1, transb = 0) and the input gradient
+ * dX = dZ W (transa = 0, transb = 0) of one Linear / CrossNet layer, the two `aten::mm` of its autograd
+ * (mlp_block.py:96, cross_net.py:128 at rank_model.py:320), which share dZ and are independent; for
+ * DCNv2's parallel structure also the cross and the deep layer of one depth (DCNv2.py:108-132) — leave
+ * as ONE grid on 128-row tiles with two workgroups per CU: the tile (128x128 | 128x64) and the K split
+ * of every problem are chosen together for the launch by a list-scheduling model of the 256 CUs.
+ * A problem's split_k is the LARGEST number of K slabs its workspace holds (split_k * M * (N + 1)
+ * floats); the library never uses more.  problems_host is a HOST array. */
 typedef struct fx_gemm_problem {
     int32_t transa, transb;
     int64_t M, N, K;

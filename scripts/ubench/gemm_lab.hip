@@ -11,6 +11,8 @@
 
 #include <stdarg.h>
 
+#include <math.h>
+
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -232,6 +234,48 @@ static void run_pair(const char* name, int64_t M, int64_t N, int64_t K, int sk, 
     const double tf = 4.0 * M * N * K / (best * 1e-6) / 1e12;
     printf("[%s] %-40s %8.2f us  %7.2f TF  %.3f  (incl. slab reduce)\n", g_tag.c_str(), name, best, tf,
            tf / 157.3);
+    if (g_check) {
+        float* r1 = dalloc(N * K, 14);
+        float* r2 = dalloc(M * K, 15);
+        GemmArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.A = dz; ra.lda = N; ra.B = x; ra.ldb = K; ra.C = r1; ra.ldc = K; ra.M = N; ra.N = K; ra.K = M;
+        hipLaunchKernelGGL(k_ref, dim3(4096), dim3(256), 0, 0, ra, 1, 0);
+        memset(&ra, 0, sizeof(ra));
+        ra.A = dz; ra.lda = N; ra.B = W; ra.ldb = K; ra.C = r2; ra.ldc = K; ra.M = M; ra.N = K; ra.K = N;
+        ra.epi = e2;
+        hipLaunchKernelGGL(k_ref, dim3(4096), dim3(256), 0, 0, ra, 0, 0);
+        launch();
+        HC(hipDeviceSynchronize());
+        auto cmp = [&](const char* what, float* got, float* ref, int64_t n, bool exact) {
+            std::vector<float> h1((size_t)n), h2((size_t)n);
+            HC(hipMemcpy(h1.data(), got, (size_t)n * 4, hipMemcpyDeviceToHost));
+            HC(hipMemcpy(h2.data(), ref, (size_t)n * 4, hipMemcpyDeviceToHost));
+            double md = 0, mx = 0;
+            int64_t nbad = 0;
+            for (size_t i = 0; i < h1.size(); ++i) {
+                md = std::max(md, fabs((double)h1[i] - (double)h2[i]));
+                mx = std::max(mx, fabs((double)h2[i]));
+                if (memcmp(&h1[i], &h2[i], 4) != 0) ++nbad;
+            }
+            printf("  check %s: max |d| %.3e (max |ref| %.3e), %lld not bit-identical%s\n", what, md, mx,
+                   (long long)nbad, ((exact && nbad) || md > 2e-5 * mx * sqrt((double)M)) ? "   <-- MISMATCH" : "");
+        };
+        cmp("dW", dW, r1, N * K, false);
+        cmp("dX", dx, r2, M * K, true);
+        // bias gradient
+        std::vector<float> hb((size_t)N), hz((size_t)M * N);
+        HC(hipMemcpy(hb.data(), e1.rowsum, (size_t)N * 4, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(hz.data(), dz, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        double mdb = 0;
+        for (int64_t n2 = 0; n2 < N; ++n2) {
+            double sacc = 0;
+            for (int64_t m2 = 0; m2 < M; ++m2) sacc += hz[(size_t)m2 * N + n2];
+            mdb = std::max(mdb, fabs(sacc - (double)hb[n2]));
+        }
+        printf("  check db: max |d| %.3e%s\n", mdb, mdb > 1e-2 ? "   <-- MISMATCH" : "");
+        HC(hipFree(r1)); HC(hipFree(r2));
+    }
     HC(hipFree(dz)); HC(hipFree(x)); HC(hipFree(W)); HC(hipFree(dW)); HC(hipFree(dx)); HC(hipFree(ws));
 }
 
@@ -245,6 +289,32 @@ int main(int argc, char** argv) {
     auto env = [](const char* k, const char* d) { const char* e = getenv(k); return std::string(e ? e : d); };
     g_tag = "tile=" + env("FX_GEMM_TILE", "auto") + " tr=" + env("FX_GEMM_TR", "1") + env("FX_LAB_TAG", "");
     const int64_t B = 4096;
+    {   // DVFS / power-state warm-up: ~60 ms of GEMMs before anything is timed (the first cases of a cold
+        // process measured ~12 % slow in visit a)
+        float* wa = dalloc(4096 * 1024, 21);
+        float* wb = dalloc(1024 * 1024, 22);
+        float* wc = dalloc(4096 * 1024, 23);
+        for (int i = 0; i < 600; ++i)
+            fx_gemm_f32(0, 1, 4096, 1024, 1024, wa, 1024, wb, 1024, wc, 1024, nullptr, 1, nullptr, nullptr);
+        HC(hipDeviceSynchronize());
+        HC(hipFree(wa)); HC(hipFree(wb)); HC(hipFree(wc));
+    }
+    if (suite == "two") {   // two 128x128 workgroups per CU: how well do they share the matrix pipes?
+        run_case({"fwd 8192x1024x1024 bias+relu", 0, 1, 8192, 1024, 1024, 1, true, true, false, false, false, false, false});
+        run_case({"fwd 8192x1024x1024 plain", 0, 1, 8192, 1024, 1024, 1, false, false, false, false, false, false, false});
+        run_case({"fwd 4096x1024x1024 plain", 0, 1, B, 1024, 1024, 1, false, false, false, false, false, false, false});
+        run_case({"dW 1024x1024x4096 sk8 rowsum", 1, 0, 1024, 1024, B, 8, false, false, false, false, false, false, true});
+        run_case({"dX 4096x1024x1024 plain", 0, 0, B, 1024, 1024, 1, false, false, false, false, false, false, false});
+        run_case({"dX 4096x1024x1024 relu mask", 0, 0, B, 1024, 1024, 1, false, false, true, false, false, false, false});
+    }
+    if (suite == "pairs") {
+        run_pair("pair 4096x1024x1024 (dW + dX mask)", B, 1024, 1024, 8, true, false);
+        run_pair("pair 4096x1024x624 (dW + dX)", B, 1024, 624, 8, false, false);
+        run_pair("cross pair 4096x624x624 (dW + dX add)", B, 624, 624, 8, false, true);
+        run_pair("pair 4096x512x1024 (dW + dX mask)", B, 512, 1024, 8, true, false);
+        run_pair("pair 4096x256x512 (dW + dX mask)", B, 256, 512, 8, true, false);
+        run_pair("pair 4096x1024x368 (dW + dX)", B, 1024, 368, 8, false, false);
+    }
     if (suite == "tower" || suite == "all") {
         run_case({"fwd 4096x1024x1024 bias+relu", 0, 1, B, 1024, 1024, 1, true, true, false, false, false, false, false});
         run_case({"fwd 4096x1024x624 bias+relu", 0, 1, B, 1024, 624, 1, true, true, false, false, false, false, false});

@@ -388,33 +388,67 @@ def test_gemm_all_layouts(M, N, K, ta, tb):
                                    (2048, 512, 128), (300, 70, 52), (257, 33, 9)])
 def test_gemm_dw_dx_pair_is_bit_identical_to_the_two_gemms(M, N, K):
     """fx_gemm_f32_batch: the weight- and input-gradient products of a layer as ONE grid (the aligned
-    tower shapes) or problem by problem (ragged shapes) — the same bits as two fx_gemm_f32 calls, with
-    the fused bias gradient, the ReLU mask and the residual add; and both equal fp64 within bound."""
+    tower shapes: 128-row tiles, two workgroups per CU, tiles and K slabs chosen per launch) or problem
+    by problem (ragged shapes), with the fused bias gradient, the ReLU mask and the residual add.
+    dX (no K split: one k-ordered chain per element) carries the same bits as fx_gemm_f32; dW may be
+    split differently, so it is compared with fp64 within the fp32 bound; two runs are bit-identical."""
     g = torch.Generator().manual_seed(M + N + K)
     dz, x = _dev(torch.randn(M, N, generator=g)), _dev(torch.randn(M, K, generator=g))
     W = _dev(torch.randn(N, K, generator=g) * 0.1)
     mask, add = _dev(torch.randn(M, K, generator=g)), _dev(torch.randn(M, K, generator=g))
-    sk = 4 if M >= 2048 else 2
+    sk = 8 if M >= 2048 else 2
     ws = torch.empty(sk * N * (K + 1) + 64, device=DEV)
     out = []
-    for pair in (True, False):
+    for pair in (True, True, False):
         dW = torch.full((N, K), float("nan"), device=DEV)
         dx = torch.full((M, K), float("nan"), device=DEV)
         db = torch.full((N,), float("nan"), device=DEV)
         if pair:
             ops.gemm_dw_dx(dz, x, W, dW, dx, split_k=sk, workspace=ws, rowsum=db, mask=mask, add=add)
         else:
-            ops.gemm(dz, x, dW, transa=True, transb=False, split_k=sk, workspace=ws, rowsum=db)
+            ops.gemm(dz, x, dW, transa=True, transb=False, split_k=min(sk, 4), workspace=ws, rowsum=db)
             ops.gemm(dz, W, dx, transa=False, transb=False, mask=mask, add=add)
         out.append((dW, dx, db))
-    for a, b in zip(*out):
-        assert torch.equal(a, b)
-    dW, dx, db = out[0]
-    ref_w = dz.double().t() @ x.double()
-    assert (dW.double() - ref_w).abs().max().item() <= 3e-6 * (dz.abs().double().t() @ x.abs().double()).max().item()
-    ref_x = torch.where(mask > 0, dz.double() @ W.double(), torch.zeros((), dtype=torch.float64, device=DEV)) + add.double()
-    assert (dx.double() - ref_x).abs().max().item() <= 3e-6 * (dz.abs().double() @ W.abs().double()).max().item() + 1e-6
-    assert (db.double() - dz.double().sum(0)).abs().max().item() <= 1e-5 * dz.abs().double().sum(0).max().item()
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)                         # deterministic
+    assert torch.equal(out[0][1], out[2][1])             # dX: same bits as the single GEMM
+    for dW, dx, db in (out[0], out[2]):
+        ref_w = dz.double().t() @ x.double()
+        assert (dW.double() - ref_w).abs().max().item() <= 3e-6 * (dz.abs().double().t() @ x.abs().double()).max().item()
+        ref_x = torch.where(mask > 0, dz.double() @ W.double(), torch.zeros((), dtype=torch.float64, device=DEV)) + add.double()
+        assert (dx.double() - ref_x).abs().max().item() <= 3e-6 * (dz.abs().double() @ W.abs().double()).max().item() + 1e-6
+        assert (db.double() - dz.double().sum(0)).abs().max().item() <= 1e-5 * dz.abs().double().sum(0).max().item()
+
+
+def test_gemm_batch_of_four_problems_in_one_grid():
+    """fx_gemm_f32_batch with four problems (DCNv2's parallel structure: the cross and the deep layer of
+    one depth, dW + dX each) == the same four products as single launches, within the fp32 bound."""
+    g = torch.Generator().manual_seed(11)
+    M = 4096
+    items = []
+    for N, K in ((624, 624), (1024, 624)):
+        dz, x = _dev(torch.randn(M, N, generator=g)), _dev(torch.randn(M, K, generator=g))
+        W = _dev(torch.randn(N, K, generator=g) * 0.1)
+        items.append((dz, x, W))
+    probs, outs, keep = [], [], []
+    for dz, x, W in items:
+        N, K = W.shape
+        dW, dx = torch.full((N, K), float("nan"), device=DEV), torch.full((M, K), float("nan"), device=DEV)
+        db = torch.full((N,), float("nan"), device=DEV)
+        ws = torch.empty(8 * N * (K + 1) + 64, device=DEV)
+        probs.append(ops.gemm_problem(dz, x, dW, transa=True, transb=False, split_k=8, workspace=ws,
+                                      rowsum=db))
+        probs.append(ops.gemm_problem(dz, W, dx, transa=False, transb=False))
+        outs.append((dW, dx, db))
+        keep.append(ws)
+    ops.gemm_batch(probs)
+    torch.cuda.synchronize()
+    for (dz, x, W), (dW, dx, db) in zip(items, outs):
+        ref_w = dz.double().t() @ x.double()
+        assert (dW.double() - ref_w).abs().max().item() <= 3e-6 * (dz.abs().double().t() @ x.abs().double()).max().item()
+        ref_x = dz.double() @ W.double()
+        assert (dx.double() - ref_x).abs().max().item() <= 3e-6 * (dz.abs().double() @ W.abs().double()).max().item()
+        assert (db.double() - dz.double().sum(0)).abs().max().item() <= 1e-5 * dz.abs().double().sum(0).max().item()
 
 
 @pytest.mark.parametrize("widths", [(16, 1), (16,), (8, 4, 1), (3,)])
