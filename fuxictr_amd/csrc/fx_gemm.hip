@@ -46,7 +46,7 @@ unsigned long long* fx_gemm_lab_trace = nullptr;   // set by the lab before a tr
 #define FX_LAB_STAMP(slot)                                                                    \
     do {                                                                                      \
         if (a.trace && threadIdx.x == 0)                                                      \
-            a.trace[((int64_t)z * a.tiles_m * a.tiles_n + L) * 8 + (slot)] = wall_clock64();  \
+            a.trace[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
     } while (0)
 #else
 #define FX_LAB_STAMP(slot) do {} while (0)
@@ -714,7 +714,7 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FX_LAB_STAMP(3);
         if (threadIdx.x == 0) {
-            const int64_t w = ((int64_t)z * a.tiles_m * a.tiles_n + L) * 8;
+            const int64_t w = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
             a.trace[w + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
             a.trace[w + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
         }
@@ -776,12 +776,15 @@ void k_gemm_f32_multi(MultiArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[FM];
     int i = 0;
     while (i + 1 < a.n && (int32_t)blockIdx.x >= a.start[i + 1]) ++i;
-    const GemmArgs& g = a.p[i];
+    // the problem's arguments are read through the kernarg segment pointer (uniform scalar loads):
+    // indexing the by-value struct with a run-time index made the compiler copy it to scratch
+    const MultiArgs* ka = reinterpret_cast<const MultiArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
+    const GemmArgs& g = ka->p[i];
     int64_t L = (int64_t)blockIdx.x - a.start[i];
     const int64_t nt = (int64_t)g.tiles_m * g.tiles_n;
     const int z = (int)(L / nt);
     L -= (int64_t)z * nt;
-    switch (a.cfg[i]) {
+    switch (ka->cfg[i]) {
         case 0: fx_gemm_pipe_tile<128, 128, false, false, true>(g, L, z, smem); break;
         case 1: fx_gemm_pipe_tile<128, 128, true, false, true>(g, L, z, smem); break;
         case 2: fx_gemm_pipe_tile<128, 128, false, true, true>(g, L, z, smem); break;

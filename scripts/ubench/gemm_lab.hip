@@ -279,6 +279,86 @@ static void run_pair(const char* name, int64_t M, int64_t N, int64_t K, int sk, 
     HC(hipFree(dz)); HC(hipFree(x)); HC(hipFree(W)); HC(hipFree(dW)); HC(hipFree(dx)); HC(hipFree(ws));
 }
 
+// several problems through fx_gemm_f32_batch: kind 'f' = forward (A[M,K] x W[N,K]^T, bias + relu),
+// 'x' = input gradient (dz[M,N'] x W[N',K']), 'w' = weight gradient (dz^T x, split-K, rowsum)
+static void run_mix(const char* name, const char* kinds, int64_t M, int64_t N, int64_t K, int sk,
+                    int reps = 20) {
+    const int n = (int)strlen(kinds);
+    fx_gemm_problem p[4];
+    fx_gemm_epilogue e[4];
+    memset(p, 0, sizeof(p));
+    memset(e, 0, sizeof(e));
+    double flops = 0;
+    for (int i = 0; i < n; ++i) {
+        if (kinds[i] == 'f') {
+            p[i].transa = 0; p[i].transb = 1; p[i].M = M; p[i].N = N; p[i].K = K;
+            p[i].A = dalloc(M * K, 31 + i); p[i].lda = K; p[i].B = dalloc(N * K, 41 + i); p[i].ldb = K;
+            p[i].C = dalloc(M * N, 51 + i); p[i].ldc = N;
+            e[i].bias = dalloc(N, 61 + i); e[i].act = 1;
+            p[i].split_k = 1;
+        } else if (kinds[i] == 'x') {
+            p[i].transa = 0; p[i].transb = 0; p[i].M = M; p[i].N = K; p[i].K = N;
+            p[i].A = dalloc(M * N, 31 + i); p[i].lda = N; p[i].B = dalloc(N * K, 41 + i); p[i].ldb = K;
+            p[i].C = dalloc(M * K, 51 + i); p[i].ldc = K;
+            e[i].mask = dalloc(M * K, 61 + i); e[i].ldmask = K;
+            p[i].split_k = 1;
+        } else {
+            p[i].transa = 1; p[i].transb = 0; p[i].M = N; p[i].N = K; p[i].K = M;
+            p[i].A = dalloc(M * N, 31 + i); p[i].lda = N; p[i].B = dalloc(M * K, 41 + i); p[i].ldb = K;
+            p[i].C = dalloc(N * K, 51 + i); p[i].ldc = K;
+            e[i].rowsum = dalloc(N, 61 + i);
+            p[i].split_k = sk; p[i].workspace = dalloc((int64_t)sk * N * (K + 1) + 1024, 71 + i);
+        }
+        p[i].epilogue = &e[i];
+        flops += 2.0 * M * N * K;
+    }
+    auto launch = [&]() {
+        if (fx_gemm_f32_batch(p, n, nullptr) != FX_OK) { fprintf(stderr, "batch failed\n"); exit(3); }
+    };
+    for (int i = 0; i < 3; ++i) launch();
+    HC(hipDeviceSynchronize());
+    hipEvent_t e0, e1v;
+    HC(hipEventCreate(&e0));
+    HC(hipEventCreate(&e1v));
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        HC(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) launch();
+        HC(hipEventRecord(e1v, 0));
+        HC(hipEventSynchronize(e1v));
+        float ms;
+        HC(hipEventElapsedTime(&ms, e0, e1v));
+        best = std::min(best, ms * 1000.f / reps);
+    }
+    const double tf = flops / (best * 1e-6) / 1e12;
+    printf("[%s] %-40s %8.2f us  %7.2f TF  %.3f\n", g_tag.c_str(), name, best, tf, tf / 157.3);
+    if (g_trace) {
+        const int64_t words = (int64_t)1 << 20;
+        unsigned long long* tr;
+        HC(hipMalloc(&tr, words * 8));
+        HC(hipMemset(tr, 0, words * 8));
+        fx_gemm_lab_trace = tr;
+        launch();
+        HC(hipDeviceSynchronize());
+        fx_gemm_lab_trace = nullptr;
+        std::vector<unsigned long long> h(words);
+        HC(hipMemcpy(h.data(), tr, words * 8, hipMemcpyDeviceToHost));
+        int64_t nwg = 0;
+        while (nwg < words / 8 && h[nwg * 8] != 0) ++nwg;
+        if (nwg > 0) {
+            analyse_trace(h, nwg);
+            // first / second half of the grid separately (problem order inside a multi launch)
+            std::vector<unsigned long long> h1(h.begin(), h.begin() + (nwg / 2) * 8);
+            std::vector<unsigned long long> h2(h.begin() + (nwg / 2) * 8, h.begin() + nwg * 8);
+            printf("  -- first half of the grid\n");
+            analyse_trace(h1, nwg / 2);
+            printf("  -- second half of the grid\n");
+            analyse_trace(h2, nwg - nwg / 2);
+        }
+        HC(hipFree(tr));
+    }
+}
+
 int main(int argc, char** argv) {
     std::string suite = "tower";
     for (int i = 1; i < argc; ++i) {
@@ -306,6 +386,17 @@ int main(int argc, char** argv) {
         run_case({"dW 1024x1024x4096 sk8 rowsum", 1, 0, 1024, 1024, B, 8, false, false, false, false, false, false, true});
         run_case({"dX 4096x1024x1024 plain", 0, 0, B, 1024, 1024, 1, false, false, false, false, false, false, false});
         run_case({"dX 4096x1024x1024 relu mask", 0, 0, B, 1024, 1024, 1, false, false, true, false, false, false, false});
+    }
+    if (suite == "mix") {   // where does a multi-problem launch lose time?
+        run_mix("multi: fwd alone (n = 1)", "f", B, 1024, 1024, 1);
+        run_mix("multi: fwd + fwd", "ff", B, 1024, 1024, 1);
+        run_mix("multi: dX alone", "x", B, 1024, 1024, 1);
+        run_mix("multi: dX + dX", "xx", B, 1024, 1024, 1);
+        run_mix("multi: dW alone (cap 4)", "w", B, 1024, 1024, 4);
+        run_mix("multi: dW + dW (cap 4)", "ww", B, 1024, 1024, 4);
+        run_mix("multi: dW + dX (cap 4)", "wx", B, 1024, 1024, 4);
+        run_mix("multi: fwd + dX", "fx", B, 1024, 1024, 1);
+        run_mix("multi: dW + fwd (cap 4)", "wf", B, 1024, 1024, 4);
     }
     if (suite == "pairs") {
         run_pair("pair 4096x1024x1024 (dW + dX mask)", B, 1024, 1024, 8, true, false);

@@ -18,6 +18,19 @@ from fuxictr_amd import synthetic
 CASES = ("c2_deepfm", "c3_dcnv2", "c4_din", "c5_dlrm")
 
 
+def _yardstick_rms(case, dist):
+    """8-seed RMS of the reference algorithm's own yardsticks for `case` / `dist` (see run_parity)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_yardsticks.json")
+    with open(path) as f:
+        tab = json.load(f)
+    ent = tab.get("%s/%s" % (case, dist))
+    if ent is None:
+        return {"dAUC": 0.0, "dLL": 0.0}
+    return {"dAUC": float(ent["dAUC"]["rms"]), "dLL": float(ent["dLL"]["rms"])}
+
+
 def scaled_cards(scale):
     return [max(3, int(c * scale)) for c in synthetic.CRITEO_CARDS]
 
@@ -188,16 +201,21 @@ def run_parity(case, dist, model, features, cfg, spec, cards, oracle_mod, B=4096
 
     def yard(fn):
         return max(fn(k) for k in yards)
-    # mean |dlogit| over 64 k samples is the stable statistic (slack x); the maximum is an extreme
-    # value (slack + 1); AUC / logloss differences are signed sums of those errors and scatter by up
-    # to ~6x between one yardstick and the other on ONE seed (scripts/parity_probe.py over 4 model
-    # seeds: native, ref64 and refgpu have the same RMS deviation), hence 10 x there
+    # mean |dlogit| over 64 k samples is the stable statistic (slack x the same-run yardsticks); the
+    # maximum is an extreme value (slack + 1).  AUC / logloss differences are signed sums of those
+    # errors: on ONE seed a yardstick's own dAUC can be ~0 by chance while another's is 10x larger, so the
+    # same-run value is no scale.  Their scale is the 8-seed RMS of the two yardsticks, measured once on
+    # an MI355X (scripts/parity_sweep.py -> tests/golden/parity_yardsticks.json; over those seeds the
+    # native path's RMS is 0.5 - 1.5 x the yardsticks', profiles/r03_parity_sweep_summary.txt): the
+    # bound is slack x that RMS (no more 10 x the same-run value).
+    rms8 = _yardstick_rms(case, dist)
     bound = {"loss": max(loss_tol, slack * yard(lambda k: res["loss"][k])),
              "max": max(logit_tol, (slack + 1) * yard(lambda k: res[k]["max"])),
              "mean": max(0.1 * logit_tol, slack * yard(lambda k: res[k]["mean"])),
-             "auc": max(metric_tol, 10 * yard(lambda k: abs(res[k]["auc"] - ref["auc"]))),
-             "logloss": max(metric_tol,
-                            10 * yard(lambda k: abs(res[k]["logloss"] - ref["logloss"])))}
+             "auc": max(metric_tol, slack * rms8["dAUC"],
+                        slack * yard(lambda k: abs(res[k]["auc"] - ref["auc"]))),
+             "logloss": max(metric_tol, slack * rms8["dLL"],
+                            slack * yard(lambda k: abs(res[k]["logloss"] - ref["logloss"])))}
     res["bounds"] = bound
     assert res["loss"]["native"] <= bound["loss"], ("loss trajectory", res)
     assert res["native"]["max"] <= bound["max"], ("trained logits (max)", res)
