@@ -485,8 +485,17 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
-    const bool do_rowsum = (a.epi.rowsum != nullptr) && (n0 == 0);
-    float rsum = 0.f;
+    // Fused row sums of op(A) (the bias gradient when op(A) = dZ^T): a by-product of the A fragments the
+    // waves of the first tile column hold anyway — lane l sums A[row l & 31][k] over the k of its half,
+    // one exact fma (x * 1 + s) per fragment beside the MFMAs, the two halves meet in one shuffle at
+    // the end.  (Round 2 summed 32 LDS values per row and k-tile at the top of the tile body: the
+    // n0 == 0 workgroups ran 10 % longer than the rest and ended the launch late,
+    // profiles/r03_gemm_lab_b.txt.)  rs_scale = 0 for every other wave: no branch in the loop.
+    const bool do_rowsum = (a.epi.rowsum != nullptr) && (n0 == 0) && (wn == 0);
+    const float rs_scale = do_rowsum ? 1.f : 0.f;
+    float rs[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) rs[i] = 0.f;
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -538,11 +547,7 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
             const float* bsn = Bs0 + sn * SB + foff_b;
             float* wa = As0 + sn * SA;
             float* wb = Bs0 + sn * SB;
-            if (do_rowsum && threadIdx.x < BM) {
-                const float* col = As0 + s * SA + threadIdx.x;
-#pragma unroll
-                for (int k = 0; k < FX_BK; ++k) rsum += col[k * LDA];
-            }
+
             // One k-pair group = MI*NJ MFMAs.  Its LDS work — MI+NJ fragment reads for group g+2
             // and this group's share of the refill writes — is issued ONE instruction after each
             // MFMA (measured, scripts/ubench/mfma_stream*.hip: a clump of 8 LDS instructions between
@@ -603,7 +608,13 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
                     __builtin_amdgcn_sched_barrier(0);
                 });
 #pragma unroll
-                for (int i = 0; i < MI; ++i) fa[c][i] = nfa[i];
+                for (int i = 0; i < MI; ++i) {
+                    // (inline asm on purpose: left to the compiler the MI fmas are SLP-packed into
+                    // v_pk_fma_f32, which costs the matrix pipe ~22 cycles per issue beside MFMAs —
+                    // MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+                    asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(rs[i]) : "s"(rs_scale), "v"(fa[c][i]));
+                    fa[c][i] = nfa[i];
+                }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) fb[c][j] = nfb[j];
                 // Barrier once per tile, after group NG-3: every read of stage s has been issued (the
@@ -639,9 +650,16 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
     }
     FX_LAB_STAMP(2);
 
-    if (do_rowsum && threadIdx.x < BM && m0 + threadIdx.x < a.M) {
-        if (a.split_k > 1) a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + m0 + threadIdx.x] = rsum;
-        else a.epi.rowsum[m0 + threadIdx.x] = rsum;
+    if (a.epi.rowsum != nullptr && n0 == 0) {         // workgroup-uniform
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float tot = rs[i] + __shfl_xor(rs[i], 32, 64);
+            const int64_t m = m0 + wm * (BM / 2) + i * 32 + l31;
+            if (do_rowsum && half == 0 && m < a.M) {
+                if (a.split_k > 1) a.ws[(int64_t)a.split_k * a.M * a.N + (int64_t)z * a.M + m] = tot;
+                else a.epi.rowsum[m] = tot;
+            }
+        }
     }
     if constexpr (TR) {
         // lane: row m = l31 of the wave tile; registers 4q .. 4q+3: columns 8q + 4*half + 0..3
@@ -778,7 +796,7 @@ void k_gemm_f32_multi(MultiArgs a) {
     while (i + 1 < a.n && (int32_t)blockIdx.x >= a.start[i + 1]) ++i;
     // the problem's arguments are read through the kernarg segment pointer (uniform scalar loads):
     // indexing the by-value struct with a run-time index made the compiler copy it to scratch
-    const MultiArgs* ka = reinterpret_cast<const MultiArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
+    const MultiArgs* ka = (const MultiArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const GemmArgs& g = ka->p[i];
     int64_t L = (int64_t)blockIdx.x - a.start[i];
     const int64_t nt = (int64_t)g.tiles_m * g.tiles_n;
@@ -1643,7 +1661,9 @@ static void fx_multi_plan(const MultiShape* sh, int n, MultiPlanItem* plan) {
         double wl[FX_MULTI_MAX];
         for (int i = 0; i < n; ++i) {
             order[i] = i;
-            wl[i] = (double)fx_ceil_div(sh[i].K, cur[i].sk) * (cur[i].tile ? 64 : 128);
+            // (ties: the problem with the direct epilogue — mask / add / bias loads, the longer drain —
+            // before the slab writer, so that its drain runs beside the other's K loop)
+            wl[i] = (double)fx_ceil_div(sh[i].K, cur[i].sk) * (cur[i].tile ? 64 : 128) + (cur[i].sk == 1 ? 1.0 : 0.0);
         }
         for (int a2 = 0; a2 < n; ++a2)
             for (int b2 = a2 + 1; b2 < n; ++b2)
@@ -1715,7 +1735,7 @@ static int fx_gemm_try_multi(const fx_gemm_problem* p, int32_t n, fx_stream_t st
     double wl[FX_MULTI_MAX];
     for (int i = 0; i < n; ++i) {
         order[i] = i;
-        wl[i] = (double)fx_ceil_div(p[i].K, plan[i].sk) * (plan[i].tile ? 64 : 128);
+        wl[i] = (double)fx_ceil_div(p[i].K, plan[i].sk) * (plan[i].tile ? 64 : 128) + (plan[i].sk == 1 ? 1.0 : 0.0);
     }
     for (int a2 = 0; a2 < n; ++a2)
         for (int b2 = a2 + 1; b2 < n; ++b2)

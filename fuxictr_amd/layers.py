@@ -1546,7 +1546,7 @@ def linear_grads(dz, x, W, need_bias, mask=None, add=None):
     if N_out > 4 and K_in > 8 and not _FORCE_SPLITK:
         sk = max(sk, min(8, Bsz // 256))
     sk = max(sk, 1)
-    ws = _Workspace.get(dz.device, sk * N_out * (K_in + 1))
+    ws = _Workspace.get(dz.device, ops.gemm_workspace_floats(N_out, K_in, sk))
     db = torch.empty(N_out, dtype=torch.float32, device=dz.device) if need_bias else None
     ops.gemm_dw_dx(dz, x, W, dW, dx, split_k=sk, workspace=ws, rowsum=db, mask=mask, add=add)
     return dW, db, dx
@@ -1558,7 +1558,7 @@ def linear_weight_grads(dz, x, W_shape, need_bias):
     K_in = x.shape[1]
     dW = torch.empty(N_out, K_in, dtype=torch.float32, device=dz.device)
     sk = _split_k_for(N_out, K_in, Bsz)
-    ws = _Workspace.get(dz.device, sk * N_out * (K_in + 1))
+    ws = _Workspace.get(dz.device, ops.gemm_workspace_floats(N_out, K_in, sk))
     db = torch.empty(N_out, dtype=torch.float32, device=dz.device) if need_bias else None
     # the bias gradient (column sums of dz) rides along in the dW GEMM: its A tiles ARE dz
     ops.gemm(dz, x, dW, transa=True, transb=False, split_k=sk, workspace=ws, rowsum=db)

@@ -481,6 +481,12 @@ def lr_fwd(table1, ids, col_row_base, col_vocab, dense, num_w1, bias, out, scal)
     return out
 
 
+def gemm_workspace_floats(M, N, split_k):
+    """Floats of split-K workspace for an [M, N] product: split_k slabs + the partial row sums of the fused
+    bias gradient (one vector per slab and 64-wide tile column, include/fxctr.h)."""
+    return split_k * M * (N + N // 64 + 2) + 64
+
+
 def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul=None, mask=None,
          add=None, split_k=1, workspace=None, rowsum=None):
     """C = epilogue(op(A) . op(B)).  A, B, C: 2-D fp32 with unit inner stride."""
@@ -540,7 +546,7 @@ class _GemmProblem(object):
 def gemm_problem(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul=None,
                  mask=None, add=None, split_k=1, workspace=None, rowsum=None):
     """-> one entry for gemm_batch(); same arguments as gemm().  split_k is the LARGEST number of K slabs
-    `workspace` holds (split_k * M * (N + 1) floats); the library chooses the actual split."""
+    `workspace` holds (gemm_workspace_floats(M, N, split_k)); the library chooses the actual split."""
     epi = _epilogue(bias, act, zout, mul, mask, add, rowsum)
     return _GemmProblem(A, B_, C_, transa, transb, split_k, workspace, epi,
                         (A, B_, C_, bias, zout, mul, mask, add, workspace, rowsum))

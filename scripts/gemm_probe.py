@@ -19,7 +19,7 @@ def run(name, ta, tb, M, N, K, sk=1, bias=False, act=0, mask=False, add=False, r
     A = torch.randn((K, M) if ta else (M, K), device=dev, generator=g)
     Bm = torch.randn((N, K) if tb else (K, N), device=dev, generator=g)
     C = torch.empty(M, N, device=dev)
-    ws = torch.empty(max(sk * M * (N + 1), 1), device=dev)
+    ws = torch.empty(ops.gemm_workspace_floats(M, N, sk), device=dev)
     kw = dict(transa=bool(ta), transb=bool(tb), split_k=sk, workspace=ws)
     if bias:
         kw["bias"] = torch.randn(N, device=dev, generator=g)

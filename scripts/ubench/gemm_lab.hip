@@ -114,7 +114,7 @@ static void run_case(const Case& c, int reps = 20) {
     float* B = dalloc(N * K, 2);
     float* C = dalloc(M * N, 3);
     float* Cref = g_check ? dalloc(M * N, 4) : nullptr;
-    float* ws = dalloc((int64_t)std::max(c.sk, 1) * M * (N + 1) + 1024, 5);
+    float* ws = dalloc((int64_t)std::max(c.sk, 1) * M * (N + N / 64 + 2) + 1024, 5);
     fx_gemm_epilogue e;
     memset(&e, 0, sizeof(e));
     if (c.bias) e.bias = dalloc(N, 6);
@@ -198,7 +198,7 @@ static void run_pair(const char* name, int64_t M, int64_t N, int64_t K, int sk, 
     float* W = dalloc(N * K, 3);
     float* dW = dalloc(N * K, 4);
     float* dx = dalloc(M * K, 5);
-    float* ws = dalloc((int64_t)sk * N * (K + 1) + 1024, 6);
+    float* ws = dalloc((int64_t)sk * N * (K + K / 64 + 2) + 1024, 6);
     fx_gemm_epilogue e1, e2;
     memset(&e1, 0, sizeof(e1));
     memset(&e2, 0, sizeof(e2));
@@ -307,7 +307,7 @@ static void run_mix(const char* name, const char* kinds, int64_t M, int64_t N, i
             p[i].A = dalloc(M * N, 31 + i); p[i].lda = N; p[i].B = dalloc(M * K, 41 + i); p[i].ldb = K;
             p[i].C = dalloc(N * K, 51 + i); p[i].ldc = K;
             e[i].rowsum = dalloc(N, 61 + i);
-            p[i].split_k = sk; p[i].workspace = dalloc((int64_t)sk * N * (K + 1) + 1024, 71 + i);
+            p[i].split_k = sk; p[i].workspace = dalloc((int64_t)sk * N * (K + K / 64 + 2) + 1024, 71 + i);
         }
         p[i].epilogue = &e[i];
         flops += 2.0 * M * N * K;

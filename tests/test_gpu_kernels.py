@@ -397,7 +397,7 @@ def test_gemm_dw_dx_pair_is_bit_identical_to_the_two_gemms(M, N, K):
     W = _dev(torch.randn(N, K, generator=g) * 0.1)
     mask, add = _dev(torch.randn(M, K, generator=g)), _dev(torch.randn(M, K, generator=g))
     sk = 8 if M >= 2048 else 2
-    ws = torch.empty(sk * N * (K + 1) + 64, device=DEV)
+    ws = torch.empty(ops.gemm_workspace_floats(N, K, sk), device=DEV)
     out = []
     for pair in (True, True, False):
         dW = torch.full((N, K), float("nan"), device=DEV)
@@ -435,7 +435,7 @@ def test_gemm_batch_of_four_problems_in_one_grid():
         N, K = W.shape
         dW, dx = torch.full((N, K), float("nan"), device=DEV), torch.full((M, K), float("nan"), device=DEV)
         db = torch.full((N,), float("nan"), device=DEV)
-        ws = torch.empty(8 * N * (K + 1) + 64, device=DEV)
+        ws = torch.empty(ops.gemm_workspace_floats(N, K, 8), device=DEV)
         probs.append(ops.gemm_problem(dz, x, dW, transa=True, transb=False, split_k=8, workspace=ws,
                                       rowsum=db))
         probs.append(ops.gemm_problem(dz, W, dx, transa=False, transb=False))
@@ -500,7 +500,7 @@ def test_gemm_unaligned_rows_with_epilogues_split_k_and_views():
     dz = _dev(torch.randn(M, N, generator=g))
     dW = torch.empty(N, K, device=DEV)
     db = torch.empty(N, device=DEV)
-    ws = torch.empty(3 * N * (K + 1) + 64, device=DEV)
+    ws = torch.empty(ops.gemm_workspace_floats(N, K, 3), device=DEV)
     ops.gemm(dz, A, dW, transa=True, transb=False, split_k=3, workspace=ws, rowsum=db)
     refw = dz.double().t() @ A.double()
     assert (dW.double() - refw).abs().max().item() <= 3e-6 * (dz.abs().double().t() @ A.abs().double()).max().item()
@@ -569,7 +569,7 @@ def test_gemm_fused_rowsum_is_the_bias_gradient(M, N, K, sk):
     x = torch.randn(K, N, generator=g)           # [batch, K_in]
     dW = torch.empty(M, N, device=DEV)
     db = torch.full((M,), float("nan"), device=DEV)
-    ws = torch.empty(sk * M * (N + 1) + 64, device=DEV)
+    ws = torch.empty(ops.gemm_workspace_floats(M, N, sk), device=DEV)
     ops.gemm(_dev(dz), _dev(x), dW, transa=True, split_k=sk, workspace=ws, rowsum=db)
     ref = dz.double().t() @ x.double()
     assert (dW.cpu().double() - ref).abs().max().item() <= 3e-6 * (dz.abs().double().t() @ x.abs().double()).max().item()
