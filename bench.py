@@ -461,8 +461,10 @@ def rooflines(m, args, world):
     # of the tower and its two gradients run on the skinny HBM-bound kernels, not on k_gemm_f32_pipe)
     # ("gemm MxNxK": one product; "gemm2 MxNxK": the dW + dX pair of a layer as one launch, 4 M N K flops)
     def dims(k):
-        return [int(x) for x in k.split(" ", 1)[1].split("x")]
-    mf = [v for k, v in kt.items() if k.startswith(("gemm ", "gemm2 ")) and min(dims(k)) >= 64]
+        return [int(x) for part in k.split(" ", 1)[1].split("+") for x in part.split("x")]
+    # ("gemmN a+b+...": several independent products of one depth as ONE grid — DCNv2's cross and deep
+    # layer, forward, or their dW / dX products, backward)
+    mf = [v for k, v in kt.items() if k.startswith(("gemm ", "gemm2 ", "gemmN ")) and min(dims(k)) >= 64]
     g = None
     if mf:
         g = {"launches": sum(v["launches"] for v in mf), "total_ms": sum(v["total_ms"] for v in mf),
@@ -483,10 +485,12 @@ def rooflines(m, args, world):
                            "timing": m["timing_mode"]}
         shapes = {}
         for k, v in kt.items():
-            if k.startswith(("gemm ", "gemm2 ")) and v["total_ms"] > 0:
+            if k.startswith(("gemm ", "gemm2 ", "gemmN ")) and v["total_ms"] > 0:
                 tf = v["work"] / (v["total_ms"] * 1e-3) / 1e12
                 label = k.split(" ", 1)[1] + (" (dW+dX pair, incl. slab reduce)"
-                                              if k.startswith("gemm2 ") else "")
+                                              if k.startswith("gemm2 ") else
+                                              " (one grid, incl. slab reduces)"
+                                              if k.startswith("gemmN ") else "")
                 shapes[label] = {"launches_per_step": v["launches"] / n_inst,
                                  "avg_launch_us": round(v["avg_us"], 2),
                                  "tflops": round(tf, 1),

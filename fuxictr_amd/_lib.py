@@ -102,7 +102,7 @@ SIGNATURES = {
     "fx_gemm_f32": (i32, [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64,
                           C.POINTER(GemmEpilogue), i32, vp, vp]),
     "fx_colsum": (i32, [vp, i64, i64, i64, vp, vp, vp]),
-    "fx_mask_mul": (i32, [vp, i64, vp, vp, i64, i64, vp]),
+    "fx_mask_mul": (i32, [vp, i64, vp, i64, vp, i64, i64, vp]),
     "fx_cross_bwd_prep": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, vp]),
     "fx_sigmoid_bce": (i32, [vp, vp, i64, vp, vp, vp, vp]),
     "fx_din_concat_fwd": (i32, [vp, i64, vp, i64, i64, i64, i32, i32, vp, vp]),

@@ -1643,8 +1643,12 @@ static void fx_multi_plan(const MultiShape* sh, int n, MultiPlanItem* plan) {
     MultiPlanItem cand[FX_MULTI_MAX][16];
     for (int i = 0; i < n; ++i) {
         ncand[i] = 0;
+        const int64_t t128 = fx_ceil_div(sh[i].M, 128) * fx_ceil_div(sh[i].N, 128);
         for (int tile = 0; tile < 2; ++tile) {
             if (tile == 0 && sh[i].N <= 64) continue;
+            // (128x64 only for narrow or small outputs: on the big ones it measured no better than
+            // 128x128, profiles/r03_gemm_lab_b.txt, and the joint search stays small)
+            if (tile == 1 && sh[i].N > 64 && t128 >= 128) continue;
             for (int s = 0; s < 7; ++s) {
                 const int sk = SKS[s];
                 if (sk > 1 && (sk > sh[i].splittable || sh[i].K / sk < 256)) continue;
@@ -1925,25 +1929,25 @@ extern "C" int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, floa
 // joins the towers' outputs hands out strided views: read in place through its row stride instead of
 // a .contiguous() copy first)
 __global__ __launch_bounds__(256) void k_mask_mul(const float* dy, int64_t dy_ld, const float* y,
-                                                  float* out, uint32_t n, uint32_t cols) {
+                                                  int64_t y_ld, float* out, uint32_t n, uint32_t cols) {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t r = i / cols;
-        const float d = dy[(int64_t)r * dy_ld + (i - r * cols)];
-        out[i] = y[i] > 0.f ? d : 0.f;
+        const uint32_t r = i / cols, c = i - r * cols;
+        const float d = dy[(int64_t)r * dy_ld + c];
+        out[i] = y[(int64_t)r * y_ld + c] > 0.f ? d : 0.f;
     }
 }
 
-extern "C" int fx_mask_mul(const float* dy, int64_t dy_ld, const float* y, float* out, int64_t rows,
-                           int64_t cols, fx_stream_t stream) {
+extern "C" int fx_mask_mul(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, float* out,
+                           int64_t rows, int64_t cols, fx_stream_t stream) {
     const int64_t n = rows * cols;
     if (n <= 0) return FX_OK;
-    FX_CHECK_ARG(dy && y && out && dy_ld >= cols, "fx_mask_mul: bad arguments");
+    FX_CHECK_ARG(dy && y && out && dy_ld >= cols && y_ld >= cols, "fx_mask_mul: bad arguments");
     // (32-bit grid-stride counter: i += gridDim.x * 256 must not wrap)
     FX_CHECK_ARG(n < ((int64_t)1 << 31), "fx_mask_mul: more than 2^31 elements");
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_mask_mul, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), dy,
-                       dy_ld, y, out, (uint32_t)n, (uint32_t)cols);
+                       dy_ld, y, y_ld, out, (uint32_t)n, (uint32_t)cols);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

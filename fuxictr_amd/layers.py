@@ -2131,6 +2131,130 @@ class _CrossNetV2Fn(torch.autograd.Function):
         return (dxn,) + tuple(grads)
 
 
+def _dw_problem(dz, x, W, need_bias):
+    """-> (problem, dW, db) for dW[N_out, K_in] = dz^T x with the fused bias gradient."""
+    Bsz, N_out = dz.shape
+    K_in = x.shape[1]
+    dW = torch.empty(N_out, K_in, dtype=torch.float32, device=dz.device)
+    sk = max(_split_k_for(N_out, K_in, Bsz), 1 if _FORCE_SPLITK else min(8, Bsz // 256), 1)
+    ws = torch.empty(ops.gemm_workspace_floats(N_out, K_in, sk), dtype=torch.float32, device=dz.device)
+    db = torch.empty(N_out, dtype=torch.float32, device=dz.device) if need_bias else None
+    return ops.gemm_problem(dz, x, dW, transa=True, transb=False, split_k=sk, workspace=ws,
+                            rowsum=db), dW, db
+
+
+class _CrossDeepFn(torch.autograd.Function):
+    """DCNv2 `model_structure: parallel` (model_zoo/DCNv2/src/DCNv2.py:108-132): CrossNetV2 over x0
+    (cross_net.py:126-129) and the deep tower over x0 (mlp_block.py:96) are independent until the head,
+    so layer i of one and layer i of the other leave as ONE grid (fx_gemm_f32_batch: the 160 tiles of a
+    624-wide cross product fill the second workgroup slot of the CUs beside the deep layer's tiles —
+    alone they occupy 62 % of the chip).  The two results are written side by side into one
+    [B, D0 + H] buffer: the concatenation that feeds `fc` is never a launch.
+    Backward pairs the layers from the top so that the tower with more layers finishes LAST and alone:
+    its final dX takes the other tower's x0 gradient in its epilogue (no separate add).
+    args = (x0, n_cross, acts, cross W0, b0, ..., deep W0, b0, ...)."""
+
+    @staticmethod
+    def forward(ctx, x0, n_cross, acts, *wb):
+        x0 = x0.contiguous()
+        B, D0 = x0.shape
+        cwb, dwb = wb[:2 * n_cross], wb[2 * n_cross:]
+        n_deep = len(acts)
+        H = dwb[2 * (n_deep - 1)].shape[0]
+        out = torch.empty(B, D0 + H, dtype=torch.float32, device=x0.device)
+        xs, zs, hs = [x0], [], [x0]
+        for i in range(max(n_cross, n_deep)):
+            probs = []
+            if i < n_cross:
+                W, b = cwb[2 * i], cwb[2 * i + 1]
+                z = torch.empty_like(x0)
+                xn = out[:, :D0] if i == n_cross - 1 else torch.empty_like(x0)
+                probs.append(ops.gemm_problem(xs[-1], W, xn, transb=True, bias=b, zout=z, mul=x0,
+                                              add=xs[-1]))
+                xs.append(xn)
+                zs.append(z)
+            if i < n_deep:
+                W, b = dwb[2 * i], dwb[2 * i + 1]
+                y = out[:, D0:] if i == n_deep - 1 else \
+                    torch.empty(B, W.shape[0], dtype=torch.float32, device=x0.device)
+                probs.append(ops.gemm_problem(hs[-1], W, y, transb=True, bias=b,
+                                              act=1 if acts[i] else 0))
+                hs.append(y)
+            ops.gemm_batch(probs)
+        ctx.n_cross, ctx.acts, ctx.wb = n_cross, acts, wb
+        ctx.xs, ctx.zs, ctx.hs, ctx.D0 = xs, zs, hs, D0
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n_cross, acts, wb = ctx.n_cross, ctx.acts, ctx.wb
+        xs, zs, hs, D0 = ctx.xs, ctx.zs, ctx.hs, ctx.D0
+        cwb, dwb = wb[:2 * n_cross], wb[2 * n_cross:]
+        n_deep = len(acts)
+        x0 = xs[0]
+        if dout.stride(-1) != 1:
+            dout = dout.contiguous()
+        dxn = dout[:, :D0]                                  # row-strided views, read in place
+        ddeep = dout[:, D0:]
+        if acts[n_deep - 1]:
+            dz = ops.mask_mul(ddeep, hs[n_deep], torch.empty_like(hs[n_deep]))
+        else:
+            dz = ddeep.contiguous()
+        dx0 = torch.empty_like(x0)
+        t = torch.empty_like(x0)
+        grads = [None] * (2 * (n_cross + n_deep))
+        ic, idp = n_cross - 1, n_deep - 1
+        g_cross = g_deep = None        # the finished x0 gradient of a tower
+        while ic >= 0 or idp >= 0:
+            probs, post = [], []
+            # the last layer of the tower that finishes LAST adds the other tower's x0 gradient
+            if ic >= 0:
+                W, b = cwb[2 * ic], cwb[2 * ic + 1]
+                ops.cross_bwd_prep(dxn, x0, zs[ic], t, dx0, init=(ic == n_cross - 1),
+                                   add_dxn=(ic == 0))
+                pw, dW, db = _dw_problem(t, xs[ic], W, b is not None)
+                dxi = torch.empty_like(x0)
+                add = dx0 if ic == 0 else dxn
+                probs += [pw, ops.gemm_problem(t, W, dxi, add=add)]
+                grads[2 * ic], grads[2 * ic + 1] = dW, db
+                post.append(("c", dxi))
+            if idp >= 0:
+                W, b = dwb[2 * idp], dwb[2 * idp + 1]
+                pw, dW, db = _dw_problem(dz, hs[idp], W, b is not None)
+                dh = torch.empty_like(hs[idp])
+                mask = hs[idp] if (idp > 0 and acts[idp - 1]) else None
+                add = g_cross if (idp == 0 and ic < 0 and g_cross is not None) else None
+                probs += [pw, ops.gemm_problem(dz, W, dh, mask=mask, add=add)]
+                grads[2 * (n_cross + idp)], grads[2 * (n_cross + idp) + 1] = dW, db
+                post.append(("d", dh))
+            if ic == 0 and idp < 0 and g_deep is not None:
+                # cross finishes last and alone: its epilogue already adds dx0; the deep tower's x0
+                # gradient joins through dx0 (one elementwise add on 10 MB, only in this rare shape)
+                dx0.add_(g_deep)
+                g_deep = None
+            ops.gemm_batch(probs)
+            for kind, val in post:
+                if kind == "c":
+                    dxn = val
+                    if ic == 0:
+                        g_cross = val
+                else:
+                    dz = val
+                    if idp == 0:
+                        g_deep = val
+            if ic >= 0:
+                ic -= 1
+            if idp >= 0:
+                idp -= 1
+        # both finished in the same launch (equal depth), or cross last with the add above
+        if g_cross is not None and g_deep is not None:
+            used_add = (n_deep > n_cross)               # deep's last dX took g_cross in its epilogue
+            dx = g_deep if used_add else g_cross + g_deep
+        else:
+            dx = g_cross if g_cross is not None else g_deep
+        return (dx, None, None) + tuple(grads)
+
+
 class CrossNetV2(nn.Module):
     """cross_net.py:95-129."""
 

@@ -604,7 +604,7 @@ def colsum(X, out, workspace):
 def mask_mul(dy, y, out):
     """dy: [rows, cols] with unit inner stride (a column slice of a wider tensor is read in place)."""
     rows, cols = dy.shape
-    check(_lib.load().fx_mask_mul(ptr(dy), dy.stride(0), ptr(y), ptr(out), rows, cols,
+    check(_lib.load().fx_mask_mul(ptr(dy), dy.stride(0), ptr(y), y.stride(0), ptr(out), rows, cols,
                                   stream_ptr(dy.device)), "fx_mask_mul")
     return out
 

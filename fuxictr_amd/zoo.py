@@ -92,12 +92,33 @@ class DCNv2(_ZooModel):
         X = self.get_inputs(inputs)
         flat = self.embedding_layer(X, flatten_emb=True)    # [B, F*D]
         stacked, parallel = self._STRUCTURES[self.model_structure]
-        branch = self.crossnet(flat)
-        if stacked:
-            branch = self.stacked_dnn(branch)
-        if parallel:
-            branch = torch.cat([branch, self.parallel_dnn(flat)], dim=-1)
+        fused = self._fused_parallel(flat) if (parallel and not stacked) else None
+        if fused is not None:
+            branch = fused                                   # [cross | deep], one buffer, no cat
+        else:
+            branch = self.crossnet(flat)
+            if stacked:
+                branch = self.stacked_dnn(branch)
+            if parallel:
+                branch = torch.cat([branch, self.parallel_dnn(flat)], dim=-1)
         return {"y_pred": self.output_activation(self.fc(branch))}
+
+    def _fused_parallel(self, flat):
+        """`parallel`: cross layer i and deep layer i as one grid (layers._CrossDeepFn) when the deep
+        tower is a plain Linear / ReLU stack over 16-byte aligned rows; else None."""
+        from .layers import _CrossDeepFn
+        fz = getattr(self.parallel_dnn, "_fused", None)
+        if fz is None or fz[1] or flat.dim() != 2 or flat.shape[1] % 4 or self.crossnet.num_layers < 1:
+            return None
+        stack = fz[0]
+        if any(lin.weight.shape[0] % 4 for lin, _ in stack):
+            return None
+        wb = []
+        for lin in self.crossnet.cross_layers:
+            wb += [lin.weight, lin.bias]
+        for lin, _ in stack:
+            wb += [lin.weight, lin.bias]
+        return _CrossDeepFn.apply(flat, self.crossnet.num_layers, tuple(r for _, r in stack), *wb)
 
 
 def _fields(spec):

@@ -394,8 +394,9 @@ int fx_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, flo
 /* ReLU backward for a tower whose LAST layer is activated (e.g. DCNv2 parallel_dnn,
  * mlp_block.py:80-81 with output_dim=None): out[i] = y[i] > 0 ? dy[i] : 0.  (Inner layers get
  * this mask for free in the dX GEMM epilogue.)  dy is [rows, cols] with row stride dy_ld (it may be a
- * column slice of the gradient of a torch.cat); y and out are contiguous. */
-int fx_mask_mul(const float* dy, int64_t dy_ld, const float* y, float* out, int64_t rows,
+ * column slice of the gradient of a torch.cat), y [rows, cols] with row stride y_ld (it may be a column
+ * slice of the [cross | deep] buffer that feeds DCNv2's head); out is contiguous. */
+int fx_mask_mul(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, float* out, int64_t rows,
                 int64_t cols, fx_stream_t stream);
 
 /* CrossNetV2 backward glue (autograd of cross_net.py:128), one pass over [n] elements:

@@ -279,28 +279,40 @@ static void run_pair(const char* name, int64_t M, int64_t N, int64_t K, int sk, 
     HC(hipFree(dz)); HC(hipFree(x)); HC(hipFree(W)); HC(hipFree(dW)); HC(hipFree(dx)); HC(hipFree(ws));
 }
 
-// several problems through fx_gemm_f32_batch: kind 'f' = forward (A[M,K] x W[N,K]^T, bias + relu),
-// 'x' = input gradient (dz[M,N'] x W[N',K']), 'w' = weight gradient (dz^T x, split-K, rowsum)
-static void run_mix(const char* name, const char* kinds, int64_t M, int64_t N, int64_t K, int sk,
-                    int reps = 20) {
-    const int n = (int)strlen(kinds);
+// several problems through fx_gemm_f32_batch.  spec: "k:M,N,K;k:M,N,K;..." (layer sizes: batch M, out N,
+// in K) with kind k = f forward (bias + relu), c cross forward (bias + zout + mul + add), x input gradient
+// (relu mask), a input gradient (residual add), w weight gradient (K split allowed, fused bias gradient)
+static void run_mix(const char* name, const char* spec, int sk, int reps = 20) {
     fx_gemm_problem p[4];
     fx_gemm_epilogue e[4];
     memset(p, 0, sizeof(p));
     memset(e, 0, sizeof(e));
     double flops = 0;
-    for (int i = 0; i < n; ++i) {
-        if (kinds[i] == 'f') {
+    int n = 0;
+    const char* q = spec;
+    while (*q && n < 4) {
+        const char kind = *q;
+        long long M = 0, N = 0, K = 0;
+        sscanf(q + 2, "%lld,%lld,%lld", &M, &N, &K);
+        const int i = n++;
+        if (kind == 'f' || kind == 'c') {
             p[i].transa = 0; p[i].transb = 1; p[i].M = M; p[i].N = N; p[i].K = K;
             p[i].A = dalloc(M * K, 31 + i); p[i].lda = K; p[i].B = dalloc(N * K, 41 + i); p[i].ldb = K;
             p[i].C = dalloc(M * N, 51 + i); p[i].ldc = N;
-            e[i].bias = dalloc(N, 61 + i); e[i].act = 1;
+            e[i].bias = dalloc(N, 61 + i);
+            if (kind == 'f') e[i].act = 1;
+            else {
+                e[i].zout = dalloc(M * N, 81 + i); e[i].ldz = N;
+                e[i].mul = dalloc(M * N, 91 + i); e[i].ldmul = N;
+                e[i].add = dalloc(M * N, 101 + i); e[i].ldadd = N;
+            }
             p[i].split_k = 1;
-        } else if (kinds[i] == 'x') {
+        } else if (kind == 'x' || kind == 'a') {
             p[i].transa = 0; p[i].transb = 0; p[i].M = M; p[i].N = K; p[i].K = N;
             p[i].A = dalloc(M * N, 31 + i); p[i].lda = N; p[i].B = dalloc(N * K, 41 + i); p[i].ldb = K;
             p[i].C = dalloc(M * K, 51 + i); p[i].ldc = K;
-            e[i].mask = dalloc(M * K, 61 + i); e[i].ldmask = K;
+            if (kind == 'x') { e[i].mask = dalloc(M * K, 61 + i); e[i].ldmask = K; }
+            else { e[i].add = dalloc(M * K, 61 + i); e[i].ldadd = K; }
             p[i].split_k = 1;
         } else {
             p[i].transa = 1; p[i].transb = 0; p[i].M = N; p[i].N = K; p[i].K = M;
@@ -311,6 +323,8 @@ static void run_mix(const char* name, const char* kinds, int64_t M, int64_t N, i
         }
         p[i].epilogue = &e[i];
         flops += 2.0 * M * N * K;
+        while (*q && *q != ';') ++q;
+        if (*q == ';') ++q;
     }
     auto launch = [&]() {
         if (fx_gemm_f32_batch(p, n, nullptr) != FX_OK) { fprintf(stderr, "batch failed\n"); exit(3); }
@@ -388,15 +402,25 @@ int main(int argc, char** argv) {
         run_case({"dX 4096x1024x1024 relu mask", 0, 0, B, 1024, 1024, 1, false, false, true, false, false, false, false});
     }
     if (suite == "mix") {   // where does a multi-problem launch lose time?
-        run_mix("multi: fwd alone (n = 1)", "f", B, 1024, 1024, 1);
-        run_mix("multi: fwd + fwd", "ff", B, 1024, 1024, 1);
-        run_mix("multi: dX alone", "x", B, 1024, 1024, 1);
-        run_mix("multi: dX + dX", "xx", B, 1024, 1024, 1);
-        run_mix("multi: dW alone (cap 4)", "w", B, 1024, 1024, 4);
-        run_mix("multi: dW + dW (cap 4)", "ww", B, 1024, 1024, 4);
-        run_mix("multi: dW + dX (cap 4)", "wx", B, 1024, 1024, 4);
-        run_mix("multi: fwd + dX", "fx", B, 1024, 1024, 1);
-        run_mix("multi: dW + fwd (cap 4)", "wf", B, 1024, 1024, 4);
+        run_mix("multi: fwd alone (n = 1)", "f:4096,1024,1024", 1);
+        run_mix("multi: fwd + fwd", "f:4096,1024,1024;f:4096,1024,1024", 1);
+        run_mix("multi: dX + dX", "x:4096,1024,1024;x:4096,1024,1024", 1);
+        run_mix("multi: dW alone (cap 4)", "w:4096,1024,1024", 4);
+        run_mix("multi: dW + dW (cap 4)", "w:4096,1024,1024;w:4096,1024,1024", 4);
+        run_mix("multi: dW + dX (cap 4)", "w:4096,1024,1024;x:4096,1024,1024", 4);
+        run_mix("multi: fwd + dX", "f:4096,1024,1024;x:4096,1024,1024", 1);
+    }
+    if (suite == "dcn") {   // DCNv2 parallel: cross layer + deep layer of one depth
+        run_mix("cross fwd alone", "c:4096,624,624", 1);
+        run_mix("deep fwd 1024x1024 alone", "f:4096,1024,1024", 1);
+        run_mix("deep fwd 1024x624 alone", "f:4096,1024,624", 1);
+        run_mix("cross fwd + deep fwd 1024x1024", "c:4096,624,624;f:4096,1024,1024", 1);
+        run_mix("cross fwd + deep fwd 1024x624", "c:4096,624,624;f:4096,1024,624", 1);
+        run_mix("cross pair alone (dW + dX add)", "w:4096,624,624;a:4096,624,624", 8);
+        run_mix("deep pair 1024x1024 alone", "w:4096,1024,1024;x:4096,1024,1024", 8);
+        run_mix("deep pair 1024x624 alone", "w:4096,1024,624;a:4096,1024,624", 8);
+        run_mix("cross pair + deep pair 1024x1024", "w:4096,624,624;a:4096,624,624;w:4096,1024,1024;x:4096,1024,1024", 8);
+        run_mix("cross pair + deep pair 1024x624", "w:4096,624,624;a:4096,624,624;w:4096,1024,624;a:4096,1024,624", 8);
     }
     if (suite == "pairs") {
         run_pair("pair 4096x1024x1024 (dW + dX mask)", B, 1024, 1024, 8, true, false);

@@ -348,6 +348,19 @@ def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul
     return C_
 
 
+def gemm_problem(A, B_, C_, **kw):
+    return (A, B_, C_, kw)
+
+
+def gemm_batch(problems):
+    for A, B_, C_, kw in problems:
+        gemm(A, B_, C_, **kw)
+
+
+def gemm_workspace_floats(M, N, split_k):
+    return split_k * M * (N + N // 64 + 2) + 64
+
+
 def gemm_dw_dx(dz, x, W, dW, dx, split_k=1, workspace=None, rowsum=None, mask=None, add=None):
     gemm(dz, x, dW, transa=True, transb=False, split_k=split_k, workspace=workspace, rowsum=rowsum)
     gemm(dz, W, dx, transa=False, transb=False, mask=mask, add=add)
@@ -812,7 +825,8 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats", "adam_catchup_all", "adam_catchup_rows",
          "dice_local_sums", "dice_fwd_from_sums", "dice_bwd_local_sums", "dice_bwd_from_sums",
          "din_attn_workspace_floats", "din_attn_stats", "dice_stats_from_sums", "din_attn_fwd",
-         "din_attn_bwd_sums", "din_attn_bwd", "gemm_dw_dx", "split_rows"]
+         "din_attn_bwd_sums", "din_attn_bwd", "gemm_dw_dx", "split_rows", "gemm_problem", "gemm_batch",
+         "gemm_workspace_floats"]
 
 
 def install_plain():
