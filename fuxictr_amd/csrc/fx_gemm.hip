@@ -1488,11 +1488,10 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
 
 // ---------------------------------------------------------------------------------------------
 // fx_gemm_f32_batch: several independent GEMMs in as few launches as possible.
-//   multi path  (default for <= FX_MULTI_MAX aligned, non-skinny problems): ONE k_gemm_f32_multi grid on
-//               128-row tiles, two workgroups per CU; per problem the tile (128x128 | 128x64) and — where
-//               the caller allows a K split (split_k > 1) — the number of K slabs are chosen by a small
-//               list-scheduling model of the launch (256 CUs x 2 slots, workgroups handed out in index
-//               order, longest problem first), cached per shape signature;
+//   multi path  (default for 2 .. FX_MULTI_MAX aligned, non-skinny problems of a backward pass): ONE
+//               k_gemm_f32_multi grid on 128-row tiles, two workgroups per CU; per problem the tile
+//               (128x128 | 128x64) and — where the caller allows a K split (split_k > 1) — the number of
+//               K slabs follow fx_multi_plan's rules, longest workgroups first in the grid;
 //   pair path   (FX_GEMM_MULTI=0): the dW / dX pair of round 2 on 64x64 tiles;
 //   else        problem by problem.
 // ---------------------------------------------------------------------------------------------
@@ -1501,191 +1500,48 @@ struct MultiPlanItem {
     int sk;
 };
 
-// time of one launch under the model: each workgroup carries `w` us of matrix-pipe work (at full rate) +
-// a fixed prologue / epilogue cost; a CU with two resident workgroups shares its pipes evenly at
-// FX_E2 efficiency, a workgroup alone runs at FX_E1[tile]
-static double fx_multi_simulate(const double* w, const int* tile, int nwg) {
-    constexpr int CUS = 256;
-    static const double E1[2] = {0.90, 0.84};
-    constexpr double E2 = 0.96, FIXED = 2.5;
-    double rem[CUS][2];
-    int til[CUS][2], cnt[CUS];
-    double now[CUS];
-    for (int c = 0; c < CUS; ++c) { cnt[c] = 0; now[c] = 0.0; }
-    int next = 0;
-    // initial placement: round-robin, one per CU, then the second slot
-    for (int slot = 0; slot < 2; ++slot)
-        for (int c = 0; c < CUS && next < nwg; ++c) {
-            rem[c][cnt[c]] = w[next] + FIXED;
-            til[c][cnt[c]] = tile[next];
-            ++cnt[c];
-            ++next;
-        }
-    double makespan = 0.0;
-    // event loop: repeatedly take the CU whose next completion is earliest
-    while (true) {
-        int best = -1;
-        double bt = 1e300;
-        for (int c = 0; c < CUS; ++c) {
-            if (cnt[c] == 0) continue;
-            double t;
-            if (cnt[c] == 1) t = now[c] + rem[c][0] / E1[til[c][0]];
-            else {
-                const double r = rem[c][0] < rem[c][1] ? rem[c][0] : rem[c][1];
-                t = now[c] + r / (0.5 * E2);
-            }
-            if (t < bt) { bt = t; best = c; }
-        }
-        if (best < 0) break;
-        const int c = best;
-        const double dt = bt - now[c];
-        if (cnt[c] == 1) {
-            cnt[c] = 0;
-        } else {
-            const int f = rem[c][0] < rem[c][1] ? 0 : 1;
-            const double done = dt * 0.5 * E2;
-            rem[c][1 - f] -= done;
-            if (f == 0) { rem[c][0] = rem[c][1]; til[c][0] = til[c][1]; }
-            cnt[c] = 1;
-        }
-        now[c] = bt;
-        makespan = bt;
-        if (next < nwg) {
-            rem[c][cnt[c]] = w[next] + FIXED;
-            til[c][cnt[c]] = tile[next];
-            ++cnt[c];
-            ++next;
-        }
-    }
-    return makespan;
-}
-
 struct MultiShape {
     int64_t M, N, K;
     int splittable;      // 0: no K split; else the LARGEST number of slabs the caller's workspace holds
 };
 
-static double fx_multi_cost(const MultiShape* sh, int n, const MultiPlanItem* plan, const int* order,
-                            double* wbuf, int* tbuf, int cap) {
-    int nwg = 0;
-    double extra = 0.0;
-    for (int oi = 0; oi < n; ++oi) {
-        const int i = order[oi];
-        const int bn = plan[i].tile ? 64 : 128;
-        const int64_t tiles = fx_ceil_div(sh[i].M, 128) * fx_ceil_div(sh[i].N, bn);
-        const int64_t kc = fx_ceil_div(fx_ceil_div(sh[i].K, plan[i].sk), FX_BK) * FX_BK;
-        const int sk = (int)fx_ceil_div(sh[i].K, kc);
-        const double w = (double)kc * 128.0 * bn / 307200.0;      // us at the full matrix-pipe rate
-        for (int z = 0; z < sk; ++z) {
-            const int64_t klen = (z + 1) * kc <= sh[i].K ? kc : sh[i].K - z * kc;
-            for (int64_t t = 0; t < tiles; ++t) {
-                if (nwg >= cap) return 1e300;
-                wbuf[nwg] = w * (double)klen / (double)kc;
-                tbuf[nwg] = plan[i].tile;
-                ++nwg;
-            }
-        }
-        if (sk > 1)     // slab reduce: (sk reads + 1 write) of the output at ~3.5 TB/s + a launch
-            extra += 2.0 + (double)(sk + 1) * sh[i].M * sh[i].N * 4.0 / 3.5e6;
-    }
-    return fx_multi_simulate(wbuf, tbuf, nwg) + extra;
-}
-
-// -> plan[i] for every problem (cached per shape signature; FX_MULTI_CFG="tile,sk;tile,sk;..." overrides)
+// Tile and K split of every problem of one multi-problem launch.  Rules read off the forced-configuration
+// sweeps of round 3 (profiles/r03_gemm_lab_f.txt; a list-scheduling model of the launch was tried first
+// and ranked the candidates poorly — 16 % off the best configuration on DCNv2's first layer):
+//   * a K split brings the slabs of a weight gradient to ~1024 deep (what the other problems of the
+//     launch run: equal workgroup lengths pack best), within the caller's cap;
+//   * 128x128 tiles, unless the problem then has fewer workgroups than CUs: 128x64 doubles them (the
+//     624-wide CrossNet products: 100 / 160 -> 200 / 320 workgroups fill the second slot of the CUs
+//     beside the deep layer's 256 + 256) — 258 -> 234 us on cross + deep 1024, 201 -> 182 us on the
+//     first layer.
+// FX_MULTI_CFG="tile,sk;tile,sk;..." overrides (experiments).
 static void fx_multi_plan(const MultiShape* sh, int n, MultiPlanItem* plan) {
+    for (int i = 0; i < n; ++i) {
+        int sk = 1;
+        if (sh[i].splittable > 1) {
+            sk = (int)((sh[i].K + 512) / 1024);
+            if (sk > sh[i].splittable) sk = sh[i].splittable;
+            if (sk < 1) sk = 1;
+        }
+        const int64_t t128 = fx_ceil_div(sh[i].M, 128) * fx_ceil_div(sh[i].N, 128);
+        plan[i].sk = sk;
+        plan[i].tile = (sh[i].N <= 64 || t128 * sk < 256) ? 1 : 0;
+    }
     static const char* forced = getenv("FX_MULTI_CFG");
     if (forced) {
         const char* q = forced;
-        for (int i = 0; i < n; ++i) {
-            plan[i].tile = 0;
-            plan[i].sk = sh[i].splittable >= 4 ? 4 : (sh[i].splittable ? sh[i].splittable : 1);
-            if (*q) {
-                plan[i].tile = atoi(q);
-                while (*q && *q != ',' && *q != ';') ++q;
-                if (*q == ',') {
-                    ++q;
-                    const int sk = atoi(q);
-                    if (sk >= 1 && sk <= (sh[i].splittable ? sh[i].splittable : 1)) plan[i].sk = sk;
-                    while (*q && *q != ';') ++q;
-                }
-                if (*q == ';') ++q;
+        for (int i = 0; i < n && *q; ++i) {
+            plan[i].tile = atoi(q);
+            while (*q && *q != ',' && *q != ';') ++q;
+            if (*q == ',') {
+                ++q;
+                const int sk = atoi(q);
+                if (sk >= 1 && sk <= (sh[i].splittable ? sh[i].splittable : 1)) plan[i].sk = sk;
+                while (*q && *q != ';') ++q;
             }
+            if (*q == ';') ++q;
             if (sh[i].N <= 64) plan[i].tile = 1;
         }
-        return;
-    }
-    struct Entry {
-        MultiShape sh[FX_MULTI_MAX];
-        int n;
-        MultiPlanItem plan[FX_MULTI_MAX];
-    };
-    static Entry cache[64];
-    static int ncache = 0;
-    for (int e = 0; e < ncache; ++e) {
-        if (cache[e].n != n) continue;
-        bool same = true;
-        for (int i = 0; i < n && same; ++i)
-            same = cache[e].sh[i].M == sh[i].M && cache[e].sh[i].N == sh[i].N &&
-                   cache[e].sh[i].K == sh[i].K && cache[e].sh[i].splittable == sh[i].splittable;
-        if (same) {
-            for (int i = 0; i < n; ++i) plan[i] = cache[e].plan[i];
-            return;
-        }
-    }
-    static const int SKS[] = {1, 2, 3, 4, 5, 6, 8};
-    constexpr int CAP = 16384;
-    static double wbuf[CAP];
-    static int tbuf[CAP];
-    int order[FX_MULTI_MAX];
-    MultiPlanItem cur[FX_MULTI_MAX], best[FX_MULTI_MAX];
-    double best_t = 1e300;
-    int ncand[FX_MULTI_MAX];
-    MultiPlanItem cand[FX_MULTI_MAX][16];
-    for (int i = 0; i < n; ++i) {
-        ncand[i] = 0;
-        const int64_t t128 = fx_ceil_div(sh[i].M, 128) * fx_ceil_div(sh[i].N, 128);
-        for (int tile = 0; tile < 2; ++tile) {
-            if (tile == 0 && sh[i].N <= 64) continue;
-            // (128x64 only for narrow or small outputs: on the big ones it measured no better than
-            // 128x128, profiles/r03_gemm_lab_b.txt, and the joint search stays small)
-            if (tile == 1 && sh[i].N > 64 && t128 >= 128) continue;
-            for (int s = 0; s < 7; ++s) {
-                const int sk = SKS[s];
-                if (sk > 1 && (sk > sh[i].splittable || sh[i].K / sk < 256)) continue;
-                cand[i][ncand[i]].tile = tile;
-                cand[i][ncand[i]].sk = sk;
-                ++ncand[i];
-            }
-        }
-    }
-    int idx[FX_MULTI_MAX] = {0, 0, 0, 0};
-    while (true) {
-        for (int i = 0; i < n; ++i) cur[i] = cand[i][idx[i]];
-        // longest workgroups first
-        double wl[FX_MULTI_MAX];
-        for (int i = 0; i < n; ++i) {
-            order[i] = i;
-            // (ties: the problem with the direct epilogue — mask / add / bias loads, the longer drain —
-            // before the slab writer, so that its drain runs beside the other's K loop)
-            wl[i] = (double)fx_ceil_div(sh[i].K, cur[i].sk) * (cur[i].tile ? 64 : 128) + (cur[i].sk == 1 ? 1.0 : 0.0);
-        }
-        for (int a2 = 0; a2 < n; ++a2)
-            for (int b2 = a2 + 1; b2 < n; ++b2)
-                if (wl[order[b2]] > wl[order[a2]]) { const int t = order[a2]; order[a2] = order[b2]; order[b2] = t; }
-        const double t = fx_multi_cost(sh, n, cur, order, wbuf, tbuf, CAP);
-        if (t < best_t) {
-            best_t = t;
-            for (int i = 0; i < n; ++i) best[i] = cur[i];
-        }
-        int d = 0;
-        while (d < n && ++idx[d] == ncand[d]) { idx[d] = 0; ++d; }
-        if (d == n) break;
-    }
-    for (int i = 0; i < n; ++i) plan[i] = best[i];
-    if (ncache < 64) {
-        Entry& e = cache[ncache++];
-        e.n = n;
-        for (int i = 0; i < n; ++i) { e.sh[i] = sh[i]; e.plan[i] = best[i]; }
     }
 }
 
@@ -1722,7 +1578,12 @@ static int fx_gemm_multi_mode() {     // FX_GEMM_MULTI=0: the 64x64 pair / per-p
 // -> FX_OK and *launched = true when the problems went out as one k_gemm_f32_multi grid
 static int fx_gemm_try_multi(const fx_gemm_problem* p, int32_t n, fx_stream_t stream, bool* launched) {
     *launched = false;
-    if (n < 1 || n > FX_MULTI_MAX || !fx_gemm_multi_mode()) return FX_OK;
+    if (n < 2 || n > FX_MULTI_MAX || !fx_gemm_multi_mode()) return FX_OK;
+    // (two forward-type products — no K split anywhere — measured no better as one grid than as two
+    // launches with their own tile shapes: 125 vs 122 us for DCNv2's cross + deep forward)
+    bool any_split = false;
+    for (int i = 0; i < n; ++i) any_split = any_split || (p[i].split_k > 1 && p[i].workspace);
+    if (!any_split) return FX_OK;
     MultiShape sh[FX_MULTI_MAX];
     for (int i = 0; i < n; ++i) {
         const fx_gemm_problem& q = p[i];

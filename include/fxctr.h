@@ -366,8 +366,9 @@ int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
  * dX = dZ W (transa = 0, transb = 0) of one Linear / CrossNet layer, the two `aten::mm` of its autograd
  * (mlp_block.py:96, cross_net.py:128 at rank_model.py:320), which share dZ and are independent; for
  * DCNv2's parallel structure also the cross and the deep layer of one depth (DCNv2.py:108-132) — leave
- * as ONE grid on 128-row tiles with two workgroups per CU: the tile (128x128 | 128x64) and the K split
- * of every problem are chosen together for the launch by a list-scheduling model of the 256 CUs.
+ * as ONE grid on 128-row tiles with two workgroups per CU (launches that contain a K-split problem, i.e.
+ * backward passes; two forward products go out as two launches): per problem a 128x128 tile, or 128x64
+ * when that leaves fewer workgroups than CUs, and K slabs ~1024 deep.
  * A problem's split_k is the LARGEST number of K slabs its workspace holds (split_k * M * (N + 1)
  * floats); the library never uses more.  problems_host is a HOST array. */
 typedef struct fx_gemm_problem {
