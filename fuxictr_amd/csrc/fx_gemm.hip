@@ -1510,12 +1510,22 @@ struct MultiShape {
 // and ranked the candidates poorly — 16 % off the best configuration on DCNv2's first layer):
 //   * a K split brings the slabs of a weight gradient to ~1024 deep (what the other problems of the
 //     launch run: equal workgroup lengths pack best), within the caller's cap;
-//   * 128x128 tiles, unless the problem then has fewer workgroups than CUs: 128x64 doubles them (the
+//   * 128x128 tiles, unless the problem then has fewer workgroups than CUs AND is one of the small
+//     products of the launch (< 0.7 of the largest one's flops): 128x64 doubles its workgroups (the
 //     624-wide CrossNet products: 100 / 160 -> 200 / 320 workgroups fill the second slot of the CUs
 //     beside the deep layer's 256 + 256) — 258 -> 234 us on cross + deep 1024, 201 -> 182 us on the
-//     first layer.
+//     first layer;
+//   * returns the launch's workgroup count on 128x128 tiles: below 512 (two per CU) the grid cannot
+//     keep both slots busy and the 64x64 pair kernel / single launches win (pair 1024x624: 147 vs 126
+//     us, 256x512: 57 vs 30 us, profiles/r03_gemm_lab_g.txt) — the caller falls back.
 // FX_MULTI_CFG="tile,sk;tile,sk;..." overrides (experiments).
-static void fx_multi_plan(const MultiShape* sh, int n, MultiPlanItem* plan) {
+static int64_t fx_multi_plan(const MultiShape* sh, int n, MultiPlanItem* plan) {
+    double fmax = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double f = (double)sh[i].M * sh[i].N * sh[i].K;
+        if (f > fmax) fmax = f;
+    }
+    int64_t wg128 = 0;         // workgroups of the launch on 128x128 tiles
     for (int i = 0; i < n; ++i) {
         int sk = 1;
         if (sh[i].splittable > 1) {
@@ -1524,8 +1534,10 @@ static void fx_multi_plan(const MultiShape* sh, int n, MultiPlanItem* plan) {
             if (sk < 1) sk = 1;
         }
         const int64_t t128 = fx_ceil_div(sh[i].M, 128) * fx_ceil_div(sh[i].N, 128);
+        const double f = (double)sh[i].M * sh[i].N * sh[i].K;
         plan[i].sk = sk;
-        plan[i].tile = (sh[i].N <= 64 || t128 * sk < 256) ? 1 : 0;
+        plan[i].tile = (sh[i].N <= 64 || (t128 * sk < 256 && f < 0.7 * fmax)) ? 1 : 0;
+        wg128 += t128 * sk;
     }
     static const char* forced = getenv("FX_MULTI_CFG");
     if (forced) {
@@ -1542,7 +1554,9 @@ static void fx_multi_plan(const MultiShape* sh, int n, MultiPlanItem* plan) {
             if (*q == ';') ++q;
             if (sh[i].N <= 64) plan[i].tile = 1;
         }
+        return 1 << 20;
     }
+    return wg128;
 }
 
 // split_k of a problem is the LARGEST slab count its workspace holds; the 64x64 paths use the rule of
@@ -1592,7 +1606,7 @@ static int fx_gemm_try_multi(const fx_gemm_problem* p, int32_t n, fx_stream_t st
         sh[i].splittable = (q.split_k > 1 && q.workspace) ? q.split_k : 0;
     }
     MultiPlanItem plan[FX_MULTI_MAX];
-    fx_multi_plan(sh, n, plan);
+    if (fx_multi_plan(sh, n, plan) < 512) return FX_OK;
     MultiArgs ma;
     memset(&ma, 0, sizeof(ma));
     // longest workgroups first
