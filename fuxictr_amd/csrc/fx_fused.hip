@@ -23,7 +23,6 @@
 //   (rank_model.py:321) and of torch.optim.Adam.step (rank_model.py:322).
 #include "fx_common.h"
 
-#include <rocprim/rocprim.hpp>
 
 // ---------------------------------------------------------------------------------------------
 // shared device pieces
@@ -127,23 +126,46 @@ __device__ __forceinline__ void fx_catchup_tables(const FxTableDev* t, int n_tab
 }
 
 // ---------------------------------------------------------------------------------------------
-// fx_dedup_catchup, launch 1: one workgroup sorts one id column in LDS (as k_sort_columns of
-// fx_sparse.hip); block 0 also opens the optimizer step (fx_opt_begin_step fused).
+// fx_dedup_catchup, launch 1: one workgroup sorts one id column in LDS — a hand-written stable LSD
+// radix sort, 8 bits a pass over only the bits the column's vocabulary uses (a 10 M-row table: 3
+// passes; the many Criteo columns with < 256 values: 1), 16 waves x IPT rounds of 64 keys:
+//   rank    per round, the lanes that hold the same digit find each other with 8 ballots (one per
+//           digit bit); a key's rank inside its wave's chunk = the wave's running count of that digit
+//           (a private 256-entry histogram row in LDS, read by every lane of the match group, bumped
+//           by its lowest lane) + the number of lower lanes of the group — chunk order is index order,
+//           so the sort is stable and the order of a row's lookups (hence its gradient sum) is fixed;
+//   offsets 256 threads turn the 16 histogram rows into exclusive per-wave offsets and scan the digit
+//           totals (wave shuffles);
+//   scatter key and position move to the other LDS buffer.
+// Then head flags, a block scan of them, and the sorted column leaves for global memory with its
+// running unique count.  Block 0 also opens the optimizer step (fx_opt_begin_step fused).
+// (Round 2 used rocprim::block_radix_sort here — 4 bits a pass, 23 us for the 26 Criteo columns.)
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fx_wave_incl_scan_u32(uint32_t x, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    return x;
+}
+
 template <int IPT>
-__global__ __launch_bounds__(1024) void k_sort_columns2(const int32_t* ids, int64_t ids_ld, int64_t B,
+__global__ __launch_bounds__(1024) void k_sort_columns3(const int32_t* ids, int64_t ids_ld, int64_t B,
                                                         const int64_t* col_row_base,
                                                         const int32_t* col_vocab,
                                                         const int32_t* col_pad, int C,
                                                         uint32_t* sorted_key, uint32_t* sorted_pos,
                                                         uint32_t* col_scan, uint32_t* col_cnt,
                                                         fx_scalars* begin_scal) {
-    using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t>;
-    using Scan = rocprim::block_scan<uint32_t, 1024>;
-    __shared__ typename Sort::storage_type storage;
-    __shared__ typename Scan::storage_type scan_storage;
-    __shared__ uint32_t lastk[1024];
+    constexpr int N = IPT * 1024;
+    __shared__ uint32_t kbuf[2][N];
+    __shared__ uint32_t pbuf[2][N];
+    __shared__ uint32_t hist[16][256];
+    __shared__ uint32_t dbase[256];
+    __shared__ uint32_t wtot[16];
     const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (begin_scal != nullptr && c == 0 && threadIdx.x == 0) {
         // torch.optim.Adam: bias_correction1 = 1 - beta1 ** step (python double), step_size =
         // lr / bias_correction1, bias_correction2_sqrt = (1 - beta2 ** step) ** 0.5
@@ -161,33 +183,98 @@ __global__ __launch_bounds__(1024) void k_sort_columns2(const int32_t* ids, int6
     int bits = 1;
     while ((1u << bits) < (uint32_t)V && bits < 31) ++bits;
     const uint32_t fill = (1u << bits) - 1u;   // >= every real id; ties keep real items first
-    uint32_t k[IPT], v[IPT];
+    // load: item i = position b of the column (coalescing does not matter: one 4-byte id per row)
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        const int64_t b = (int64_t)threadIdx.x * IPT + j;
-        k[j] = fill;
-        v[j] = 0xFFFFFFFFu;
-        if (b < B) {
-            const int32_t id = ids[b * ids_ld + c];
+    for (int r = 0; r < IPT; ++r) {
+        const int i = r * 1024 + threadIdx.x;
+        uint32_t k = fill, v = 0xFFFFFFFFu;
+        if (i < B) {
+            const int32_t id = ids[(int64_t)i * ids_ld + c];
             const bool in_range = id >= 0 && id < V;
-            k[j] = in_range ? (uint32_t)id : 0u;
-            if (in_range && id != pad) v[j] = (uint32_t)(b * C + c);
+            k = in_range ? (uint32_t)id : 0u;
+            if (in_range && id != pad) v = (uint32_t)((int64_t)i * C + c);
         }
+        kbuf[0][i] = k;
+        pbuf[0][i] = v;
     }
-    Sort().sort(k, v, storage, 0, bits);
-    lastk[threadIdx.x] = k[IPT - 1];
     __syncthreads();
-    uint32_t flag[IPT], h = 0;
+    int src = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        // -- rank inside the wave's chunk
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hist[w][lane + 64 * j] = 0u;
+        uint32_t kk[IPT], pp[IPT], rk[IPT];
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            const int i = (w * IPT + r) * 64 + lane;
+            kk[r] = kbuf[src][i];
+            pp[r] = pbuf[src][i];
+            const uint32_t d = (kk[r] >> shift) & 255u;
+            uint64_t m = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const uint32_t below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t base = hist[w][d];           // every lane of the group reads the same word
+            __builtin_amdgcn_wave_barrier();
+            if (below == 0u) hist[w][d] = base + (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            rk[r] = base + below;
+        }
+        __syncthreads();
+        // -- per-wave exclusive offsets of every digit, digit totals, their exclusive scan
+        if (threadIdx.x < 256) {
+            const int d = threadIdx.x;
+            uint32_t run = 0;
+#pragma unroll
+            for (int ww = 0; ww < 16; ++ww) {
+                const uint32_t t = hist[ww][d];
+                hist[ww][d] = run;
+                run += t;
+            }
+            const uint32_t inc = fx_wave_incl_scan_u32(run, lane);
+            if (lane == 63) wtot[w] = inc;
+            dbase[d] = inc - run;                        // exclusive inside the wave
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            uint32_t add = 0;
+            for (int ww = 0; ww < w; ++ww) add += wtot[ww];
+            dbase[threadIdx.x] += add;
+        }
+        __syncthreads();
+        // -- scatter
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            const uint32_t d = (kk[r] >> shift) & 255u;
+            const uint32_t dst = dbase[d] + hist[w][d] + rk[r];
+            kbuf[src ^ 1][dst] = kk[r];
+            pbuf[src ^ 1][dst] = pp[r];
+        }
+        __syncthreads();
+        src ^= 1;
+    }
+    // head flags over the sorted column (thread t owns the IPT consecutive items t*IPT ...), block scan
+    uint32_t k[IPT], flag[IPT], h = 0;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) k[j] = kbuf[src][threadIdx.x * IPT + j];
+    const uint32_t prev0 = threadIdx.x > 0 ? kbuf[src][threadIdx.x * IPT - 1] : 0u;
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const int64_t i = (int64_t)threadIdx.x * IPT + j;
-        const uint32_t prev = j > 0 ? k[j - 1] : (threadIdx.x > 0 ? lastk[threadIdx.x - 1] : 0u);
+        const uint32_t prev = j > 0 ? k[j - 1] : prev0;
         flag[j] = (i < B && (i == 0 || k[j] != prev)) ? 1u : 0u;
         h += flag[j];
     }
-    uint32_t before = 0, total = 0;
-    Scan().exclusive_scan(h, before, 0u, total, scan_storage);
-    if (threadIdx.x == 0) col_cnt[c] = total;
+    const uint32_t inc = fx_wave_incl_scan_u32(h, lane);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    uint32_t before = inc - h;
+    for (int ww = 0; ww < w; ++ww) before += wtot[ww];
+    if (threadIdx.x == 1023) col_cnt[c] = before + h;
     const uint32_t base = (uint32_t)col_row_base[c];
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
@@ -195,7 +282,7 @@ __global__ __launch_bounds__(1024) void k_sort_columns2(const int32_t* ids, int6
         before += flag[j];
         if (i < B) {
             sorted_key[(int64_t)c * B + i] = base + k[j];
-            sorted_pos[(int64_t)c * B + i] = v[j];
+            sorted_pos[(int64_t)c * B + i] = pbuf[src][i];
             col_scan[(int64_t)c * B + i] = before;
         }
     }
@@ -334,7 +421,7 @@ extern "C" int fx_dedup_catchup(const int32_t* ids, int64_t ids_ld, int64_t B, i
     if (st != FX_OK) return st;
     hipStream_t s = fx_hip_stream(stream);
 #define FX_SORT2(IPT)                                                                             \
-    hipLaunchKernelGGL(k_sort_columns2<IPT>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,           \
+    hipLaunchKernelGGL(k_sort_columns3<IPT>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,           \
                        col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos, col_scan, \
                        col_cnt, begin_scal)
     if (B <= 1024) FX_SORT2(1);
