@@ -1325,11 +1325,9 @@ static int fx_gemm_prepare(int32_t transa, int32_t transb, int64_t M, int64_t N,
             bn = 64;   // e.g. the DIN attention MLP: 204800 x 64 x 64 — do not pad N to 128
         } else if (forced == 0 && !fx_gemm_pipe_mode()) {
             if (t128 < 448) { bm = 64; bn = 64; }      // the unpipelined kernel's rule
-        } else if (forced == 0 && t128 >= 224 && t128 <= 256) {
-            // one 128x128 workgroup per CU: with the 16-byte epilogue (round 3) its K loop streams at
-            // 0.91-0.95 of the matrix-pipe peak and the launch beats four 64x64 workgroups per CU, which
-            // drift apart under the SIMD's oldest-first arbitration (profiles/r03_gemm_lab_a.txt:
-            // 4096x1024x1024 plain 68.0 vs 73.7 us)
+        // (round 3: with the 16-byte epilogue a 128x128 workgroup per CU ties with four 64x64 ones on
+        // some boxes — 71.3 vs 71.4 us for 4096x1024x1024 — and loses 4 % on others — 78.2 vs 75.2 us,
+        // whole DeepFM step 1.043 vs 1.026 ms, profiles/r03_gemm_lab_h.txt: the single launches keep 64x64)
         } else if (forced == 0 && t128 < 1024) {
             if (t12864 >= 2048) bn = 64;
             else { bm = 64; bn = 64; }
