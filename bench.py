@@ -61,6 +61,13 @@ def parse():
                     help="distinct synthetic batches cycled (bounded by warmup + steps + 24)")
     ap.add_argument("--no-dcnv2", action="store_true",
                     help="skip the DCNv2 (configs[2]) sub-measurement of the default DeepFM run")
+    ap.add_argument("--probe-loss", action="store_true",
+                    help="before the warm-up: seeded weights (by parameter NAME and global row, so any "
+                         "shard layout holds the same model) and two training steps on a seeded GLOBAL "
+                         "batch; their losses go into the line as probe_loss and must not depend on the "
+                         "number of ranks (tests/test_gpu_dist.py)")
+    ap.add_argument("--probe-world", type=int, default=0,
+                    help="with --probe-loss on fewer ranks: the world size whose global batch to probe")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the step eagerly instead of replaying a captured hipGraph")
     return ap.parse_args()
@@ -245,6 +252,41 @@ def make_pool(args, rank, cards, spec, dev, n_pool):
     return pool
 
 
+def probe_losses(args, model, cards, spec, rank, world, dev, dist, sharded):
+    """--probe-loss: the same model and the same global batch on any number of ranks -> the same losses."""
+    import zlib
+    from fuxictr_amd import synthetic
+    G = args.batch * max(world, args.probe_world, 1)
+    ref = model.full_state_dict() if sharded else model.state_dict()
+    full = {}
+    for k in sorted(ref):
+        v = ref[k]
+        if not torch.is_floating_point(v):
+            continue
+        g = torch.Generator().manual_seed(zlib.crc32(k.encode()) & 0x7FFFFFFF)
+        scale = 0.0 if k.endswith(".bias") else (0.01 if ".embedding_layers." in k else 0.03)
+        full[k] = (torch.randn(v.shape, generator=g) * scale).to(torch.float32)
+    if sharded:
+        model.load_full_state_dict({k: v.to(dev) for k, v in full.items()})
+    else:
+        model.load_state_dict({k: v.to(dev) for k, v in full.items()}, strict=False)
+    rng = np.random.default_rng(777)
+    use_graph, model._use_graph = model._use_graph, False
+    lo, n_loc = rank * G // max(world, 1), G // max(world, 1)
+    out = []
+    for _ in range(2):
+        b = synthetic.taobao_batch(rng, G, spec, dist=args.dist) if args.model == "DIN" \
+            else synthetic.criteo_batch(rng, G, cards=cards, dist=args.dist)
+        mine = {k: torch.from_numpy(np.ascontiguousarray(v[lo:lo + n_loc])).to(dev) for k, v in b.items()}
+        loss = model.train_step(mine).detach().reshape(1).to(torch.float64)
+        if dist is not None:
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+            loss = loss / world
+        out.append(float(loss.item()))
+    model._use_graph = use_graph
+    return out
+
+
 SPARSE_RECORD_STEPS = 32
 C5_BATCH = 32768
 
@@ -300,6 +342,10 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         if world > 1:
             parallelism = "%d independent replicas (--replicas; no data-path collective)" % world
     model.train()
+    probe = None
+    if args.probe_loss:
+        probe = probe_losses(args, model, cards, spec, rank, world, dev, dist,
+                             sharded=(world > 1 or world1) and not args.replicas)
     n_pool = min(args.pool, max(8, args.warmup + args.steps + 40))
     pool = make_pool(args, rank, cards, spec, dev, n_pool)
 
@@ -410,7 +456,8 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
     gc.collect()
     torch.cuda.empty_cache()
     return {"dt": dt, "ktimes": ktimes, "launch": launch, "parallelism": parallelism,
-            "cards": cards, "timing_mode": timing_mode, "rows": rows, "n_pool": n_pool}
+            "cards": cards, "timing_mode": timing_mode, "rows": rows, "n_pool": n_pool,
+            "probe": probe}
 
 
 def _traffic(model, batch, world):
@@ -654,6 +701,8 @@ def main():
                        "parallelism": m["parallelism"]},
         }
         out.update(rooflines(m, args, world))
+        if m.get("probe") is not None:
+            out["probe_loss"] = m["probe"]
         if second is not None:
             args2, m2 = second
             sub = {"workload": workload_name(args2, m2["rows"]),

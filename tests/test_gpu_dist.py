@@ -38,3 +38,39 @@ def test_rccl_backend_one_rank_full_exchange_path(case, graph, tmp_path):
                     env={"FX_SHARD_WORLD1": "1", "FX_TEST_BACKEND": "nccl", "FX_HIP_GRAPH": graph})
     assert bool(z["sharded"][0])
     check_against_golden(z, g)
+
+
+def _bench_line(args, env=None):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True,
+                       text=True, env=e, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]            # ONE JSON line, printed by rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_launch_with_two_ranks_reports_two_gpus_and_the_one_rank_losses():
+    """the launch path the driver uses for N > 1 (`bench.py --gpus N` -> torch.distributed.run
+    -> one rank per device -> row-sharded tables, all-to-alls, one all-reduce, hipGraph segments), here with
+    both ranks on cuda:0 and the collectives staged through gloo.  The line must say n_gpus = 2, name the
+    parallelism, scale the global batch, and — same seeded model, same seeded GLOBAL batch — reproduce the
+    losses of the one-rank run."""
+    common = ["--vocab-scale", "0.01", "--steps", "3", "--warmup", "5", "--no-cpu-baseline",
+              "--no-kernel-timing", "--no-dcnv2", "--probe-loss"]
+    one = _bench_line(["--gpus", "1", "--probe-world", "2"] + common)
+    two = _bench_line(["--gpus", "2"] + common, env={"FX_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["global_batch"] == 2 * two["config"]["per_gpu_batch"] == 8192
+    assert "row-sharded" in two["config"]["parallelism"] and "all-to-all" in two["config"]["parallelism"]
+    assert two["scaling"] == "weak" and two["value"] > 0
+    assert len(one["probe_loss"]) == len(two["probe_loss"]) == 2
+    for a, b in zip(one["probe_loss"], two["probe_loss"]):
+        assert abs(a - b) <= 2e-5, (one["probe_loss"], two["probe_loss"])
+    assert one["probe_loss"][0] != one["probe_loss"][1]          # the model did move between the steps
