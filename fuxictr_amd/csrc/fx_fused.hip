@@ -390,6 +390,10 @@ static int fx_fill_tables(const fx_row_state* tables_host, int32_t n_tables, FxT
     return FX_OK;
 }
 
+static int fx_launch_catchup_rows(const FxTableDev* t, int n_tables, int gl, const uint32_t* uniq_row,
+                                  const int32_t* n_unique, int64_t n_max, int32_t upto_offset,
+                                  const fx_scalars* scal, hipStream_t s);
+
 extern "C" int fx_dedup_catchup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
                                 const int64_t* col_row_base, const int32_t* col_vocab,
                                 const int32_t* col_pad, void* workspace, size_t workspace_bytes,
@@ -440,13 +444,23 @@ extern "C" int fx_dedup_catchup(const int32_t* ids, int64_t ids_ld, int64_t B, i
     fa.scal = scal;
     fa.B = B;
     fa.C = C;
-    fa.n_tables = n_tables;
-    fa.group_log2 = gl;
+    // The catch-up of the unique rows runs as its OWN dense launch over uniq_row (FX_SPLIT_CATCHUP=0: inside
+    // the scan / scatter launch, as in round 2): there a lane group exists per LOOKUP and only the 24 % that
+    // head a run have a row to replay — 99 % of the waves walked the row path with a quarter of their
+    // lanes; over the compacted rows every lane works (profiles/r03_sparse_ab.txt).
+    static const bool split = []() {
+        const char* e = getenv("FX_SPLIT_CATCHUP");
+        return !(e && atoi(e) == 0);
+    }();
+    const bool two = split && n_tables > 0;
+    fa.n_tables = two ? 0 : n_tables;
+    fa.group_log2 = two ? 0 : gl;
     fa.upto_offset = upto_offset;
-    int64_t blocks = fx_ceil_div(n, 256 >> gl);
+    int64_t blocks = fx_ceil_div(n, 256 >> fa.group_log2);
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(k_finish_catchup, dim3((unsigned)blocks), dim3(256), 0, s, fa);
     FX_CHECK_LAUNCH();
+    if (two) return fx_launch_catchup_rows(fa.t, n_tables, gl, uniq_row, n_unique, n, upto_offset, scal, s);
     return FX_OK;
 }
 
@@ -1309,6 +1323,25 @@ __global__ __launch_bounds__(256) void k_catchup_rows(CatchRowsArgs a) {
     for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.group_log2); u < nu;
          u += (int64_t)gridDim.x * rpb)
         fx_catchup_tables(a.t, a.n_tables, (int64_t)a.uniq_row[u], sub, sc, upto, lb1, lb2);
+}
+
+static int fx_launch_catchup_rows(const FxTableDev* t, int n_tables, int gl, const uint32_t* uniq_row,
+                                  const int32_t* n_unique, int64_t n_max, int32_t upto_offset,
+                                  const fx_scalars* scal, hipStream_t s) {
+    CatchRowsArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n_tables; ++i) a.t[i] = t[i];
+    a.uniq_row = uniq_row;
+    a.n_unique = n_unique;
+    a.scal = scal;
+    a.n_tables = n_tables;
+    a.group_log2 = gl;
+    a.upto_offset = upto_offset;
+    int64_t blocks = fx_ceil_div(n_max, 256 >> gl);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_catchup_rows, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
 }
 
 extern "C" int fx_adam_catchup_rows(const fx_row_state* tables_host, int32_t n_tables,

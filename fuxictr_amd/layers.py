@@ -1582,7 +1582,9 @@ class _MLPFn(torch.autograd.Function):
     epilogue, split-K dW GEMM, column-sum db.  args = (x, acts, W0, b0, W1, b1, ...)."""
 
     @staticmethod
-    def forward(ctx, x, acts, *wb):
+    def forward(ctx, x, acts, out_add, *wb):
+        """out_add: optional [B, N_last] tensor added to the last layer's output in its epilogue (DeepFM:
+        logit = fm + mlp, DeepFM.py:87 — one ATen add launch less); its gradient is dy."""
         need_dx = x.requires_grad
         x = x.contiguous()
         n = len(acts)
@@ -1603,9 +1605,11 @@ class _MLPFn(torch.autograd.Function):
             if i == 0 and W0p is not None:
                 W = W0p
             y = torch.empty(h.shape[0], W.shape[0], dtype=torch.float32, device=h.device)
-            ops.gemm(h, W, y, transa=False, transb=True, bias=b, act=1 if acts[i] else 0)
+            ops.gemm(h, W, y, transa=False, transb=True, bias=b, act=1 if acts[i] else 0,
+                     add=out_add if (i == n - 1 and out_add is not None) else None)
             hs.append(y)
             h = y
+        ctx.has_add = out_add is not None
         ctx.acts = acts
         ctx.wb = wb
         ctx.hs = hs
@@ -1643,7 +1647,7 @@ class _MLPFn(torch.autograd.Function):
                 dW = dW[:, :ctx.K0]
                 dx = dx[:, :ctx.K0] if dx is not None else None
             grads[2 * i], grads[2 * i + 1] = dW, db
-        return (dx, None) + tuple(grads)
+        return (dx, None, dy if ctx.has_add else None) + tuple(grads)
 
 
 class FxLinear(nn.Linear):
@@ -1651,7 +1655,7 @@ class FxLinear(nn.Linear):
 
     def forward(self, x):
         lead = x.shape[:-1]
-        y = _MLPFn.apply(x.reshape(-1, x.shape[-1]), (False,), self.weight, self.bias)
+        y = _MLPFn.apply(x.reshape(-1, x.shape[-1]), (False,), None, self.weight, self.bias)
         return y.reshape(*lead, self.out_features)
 
 
@@ -1815,17 +1819,25 @@ class MLP_Block(nn.Module):
             return None
         return stack, mods[i:]
 
-    def forward(self, inputs):
+    def forward(self, inputs, out_add=None):
+        """out_add (native extension, not in the reference's signature): a tensor the caller would add
+        to the result anyway; when the whole stack is the fused Linear / ReLU node it rides in the last
+        GEMM's epilogue."""
         if self._fused is None or inputs.dim() != 2:
-            return self.mlp(inputs)
+            out = self.mlp(inputs)
+            return out if out_add is None else out + out_add
         stack, tail = self._fused
         acts = tuple(r for _, r in stack)
         wb = []
         for lin, _ in stack:
             wb += [lin.weight, lin.bias]
-        out = _MLPFn.apply(inputs, acts, *wb)
+        fuse_add = out_add is not None and not tail and not acts[-1] and out_add.is_contiguous() \
+            and out_add.shape == (inputs.shape[0], stack[-1][0].weight.shape[0])
+        out = _MLPFn.apply(inputs, acts, out_add if fuse_add else None, *wb)
         for mod in tail:
             out = mod(out)
+        if out_add is not None and not fuse_add:
+            out = out + out_add
         return out
 
 

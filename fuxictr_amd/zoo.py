@@ -53,7 +53,7 @@ class DeepFM(_ZooModel):
         X = self.get_inputs(inputs)
         emb = self.embedding_layer(X)                       # [B, F, D]
         logit = self.fm(X, emb)                             # first order + FM second order
-        logit += self.mlp(emb.flatten(start_dim=1))
+        logit = self.mlp(emb.flatten(start_dim=1), out_add=logit)   # += in the head GEMM's epilogue
         return {"y_pred": self.output_activation(logit)}
 
 
