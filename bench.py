@@ -278,7 +278,16 @@ def probe_losses(args, model, cards, spec, rank, world, dev, dist, sharded):
         b = synthetic.taobao_batch(rng, G, spec, dist=args.dist) if args.model == "DIN" \
             else synthetic.criteo_batch(rng, G, cards=cards, dist=args.dist)
         mine = {k: torch.from_numpy(np.ascontiguousarray(v[lo:lo + n_loc])).to(dev) for k, v in b.items()}
-        loss = model.train_step(mine).detach().reshape(1).to(torch.float64)
+        if use_graph:
+            # eager, but on the stream the later capture uses (autograd's AccumulateGrad nodes are tied to
+            # the stream of the first backward: a probe on the default stream broke the segmented capture)
+            if not getattr(model.optimizer, "_max_norm_explicit", False):
+                model.optimizer.set_max_norm(model._max_gradient_norm, _from_model=True)
+            model.optimizer.sync_lr()
+            loss = model._side_stream_step(mine)
+        else:
+            loss = model.train_step(mine)
+        loss = loss.detach().reshape(1).to(torch.float64)
         if dist is not None:
             dist.all_reduce(loss, op=dist.ReduceOp.SUM)
             loss = loss / world
