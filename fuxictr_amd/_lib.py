@@ -67,7 +67,7 @@ SIGNATURES = {
                                   vp, vp]),
     "fx_dedup_workspace_bytes": (C.c_size_t, [i64]),
     "fx_dedup": (i32, [vp, i64, i64, i32, vp, vp, vp, i64, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
-                       i32, i32, vp]),
+                       i32, i32, vp, vp]),
     "fx_dedup_sorted_runs": (i32, [vp, i32, i64, i32, i32, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
                                    vp]),
     "fx_shard_plan_workspace_ints": (i64, [i64, i32]),

@@ -43,6 +43,15 @@ int fx_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
                       uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n,
                       unsigned end_bit, void* temp, bool zeroed, hipStream_t s);
 
+// ---- fx_fused.hip: the column fast path of the de-dup (one in-LDS sort per id column + scan / scatter of
+// the unique rows), also used by fx_dedup (fx_sparse.hip).  col_cnt: >= C words, col_scan: >= B*C words.
+int fx_dedup_columns_launch(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
+                            const int64_t* col_row_base, const int32_t* col_vocab,
+                            const int32_t* col_pad, uint32_t* col_cnt, uint32_t* col_scan,
+                            uint32_t* sorted_key, uint32_t* sorted_pos, uint32_t* uniq_row,
+                            uint32_t* seg_start, int32_t* n_unique, uint32_t* sorted_uid,
+                            fx_scalars* begin_scal, hipStream_t s);
+
 // Row-vector geometry: a D-float row is handled by G lanes (power of two) holding VEC floats each.
 struct FxRowGeom {
     int vec;    // 4, 2 or 1
@@ -60,6 +69,21 @@ static inline FxRowGeom fx_row_geom(int D) {
 
 #ifdef __HIPCC__
 // ---- device helpers -------------------------------------------------------------------------
+// Opens an optimizer step: t += 1 and torch.optim.Adam's per-step scalars — bias_correction1 =
+// 1 - beta1 ** step (python double), step_size = lr / bias_correction1, bias_correction2_sqrt =
+// (1 - beta2 ** step) ** 0.5.  One thread of one kernel per step (fx_opt_begin_step, or fused into
+// the first launch of the de-dup).
+__device__ __forceinline__ void fx_begin_step_dev(fx_scalars* sc) {
+    const int t = sc->step + 1;
+    sc->step = t;
+    const double b1 = (double)sc->beta1, b2 = (double)sc->beta2;
+    const double bc1 = 1.0 - pow(b1, (double)t);
+    const double bc2 = 1.0 - pow(b2, (double)t);
+    sc->bc1 = (float)bc1;
+    sc->bc2_sqrt = (float)sqrt(bc2);
+    sc->step_size = (float)((double)sc->lr / bc1);
+}
+
 template <int VEC>
 struct FxVec;
 template <>

@@ -166,19 +166,7 @@ __global__ __launch_bounds__(1024) void k_sort_columns3(const int32_t* ids, int6
     __shared__ uint32_t wtot[16];
     const int c = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (begin_scal != nullptr && c == 0 && threadIdx.x == 0) {
-        // torch.optim.Adam: bias_correction1 = 1 - beta1 ** step (python double), step_size =
-        // lr / bias_correction1, bias_correction2_sqrt = (1 - beta2 ** step) ** 0.5
-        fx_scalars* sc = begin_scal;
-        const int t = sc->step + 1;
-        sc->step = t;
-        const double b1 = (double)sc->beta1, b2 = (double)sc->beta2;
-        const double bc1 = 1.0 - pow(b1, (double)t);
-        const double bc2 = 1.0 - pow(b2, (double)t);
-        sc->bc1 = (float)bc1;
-        sc->bc2_sqrt = (float)sqrt(bc2);
-        sc->step_size = (float)((double)sc->lr / bc1);
-    }
+    if (begin_scal != nullptr && c == 0 && threadIdx.x == 0) fx_begin_step_dev(begin_scal);
     const int32_t V = col_vocab[c], pad = col_pad[c];
     int bits = 1;
     while ((1u << bits) < (uint32_t)V && bits < 31) ++bits;
@@ -394,6 +382,51 @@ static int fx_launch_catchup_rows(const FxTableDev* t, int n_tables, int gl, con
                                   const int32_t* n_unique, int64_t n_max, int32_t upto_offset,
                                   const fx_scalars* scal, hipStream_t s);
 
+static void fx_launch_sort_columns(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
+                                   const int64_t* col_row_base, const int32_t* col_vocab,
+                                   const int32_t* col_pad, uint32_t* sorted_key, uint32_t* sorted_pos,
+                                   uint32_t* col_scan, uint32_t* col_cnt, fx_scalars* begin_scal,
+                                   hipStream_t s) {
+#define FX_SORT3(IPT)                                                                             \
+    hipLaunchKernelGGL(k_sort_columns3<IPT>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,           \
+                       col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos, col_scan, \
+                       col_cnt, begin_scal)
+    if (B <= 1024) FX_SORT3(1);
+    else if (B <= 2048) FX_SORT3(2);
+    else if (B <= 4096) FX_SORT3(4);
+    else FX_SORT3(8);
+#undef FX_SORT3
+}
+
+// the column fast path without tables, for fx_dedup (declared in fx_common.h)
+int fx_dedup_columns_launch(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
+                            const int64_t* col_row_base, const int32_t* col_vocab,
+                            const int32_t* col_pad, uint32_t* col_cnt, uint32_t* col_scan,
+                            uint32_t* sorted_key, uint32_t* sorted_pos, uint32_t* uniq_row,
+                            uint32_t* seg_start, int32_t* n_unique, uint32_t* sorted_uid,
+                            fx_scalars* begin_scal, hipStream_t s) {
+    fx_launch_sort_columns(ids, ids_ld, B, C, col_row_base, col_vocab, col_pad, sorted_key, sorted_pos,
+                           col_scan, col_cnt, begin_scal, s);
+    FX_CHECK_LAUNCH();
+    FinishArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.key = sorted_key;
+    fa.col_scan = col_scan;
+    fa.col_cnt = col_cnt;
+    fa.uniq_row = uniq_row;
+    fa.seg_start = seg_start;
+    fa.n_unique = n_unique;
+    fa.sorted_uid = sorted_uid;
+    fa.B = B;
+    fa.C = C;
+    const int64_t n = B * (int64_t)C;
+    int64_t blocks = fx_ceil_div(n, 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_finish_catchup, dim3((unsigned)blocks), dim3(256), 0, s, fa);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
 extern "C" int fx_dedup_catchup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
                                 const int64_t* col_row_base, const int32_t* col_vocab,
                                 const int32_t* col_pad, void* workspace, size_t workspace_bytes,
@@ -424,15 +457,8 @@ extern "C" int fx_dedup_catchup(const int32_t* ids, int64_t ids_ld, int64_t B, i
     const int st = fx_fill_tables(tables_host, n_tables, fa.t, &gl, "fx_dedup_catchup", true);
     if (st != FX_OK) return st;
     hipStream_t s = fx_hip_stream(stream);
-#define FX_SORT2(IPT)                                                                             \
-    hipLaunchKernelGGL(k_sort_columns3<IPT>, dim3(C), dim3(1024), 0, s, ids, ids_ld, B,           \
-                       col_row_base, col_vocab, col_pad, (int)C, sorted_key, sorted_pos, col_scan, \
-                       col_cnt, begin_scal)
-    if (B <= 1024) FX_SORT2(1);
-    else if (B <= 2048) FX_SORT2(2);
-    else if (B <= 4096) FX_SORT2(4);
-    else FX_SORT2(8);
-#undef FX_SORT2
+    fx_launch_sort_columns(ids, ids_ld, B, C, col_row_base, col_vocab, col_pad, sorted_key, sorted_pos,
+                           col_scan, col_cnt, begin_scal, s);
     FX_CHECK_LAUNCH();
     fa.key = sorted_key;
     fa.col_scan = col_scan;

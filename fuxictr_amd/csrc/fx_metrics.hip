@@ -13,7 +13,6 @@
 #include "fx_common.h"
 
 #include <float.h>
-#include <rocprim/rocprim.hpp>
 
 #define FX_METRIC_BLOCKS 1024
 

@@ -378,14 +378,15 @@ class _TableGroup(object):
         ckey = ("dedup", plan.sig, self.total_rows)
         if cache is not None and ckey in cache:
             return cache[ckey]
-        if self.opt is not None:
-            self.opt.flush_begin()
         n = ids.shape[0] * ids.shape[1]
         if self.dedup_ws is None or self.dedup_ws[0] != n:
             self.dedup_ws = (n, torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8,
                                             device=self.device))
+        # (the optimizer step's device-side opening rides in the de-dup's first launch)
+        begin = self.opt.take_begin() if self.opt is not None else None
         dd = ops.dedup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad, self.total_rows,
-                       self.dedup_ws[1], columns_sorted=plan.columns_sorted, want_uid=True)
+                       self.dedup_ws[1], columns_sorted=plan.columns_sorted, want_uid=True,
+                       begin_scal=begin)
         if cache is not None:
             cache[ckey] = dd
         return dd
@@ -501,10 +502,10 @@ class _TableGroup(object):
                                             device=dev))
         # unique GLOBAL rows in ascending order (the column fast path applies); owners and slots are
         # derived by counting in fx_shard_plan(global_keys), no owner-major device sort
-        if self.opt is not None:
-            self.opt.flush_begin()
+        begin = self.opt.take_begin() if self.opt is not None else None
         dd = ops.dedup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad, self.total_rows,
-                       self.dedup_ws[1], want_uid=True, columns_sorted=plan.columns_sorted)
+                       self.dedup_ws[1], want_uid=True, columns_sorted=plan.columns_sorted,
+                       begin_scal=begin)
         cap = self.a2a_cap(n)
         sx = _ShardExchange()
         sx.dd, sx.cap = dd, cap

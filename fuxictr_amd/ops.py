@@ -245,7 +245,7 @@ class DedupResult(object):
 
 @_timed("dedup", "sparse_path")
 def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None,
-          n_shards=1, want_uid=False, columns_sorted=False):
+          n_shards=1, want_uid=False, columns_sorted=False, begin_scal=None):
     lib = _lib.load()
     B, C_ = ids.shape
     if result is None:
@@ -254,7 +254,7 @@ def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=N
                        ptr(col_pad), total_rows, ptr(workspace), workspace.numel(),
                        ptr(result.sorted_key), ptr(result.sorted_pos), ptr(result.uniq_row),
                        ptr(result.seg_start), ptr(result.n_unique), ptr(result.sorted_uid),
-                       n_shards, 1 if (columns_sorted and n_shards == 1) else 0,
+                       n_shards, 1 if (columns_sorted and n_shards == 1) else 0, ptr(begin_scal),
                        stream_ptr(ids.device)),
           "fx_dedup")
     return result

@@ -124,7 +124,9 @@ int fx_emb_seq_pool_fwd(const float* table, int32_t D, const int32_t* ids, int64
  * n_shards = 1 for an unsharded table (see fx_shard_plan for n_shards > 1).
  * columns_sorted != 0 (hint; needs n_shards = 1): every id column owns its own table and
  * col_row_base is strictly increasing — each column is then sorted by one workgroup entirely in
- * LDS over only the bits its vocabulary needs (B <= 8192; larger batches use the generic path).  In that mode padding_idx / bad-id lookups stay inside their column's key range with
+ * LDS (a hand-written stable radix sort, 8 bits a pass) over only the bits its vocabulary needs
+ * (B <= 8192; larger batches use the generic path: key build + device-wide LSD radix sort + a two-launch
+ * scan / scatter of the unique rows — all own kernels, no library).  In that mode padding_idx / bad-id lookups stay inside their column's key range with
  * sorted_pos = 0xFFFFFFFF ("contributes nothing"): the padding row may appear as a unique row
  * whose reduced gradient is exactly zero.
  * This replaces the zero-filled dense [V,D] gradient + index_add of aten::embedding_dense_backward
@@ -136,7 +138,9 @@ int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
              const int64_t* col_row_base, const int32_t* col_vocab, const int32_t* col_pad,
              int64_t total_rows, void* workspace, size_t workspace_bytes, uint32_t* sorted_key,
              uint32_t* sorted_pos, uint32_t* uniq_row, uint32_t* seg_start, int32_t* n_unique,
-             uint32_t* sorted_uid, int32_t n_shards, int32_t columns_sorted, fx_stream_t stream);
+             uint32_t* sorted_uid, int32_t n_shards, int32_t columns_sorted,
+             fx_scalars* begin_scal /* or NULL: fx_opt_begin_step fused into the first launch */,
+             fx_stream_t stream);
 
 /* The same de-dup for keys that arrive as n_runs consecutive runs of run_len ids of ONE table
  * (rows [0, vocab), `pad` = the id that means "nothing"), each run ascending with its pad entries at

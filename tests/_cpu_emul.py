@@ -73,7 +73,9 @@ class DedupResult(object):
 
 
 def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None,
-          n_shards=1, want_uid=False, columns_sorted=False):
+          n_shards=1, want_uid=False, columns_sorted=False, begin_scal=None):
+    if begin_scal is not None:
+        opt_begin_step(begin_scal)
     B, C = ids.shape
     keys = ids.long() + col_row_base.view(1, -1)
     valid = (ids != col_pad.view(1, -1)) & (ids >= 0) & (ids < col_vocab.view(1, -1))
