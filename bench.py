@@ -498,8 +498,9 @@ def _sparse_traffic(model, batch, world, kernel=None):
         try:
             with open(os.path.join(here, name)) as f:
                 d = json.load(f)
-            unit = ("bytes (L2 fabric requests incl. Infinity-Cache hits, FETCH x2 + WRITE; profiles/%s)"
-                    % name)
+            unit = ("bytes (L2 fabric requests incl. Infinity-Cache hits, FETCH x2 + WRITE — the x2 is the "
+                    "gfx950 correction for wide coalesced reads and overstates 64-byte row reads; "
+                    "profiles/%s)" % name)
             if kernel is None:
                 return d["sparse_traffic_bytes_per_step"], unit + " per step"
             return d["per_kernel_bytes_per_launch"][kernel], unit + " per launch"
@@ -569,8 +570,8 @@ def rooflines(m, args, world):
             "algorithmic_bytes_per_sample": per_sample, "us_per_step": us_step,
             "launches_per_step": sp["launches"] / n_inst,
             "distinct_batches_replayed": sp.get("steps", 1),
-            "by_launch_us": {k: round(v["avg_us"] * v["launches"], 2) for k, v in kt.items()
-                             if k in SPARSE_LAUNCH_NAMES and v["total_ms"] > 0}}
+            "per_kernel": "profiles/r03_step_timeline_deepfm_final.txt (rocprofv3 kernel trace of one "
+                          "step of the timed region)"}
         tr = _sparse_traffic(args.model, args.batch, world)
         if tr is not None:
             out["roofline_sparse"]["traffic"] = tr[0]
