@@ -2033,17 +2033,23 @@ class _CINFn(torch.autograd.Function):
         n = len(wb) // 2
         total = sum(wb[2 * i].shape[0] for i in range(n))
         pooled = torch.empty(B, total, dtype=torch.float32, device=x0.device)
-        xs = [x0]
+        xs, imgs = [x0], []
         xi, off = x0, 0
         for i in range(n):
             W, b = wb[2 * i], wb[2 * i + 1]
             O = W.shape[0]
             xn = torch.empty(B, O, D, dtype=torch.float32, device=x0.device)
-            ops.cin_fwd(x0, xi, W.view(O, -1), b, xn, pooled[:, off:off + O])
+            nimg = ops.cin_wimg_floats(F0, xi.shape[1], D, O)
+            img = None
+            if nimg:        # matrix-core shapes: W laid out once as the kernels' LDS images
+                img = ops.cin_pack_w(W.view(O, -1), F0, xi.shape[1], D,
+                                     torch.empty(nimg, dtype=torch.float32, device=x0.device))
+            imgs.append(img)
+            ops.cin_fwd(x0, xi, W.view(O, -1), b, xn, pooled[:, off:off + O], img)
             xs.append(xn)
             xi = xn
             off += O
-        ctx.wb, ctx.xs = wb, xs
+        ctx.wb, ctx.xs, ctx.imgs = wb, xs, imgs
         return pooled
 
     @staticmethod
@@ -2068,7 +2074,7 @@ class _CINFn(torch.autograd.Function):
             partial = torch.empty(G, O * C + O, dtype=torch.float32, device=x0.device)
             dxi = torch.empty_like(xi)
             ops.cin_bwd(x0, xi, W.view(O, -1), dxn, dpooled[:, offs[i]:offs[i + 1]], dx0,
-                        accumulate_dx0=(i != n - 1), dXi=dxi, partial=partial)
+                        accumulate_dx0=(i != n - 1), dXi=dxi, partial=partial, w_img=ctx.imgs[i])
             red = torch.empty(O * C + O, dtype=torch.float32, device=x0.device)
             ws = _Workspace.get(x0.device, _lib.FX_COLSUM_CHUNKS * (O * C + O))
             ops.colsum(partial, red, ws)

@@ -806,23 +806,36 @@ def cin_workgroups():
     return int(_lib.load().fx_cin_workgroups())
 
 
-def cin_fwd(X0, Xi, W, bias, Xn, pool):
+def cin_wimg_floats(F0, Mi, D, O):
+    """Floats of the packed LDS images of W the matrix-core CIN kernels copy (0: this shape runs on
+    the VALU kernels, no image)."""
+    return int(_lib.load().fx_cin_wimg_floats(F0, Mi, D, O))
+
+
+def cin_pack_w(W, F0, Mi, D, w_img):
+    """W [O, F0*Mi] -> w_img (cin_wimg_floats floats), once per step; cin_fwd / cin_bwd take it."""
+    check(_lib.load().fx_cin_pack_w(ptr(W), F0, Mi, D, W.shape[0], ptr(w_img), stream_ptr(W.device)),
+          "fx_cin_pack_w")
+    return w_img
+
+
+def cin_fwd(X0, Xi, W, bias, Xn, pool, w_img=None):
     """X0 [B,F0,D], Xi [B,Mi,D] contiguous; W [O, F0*Mi]; Xn [B,O,D]; pool: [B,O] view (stride ok)."""
     B, F0, D = X0.shape
     Mi, O = Xi.shape[1], W.shape[0]
     check(_lib.load().fx_cin_fwd(ptr(X0), X0.stride(0), F0, ptr(Xi), Xi.stride(0), Mi, D, ptr(W),
                                  ptr(bias), O, ptr(Xn), ptr(pool),
-                                 0 if pool is None else pool.stride(0), B,
+                                 0 if pool is None else pool.stride(0), B, ptr(w_img),
                                  stream_ptr(X0.device)), "fx_cin_fwd")
 
 
-def cin_bwd(X0, Xi, W, dXn, dpool, dX0, accumulate_dx0, dXi, partial):
+def cin_bwd(X0, Xi, W, dXn, dpool, dX0, accumulate_dx0, dXi, partial, w_img=None):
     B, F0, D = X0.shape
     Mi, O = Xi.shape[1], W.shape[0]
     check(_lib.load().fx_cin_bwd(ptr(X0), X0.stride(0), F0, ptr(Xi), Xi.stride(0), Mi, D, ptr(W), O,
                                  ptr(dXn), ptr(dpool), 0 if dpool is None else dpool.stride(0),
                                  ptr(dX0), dX0.stride(0), 1 if accumulate_dx0 else 0, ptr(dXi),
-                                 dXi.stride(0), ptr(partial), B, stream_ptr(X0.device)),
+                                 dXi.stride(0), ptr(partial), B, ptr(w_img), stream_ptr(X0.device)),
           "fx_cin_bwd")
 
 

@@ -627,7 +627,15 @@ def cin_workgroups():
     return 4
 
 
-def cin_fwd(X0, Xi, W, bias, Xn, pool):
+def cin_wimg_floats(F0, Mi, D, O):
+    return 0
+
+
+def cin_pack_w(W, F0, Mi, D, w_img):
+    return w_img
+
+
+def cin_fwd(X0, Xi, W, bias, Xn, pool, w_img=None):
     had = torch.einsum("bhd,bmd->bhmd", X0, Xi).reshape(X0.shape[0], -1, X0.shape[2])
     out = torch.einsum("oc,bcd->bod", W, had) + bias.view(1, -1, 1)
     Xn.copy_(out)
@@ -635,7 +643,7 @@ def cin_fwd(X0, Xi, W, bias, Xn, pool):
         pool.copy_(out.sum(-1))
 
 
-def cin_bwd(X0, Xi, W, dXn, dpool, dX0, accumulate_dx0, dXi, partial):
+def cin_bwd(X0, Xi, W, dXn, dpool, dX0, accumulate_dx0, dXi, partial, w_img=None):
     B, F0, D = X0.shape
     Mi, O = Xi.shape[1], W.shape[0]
     g = torch.zeros(B, O, D)
@@ -821,7 +829,7 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "colsum", "mask_mul", "cross_bwd_prep", "sigmoid_bce", "shard_plan", "scatter_rows",
          "sum_parts", "din_concat_fwd", "din_concat_bwd", "din_pool_fwd", "din_pool_bwd",
          "dice_workspace_floats", "dice_fwd", "dice_bwd", "dot_interact_fwd", "dot_interact_bwd",
-         "cin_workgroups", "cin_fwd", "cin_bwd", "reg_stats", "reg_cross", "reg_dense_update",
+         "cin_workgroups", "cin_fwd", "cin_bwd", "cin_wimg_floats", "cin_pack_w", "reg_stats", "reg_cross", "reg_dense_update",
          "shard_plan_workspace_ints", "emb_seq_pool_fwd", "dedup_sorted_runs", "RowState",
          "dedup_catchup", "emb_fm_fwd", "emb_fm_bwd", "sparse_update_multi", "pack_columns_multi",
          "emb_fm_bwd_partials", "emb_fm_bwd_workspace_floats", "adam_catchup_all", "adam_catchup_rows",

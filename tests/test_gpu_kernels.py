@@ -720,7 +720,11 @@ def test_dot_interaction_matches_bmm_triu(F, D):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("F0,D,units,B", [(39, 16, [16, 16, 16], 700), (9, 8, [12, 6, 5], 130),
-                                          (5, 10, [7], 3), (26, 40, [8, 4], 260)])
+                                          (5, 10, [7], 3), (26, 40, [8, 4], 260),
+                                          # D = 16, O <= 16: the MFMA kernels (ragged O, Mi, B)
+                                          (7, 16, [16, 9, 3], 50), (23, 16, [5, 16], 1001),
+                                          (40, 16, [13], 4133), (1, 16, [1, 1], 17),
+                                          (39, 16, [16, 16, 16], 4096)])
 def test_cin_stack_matches_einsum_conv1d(F0, D, units, B):
     """fx_cin_fwd/bwd through the autograd node vs the oracle's einsum + conv1d (fp32: sums of up
     to F0*Mi products, tolerance relative to the output scale)."""
@@ -754,6 +758,39 @@ def test_cin_stack_matches_einsum_conv1d(F0, D, units, B):
     for a, r in zip(dl, leaves):
         scale = max(1.0, r.grad.abs().max().item())
         assert (a.grad.cpu() - r.grad).abs().max().item() <= 5e-5 * scale, (tuple(r.shape), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F0,Mi,O,B", [(39, 39, 16, 333), (39, 16, 16, 4096), (11, 20, 7, 65)])
+def test_cin_packed_weight_image_is_only_a_layout(F0, Mi, O, B):
+    """fx_cin_pack_w's image vs the kernels gathering W themselves (w_img = NULL): identical bits, in
+    the forward, dX0 (accumulating), dXi and the dW partials."""
+    g = torch.Generator().manual_seed(F0 + Mi + O)
+    x0 = _dev(torch.randn(B, F0, 16, generator=g))
+    xi = _dev(torch.randn(B, Mi, 16, generator=g))
+    W = _dev(torch.randn(O, F0 * Mi, generator=g))
+    bias = _dev(torch.randn(O, generator=g))
+    gxn = _dev(torch.randn(B, O, 16, generator=g))
+    gpool = _dev(torch.randn(B, O, generator=g))
+    n = ops.cin_wimg_floats(F0, Mi, 16, O)
+    assert n == F0 * (4 if Mi <= 16 else 10) * 64 + F0 * (1 if Mi <= 16 else 3) * 256
+    assert ops.cin_wimg_floats(F0, Mi, 8, O) == 0 and ops.cin_wimg_floats(F0, Mi, 16, 17) == 0
+    img = ops.cin_pack_w(W, F0, Mi, 16, torch.empty(n, device=DEV))
+    outs = []
+    for w_img in (img, None):
+        xn = torch.empty(B, O, 16, device=DEV)
+        pool = torch.empty(B, O, device=DEV)
+        ops.cin_fwd(x0, xi, W, bias, xn, pool, w_img)
+        dx0 = torch.ones(B, F0, 16, device=DEV)
+        dxi = torch.empty(B, Mi, 16, device=DEV)
+        partial = torch.empty(ops.cin_workgroups(), O * F0 * Mi + O, device=DEV)
+        ops.cin_bwd(x0, xi, W, gxn, gpool, dx0, True, dxi, partial, w_img)
+        outs.append([t.cpu() for t in (xn, pool, dx0, dxi, partial)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    had = torch.einsum("bhd,bmd->bhmd", x0.cpu().double(), xi.cpu().double()).reshape(B, -1, 16)
+    ref = torch.einsum("oc,bcd->bod", W.cpu().double(), had) + bias.cpu().double().view(1, -1, 1)
+    assert (outs[0][0].double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
 
 
 @pytest.mark.gpu
