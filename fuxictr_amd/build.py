@@ -12,13 +12,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libfxctr.so")
-SOURCES = ["fx_api.cpp", "fx_embed.hip", "fx_sparse.hip", "fx_gemm.hip", "fx_din.hip", "fx_din_attn.hip", "fx_cin.hip", "fx_metrics.hip", "fx_fused.hip", "fx_sort.hip"]
-HEADERS = [os.path.join(CSRC, "fx_common.h"),
+SOURCES = ["fx_api.cpp", "fx_embed.hip", "fx_sparse.hip", "fx_gemm.hip", "fx_din.hip", "fx_din_attn.hip", "fx_cin.hip", "fx_cin_mfma.hip", "fx_metrics.hip", "fx_fused.hip", "fx_sort.hip"]
+HEADERS = [os.path.join(CSRC, "fx_common.h"), os.path.join(CSRC, "fx_cin.h"),
            os.path.join(HERE, "..", "include", "fxctr.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
             "--offload-arch=" + ARCH]
+# per-file additions.  fx_cin_mfma.hip: the arithmetic on MFMA result tiles must stay scalar v_fma_f32 (a
+# packed v_pk_fma_f32 holds the matrix pipe ~22 cycles per issue)
+EXTRA_FLAGS = {"fx_cin_mfma.hip": ["-fno-slp-vectorize"]}
 
 
 def _digest(paths):
@@ -38,7 +41,7 @@ def build(force=False, verbose=True):
         sp = os.path.join(CSRC, src)
         obj = os.path.join(OBJ_DIR, src.rsplit(".", 1)[0] + ".o")
         stamp = obj + ".sha"
-        dig = _digest([sp] + HEADERS)
+        dig = _digest([sp] + HEADERS) + "".join(EXTRA_FLAGS.get(src, []))
         fresh = (not force and os.path.exists(obj) and os.path.exists(stamp)
                  and open(stamp).read() == dig)
         if not fresh:
@@ -47,7 +50,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         sp, obj, stamp, dig = job
-        cmd = [HIPCC] + CXXFLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+        cmd = [HIPCC] + CXXFLAGS + EXTRA_FLAGS.get(os.path.basename(sp), []) + ["-x", "hip", "-c", sp, "-o", obj]
         if verbose:
             print("[fuxictr_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
