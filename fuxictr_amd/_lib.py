@@ -111,10 +111,10 @@ SIGNATURES = {
     "fx_din_pool_bwd": (i32, [vp, vp, i64, vp, i64, i64, vp, i64, i32, i32, vp, vp, i64, i64, vp]),
     "fx_cin_workgroups": (i64, []),
     "fx_cin_wimg_floats": (i64, [i32, i32, i32, i32]),
-    "fx_cin_pack_w": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "fx_cin_pack_w": (i32, [i32, vp, vp, vp, i32, vp, vp, vp]),
     "fx_cin_fwd": (i32, [vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, vp, vp, i64, i64, vp, vp]),
     "fx_cin_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, vp, i32, vp, vp, i64, vp, i64, i32, vp,
-                         i64, vp, i64, vp, vp]),
+                         i64, vp, i64, i64, vp, vp]),
     "fx_binary_metrics_workspace_bytes": (C.c_size_t, [i64]),
     "fx_binary_metrics": (i32, [vp, vp, i64, vp, C.c_size_t, vp, vp, vp]),
     "fx_dice_workspace_floats": (i64, [i32]),

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_cin_bwd_dw(CinArgs a) {
         }
     }
     __syncthreads();
-    float* out = a.partial + (int64_t)blockIdx.x * (O * C + O);
+    float* out = a.partial + (int64_t)blockIdx.x * a.partial_ld;
     for (int t = threadIdx.x; t < O * C + O; t += 256) out[t] = dW[t];
 }
 
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(1024) void k_cin_bwd_dw2(CinArgs a) {
             }
         }
     }
-    float* out = a.partial + (int64_t)blockIdx.x * (O * C + O);
+    float* out = a.partial + (int64_t)blockIdx.x * a.partial_ld;
     if (own) {
 #pragma unroll
         for (int m = 0; m < MI; ++m)
@@ -412,13 +412,21 @@ extern "C" int64_t fx_cin_wimg_floats(int32_t F0, int32_t Mi, int32_t D, int32_t
     return fx_cin_mfma_shape(F0, Mi, D, O) ? fx_cin_mfma_wimg_floats(F0, Mi) : 0;
 }
 
-extern "C" int fx_cin_pack_w(const float* W, int32_t F0, int32_t Mi, int32_t D, int32_t O, float* w_img,
-                             fx_stream_t stream) {
-    FX_CHECK_ARG(W && w_img, "fx_cin_pack_w: null pointer");
-    FX_CHECK_ARG(((uintptr_t)w_img & 15) == 0, "fx_cin_pack_w: w_img must be 16-byte aligned");
-    FX_CHECK_ARG(fx_cin_mfma_shape(F0, Mi, D, O),
-                 "fx_cin_pack_w: no image for this shape (fx_cin_wimg_floats == 0)");
-    fx_cin_mfma_pack_w(W, F0, Mi, O, w_img, fx_hip_stream(stream));
+extern "C" int fx_cin_pack_w(int32_t n_layers, const float* const* W, const int32_t* F0, const int32_t* Mi,
+                             int32_t D, const int32_t* O, float* const* w_img, fx_stream_t stream) {
+    FX_CHECK_ARG(n_layers >= 1 && n_layers <= FX_CIN_PACK_MAX, "fx_cin_pack_w: 1..4 layers per call");
+    FX_CHECK_ARG(W && F0 && Mi && O && w_img, "fx_cin_pack_w: null pointer");
+    CinPackArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.n = n_layers;
+    for (int i = 0; i < n_layers; ++i) {
+        FX_CHECK_ARG(W[i] && w_img[i], "fx_cin_pack_w: null pointer");
+        FX_CHECK_ARG(((uintptr_t)w_img[i] & 15) == 0, "fx_cin_pack_w: w_img must be 16-byte aligned");
+        FX_CHECK_ARG(fx_cin_mfma_shape(F0[i], Mi[i], D, O[i]),
+                     "fx_cin_pack_w: no image for this shape (fx_cin_wimg_floats == 0)");
+        pa.W[i] = W[i]; pa.img[i] = w_img[i]; pa.F0[i] = F0[i]; pa.Mi[i] = Mi[i]; pa.O[i] = O[i];
+    }
+    fx_cin_mfma_pack_w(pa, fx_hip_stream(stream));
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
@@ -467,16 +475,18 @@ extern "C" int fx_cin_bwd(const float* X0, int64_t x0_ld, int32_t F0, const floa
                           int64_t xi_ld, int32_t Mi, int32_t D, const float* W, int32_t O,
                           const float* dXn, const float* dpool, int64_t dpool_ld, float* dX0,
                           int64_t dx0_ld, int32_t accumulate_dx0, float* dXi, int64_t dxi_ld,
-                          float* partial, int64_t B, const float* w_img, fx_stream_t stream) {
+                          float* partial, int64_t partial_ld, int64_t B, const float* w_img,
+                          fx_stream_t stream) {
     if (fx_cin_check("fx_cin_bwd", F0, Mi, D, O) != FX_OK) return FX_ERR_INVALID;
     FX_CHECK_ARG(B >= 1, "fx_cin_bwd: B must be >= 1");
     FX_CHECK_ARG(X0 && Xi && W && (dXn || dpool) && dX0 && dXi && partial,
                  "fx_cin_bwd: null pointer");
+    FX_CHECK_ARG(partial_ld >= (int64_t)O * F0 * Mi + O, "fx_cin_bwd: partial_ld < O*F0*Mi + O");
     CinArgs a;
     memset(&a, 0, sizeof(a));
     a.X0 = X0; a.x0_ld = x0_ld; a.Xi = Xi; a.xi_ld = xi_ld; a.W = W; a.dXn = dXn; a.dpool = dpool;
     a.dpool_ld = dpool_ld; a.dX0 = dX0; a.dx0_ld = dx0_ld; a.acc_dx0 = accumulate_dx0; a.dXi = dXi;
-    a.dxi_ld = dxi_ld; a.partial = partial; a.B = B; a.F0 = F0; a.Mi = Mi; a.D = D; a.O = O;
+    a.dxi_ld = dxi_ld; a.partial = partial; a.partial_ld = partial_ld; a.B = B; a.F0 = F0; a.Mi = Mi; a.D = D; a.O = O;
     int Dp = 1;
     while (Dp < D) Dp <<= 1;
     const int NH = 256 / Dp;

@@ -67,8 +67,13 @@ __device__ __forceinline__ float fx_cin_wb_elem(const float* W, int F0, int Mi, 
     return (o < O && m < Mi) ? W[(int64_t)o * F0 * Mi + h * Mi + m] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void k_cin_pack_w(const float* W, int F0, int Mi, int O, int MQ, int MT,
-                                                    float* img) {
+__global__ __launch_bounds__(256) void k_cin_pack_w(CinPackArgs pa) {      // blockIdx.y = layer
+    const CinPackArgs* ka = (const CinPackArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int L = blockIdx.y;
+    const float* W = ka->W[L];
+    float* img = ka->img[L];
+    const int F0 = ka->F0[L], Mi = ka->Mi[L], O = ka->O[L];
+    const int MQ = fx_cin_mq(Mi), MT = fx_cin_mt(Mi);
     const int nf = F0 * MQ * 64, nd = F0 * MT * 256;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < nf + nd; e += gridDim.x * 256)
         img[e] = e < nf ? fx_cin_wq_elem(W, F0, Mi, O, MQ, e) : fx_cin_wb_elem(W, F0, Mi, O, MT, e - nf);
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(64 * FX_CIN_WAVES) void k_cin_dw_mfma(CinArgs a) {
         buf ^= 1;
     }
     // partial[blockIdx][o * C + h * Mi + m]: D rows o = 4*kk + i, column m = 16*mt + r
-    float* part = a.partial + (int64_t)blockIdx.x * ((int64_t)O * C + O);
+    float* part = a.partial + (int64_t)blockIdx.x * a.partial_ld;
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh) {
         const int h = wave + NW * hh;
@@ -493,10 +498,13 @@ int64_t fx_cin_mfma_wimg_floats(int32_t F0, int32_t Mi) {
     return (int64_t)F0 * fx_cin_mq(Mi) * 64 + (int64_t)F0 * fx_cin_mt(Mi) * 256;
 }
 
-void fx_cin_mfma_pack_w(const float* W, int32_t F0, int32_t Mi, int32_t O, float* w_img, hipStream_t s) {
-    const int64_t n = fx_cin_mfma_wimg_floats(F0, Mi);
-    hipLaunchKernelGGL(k_cin_pack_w, dim3((unsigned)fx_ceil_div(n, 256)), dim3(256), 0, s, W, F0, Mi, O,
-                       fx_cin_mq(Mi), fx_cin_mt(Mi), w_img);
+void fx_cin_mfma_pack_w(const CinPackArgs& pa, hipStream_t s) {
+    int64_t n = 0;
+    for (int i = 0; i < pa.n; ++i) {
+        const int64_t ni = fx_cin_mfma_wimg_floats(pa.F0[i], pa.Mi[i]);
+        n = ni > n ? ni : n;
+    }
+    hipLaunchKernelGGL(k_cin_pack_w, dim3((unsigned)fx_ceil_div(n, 256), (unsigned)pa.n), dim3(256), 0, s, pa);
 }
 
 static unsigned fx_cin_sample_grid(int64_t B) {

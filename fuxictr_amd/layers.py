@@ -2033,19 +2033,24 @@ class _CINFn(torch.autograd.Function):
         n = len(wb) // 2
         total = sum(wb[2 * i].shape[0] for i in range(n))
         pooled = torch.empty(B, total, dtype=torch.float32, device=x0.device)
-        xs, imgs = [x0], []
+        # matrix-core shapes: every layer's W laid out once as its kernels' LDS images (one launch per 4)
+        imgs, todo, Mi = [None] * n, [], F0
+        for i in range(n):
+            O = wb[2 * i].shape[0]
+            nimg = ops.cin_wimg_floats(F0, Mi, D, O)
+            if nimg:
+                imgs[i] = torch.empty(nimg, dtype=torch.float32, device=x0.device)
+                todo.append((wb[2 * i].view(O, -1), F0, Mi, imgs[i]))
+            Mi = O
+        for k in range(0, len(todo), 4):
+            ops.cin_pack_w(todo[k:k + 4], D)
+        xs = [x0]
         xi, off = x0, 0
         for i in range(n):
             W, b = wb[2 * i], wb[2 * i + 1]
             O = W.shape[0]
             xn = torch.empty(B, O, D, dtype=torch.float32, device=x0.device)
-            nimg = ops.cin_wimg_floats(F0, xi.shape[1], D, O)
-            img = None
-            if nimg:        # matrix-core shapes: W laid out once as the kernels' LDS images
-                img = ops.cin_pack_w(W.view(O, -1), F0, xi.shape[1], D,
-                                     torch.empty(nimg, dtype=torch.float32, device=x0.device))
-            imgs.append(img)
-            ops.cin_fwd(x0, xi, W.view(O, -1), b, xn, pooled[:, off:off + O], img)
+            ops.cin_fwd(x0, xi, W.view(O, -1), b, xn, pooled[:, off:off + O], imgs[i])
             xs.append(xn)
             xi = xn
             off += O
@@ -2061,26 +2066,33 @@ class _CINFn(torch.autograd.Function):
         dpooled = dpooled.contiguous()
         G = ops.cin_workgroups()
         dx0 = torch.empty_like(x0)
-        grads = [None] * (2 * n)
-        offs = [0]
+        offs, cols = [0], [0]
         for i in range(n):
-            offs.append(offs[-1] + wb[2 * i].shape[0])
+            W = wb[2 * i]
+            offs.append(offs[-1] + W.shape[0])
+            cols.append(cols[-1] + W.shape[0] * W.shape[1] + W.shape[0])
+        # the layers' per-workgroup dW / dbias sums are column slices of one buffer: one column sum at
+        # the end finishes all of them
+        partial = torch.empty(G, cols[-1], dtype=torch.float32, device=x0.device)
         dxn = None
         for i in range(n - 1, -1, -1):
             W = wb[2 * i]
             O = W.shape[0]
             xi = xs[i]
-            C = W.shape[1]
-            partial = torch.empty(G, O * C + O, dtype=torch.float32, device=x0.device)
             dxi = torch.empty_like(xi)
             ops.cin_bwd(x0, xi, W.view(O, -1), dxn, dpooled[:, offs[i]:offs[i + 1]], dx0,
-                        accumulate_dx0=(i != n - 1), dXi=dxi, partial=partial, w_img=ctx.imgs[i])
-            red = torch.empty(O * C + O, dtype=torch.float32, device=x0.device)
-            ws = _Workspace.get(x0.device, _lib.FX_COLSUM_CHUNKS * (O * C + O))
-            ops.colsum(partial, red, ws)
-            grads[2 * i] = red[:O * C].view(W.shape)
-            grads[2 * i + 1] = red[O * C:]
+                        accumulate_dx0=(i != n - 1), dXi=dxi, partial=partial[:, cols[i]:cols[i + 1]],
+                        w_img=ctx.imgs[i])
             dxn = dxi
+        red = torch.empty(cols[-1], dtype=torch.float32, device=x0.device)
+        ws = _Workspace.get(x0.device, _lib.FX_COLSUM_CHUNKS * cols[-1])
+        ops.colsum(partial, red, ws)
+        grads = [None] * (2 * n)
+        for i in range(n):
+            W = wb[2 * i]
+            nw = W.shape[0] * W.shape[1]
+            grads[2 * i] = red[cols[i]:cols[i] + nw].view(W.shape)
+            grads[2 * i + 1] = red[cols[i] + nw:cols[i + 1]]
         dx0 = dx0 + dxn        # layer 1 reads X0 on both sides of the outer product
         return (dx0,) + tuple(grads)
 

@@ -812,11 +812,18 @@ def cin_wimg_floats(F0, Mi, D, O):
     return int(_lib.load().fx_cin_wimg_floats(F0, Mi, D, O))
 
 
-def cin_pack_w(W, F0, Mi, D, w_img):
-    """W [O, F0*Mi] -> w_img (cin_wimg_floats floats), once per step; cin_fwd / cin_bwd take it."""
-    check(_lib.load().fx_cin_pack_w(ptr(W), F0, Mi, D, W.shape[0], ptr(w_img), stream_ptr(W.device)),
+def cin_pack_w(layers, D):
+    """layers: [(W [O, F0*Mi], F0, Mi, w_img)] (<= 4): every W laid out as its kernels' LDS images in ONE
+    launch, once per step; cin_fwd / cin_bwd take the w_img."""
+    import ctypes as C
+    n = len(layers)
+    Ws = (C.c_void_p * n)(*[ptr(t[0]) for t in layers])
+    imgs = (C.c_void_p * n)(*[ptr(t[3]) for t in layers])
+    F0s = (C.c_int32 * n)(*[t[1] for t in layers])
+    Mis = (C.c_int32 * n)(*[t[2] for t in layers])
+    Os = (C.c_int32 * n)(*[t[0].shape[0] for t in layers])
+    check(_lib.load().fx_cin_pack_w(n, Ws, F0s, Mis, D, Os, imgs, stream_ptr(layers[0][0].device)),
           "fx_cin_pack_w")
-    return w_img
 
 
 def cin_fwd(X0, Xi, W, bias, Xn, pool, w_img=None):
@@ -830,12 +837,14 @@ def cin_fwd(X0, Xi, W, bias, Xn, pool, w_img=None):
 
 
 def cin_bwd(X0, Xi, W, dXn, dpool, dX0, accumulate_dx0, dXi, partial, w_img=None):
+    """partial: [G, O*F0*Mi + O] (a column slice of a wider [G, .] buffer is written in place)."""
     B, F0, D = X0.shape
     Mi, O = Xi.shape[1], W.shape[0]
     check(_lib.load().fx_cin_bwd(ptr(X0), X0.stride(0), F0, ptr(Xi), Xi.stride(0), Mi, D, ptr(W), O,
                                  ptr(dXn), ptr(dpool), 0 if dpool is None else dpool.stride(0),
                                  ptr(dX0), dX0.stride(0), 1 if accumulate_dx0 else 0, ptr(dXi),
-                                 dXi.stride(0), ptr(partial), B, ptr(w_img), stream_ptr(X0.device)),
+                                 dXi.stride(0), ptr(partial), partial.stride(0), B, ptr(w_img),
+                                 stream_ptr(X0.device)),
           "fx_cin_bwd")
 
 

@@ -538,26 +538,28 @@ int fx_din_attn_bwd(const float* q, int64_t q_ld, const float* K, int64_t k_ldb,
  * slot of the concatenated pooling vector.  The einsum tensor [B, F0*Mi, D] is never materialised.
  * fx_cin_bwd: with g = dXn (nullable) + dpool (nullable, broadcast over d):
  *     dX0 (+)= ..., dXi = ..., partial[G][O*F0*Mi + O] = per-workgroup sums of dW and dbias
- *     (G = fx_cin_workgroups(); finish with fx_colsum over G).
+ *     (G = fx_cin_workgroups(), row stride partial_ld >= O*F0*Mi + O: the layers of a stack write column
+ *     slices of ONE [G, sum] buffer; finish with one fx_colsum over G).
  * Limits: O*F0*Mi + O <= 30720 floats per call (LDS-resident weights), D <= 256.
  * D = 16, O <= 16, F0 <= 40, Mi <= 40 (the BASELINE xDeepFM: 39 fields, 16 dims, 16 maps) run on the
  * matrix cores: per sample the compress step is W [16 x F0*Mi] times the outer product [F0*Mi x 16],
- * formed in registers.  For those shapes fx_cin_wimg_floats > 0 and fx_cin_pack_w lays W out once per
- * step as the LDS images the forward and dX kernels copy (w_img, 16-byte aligned, valid until W
- * changes); w_img = NULL is accepted everywhere (the kernels then gather the image from W themselves).
+ * formed in registers.  For those shapes fx_cin_wimg_floats > 0 and fx_cin_pack_w lays the W of up to 4
+ * layers out in one launch, once per step, as the LDS images the forward and dX kernels copy (w_img,
+ * 16-byte aligned, valid until W changes); w_img = NULL is accepted everywhere (the kernels then gather
+ * the image from W themselves).
  * ------------------------------------------------------------------------------------------ */
 int64_t fx_cin_workgroups(void);
 int64_t fx_cin_wimg_floats(int32_t F0, int32_t Mi, int32_t D, int32_t O);
-int fx_cin_pack_w(const float* W, int32_t F0, int32_t Mi, int32_t D, int32_t O, float* w_img,
-                  fx_stream_t stream);
+int fx_cin_pack_w(int32_t n_layers, const float* const* W, const int32_t* F0, const int32_t* Mi,
+                  int32_t D, const int32_t* O, float* const* w_img, fx_stream_t stream);
 int fx_cin_fwd(const float* X0, int64_t x0_ld, int32_t F0, const float* Xi, int64_t xi_ld,
                int32_t Mi, int32_t D, const float* W, const float* bias, int32_t O, float* Xn,
                float* pool, int64_t pool_ld, int64_t B, const float* w_img, fx_stream_t stream);
 int fx_cin_bwd(const float* X0, int64_t x0_ld, int32_t F0, const float* Xi, int64_t xi_ld,
                int32_t Mi, int32_t D, const float* W, int32_t O, const float* dXn,
                const float* dpool, int64_t dpool_ld, float* dX0, int64_t dx0_ld,
-               int32_t accumulate_dx0, float* dXi, int64_t dxi_ld, float* partial, int64_t B,
-               const float* w_img, fx_stream_t stream);
+               int32_t accumulate_dx0, float* dXi, int64_t dxi_ld, float* partial, int64_t partial_ld,
+               int64_t B, const float* w_img, fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * On-device evaluation metrics for BaseModel.evaluate (rank_model.py:350-381, metrics.py:49-51):

@@ -46,7 +46,9 @@ def main():
             dxi = torch.empty(B, Mi, D, device=DEV)
             partial = torch.empty(ops.cin_workgroups(), O * F0 * Mi + O, device=DEV)
             n = ops.cin_wimg_floats(F0, Mi, D, O)
-            img = ops.cin_pack_w(W, F0, Mi, D, torch.empty(n, device=DEV)) if n else None
+            img = torch.empty(n, device=DEV) if n else None
+            if n:
+                ops.cin_pack_w([(W, F0, Mi, img)], D)
             tf = timed(lambda: ops.cin_fwd(x0, xi, W, bias, xn, pool, img))
             tb = timed(lambda: ops.cin_bwd(x0, xi, W, gxn, gpool, dx0, Mi == 16, dxi, partial, img))
             floor = 2.0 * B * O * F0 * Mi * D / 157.3e12 * 1e6

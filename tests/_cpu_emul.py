@@ -631,8 +631,8 @@ def cin_wimg_floats(F0, Mi, D, O):
     return 0
 
 
-def cin_pack_w(W, F0, Mi, D, w_img):
-    return w_img
+def cin_pack_w(layers, D):
+    return None
 
 
 def cin_fwd(X0, Xi, W, bias, Xn, pool, w_img=None):

@@ -775,7 +775,8 @@ def test_cin_packed_weight_image_is_only_a_layout(F0, Mi, O, B):
     n = ops.cin_wimg_floats(F0, Mi, 16, O)
     assert n == F0 * (4 if Mi <= 16 else 10) * 64 + F0 * (1 if Mi <= 16 else 3) * 256
     assert ops.cin_wimg_floats(F0, Mi, 8, O) == 0 and ops.cin_wimg_floats(F0, Mi, 16, 17) == 0
-    img = ops.cin_pack_w(W, F0, Mi, 16, torch.empty(n, device=DEV))
+    img = torch.empty(n, device=DEV)
+    ops.cin_pack_w([(W, F0, Mi, img)], 16)
     outs = []
     for w_img in (img, None):
         xn = torch.empty(B, O, 16, device=DEV)
