@@ -79,6 +79,7 @@ struct DinAttnArgs {
     float* da_out;           // [B*L]
     float* dq;
     int64_t dq_ld;
+    int32_t dq_acc;            // dq += instead of dq = (the row already holds another gradient share)
     float* dK;
     int64_t dk_ldb, dk_ldl;
     float* partial;          // per-workgroup partial sums
@@ -275,7 +276,7 @@ __device__ __forceinline__ void da_gemm_h(const float* __restrict__ W1s, const f
 // feature ends with the same bits); smaller L: lane e walks the positions in order.
 __device__ __forceinline__ void da_seg_sum(const float* T, int E, int L, int lane, int nvalid,
                                            uint32_t& bcur, int& lcur, float& run, float* out,
-                                           int64_t out_ld, float extra = 0.f) {
+                                           int64_t out_ld, float extra = 0.f, bool acc = false) {
     if (L >= 32) {
         const int e = lane & 15, g = lane >> 4;
         const int c = (L - lcur < nvalid) ? L - lcur : nvalid;   // positions that belong to sample bcur
@@ -297,7 +298,10 @@ __device__ __forceinline__ void da_seg_sum(const float* T, int E, int L, int lan
         v1 += __shfl_xor(v1, 32, 64);
         run += v0;
         if (lcur + c == L) {
-            if (lane < E) out[(int64_t)bcur * out_ld + lane] = run + extra;   // extra: per-sample term
+            if (lane < E) {              // extra: per-sample term; acc: added to what the row holds
+                float* o = out + (int64_t)bcur * out_ld + lane;
+                *o = acc ? *o + (run + extra) : run + extra;
+            }
             run = v1;
             ++bcur;
             lcur = nvalid - c;
@@ -308,7 +312,10 @@ __device__ __forceinline__ void da_seg_sum(const float* T, int E, int L, int lan
         for (int i = 0; i < nvalid; ++i) {
             if (lane < E) run += T[lane * DA_LDX + i];
             if (++lcur == L) {
-                if (lane < E) out[(int64_t)bcur * out_ld + lane] = run;
+                if (lane < E) {
+                    float* o = out + (int64_t)bcur * out_ld + lane;
+                    *o = acc ? *o + run : run;
+                }
                 run = 0.f;
                 lcur = 0;
                 ++bcur;
@@ -699,7 +706,8 @@ void k_din_attn_bwd(DinAttnArgs a) {
             }
         }
         const int nvalid = (R1 - rb < 32) ? (int)(R1 - rb) : 32;
-        da_seg_sum(Xs + 2 * E * DA_LDX, E, L, lane, nvalid, bcur, lcur, dq_run, a.dq, a.dq_ld);
+        da_seg_sum(Xs + 2 * E * DA_LDX, E, L, lane, nvalid, bcur, lcur, dq_run, a.dq, a.dq_ld, 0.f,
+                   a.dq_acc != 0);
     }
     __syncthreads();                               // both waves have left their tile loops
     float* scratch = &sm.Xs[0][0];                 // wave 1's dW1 accumulators: NB*FB*16*64 floats
@@ -1259,7 +1267,8 @@ void k_din_attn2_bwd(DinAttnArgs a) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) dhs_run[j] += dhs0[j];
         }
-        da_seg_sum(Xs + EC * DA_LDX, EC, L, lane, nvalid, bcur, lcur, dq_run, a.dq, a.dq_ld, extra);
+        da_seg_sum(Xs + EC * DA_LDX, EC, L, lane, nvalid, bcur, lcur, dq_run, a.dq, a.dq_ld, extra,
+                   a.dq_acc != 0);
     }
     // ---- per-workgroup partial of dW1 (assembled from dWq, dW') and db1
     __syncthreads();
@@ -1333,8 +1342,10 @@ __global__ __launch_bounds__(256) void k_da_chunks_sum(const float* partial, int
 __global__ __launch_bounds__(256) void k_da_stats_from_sums(const float* sums, int H, double n_total,
                                                             float momentum, float* stats,
                                                             float* running_mean,
-                                                            float* running_var) {
+                                                            float* running_var,
+                                                            int64_t* num_batches_tracked) {
     const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h == 0 && num_batches_tracked) *num_batches_tracked += 1;   // nn.BatchNorm1d's step counter
     if (h >= H) return;
     const double mean = (double)sums[h] / n_total;
     double var = (double)sums[H + h] / n_total - mean * mean;
@@ -1485,13 +1496,14 @@ extern "C" int fx_din_attn_stats(const float* q, int64_t q_ld, const float* K, i
 
 extern "C" int fx_dice_stats_from_sums(const float* sums, int32_t H, int64_t n_total, float momentum,
                                        int32_t training, float* running_mean, float* running_var,
-                                       float* stats, fx_stream_t stream) {
+                                       int64_t* num_batches_tracked, float* stats, fx_stream_t stream) {
     FX_CHECK_ARG(H >= 1 && stats, "fx_dice_stats_from_sums: bad arguments");
     hipStream_t s = fx_hip_stream(stream);
     if (training) {
         FX_CHECK_ARG(sums && n_total >= 1, "fx_dice_stats_from_sums: training mode needs the sums");
         hipLaunchKernelGGL(k_da_stats_from_sums, dim3((unsigned)fx_ceil_div(H, 256)), dim3(256), 0, s,
-                           sums, (int)H, (double)n_total, momentum, stats, running_mean, running_var);
+                           sums, (int)H, (double)n_total, momentum, stats, running_mean, running_var,
+                           num_batches_tracked);
         FX_CHECK_LAUNCH();
     } else {
         FX_CHECK_ARG(running_mean && running_var, "fx_dice_stats_from_sums: null running statistics");
@@ -1560,8 +1572,8 @@ extern "C" int fx_din_attn_bwd(const float* q, int64_t q_ld, const float* K, int
                                const int32_t* mask, int64_t mask_ld, const float* a_logit,
                                const float* dout, int64_t dout_ld, const float* da,
                                const float* sums5, int64_t n_total, float* dq, int64_t dq_ld,
-                               float* dK, int64_t dk_ldb, int64_t dk_ldl, float* dW1b1,
-                               float* workspace, fx_stream_t stream) {
+                               int32_t dq_accumulate, float* dK, int64_t dk_ldb, int64_t dk_ldl,
+                               float* dW1b1, float* workspace, fx_stream_t stream) {
     int rc = da_check("fx_din_attn_bwd", q, K, B, L, E, H, W1);
     if (rc != FX_OK) return rc;
     FX_CHECK_ARG(alpha && stats && W2 && a_logit && dout && da && dq && dK && dW1b1 && workspace,
@@ -1579,7 +1591,7 @@ extern "C" int fx_din_attn_bwd(const float* q, int64_t q_ld, const float* K, int
     a.da_in = da;
     a.sums = training ? sums5 : nullptr;
     a.inv_n = training ? 1.f / (float)n_total : 0.f;
-    a.dq = dq; a.dq_ld = dq_ld; a.dK = dK; a.dk_ldb = dk_ldb; a.dk_ldl = dk_ldl;
+    a.dq = dq; a.dq_ld = dq_ld; a.dq_acc = dq_accumulate; a.dK = dK; a.dk_ldb = dk_ldb; a.dk_ldl = dk_ldl;
     a.partial = workspace;
     hipStream_t s = fx_hip_stream(stream);
     if (q2) DA2_LAUNCH(k_din_attn2_bwd, 128, g.wgs_bwd, s, a);

@@ -252,27 +252,34 @@ class _TableGroup(object):
         return self.scal
 
     # -- plans ------------------------------------------------------------------------------
-    def plan_for(self, ordered_features, pooled=None, tail=None):
+    def plan_for(self, ordered_features, pooled=None, tail=None, holes=()):
         """ordered_features: features of this group to embed, in feature_map order.
         pooled: {sequence feature: ops.POOL_SUM | ops.POOL_MEAN} — reduced inside the gather to ONE
         slot each (fx_emb_seq_pool_fwd); their id columns go last so that the plain gather takes
         the prefix [0, C_main).  tail: features whose id columns go last without being pooled here
         (the LR copy sums every column anyway and keeps the SAME column order as the embedding
-        layer's plan, so both share one de-dup / one id exchange)."""
+        layer's plan, so both share one de-dup / one id exchange).  holes: raw sequence features
+        whose positions are preceded by ONE reserved slot the gather leaves alone (DIN writes the
+        attended vector there: [.. fields .., pooled, positions ..] makes the tower's input a prefix of
+        the record and the record's gradient one buffer, no concatenation either way)."""
         pooled = pooled or {}
         last = set(pooled) | set(tail or ())
-        key = (tuple(ordered_features), tuple(sorted(pooled.items())), tuple(sorted(last)))
+        holes = tuple(f for f in holes if f in self.widths and f not in pooled)
+        key = (tuple(ordered_features), tuple(sorted(pooled.items())), tuple(sorted(last)), holes)
         plan = self.plans.get(key)
         if plan is not None:
             return plan
         p = _Plan()
         D = self.D
-        p.num_feats, p.slot, p.pooled = [], {}, dict(pooled)
+        p.num_feats, p.slot, p.pooled, p.hole = [], {}, dict(pooled), {}
         num_off = []
         slot = 0
         for f in ordered_features:           # slots follow the feature order
             if f in self.widths:
                 w = 1 if f in pooled else self.widths[f]
+                if f in holes:
+                    p.hole[f] = slot
+                    slot += 1
                 p.slot[f] = (slot, w)
                 slot += w
             else:
@@ -847,6 +854,7 @@ class FeatureEmbeddingDict(nn.Module):
         self._device = _alloc_device()
         self._groups = OrderedDict()   # D -> _TableGroup
         self._feat_group = {}          # feature -> D
+        self._pooled_holes = set()     # raw sequence features with a reserved slot in front (DIN)
         self._torch_feats = set()      # features served by stock torch modules ("embedding" type)
         self._stock_feats = set()      # id features delegated to the reference's PretrainedEmbedding
         lr_mode = (not (use_pretrain and use_sharing)) and embedding_dim == 1
@@ -1047,7 +1055,8 @@ class FeatureEmbeddingDict(nn.Module):
             feats = [f for f in fmap if f in present_set and self._feat_group.get(f) == D]
             if not feats:
                 continue
-            plan = grp.plan_for(feats, self._fused_pooling(grp, feats))
+            plan = grp.plan_for(feats, self._fused_pooling(grp, feats),
+                                holes=tuple(f for f in feats if f in self._pooled_holes))
             ids, dense = grp.pack_inputs(plan, inputs)
             track = torch.is_grad_enabled() and self.training
             anchor = self._anchor(grp)
@@ -1081,13 +1090,16 @@ class FeatureEmbeddingDict(nn.Module):
                 rec._fx_fused = front
             fused.update(plan.pooled)
             raw_seq = [fmap[f]["type"] == "sequence" and f not in plan.pooled for f in feats]
-            bounds = tuple((plan.slot[f][0], plan.slot[f][1] if r else None)
-                           for f, r in zip(feats, raw_seq))
+            # views in slot order; a reserved slot is one more (unnamed) view so that they tile the record
+            entries = [(plan.slot[f][0], plan.slot[f][1] if r else None, f)
+                       for f, r in zip(feats, raw_seq)] + [(h, None, None) for h in plan.hole.values()]
+            entries.sort(key=lambda t: t[0])
+            bounds = tuple((lo, w) for lo, w, _ in entries)
             if rec.requires_grad:
                 views = _SplitRecordFn.apply(rec, bounds)
             else:
                 views = _SplitRecordFn.forward(_NoCtx(), rec, bounds)
-            emb.update(zip(feats, views))
+            emb.update((f, v) for (_, _, f), v in zip(entries, views) if f is not None)
             emb[("__record__", D)] = (rec, plan)
         for f in present:
             if f in self._torch_feats:
@@ -1104,6 +1116,11 @@ class FeatureEmbeddingDict(nn.Module):
         feature_emb_dict._records = [v for k, v in emb.items() if isinstance(k, tuple)]
         feature_emb_dict._orig = {f: id(t) for f, t in feature_emb_dict.items()}
         return feature_emb_dict
+
+    def reserve_pooled_slot(self, feature):
+        """Native extension: keep one record slot free in front of the positions of the raw sequence
+        `feature`; a model that replaces the sequence by a pooled vector (DIN) writes it there."""
+        self._pooled_holes.add(feature)
 
     fuse_pooling = True     # class switch for A/B measurements (scripts/seqpool_bench.py)
     fuse_front = True       # class switch: the fused front / back end of csrc/fx_fused.hip
@@ -1533,13 +1550,15 @@ class _Workspace(object):
         return buf
 
 
-def linear_grads(dz, x, W, need_bias, mask=None, add=None):
+def linear_grads(dz, x, W, need_bias, mask=None, add=None, dx_out=None):
     """dW, db (as linear_weight_grads) and dx = dz W (+ the ReLU `mask` of the layer below / the
-    residual `add` in the epilogue), the two products in one launch."""
+    residual `add` in the epilogue), the two products in one launch.  dx_out: where dx goes (a
+    row-strided [B, K_in] view of a wider buffer is written in place)."""
     Bsz, N_out = dz.shape
     K_in = x.shape[1]
     dW = torch.empty(N_out, K_in, dtype=torch.float32, device=dz.device)
-    dx = torch.empty(Bsz, K_in, dtype=torch.float32, device=dz.device)
+    dx = dx_out if dx_out is not None else \
+        torch.empty(Bsz, K_in, dtype=torch.float32, device=dz.device)
     # split_k is the LARGEST slab count the workspace holds: the library picks the actual K split of
     # the launch it builds (fx_gemm_f32_batch: one grid for both products, tiles and slabs chosen
     # together), never more than this
@@ -1583,11 +1602,14 @@ class _MLPFn(torch.autograd.Function):
     epilogue, split-K dW GEMM, column-sum db.  args = (x, acts, W0, b0, W1, b1, ...)."""
 
     @staticmethod
-    def forward(ctx, x, acts, out_add, *wb):
+    def forward(ctx, x, acts, out_add, dx_into, *wb):
         """out_add: optional [B, N_last] tensor added to the last layer's output in its epilogue (DeepFM:
-        logit = fm + mlp, DeepFM.py:87 — one ATen add launch less); its gradient is dy."""
+        logit = fm + mlp, DeepFM.py:87 — one ATen add launch less); its gradient is dy.
+        dx_into: optional callable -> a [B, K0] tensor (unit inner stride) the input's gradient is
+        written into (DIN: the head of the gather record's gradient)."""
         need_dx = x.requires_grad
-        x = x.contiguous()
+        if x.stride(-1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+            x = x.contiguous()       # a 16-byte aligned row-strided view (record prefix) is read in place
         n = len(acts)
         # An input width that is not a multiple of 4 floats (DLRM's top MLP reads 27*26/2 + 16 = 367
         # columns) leaves the rows of x and W0 4-byte aligned: the GEMMs would take the unpipelined
@@ -1616,6 +1638,7 @@ class _MLPFn(torch.autograd.Function):
         ctx.hs = hs
         ctx.need_dx = need_dx
         ctx.K0, ctx.W0p = K0, W0p
+        ctx.dx_into = dx_into if (need_dx and W0p is None) else None
         return h
 
     @staticmethod
@@ -1637,7 +1660,8 @@ class _MLPFn(torch.autograd.Function):
             h_in = hs[i]
             if i > 0 or ctx.need_dx:
                 mask = h_in if (i > 0 and acts[i - 1]) else None
-                dW, db, dh = linear_grads(dz, h_in, W, b is not None, mask=mask)
+                dx_out = ctx.dx_into() if (i == 0 and ctx.dx_into is not None) else None
+                dW, db, dh = linear_grads(dz, h_in, W, b is not None, mask=mask, dx_out=dx_out)
                 if i > 0:
                     dz = dh
                 else:
@@ -1648,7 +1672,7 @@ class _MLPFn(torch.autograd.Function):
                 dW = dW[:, :ctx.K0]
                 dx = dx[:, :ctx.K0] if dx is not None else None
             grads[2 * i], grads[2 * i + 1] = dW, db
-        return (dx, None, dy if ctx.has_add else None) + tuple(grads)
+        return (dx, None, dy if ctx.has_add else None, None) + tuple(grads)
 
 
 class FxLinear(nn.Linear):
@@ -1656,7 +1680,7 @@ class FxLinear(nn.Linear):
 
     def forward(self, x):
         lead = x.shape[:-1]
-        y = _MLPFn.apply(x.reshape(-1, x.shape[-1]), (False,), None, self.weight, self.bias)
+        y = _MLPFn.apply(x.reshape(-1, x.shape[-1]), (False,), None, None, self.weight, self.bias)
         return y.reshape(*lead, self.out_features)
 
 
@@ -1820,10 +1844,10 @@ class MLP_Block(nn.Module):
             return None
         return stack, mods[i:]
 
-    def forward(self, inputs, out_add=None):
+    def forward(self, inputs, out_add=None, dx_into=None):
         """out_add (native extension, not in the reference's signature): a tensor the caller would add
         to the result anyway; when the whole stack is the fused Linear / ReLU node it rides in the last
-        GEMM's epilogue."""
+        GEMM's epilogue.  dx_into: see _MLPFn (ignored on the unfused path)."""
         if self._fused is None or inputs.dim() != 2:
             out = self.mlp(inputs)
             return out if out_add is None else out + out_add
@@ -1834,7 +1858,7 @@ class MLP_Block(nn.Module):
             wb += [lin.weight, lin.bias]
         fuse_add = out_add is not None and not tail and not acts[-1] and out_add.is_contiguous() \
             and out_add.shape == (inputs.shape[0], stack[-1][0].weight.shape[0])
-        out = _MLPFn.apply(inputs, acts, out_add if fuse_add else None, *wb)
+        out = _MLPFn.apply(inputs, acts, out_add if fuse_add else None, dx_into, *wb)
         for mod in tail:
             out = mod(out)
         if out_add is not None and not fuse_add:
@@ -1886,6 +1910,59 @@ class _DinPoolFn(torch.autograd.Function):
         return dw, dK, None
 
 
+def _din_attn_forward(q, K, mask_i32, W1, b1, alpha, W2, b2, mod, out):
+    """The fused attention forward (statistics pass, Dice statistics, apply pass) writing the pooled
+    vector into `out` ([B, E], any row stride).  -> (stats, a, training, dist, n_total)."""
+    B, L, E = K.shape
+    H = W1.shape[0]
+    dev = q.device
+    training = mod.training
+    dist = _DIST if (training and _DIST is not None and _DIST.world > 1) else None
+    ws = _Workspace.get(dev, ops.din_attn_workspace_floats(B, L, E, H), tag="din_attn")
+    stats = torch.empty(2 * H, dtype=torch.float32, device=dev)
+    n_total = B * L
+    if training:
+        sums = torch.empty(2 * H + 1, dtype=torch.float32, device=dev)
+        ops.din_attn_stats(q, K, W1, b1, sums, ws)
+        if dist is not None:
+            # row-sharded training: the reference normalises with the statistics of the WHOLE
+            # batch (activations.py:40-51) — one small all-reduce ([2H + 1] floats)
+            sums[2 * H] = float(B * L)
+            dist.all_reduce_sum(sums)
+            n_total = _global_rows(sums[2 * H], B * L, dist)
+        # (BatchNorm1d's step counter rides along in the same launch)
+        ops.dice_stats_from_sums(sums, H, n_total, mod.bn.momentum, True, mod.bn.running_mean,
+                                 mod.bn.running_var, stats, mod.bn.num_batches_tracked)
+    else:
+        ops.dice_stats_from_sums(None, H, 1, 0.0, False, mod.bn.running_mean,
+                                 mod.bn.running_var, stats)
+    a = torch.empty(B, L, dtype=torch.float32, device=dev)
+    ops.din_attn_fwd(q, K, W1, b1, alpha, mod.bn.eps, stats, W2.reshape(-1), b2, mask_i32, a, out)
+    return stats, a, training, dist, n_total
+
+
+def _din_attn_backward(q, K, mask_i32, W1, b1, alpha, W2, stats, a, eps, training, dist, n_total,
+                       dout, dq, dK, dq_accumulate=False):
+    """dout [B, E], dq [B, E], dK [B, L, E]: any row strides (slots of one record-shaped buffer).
+    -> (dW1, db1, dalpha, dW2, db2)."""
+    B, L, E = K.shape
+    H = W1.shape[0]
+    dev = q.device
+    ws = _Workspace.get(dev, ops.din_attn_workspace_floats(B, L, E, H), tag="din_attn")
+    w2 = W2.reshape(-1)
+    da = torch.empty(B, L, dtype=torch.float32, device=dev)
+    sums5 = torch.empty(5 * H, dtype=torch.float32, device=dev)
+    ops.din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, w2, mask_i32, dout, da, sums5, ws)
+    if dist is not None:
+        dist.all_reduce_sum(sums5[H:3 * H])   # sum dzhat, sum dzhat*zhat: global batch
+    dW1b1 = torch.empty(H * 4 * E + H, dtype=torch.float32, device=dev)
+    ops.din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, w2, mask_i32, a, dout, da, sums5,
+                     n_total, dq, dK, dW1b1, ws, dq_accumulate=dq_accumulate)
+    dW1 = dW1b1[:H * 4 * E].view(H, 4 * E)
+    db1 = dW1b1[H * 4 * E:] if b1 is not None else None
+    return dW1, db1, sums5[:H], sums5[3 * H:4 * H].view(W2.shape), sums5[4 * H:4 * H + 1]
+
+
 class _DinAttnFn(torch.autograd.Function):
     """target_attention.py:66-92 with its MLP_Block(4E -> H, Dice, -> 1) as ONE autograd node on the
     fused kernels of fx_din_attn.hip: neither the [B*L, 4E] concatenation nor the [B*L, H] hidden
@@ -1898,31 +1975,9 @@ class _DinAttnFn(torch.autograd.Function):
         if q.stride(-1) != 1:
             q = q.contiguous()       # a row-strided view (a slot of the gather record) is read in place
         B, L, E = K.shape
-        H = W1.shape[0]
-        dev = q.device
-        training = mod.training
-        dist = _DIST if (training and _DIST is not None and _DIST.world > 1) else None
-        ws = _Workspace.get(dev, ops.din_attn_workspace_floats(B, L, E, H), tag="din_attn")
-        stats = torch.empty(2 * H, dtype=torch.float32, device=dev)
-        n_total = B * L
-        if training:
-            sums = torch.empty(2 * H + 1, dtype=torch.float32, device=dev)
-            ops.din_attn_stats(q, K, W1, b1, sums, ws)
-            if dist is not None:
-                # row-sharded training: the reference normalises with the statistics of the WHOLE
-                # batch (activations.py:40-51) — one small all-reduce ([2H + 1] floats)
-                sums[2 * H] = float(B * L)
-                dist.all_reduce_sum(sums)
-                n_total = _global_rows(sums[2 * H], B * L, dist)
-            ops.dice_stats_from_sums(sums, H, n_total, mod.bn.momentum, True, mod.bn.running_mean,
-                                     mod.bn.running_var, stats)
-        else:
-            ops.dice_stats_from_sums(None, H, 1, 0.0, False, mod.bn.running_mean,
-                                     mod.bn.running_var, stats)
-        w2 = W2.reshape(-1)
-        a = torch.empty(B, L, dtype=torch.float32, device=dev)
-        out = torch.empty(B, E, dtype=torch.float32, device=dev)
-        ops.din_attn_fwd(q, K, W1, b1, alpha, mod.bn.eps, stats, w2, b2, mask_i32, a, out)
+        out = torch.empty(B, E, dtype=torch.float32, device=q.device)
+        stats, a, training, dist, n_total = _din_attn_forward(q, K, mask_i32, W1, b1, alpha, W2, b2,
+                                                              mod, out)
         ctx.save_for_backward(q, K, mask_i32, W1, b1, alpha, W2, stats, a)
         ctx.training, ctx.eps, ctx.dist, ctx.n_total = training, mod.bn.eps, dist, n_total
         return out
@@ -1931,26 +1986,69 @@ class _DinAttnFn(torch.autograd.Function):
     def backward(ctx, dout):
         q, K, mask_i32, W1, b1, alpha, W2, stats, a = ctx.saved_tensors
         B, L, E = K.shape
-        H = W1.shape[0]
-        dev = q.device
-        ws = _Workspace.get(dev, ops.din_attn_workspace_floats(B, L, E, H), tag="din_attn")
-        dout = dout.contiguous()
-        w2 = W2.reshape(-1)
-        da = torch.empty(B, L, dtype=torch.float32, device=dev)
-        sums5 = torch.empty(5 * H, dtype=torch.float32, device=dev)
-        ops.din_attn_bwd_sums(q, K, W1, b1, alpha, ctx.eps, stats, w2, mask_i32, dout, da, sums5, ws)
-        if ctx.dist is not None:
-            ctx.dist.all_reduce_sum(sums5[H:3 * H])   # sum dzhat, sum dzhat*zhat: global batch
-        dq = torch.empty(B, E, dtype=torch.float32, device=dev)
-        dK = torch.empty(B, L, E, dtype=torch.float32, device=dev)
-        dW1b1 = torch.empty(H * 4 * E + H, dtype=torch.float32, device=dev)
-        ops.din_attn_bwd(q, K, W1, b1, alpha, ctx.eps, ctx.training, stats, w2, mask_i32, a, dout,
-                         da, sums5, ctx.n_total, dq, dK, dW1b1, ws)
-        dW1 = dW1b1[:H * 4 * E].view(H, 4 * E)
-        db1 = dW1b1[H * 4 * E:] if b1 is not None else None
-        dW2 = sums5[3 * H:4 * H].view(W2.shape)
-        db2 = sums5[4 * H:4 * H + 1]
-        return dq, dK, None, dW1, db1, sums5[:H], dW2, db2, None
+        if dout.stride(-1) != 1:
+            dout = dout.contiguous()     # (a column slice of the tower's input gradient is read in place)
+        dq = torch.empty(B, E, dtype=torch.float32, device=q.device)
+        dK = torch.empty(B, L, E, dtype=torch.float32, device=q.device)
+        dW1, db1, dalpha, dW2, db2 = _din_attn_backward(
+            q, K, mask_i32, W1, b1, alpha, W2, stats, a, ctx.eps, ctx.training, ctx.dist, ctx.n_total,
+            dout, dq, dK)
+        return dq, dK, None, dW1, db1, dalpha, dW2, db2, None
+
+
+class _RecordGradSlot(object):
+    """Where the gradient of a record prefix goes: handed to the tower as `dx_into`, it allocates the
+    record-shaped gradient buffer when the tower's backward asks for its input gradient and gives out
+    the prefix; the node that owns the record (_DinRecordFn) picks the buffer up again."""
+
+    def __init__(self, B, n_slots, D, n_head, device):
+        self.shape, self.n_head, self.device, self.buf = (B, n_slots, D), n_head, device, None
+
+    def __call__(self):
+        B, n_slots, D = self.shape
+        self.buf = torch.empty(B, n_slots, D, dtype=torch.float32, device=self.device)
+        return self.buf.view(B, n_slots * D)[:, :self.n_head * D]
+
+
+class _DinRecordFn(torch.autograd.Function):
+    """DIN's attention working IN the gather record (native fast path of zoo.DIN for the reference's
+    configuration: one target / one sequence, the sequence the last feature).  The record is laid out
+    [field 0 .. field n-1 | reserved | position 0 .. L-1] (FeatureEmbeddingDict.reserve_pooled_slot):
+      forward : q = the target's slot, K = the positions, the attended vector is written into the
+                reserved slot -> the tower's input [fields.., pooled] IS the record's prefix (returned
+                as a view: no concatenation);
+      backward: the tower writes its input gradient into the prefix of ONE record-shaped buffer
+                (dx_into), the attention reads dout from the reserved slot, writes dK into the position
+                slots and ADDS dq into the target's slot -> the buffer is the record's gradient as the
+                embedding backward wants it: no slicing, adding or concatenating launches."""
+
+    @staticmethod
+    def forward(ctx, rec, mask_i32, W1, b1, alpha, W2, b2, mod, tslot, hole, grad_slot):
+        B, n_slots, D = rec.shape
+        L = n_slots - hole - 1
+        q, K, out = rec[:, tslot, :], rec[:, hole + 1:, :], rec[:, hole, :]
+        stats, a, training, dist, n_total = _din_attn_forward(q, K, mask_i32, W1, b1, alpha, W2, b2,
+                                                              mod, out)
+        ctx.save_for_backward(rec, mask_i32, W1, b1, alpha, W2, stats, a)
+        ctx.training, ctx.eps, ctx.dist, ctx.n_total = training, mod.bn.eps, dist, n_total
+        ctx.tslot, ctx.hole, ctx.grad_slot = tslot, hole, grad_slot
+        return rec.view(B, n_slots * D)[:, :(hole + 1) * D]
+
+    @staticmethod
+    def backward(ctx, dflat):
+        rec, mask_i32, W1, b1, alpha, W2, stats, a = ctx.saved_tensors
+        B, n_slots, D = rec.shape
+        tslot, hole, gs = ctx.tslot, ctx.hole, ctx.grad_slot
+        drec, gs.buf = gs.buf, None
+        if drec is None or dflat.data_ptr() != drec.data_ptr() or dflat.stride(0) != n_slots * D:
+            # the tower did not write in place (unfused tower, padded input): one strided copy
+            drec = torch.empty(B, n_slots, D, dtype=torch.float32, device=rec.device)
+            drec.view(B, n_slots * D)[:, :(hole + 1) * D].copy_(dflat)
+        q, K = rec[:, tslot, :], rec[:, hole + 1:, :]
+        dW1, db1, dalpha, dW2, db2 = _din_attn_backward(
+            q, K, mask_i32, W1, b1, alpha, W2, stats, a, ctx.eps, ctx.training, ctx.dist, ctx.n_total,
+            drec[:, hole, :], drec[:, tslot, :], drec[:, hole + 1:, :], dq_accumulate=True)
+        return drec, None, dW1, db1, dalpha, dW2, db2, None, None, None, None
 
 
 class DIN_Attention(nn.Module):
@@ -1986,6 +2084,18 @@ class DIN_Attention(nn.Module):
             self._fx_plan = plan
         return plan
 
+    def forward_in_record(self, rec, mask_i32, tslot, hole, grad_slot):
+        """Native fast path (see _DinRecordFn): rec [B, n_slots, D] = [fields | reserved | positions];
+        -> the tower's input [B, (hole + 1) * D] as a view of the record, or None when this
+        attention is not the fused configuration."""
+        plan = self._fused_plan()
+        if plan is None or 4 * rec.shape[2] != plan[0].in_features or mask_i32 is None \
+                or mask_i32.dtype != torch.int32 or mask_i32.stride(-1) != 1:
+            return None
+        lin1, dice, lin2 = plan
+        return _DinRecordFn.apply(rec, mask_i32, lin1.weight, lin1.bias, dice.alpha, lin2.weight,
+                                  lin2.bias, dice, tslot, hole, grad_slot)
+
     def forward(self, target_item, history_sequence, mask=None):
         seq_len = history_sequence.size(1)
         plan = self._fused_plan()
@@ -1996,8 +2106,6 @@ class DIN_Attention(nn.Module):
                 m = mask                     # e.g. the packed id columns: kept when != 0
             else:
                 m = mask.to(torch.int32).contiguous()
-            if dice.training:
-                dice.bn.num_batches_tracked += 1
             return _DinAttnFn.apply(target_item, history_sequence, m, lin1.weight, lin1.bias,
                                     dice.alpha, lin2.weight, lin2.bias, dice)
         if mask is not None and mask.dtype != torch.bool:

@@ -740,10 +740,13 @@ def din_attn_stats(q, K, W1, b1, sums, workspace):
           "fx_din_attn_stats")
 
 
-def dice_stats_from_sums(sums, H, n_total, momentum, training, running_mean, running_var, stats):
+def dice_stats_from_sums(sums, H, n_total, momentum, training, running_mean, running_var, stats,
+                         num_batches_tracked=None):
+    """num_batches_tracked (int64[1], training only): += 1 in the same launch."""
     check(_lib.load().fx_dice_stats_from_sums(ptr(sums) if sums is not None else None, H, n_total,
                                               momentum, 1 if training else 0, ptr(running_mean),
-                                              ptr(running_var), ptr(stats),
+                                              ptr(running_var),
+                                              ptr(num_batches_tracked) if training else None, ptr(stats),
                                               stream_ptr(stats.device)), "fx_dice_stats_from_sums")
 
 
@@ -774,14 +777,16 @@ def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, mask, dout, da, sums5
 
 @_timed("din_attn_bwd", "din_attention", _din_attn_flops(2))
 def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, mask, a_logit, dout, da, sums5,
-                 n_total, dq, dK, dW1b1, workspace):
+                 n_total, dq, dK, dW1b1, workspace, dq_accumulate=False):
+    """dq_accumulate: dq += (the rows already hold another share of the target's gradient)."""
     K, head = _din_attn_head(q, K)
     H = W1.shape[0]
     check(_lib.load().fx_din_attn_bwd(*head, ptr(W1), ptr(b1), H, ptr(alpha), eps,
                                       1 if training else 0, ptr(stats), ptr(W2), ptr(mask),
                                       mask.stride(0) if mask is not None else 0, ptr(a_logit),
                                       ptr(dout), dout.stride(0), ptr(da), ptr(sums5), n_total,
-                                      ptr(dq), dq.stride(0), ptr(dK), dK.stride(0), dK.stride(1),
+                                      ptr(dq), dq.stride(0), 1 if dq_accumulate else 0, ptr(dK),
+                                      dK.stride(0), dK.stride(1),
                                       ptr(dW1b1), ptr(workspace), stream_ptr(q.device)),
           "fx_din_attn_bwd")
 

@@ -7,12 +7,14 @@ classes exist because /root/reference does not travel to the GPU box; with the r
 its own model_zoo classes run unmodified on the same layers through `fuxictr_amd.patch.install()`
 (INTEGRATION.md, tests/test_dropin_reference_zoo.py).
 """
+import os as _os
+
 import torch
 from torch import nn
 
 from .layers import (CompressedInteractionNet, CrossNetV2, DIN_Attention, Dice,
                      FactorizationMachine, FeatureEmbedding, FeatureEmbeddingDict, FxLinear,
-                     InnerProductInteraction, LogisticRegression, MLP_Block)
+                     InnerProductInteraction, LogisticRegression, MLP_Block, _RecordGradSlot)
 from .rank_model import BaseModel
 
 
@@ -154,7 +156,39 @@ class DIN(_ZooModel):
             dnn_activations = [Dice(units) for units in dnn_hidden_units]
         self.dnn = self._tower(feature_map.sum_emb_out_dim(), dnn_hidden_units, dnn_activations,
                                net_dropout, batch_norm, output_activation=self.output_activation)
+        # the reference's configuration — one target field, one raw sequence that is the LAST feature —
+        # runs the attention inside the gather record (layers._DinRecordFn): no cat / slice / add launches
+        self._in_record = None
+        names = list(feature_map.features)
+        if (_os.environ.get("FX_DIN_INPLACE", "1") != "0" and len(self.din_target_field) == 1
+                and isinstance(self.din_target_field[0], str)
+                and isinstance(self.din_sequence_field[0], str)
+                and names and names[-1] == self.din_sequence_field[0]
+                and feature_map.features[names[-1]]["type"] == "sequence"
+                and not feature_map.features[names[-1]].get("feature_encoder")):
+            self._in_record = (self.din_target_field[0], self.din_sequence_field[0])
+            self.embedding_layer.reserve_pooled_slot(self.din_sequence_field[0])
         self._ready(kwargs, learning_rate)
+
+    def _record_layout(self, emb):
+        """(rec, tslot, hole) when the embedding dict is ONE gather record laid out
+        [single-slot fields.. | reserved | the sequence's positions]; None otherwise."""
+        if self._in_record is None:
+            return None
+        records = getattr(emb, "_records", None)
+        if not records or len(records) != 1 or emb._encoded:
+            return None
+        rec, plan = records[0]
+        target, seq = self._in_record
+        hole = plan.hole.get(seq)
+        if hole is None or target not in plan.slot or plan.slot[target][1] != 1 \
+                or list(emb)[-1] != seq or len(emb) != hole + 1 \
+                or plan.slot[seq][0] + plan.slot[seq][1] != plan.n_slots:
+            return None
+        for i, f in enumerate(emb):
+            if f != seq and plan.slot.get(f) != (i, 1):
+                return None
+        return rec, plan.slot[target][0], hole
 
     def get_embedding(self, field, feature_emb_dict):
         names = _fields(field)
@@ -165,6 +199,15 @@ class DIN(_ZooModel):
     def forward(self, inputs):
         X = self.get_inputs(inputs)
         emb = self.embedding_layer(X)                       # name -> [B,D] | [B,L,D]
+        layout = self._record_layout(emb)
+        if layout is not None:
+            rec, tslot, hole = layout
+            B, n_slots, D = rec.shape
+            slot = _RecordGradSlot(B, n_slots, D, hole + 1, rec.device) if rec.requires_grad else None
+            flat = self.attention_layers[0].forward_in_record(
+                rec, self.embedding_layer.packed_ids(X, self._in_record[1]), tslot, hole, slot)
+            if flat is not None:
+                return {"y_pred": self.dnn(flat, dx_into=slot)}
         for attend, target, sequence in zip(self.attention_layers, self.din_target_field,
                                             self.din_sequence_field):
             seq_names = _fields(sequence)

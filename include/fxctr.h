@@ -493,8 +493,9 @@ int fx_dice_bwd(const float* Z, const float* dY, int64_t N, int32_t H, const flo
  * mask: int32 [B, L] (row stride mask_ld; position kept when != 0; NULL = all kept).
  *   fx_din_attn_stats       sums[2H] = [sum h | sum h^2] over this rank's B*L positions
  *   fx_dice_stats_from_sums training != 0: stats from (all-reduced) sums and n_total rows + running
- *                           statistics update (momentum, unbiased variance), like
- *                           nn.BatchNorm1d(affine=False); training == 0: stats = running statistics
+ *                           statistics update (momentum, unbiased variance; num_batches_tracked += 1 when
+ *                           the pointer is given), like nn.BatchNorm1d(affine=False); training == 0:
+ *                           stats = running statistics
  *   fx_din_attn_fwd         a[b*L + l] = W2 . Dice(W1 x_bl + b1) + b2 (before the mask) and the
  *                           pooled output out[b,:] = sum_l a mask k_bl
  *   fx_din_attn_bwd_sums    from dout[B,E]: da[b*L + l] = mask (dout_b . k_bl) (written) and
@@ -509,8 +510,8 @@ int fx_din_attn_stats(const float* q, int64_t q_ld, const float* K, int64_t k_ld
                       int64_t B, int32_t L, int32_t E, const float* W1, const float* b1, int32_t H,
                       float* sums, float* workspace, fx_stream_t stream);
 int fx_dice_stats_from_sums(const float* sums, int32_t H, int64_t n_total, float momentum,
-                            int32_t training, float* running_mean, float* running_var, float* stats,
-                            fx_stream_t stream);
+                            int32_t training, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, float* stats, fx_stream_t stream);
 int fx_din_attn_fwd(const float* q, int64_t q_ld, const float* K, int64_t k_ldb, int64_t k_ldl,
                     int64_t B, int32_t L, int32_t E, const float* W1, const float* b1, int32_t H,
                     const float* alpha, float eps, const float* stats, const float* W2,
@@ -527,8 +528,8 @@ int fx_din_attn_bwd(const float* q, int64_t q_ld, const float* K, int64_t k_ldb,
                     const float* alpha, float eps, int32_t training, const float* stats,
                     const float* W2, const int32_t* mask, int64_t mask_ld, const float* a_logit,
                     const float* dout, int64_t dout_ld, const float* da, const float* sums5,
-                    int64_t n_total, float* dq, int64_t dq_ld, float* dK, int64_t dk_ldb,
-                    int64_t dk_ldl, float* dW1b1, float* workspace, fx_stream_t stream);
+                    int64_t n_total, float* dq, int64_t dq_ld, int32_t dq_accumulate, float* dK,
+                    int64_t dk_ldb, int64_t dk_ldl, float* dW1b1, float* workspace, fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * xDeepFM Compressed Interaction Network layer, fused (compressed_interaction_net.py:54-76):

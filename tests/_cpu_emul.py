@@ -529,7 +529,10 @@ def din_attn_stats(q, K, W1, b1, sums, workspace):
     sums[H:2 * H] = (h * h).sum(0)
 
 
-def dice_stats_from_sums(sums, H, n_total, momentum, training, running_mean, running_var, stats):
+def dice_stats_from_sums(sums, H, n_total, momentum, training, running_mean, running_var, stats,
+                         num_batches_tracked=None):
+    if training and num_batches_tracked is not None:
+        num_batches_tracked += 1
     if not training:
         stats[:H] = running_mean
         stats[H:] = running_var
@@ -587,7 +590,7 @@ def din_attn_bwd_sums(q, K, W1, b1, alpha, eps, stats, W2, mask, dout, da, sums5
 
 
 def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, mask, a_logit, dout, da, sums5,
-                 n_total, dq, dK, dW1b1, workspace):
+                 n_total, dq, dK, dW1b1, workspace, dq_accumulate=False):
     B, L, E = K.shape
     H = W1.shape[0]
     x, h = _din_attn_h(q, K, W1, b1)
@@ -600,7 +603,8 @@ def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, mask, a_logit, d
     dW1b1[:H * 4 * E] = (dh.t() @ x).reshape(-1)
     dW1b1[H * 4 * E:] = dh.sum(0)
     d = (dh @ W1).view(B, L, 4, E)
-    dq.copy_((d[:, :, 0] + d[:, :, 2] + d[:, :, 3] * K).sum(1))
+    dq_new = (d[:, :, 0] + d[:, :, 2] + d[:, :, 3] * K).sum(1)
+    dq.copy_(dq + dq_new if dq_accumulate else dq_new)
     wm = a_logit.view(B, L) * _din_attn_mask(mask, B, L)
     dK.copy_(d[:, :, 1] - d[:, :, 2] + d[:, :, 3] * q.unsqueeze(1) + wm.unsqueeze(-1) * dout.unsqueeze(1))
 

@@ -368,3 +368,42 @@ def test_bf16_table_storage_wiring(tmp_path, monkeypatch):
         assert abs(loss - ref) < 2e-2, (i, loss, ref)       # bf16 rounding of the rows, not exactness
     model.eval()       # flush through adam_catchup_all
     assert main.table.dtype == torch.bfloat16
+
+
+def test_din_attention_runs_inside_the_gather_record(tmp_path, monkeypatch):
+    """The reference's DIN configuration (one target, one raw sequence as the last feature) takes the
+    in-record path: the tower reads a prefix of the record, its input gradient lands in the record's
+    gradient buffer (no copy), and the trajectory equals the unfused composition's bit for bit on the
+    CPU emulation (same arithmetic, other memory layout)."""
+    from conftest import Golden
+    from fuxictr_amd import layers as L
+    g = Golden("din_adam")
+    calls = {"fwd": 0, "inplace": 0}
+    fwd0, bwd0 = L._DinRecordFn.forward, L._DinRecordFn.backward
+
+    def fwd(ctx, *a):
+        calls["fwd"] += 1
+        return fwd0(ctx, *a)
+
+    def bwd(ctx, dflat):
+        buf = ctx.grad_slot.buf
+        calls["inplace"] += int(buf is not None and dflat.data_ptr() == buf.data_ptr())
+        return bwd0(ctx, dflat)
+    monkeypatch.setattr(L._DinRecordFn, "forward", staticmethod(fwd))
+    monkeypatch.setattr(L._DinRecordFn, "backward", staticmethod(bwd))
+    model = _build(g, tmp_path, monkeypatch)
+    assert model._in_record == ("adgroup_id", "click_sequence")
+    model.train()
+    losses = [float(model.train_step(tb(g.batches[i])).item()) for i in range(g.meta["steps"])]
+    assert calls["fwd"] == g.meta["steps"] and calls["inplace"] == g.meta["steps"]
+    np.testing.assert_allclose(losses, g.expect["loss"], atol=5e-6)
+    sd = model.state_dict()
+    monkeypatch.setenv("FX_DIN_INPLACE", "0")
+    other = _build(g, tmp_path, monkeypatch)
+    assert other._in_record is None
+    other.train()
+    losses0 = [float(other.train_step(tb(g.batches[i])).item()) for i in range(g.meta["steps"])]
+    np.testing.assert_allclose(losses, losses0, atol=1e-6)
+    for k, v in other.state_dict().items():
+        np.testing.assert_allclose(sd[k].numpy(), v.numpy(), atol=2e-6, err_msg=k)
+    assert int(sd["attention_layers.0.attention_layer.mlp.1.bn.num_batches_tracked"]) == g.meta["steps"]
