@@ -345,6 +345,9 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         parallelism = ("tables row-sharded over %d ranks (RCCL all-to-all of ids / rows / row "
                        "gradients), towers data-parallel (one flat all-reduce carrying the clip "
                        "norm); %s" % (world, "eager launches" if args.no_graph else
+                                      "one hipGraph per step with the RCCL collectives recorded in it "
+                                      "(FX_GRAPH_COLLECTIVES=1)"
+                                      if os.environ.get("FX_GRAPH_COLLECTIVES") == "1" else
                                       "hipGraph segments with the collectives launched between them"))
     else:
         model, fmap, spec = build_model(args, local_rank, cards)
@@ -726,6 +729,14 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
+        if os.environ.get("FX_GRAPH_COLLECTIVES") == "1" and dist.get_backend() == "nccl":
+            # opt-in mode (collectives recorded into the step's hipGraph): ProcessGroupNCCL's shutdown
+            # never returns once RCCL kernels were captured (torch 2.10 / ROCm 7.0: the traceback of
+            # profiles/r03_graph_collectives_teardown.txt ends in destroy_process_group).  The line
+            # is out and every rank passed the barrier: leave without the destructor chain.
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
