@@ -592,6 +592,17 @@ def rooflines(m, args, world):
             "us_per_step": 1e3 * da["total_ms"] / n_inst, "launches_per_step": da["launches"] / n_inst,
             "note": "serial chain per wave (x tile -> MFMA -> Dice gate -> ...), 4 passes around the "
                     "batch statistics; see DESIGN.md section 4"}
+    cn = kt.get("cin")
+    if cn and cn["total_ms"] > 0:
+        # the CIN passes (fx_cin_mfma.hip: forward, dX, dW of every layer).  Algorithmic flops = the
+        # compress product 2 O F0 Mi D per sample, once forward and twice backward — the padding of the
+        # MFMA tiles (Mi 39 -> 40 / 48) and the tile arithmetic on the VALU are not counted as work
+        ach = cn["work"] / (cn["total_ms"] * 1e-3) / 1e12
+        out["roofline_cin"] = {
+            "kernels": "k_cin_{fwd,dx,dw}_mfma of the three CIN layers (v_mfma_f32_16x16x4_f32)",
+            "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "us_per_step": 1e3 * cn["total_ms"] / n_inst, "launches_per_step": cn["launches"] / n_inst}
     e, ename = kt.get("k_emb_fm_fwd@alone"), "k_emb_fm_fwd (gather + numeric expansion + LR + FM, one launch)"
     if not (e and e["total_ms"] > 0):
         e, ename = kt.get("k_emb_gather_fwd"), "k_emb_gather_fwd"

@@ -831,6 +831,12 @@ def cin_pack_w(layers, D):
           "fx_cin_pack_w")
 
 
+def _cin_flops(X0, Xi, W, *a, **kw):
+    # the compress product of one pass: 2 * O * F0 * Mi * D flops per sample
+    return 2.0 * X0.shape[0] * W.shape[0] * X0.shape[1] * Xi.shape[1] * X0.shape[2]
+
+
+@_timed("cin_fwd", "cin", _cin_flops)
 def cin_fwd(X0, Xi, W, bias, Xn, pool, w_img=None):
     """X0 [B,F0,D], Xi [B,Mi,D] contiguous; W [O, F0*Mi]; Xn [B,O,D]; pool: [B,O] view (stride ok)."""
     B, F0, D = X0.shape
@@ -841,6 +847,7 @@ def cin_fwd(X0, Xi, W, bias, Xn, pool, w_img=None):
                                  stream_ptr(X0.device)), "fx_cin_fwd")
 
 
+@_timed("cin_bwd", "cin", lambda *a, **kw: 2.0 * _cin_flops(*a, **kw))     # dX and dW passes
 def cin_bwd(X0, Xi, W, dXn, dpool, dX0, accumulate_dx0, dXi, partial, w_img=None):
     """partial: [G, O*F0*Mi + O] (a column slice of a wider [G, .] buffer is written in place)."""
     B, F0, D = X0.shape
