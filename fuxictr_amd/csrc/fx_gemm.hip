@@ -1699,6 +1699,40 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
             return FX_OK;
         }
     }
+    // Two FORWARD products (x W^T: the cross layer and the deep layer of one DCNv2 depth) in one grid of
+    // 64x64 tiles, the longer problem's tiles first: the 640 tiles of the 624-wide cross product leave
+    // 384 of the 1024 resident slots empty on their own and all reach their (four-operand) epilogue
+    // together; behind the deep layer's 1024 tiles they fill slots as those retire.  FX_GEMM_FWDPAIR=0:
+    // problem by problem.
+    static const bool fwdpair_on = []() {
+        const char* e = getenv("FX_GEMM_FWDPAIR");
+        return !(e && atoi(e) == 0);
+    }();
+    if (n == 2 && pair_on && fwdpair_on && !p[0].transa && p[0].transb && !p[1].transa && p[1].transb) {
+        GemmArgs a[2];
+        int bm[2], bn[2];
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; ++i) {
+            const fx_gemm_problem& q = p[i];
+            ok = q.M > 0 && q.N > 0 && !fx_gemm_skinny(q);
+            if (!ok) break;
+            const int rc = fx_gemm_prepare(q.transa, q.transb, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb,
+                                           q.C, q.ldc, q.epilogue, 1, q.workspace, a[i], bm[i], bn[i]);
+            if (rc != FX_OK) return rc;
+            a[i].tiles_m = (int32_t)fx_ceil_div(q.M, 64);
+            a[i].tiles_n = (int32_t)fx_ceil_div(q.N, 64);
+            ok = a[i].split_k == 1 && fx_gemm_pipe_ok(q.transa, q.transb, a[i]) && fx_gemm_tr_ok(a[i]);
+        }
+        if (ok) {
+            const int64_t t0 = (int64_t)a[0].tiles_m * a[0].tiles_n, t1 = (int64_t)a[1].tiles_m * a[1].tiles_n;
+            const bool swap = (double)p[1].N * p[1].K > (double)p[0].N * p[0].K;   // more work per row first
+            hipLaunchKernelGGL((k_gemm_f32_pair<64, 64, true, true, true, true, 4, true>),
+                               dim3((unsigned)(t0 + t1)), dim3(256), 0, fx_hip_stream(stream),
+                               swap ? a[1] : a[0], swap ? a[0] : a[1]);
+            FX_CHECK_LAUNCH();
+            return FX_OK;
+        }
+    }
     for (int i = 0; i < n; ++i) {
         const fx_gemm_problem& q = p[i];
         const int rc = fx_gemm_f32(q.transa, q.transb, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C,
