@@ -1726,6 +1726,9 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
         if (ok) {
             const int64_t t0 = (int64_t)a[0].tiles_m * a[0].tiles_n, t1 = (int64_t)a[1].tiles_m * a[1].tiles_n;
             const bool swap = (double)p[1].N * p[1].K > (double)p[0].N * p[0].K;   // more work per row first
+            // (alternating the two problems' tiles in proportion to their counts instead — every CU
+            // starting with a mix of long and short tiles — measured 1.490 vs 1.451 ms: worse than two
+            // launches; the longer problem first it is)
             hipLaunchKernelGGL((k_gemm_f32_pair<64, 64, true, true, true, true, 4, true>),
                                dim3((unsigned)(t0 + t1)), dim3(256), 0, fx_hip_stream(stream),
                                swap ? a[1] : a[0], swap ? a[0] : a[1]);
