@@ -451,6 +451,35 @@ def test_gemm_batch_of_four_problems_in_one_grid():
         assert (db.double() - dz.double().sum(0)).abs().max().item() <= 1e-5 * dz.abs().double().sum(0).max().item()
 
 
+@pytest.mark.parametrize("M", [4096, 1000])
+def test_gemm_batch_of_two_forward_problems_is_the_two_launches(M):
+    """fx_gemm_f32_batch with the cross layer and the deep layer of one DCNv2 depth FORWARD (x W^T with the
+    CrossNet epilogue bias / z out / Hadamard / residual, and bias + ReLU): one grid of 64x64 tiles, same
+    tiles and k order as the two single launches -> identical bits, strided outputs included."""
+    g = torch.Generator().manual_seed(M)
+    D0, H = 624, 1024
+    xi, x0 = _dev(torch.randn(M, D0, generator=g)), _dev(torch.randn(M, D0, generator=g))
+    Wc, bc = _dev(torch.randn(D0, D0, generator=g) * 0.05), _dev(torch.randn(D0, generator=g))
+    Wd, bd = _dev(torch.randn(H, D0, generator=g) * 0.05), _dev(torch.randn(H, generator=g))
+    res = []
+    for batched in (True, False):
+        out = torch.full((M, D0 + H), float("nan"), device=DEV)      # both towers write one buffer
+        z = torch.full((M, D0), float("nan"), device=DEV)
+        if batched:
+            ops.gemm_batch([ops.gemm_problem(xi, Wc, out[:, :D0], transb=True, bias=bc, zout=z, mul=x0, add=xi),
+                            ops.gemm_problem(xi, Wd, out[:, D0:], transb=True, bias=bd, act=1)])
+        else:
+            ops.gemm(xi, Wc, out[:, :D0], transb=True, bias=bc, zout=z, mul=x0, add=xi)
+            ops.gemm(xi, Wd, out[:, D0:], transb=True, bias=bd, act=1)
+        torch.cuda.synchronize()
+        res.append((out.cpu(), z.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    zr = xi.double() @ Wc.double().t() + bc.double()
+    ref = torch.cat([zr * x0.double() + xi.double(),
+                     torch.relu(xi.double() @ Wd.double().t() + bd.double())], dim=1).cpu()
+    assert (res[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("widths", [(16, 1), (16,), (8, 4, 1), (3,)])
 def test_exchange_block_scatter_and_split(widths):
     """fx_scatter_rows into the column range of a shared block (row stride > D, 16-byte aligned or
