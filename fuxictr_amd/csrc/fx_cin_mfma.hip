@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * FX_CIN_WAVES) void k_cin_dw_mfma(CinArgs a) {
     constexpr int SB = FX_CIN_DW_SB, NT = 64 * FX_CIN_WAVES, NW = FX_CIN_WAVES;
     constexpr int X0Q = (48 * 16 + NT - 1) / NT, XIQ = (MT * 256 + NT - 1) / NT;
     __shared__ float x0s[2][SB][48 * 16];  // a sample's X0 [F0 <= 40][16], zero rows up to 48; double-buffered
-    __shared__ float gs[2][SB][16 * 16];   // g[o][d]
+    __shared__ float gs[2][SB][16 * 17];   // g[o][d], rows padded to 17 floats like Xi's
     __shared__ float xis[2][SB][48 * 17];  // Xi rows padded to 17 floats (conflict-free column reads)
     const int F0 = a.F0, Mi = a.Mi, O = a.O, C = F0 * Mi;
     const int tid = threadIdx.x;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64 * FX_CIN_WAVES) void k_cin_dw_mfma(CinArgs a) {
                 const int m = (tid + NT * q) >> 4;
                 if (m < MT * 16) xis[buf][sb][m * 17 + (tid & 15)] = pxi[sb][q];
             }
-            if (tid < 256) gs[buf][sb][tid] = pg[sb];
+            if (tid < 256) gs[buf][sb][(tid >> 4) * 17 + (tid & 15)] = pg[sb];
         }
     };
     const int64_t per_round = (int64_t)SB * gridDim.x;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64 * FX_CIN_WAVES) void k_cin_dw_mfma(CinArgs a) {
             float ga[4], xr[MT][4], ah[HPW][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ga[j] = gs[buf][sb][r * 16 + 4 * j + kk];
+                ga[j] = gs[buf][sb][r * 17 + 4 * j + kk];
                 if (wave == 0) db += ga[j];
             }
 #pragma unroll

@@ -1,9 +1,9 @@
 #!/bin/bash
-# SQ counters (one --pmc pass, kernel-trace only) of the MFMA kernels inside the DCNv2 and DIN steps:
+# SQ counters (one --pmc pass, kernel-trace only) of the MFMA kernels inside the DCNv2 and DIN steps (MODELS=... for others):
 # matrix-pipe busy cycles per kernel next to its duration (eager launches, so every dispatch is attributed).
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 CTRS="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-for M in DCNv2 DIN; do
+for M in ${MODELS:-DCNv2 DIN}; do
   rm -rf /tmp/pmc_mfma_$M
   (cd /tmp && timeout 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d /tmp/pmc_mfma_$M -- \
       python $REPO/bench.py --model $M --steps 3 --warmup 5 --no-graph --no-cpu-baseline --no-kernel-timing > /dev/null 2> $OUT/pmc_mfma_$M.err)
@@ -19,7 +19,7 @@ for r in csv.DictReader(open(sys.argv[2])):
 agg = {}
 for r in rows:
     name = r["Kernel_Name"]
-    m = re.search(r"(k_gemm_f32_pipe<[^>]*>|k_gemm_f32_pair<[^>]*>|k_din_attn2?_\w+<[^>]*>|k_dot_interact_\w+)", name)
+    m = re.search(r"(k_gemm_f32_pipe<[^>]*>|k_gemm_f32_pair<[^>]*>|k_din_attn2?_\w+<[^>]*>|k_dot_interact_\w+|k_cin_\w+<[^>]*>|k_gemm_f32_multi)", name)
     if not m:
         continue
     key = (m.group(1), r.get("Grid_Size", ""))
