@@ -40,7 +40,7 @@ def test_rccl_backend_one_rank_full_exchange_path(case, graph, tmp_path):
     check_against_golden(z, g)
 
 
-def _bench_line(args, env=None):
+def _bench_line(args, env=None, timeout=900):
     import json
     import os
     import subprocess
@@ -49,7 +49,7 @@ def _bench_line(args, env=None):
     e = dict(os.environ)
     e.update(env or {})
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True,
-                       text=True, env=e, timeout=900)
+                       text=True, env=e, timeout=timeout)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]            # ONE JSON line, printed by rank 0
@@ -74,3 +74,17 @@ def test_bench_launch_with_two_ranks_reports_two_gpus_and_the_one_rank_losses():
     for a, b in zip(one["probe_loss"], two["probe_loss"]):
         assert abs(a - b) <= 2e-5, (one["probe_loss"], two["probe_loss"])
     assert one["probe_loss"][0] != one["probe_loss"][1]          # the model did move between the steps
+
+
+def test_collectives_recorded_into_the_graph_run_and_exit_on_one_rccl_rank():
+    """FX_GRAPH_COLLECTIVES=1 (opt-in): the sharded step as ONE hipGraph with the RCCL collectives recorded
+    in it.  Round 2 hung at teardown (ProcessGroupNCCL's shutdown never returns once RCCL kernels were
+    captured); the bench now leaves after its final barrier.  One rank, real RCCL: the line comes out, the
+    process ends by itself, and the probe losses equal those of the segmented step (same kernels, same
+    order)."""
+    common = ["--vocab-scale", "0.01", "--steps", "3", "--warmup", "5", "--no-cpu-baseline",
+              "--no-kernel-timing", "--no-dcnv2", "--probe-loss"]
+    seg = _bench_line(common, env={"FX_SHARD_WORLD1": "1", "FX_GRAPH_COLLECTIVES": "0"})
+    rec = _bench_line(common, env={"FX_SHARD_WORLD1": "1", "FX_GRAPH_COLLECTIVES": "1"}, timeout=240)
+    assert "recorded" in rec["config"]["parallelism"] and "segments" in seg["config"]["parallelism"]
+    assert rec["probe_loss"] == seg["probe_loss"]
