@@ -126,7 +126,8 @@ SIGNATURES = {
     "fx_dice_bwd_local_sums": (i32, [vp, vp, i64, i32, vp, C.c_float, vp, vp, vp, vp]),
     "fx_dice_bwd_from_sums": (i32, [vp, vp, i64, i32, vp, C.c_float, vp, vp, i64, vp, vp]),
     "fx_din_attn_workspace_floats": (i64, [i64, i32, i32, i32]),
-    "fx_din_attn_stats": (i32, [vp, i64, vp, i64, i64, i64, i32, i32, vp, vp, i32, vp, vp, vp]),
+    "fx_din_attn_stats": (i32, [vp, i64, vp, i64, i64, i64, i32, i32, vp, vp, i32, vp, vp, vp, C.c_float, vp,
+                                vp, vp, vp]),
     "fx_dice_stats_from_sums": (i32, [vp, i32, i64, C.c_float, i32, vp, vp, vp, vp, vp]),
     "fx_din_attn_fwd": (i32, [vp, i64, vp, i64, i64, i64, i32, i32, vp, vp, i32, vp, C.c_float, vp,
                               vp, vp, vp, i64, vp, vp, i64, vp]),

@@ -1359,6 +1359,55 @@ __global__ __launch_bounds__(256) void k_da_stats_from_sums(const float* sums, i
     }
 }
 
+// k_da_chunks_sum (k = 0, 1: sum h, sum h^2) and k_da_stats_from_sums in one launch — the single-rank
+// case, where nothing (no all-reduce) happens between them.  Same chunk order, same statistics code.
+__global__ __launch_bounds__(256) void k_da_chunks_stats(const float* partial, int chunks, int H,
+                                                         double n_total, float momentum, float* sums,
+                                                         float* stats, float* running_mean,
+                                                         float* running_var, int64_t* num_batches_tracked) {
+    __shared__ float red[2][16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int h = blockIdx.x * 16 + tx;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float s = 0.f;
+        if (h < H) {
+            int c = ty;
+            for (; c + 7 * 16 < chunks; c += 8 * 16) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = partial[((int64_t)(c + u * 16) * 2 + k) * H + h];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; c < chunks; c += 16) s += partial[((int64_t)c * 2 + k) * H + h];
+        }
+        red[k][ty][tx] = s;
+    }
+    __syncthreads();
+    if (ty == 0 && h < H) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) {
+            t0 += red[0][y][tx];
+            t1 += red[1][y][tx];
+        }
+        sums[h] = t0;
+        sums[H + h] = t1;
+        const double mean = (double)t0 / n_total;
+        double var = (double)t1 / n_total - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[h] = (float)mean;
+        stats[H + h] = (float)var;
+        if (running_mean) {
+            const double unb = n_total > 1.0 ? var * n_total / (n_total - 1.0) : var;
+            running_mean[h] = (float)((1.0 - momentum) * running_mean[h] + momentum * mean);
+            running_var[h] = (float)((1.0 - momentum) * running_var[h] + momentum * unb);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1475,7 +1524,8 @@ static bool da2_ok(const DinAttnArgs& a) {
 extern "C" int fx_din_attn_stats(const float* q, int64_t q_ld, const float* K, int64_t k_ldb,
                                  int64_t k_ldl, int64_t B, int32_t L, int32_t E, const float* W1,
                                  const float* b1, int32_t H, float* sums, float* workspace,
-                                 fx_stream_t stream) {
+                                 float* stats, float momentum, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, fx_stream_t stream) {
     int rc = da_check("fx_din_attn_stats", q, K, B, L, E, H, W1);
     if (rc != FX_OK) return rc;
     FX_CHECK_ARG(sums && workspace, "fx_din_attn_stats: null pointer");
@@ -1488,8 +1538,13 @@ extern "C" int fx_din_attn_stats(const float* q, int64_t q_ld, const float* K, i
     hipStream_t s = fx_hip_stream(stream);
     if (q2) DA2_LAUNCH(k_din_attn2_stats, 256, g.wgs_flat, s, a);
     else DA_DISPATCH(k_din_attn_stats, 256, g.wgs_flat, s, a);
-    hipLaunchKernelGGL(k_da_chunks_sum, dim3((unsigned)fx_ceil_div(H, 16), 2), dim3(256), 0, s,
-                       (const float*)workspace, (int)g.wgs_flat, 2, (int64_t)H, sums);
+    if (stats)      // one rank: the sums ARE the batch's — statistics in the same launch
+        hipLaunchKernelGGL(k_da_chunks_stats, dim3((unsigned)fx_ceil_div(H, 16)), dim3(256), 0, s,
+                           (const float*)workspace, (int)g.wgs_flat, (int)H, (double)(B * (int64_t)L), momentum,
+                           sums, stats, running_mean, running_var, num_batches_tracked);
+    else
+        hipLaunchKernelGGL(k_da_chunks_sum, dim3((unsigned)fx_ceil_div(H, 16), 2), dim3(256), 0, s,
+                           (const float*)workspace, (int)g.wgs_flat, 2, (int64_t)H, sums);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

@@ -1923,16 +1923,20 @@ def _din_attn_forward(q, K, mask_i32, W1, b1, alpha, W2, b2, mod, out):
     n_total = B * L
     if training:
         sums = torch.empty(2 * H + 1, dtype=torch.float32, device=dev)
-        ops.din_attn_stats(q, K, W1, b1, sums, ws)
-        if dist is not None:
+        if dist is None:
+            # one rank: partial sums -> statistics (+ running statistics, BatchNorm1d's step counter) in
+            # the launch that finishes the sums
+            ops.din_attn_stats(q, K, W1, b1, sums, ws, stats, mod.bn.momentum, mod.bn.running_mean,
+                               mod.bn.running_var, mod.bn.num_batches_tracked)
+        else:
+            ops.din_attn_stats(q, K, W1, b1, sums, ws)
             # row-sharded training: the reference normalises with the statistics of the WHOLE
             # batch (activations.py:40-51) — one small all-reduce ([2H + 1] floats)
             sums[2 * H] = float(B * L)
             dist.all_reduce_sum(sums)
             n_total = _global_rows(sums[2 * H], B * L, dist)
-        # (BatchNorm1d's step counter rides along in the same launch)
-        ops.dice_stats_from_sums(sums, H, n_total, mod.bn.momentum, True, mod.bn.running_mean,
-                                 mod.bn.running_var, stats, mod.bn.num_batches_tracked)
+            ops.dice_stats_from_sums(sums, H, n_total, mod.bn.momentum, True, mod.bn.running_mean,
+                                     mod.bn.running_var, stats, mod.bn.num_batches_tracked)
     else:
         ops.dice_stats_from_sums(None, H, 1, 0.0, False, mod.bn.running_mean,
                                  mod.bn.running_var, stats)

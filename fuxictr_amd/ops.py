@@ -731,12 +731,18 @@ def _din_attn_head(q, K):
 
 
 @_timed("din_attn_stats", "din_attention", _din_attn_flops(0))
-def din_attn_stats(q, K, W1, b1, sums, workspace):
-    """sums[2H] = [sum h | sum h^2] over the B*L positions, h = W1 [q,k,q-k,q*k] + b1."""
+def din_attn_stats(q, K, W1, b1, sums, workspace, stats=None, momentum=0.0, running_mean=None,
+                   running_var=None, num_batches_tracked=None):
+    """sums[2H] = [sum h | sum h^2] over the B*L positions, h = W1 [q,k,q-k,q*k] + b1.  stats given (one
+    rank): dice_stats_from_sums(training) over these B*L rows rides in the same launch."""
     K, head = _din_attn_head(q, K)
     H = W1.shape[0]
     check(_lib.load().fx_din_attn_stats(*head, ptr(W1), ptr(b1), H,
-                                        ptr(sums), ptr(workspace), stream_ptr(q.device)),
+                                        ptr(sums), ptr(workspace), ptr(stats), momentum,
+                                        ptr(running_mean) if stats is not None else None,
+                                        ptr(running_var) if stats is not None else None,
+                                        ptr(num_batches_tracked) if stats is not None else None,
+                                        stream_ptr(q.device)),
           "fx_din_attn_stats")
 
 

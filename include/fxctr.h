@@ -492,6 +492,10 @@ int fx_dice_bwd(const float* Z, const float* dY, int64_t N, int32_t H, const flo
  * W1: [H, 4E] row-major, b1: [H] or NULL, W2: [H], b2: [1] or NULL, stats: mean[H] | biased var[H],
  * mask: int32 [B, L] (row stride mask_ld; position kept when != 0; NULL = all kept).
  *   fx_din_attn_stats       sums[2H] = [sum h | sum h^2] over this rank's B*L positions
+ *   fx_din_attn_stats       sums[2H] = [sum h | sum h^2] over the B*L positions (h = W1 x + b1); with
+ *                           stats != NULL (single rank: no all-reduce in between) the statistics of
+ *                           fx_dice_stats_from_sums(training) over n_total = B*L are finished in the same
+ *                           launch (stats[2H], running statistics, num_batches_tracked)
  *   fx_dice_stats_from_sums training != 0: stats from (all-reduced) sums and n_total rows + running
  *                           statistics update (momentum, unbiased variance; num_batches_tracked += 1 when
  *                           the pointer is given), like nn.BatchNorm1d(affine=False); training == 0:
@@ -508,7 +512,8 @@ int fx_dice_bwd(const float* Z, const float* dY, int64_t N, int32_t H, const flo
 int64_t fx_din_attn_workspace_floats(int64_t B, int32_t L, int32_t E, int32_t H);
 int fx_din_attn_stats(const float* q, int64_t q_ld, const float* K, int64_t k_ldb, int64_t k_ldl,
                       int64_t B, int32_t L, int32_t E, const float* W1, const float* b1, int32_t H,
-                      float* sums, float* workspace, fx_stream_t stream);
+                      float* sums, float* workspace, float* stats, float momentum, float* running_mean,
+                      float* running_var, int64_t* num_batches_tracked, fx_stream_t stream);
 int fx_dice_stats_from_sums(const float* sums, int32_t H, int64_t n_total, float momentum,
                             int32_t training, float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, float* stats, fx_stream_t stream);

@@ -522,11 +522,15 @@ def _din_attn_h(q, K, W1, b1):
     return x, h
 
 
-def din_attn_stats(q, K, W1, b1, sums, workspace):
+def din_attn_stats(q, K, W1, b1, sums, workspace, stats=None, momentum=0.0, running_mean=None,
+                   running_var=None, num_batches_tracked=None):
     H = W1.shape[0]
     _, h = _din_attn_h(q, K, W1, b1)
     sums[:H] = h.sum(0)
     sums[H:2 * H] = (h * h).sum(0)
+    if stats is not None:
+        dice_stats_from_sums(sums, H, h.shape[0], momentum, True, running_mean, running_var, stats,
+                             num_batches_tracked)
 
 
 def dice_stats_from_sums(sums, H, n_total, momentum, training, running_mean, running_var, stats,
