@@ -1678,10 +1678,15 @@ class _MLPFn(torch.autograd.Function):
 class FxLinear(nn.Linear):
     """nn.Linear whose forward/backward run on the fp32 MFMA GEMM (same parameters/keys)."""
 
-    def forward(self, x):
+    def forward(self, x, out_add=None):
+        """out_add (native extension): a [rows, out_features] tensor added in the GEMM's epilogue."""
         lead = x.shape[:-1]
-        y = _MLPFn.apply(x.reshape(-1, x.shape[-1]), (False,), None, None, self.weight, self.bias)
-        return y.reshape(*lead, self.out_features)
+        x2 = x.reshape(-1, x.shape[-1])
+        fuse = out_add is not None and out_add.is_contiguous() \
+            and out_add.shape == (x2.shape[0], self.out_features)
+        y = _MLPFn.apply(x2, (False,), out_add if fuse else None, None, self.weight, self.bias)
+        y = y.reshape(*lead, self.out_features)
+        return y + out_add if (out_add is not None and not fuse) else y
 
 
 def _global_rows(count, n_local, dist):
@@ -2224,13 +2229,14 @@ class CompressedInteractionNet(nn.Module):
             self.cin_layer["layer_" + str(i + 1)] = nn.Conv1d(in_channels, unit, kernel_size=1,
                                                               device=dev)
 
-    def forward(self, feature_emb):
+    def forward(self, feature_emb, out_add=None):
+        """out_add (native extension): added to the result in the fc GEMM's epilogue (xDeepFM: the linear term)."""
         wb = []
         for i in range(len(self.cin_hidden_units)):
             conv = self.cin_layer["layer_" + str(i + 1)]
             wb += [conv.weight, conv.bias]
         pooled = _CINFn.apply(feature_emb, *wb)
-        return self.fc(pooled)
+        return self.fc(pooled, out_add=out_add)
 
 
 class _CrossNetV2Fn(torch.autograd.Function):

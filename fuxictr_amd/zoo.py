@@ -288,7 +288,8 @@ class xDeepFM(_ZooModel):
     def forward(self, inputs):
         X = self.get_inputs(inputs)
         emb = self.embedding_layer(X)
-        logit = self.lr_layer(X) + self.cin(emb)            # linear part + explicit interactions
+        # linear part + explicit interactions (+ implicit ones): the sums ride in the GEMM epilogues
+        logit = self.cin(emb, out_add=self.lr_layer(X))
         if self.dnn is not None:
-            logit = logit + self.dnn(emb.flatten(start_dim=1))
+            logit = self.dnn(emb.flatten(start_dim=1), out_add=logit)
         return {"y_pred": self.output_activation(logit)}
