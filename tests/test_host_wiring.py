@@ -407,3 +407,22 @@ def test_din_attention_runs_inside_the_gather_record(tmp_path, monkeypatch):
     for k, v in other.state_dict().items():
         np.testing.assert_allclose(sd[k].numpy(), v.numpy(), atol=2e-6, err_msg=k)
     assert int(sd["attention_layers.0.attention_layer.mlp.1.bn.num_batches_tracked"]) == g.meta["steps"]
+
+
+def test_din_record_with_a_reserved_slot_also_serves_the_general_composition(tmp_path, monkeypatch):
+    """The reserved slot changes the record's layout whether or not a forward takes the in-record path
+    (e.g. an attention MLP the fused kernels do not cover): the general composition — views of the
+    record, concatenation, per-view gradients — must give the same trajectory on that layout."""
+    from conftest import Golden
+    from fuxictr_amd import layers as L
+    g = Golden("din_adam")
+    monkeypatch.setattr(L.DIN_Attention, "forward_in_record", lambda self, *a, **k: None)
+    model = _build(g, tmp_path, monkeypatch)
+    assert model._in_record is not None                      # the slot IS reserved
+    model.train()
+    losses = [float(model.train_step(tb(g.batches[i])).item()) for i in range(g.meta["steps"])]
+    np.testing.assert_allclose(losses, g.expect["loss"], atol=5e-6)
+    model.eval()                    # (exact mode: leaving training mode settles the pending row replays)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    for name, got, ref in g.final_weights(sd):
+        assert_weights_close(got, ref, g.meta["lr"], g.meta["steps"], name)
