@@ -95,8 +95,8 @@ SIGNATURES = {
     "fx_mt_sgd": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
     "fx_fm_fwd": (i32, [vp, i64, i32, i32, vp, vp, i64, vp]),
     "fx_fm_bwd": (i32, [vp, i64, i32, i32, vp, vp, i64, i32, i64, vp]),
-    "fx_dot_interact_fwd": (i32, [vp, i64, i32, i32, i64, vp, vp]),
-    "fx_dot_interact_bwd": (i32, [vp, i64, vp, i32, i32, i64, vp, i64, vp]),
+    "fx_dot_interact_fwd": (i32, [vp, i64, i32, i32, i64, vp, i64, i32, vp]),
+    "fx_dot_interact_bwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i64, vp, i64, vp]),
     "fx_lr_fwd": (i32, [vp, vp, i64, vp, vp, i32, vp, i64, vp, i32, vp, vp, i64, vp, vp]),
     "fx_gemm_f32_batch": (i32, [C.POINTER(GemmProblem), i32, vp]),
     "fx_gemm_f32": (i32, [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64,

@@ -566,13 +566,18 @@ __device__ __forceinline__ int fx_pair_index(int i, int j, int F) {  // i < j
     return i * F - (i * (i + 1)) / 2 + (j - i - 1);
 }
 
+// tail > 0 (DLRM: the dense vector is the LAST field and is also concatenated to the products,
+// DLRM.py:117-120): out[b, P .. P + D) = e[b, F-1, :] and out[b, P + D .. P + D + tail - D) = 0 ride along, so
+// the row [products | dense | zero padding] leaves this launch ready for the top tower (out_ld columns).
 __global__ __launch_bounds__(256) void k_dot_interact_fwd(const float* emb, int64_t emb_ld, int F,
-                                                          int D, int64_t B, float* out) {
+                                                          int D, int64_t B, float* out, int64_t out_ld,
+                                                          int tail) {
     __shared__ float e[FX_DOT_MAX_FD];
     const int P = F * (F - 1) / 2;
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         for (int t = threadIdx.x; t < F * D; t += 256) e[t] = emb[b * emb_ld + t];
         __syncthreads();
+        for (int t = threadIdx.x; t < tail; t += 256) out[b * out_ld + P + t] = t < D ? e[(F - 1) * D + t] : 0.f;
         for (int p = threadIdx.x; p < P; p += 256) {
             // invert p -> (i, j): rows of the upper triangle have F-1, F-2, ... entries
             int i = 0, rem = p;
@@ -580,21 +585,22 @@ __global__ __launch_bounds__(256) void k_dot_interact_fwd(const float* emb, int6
             const int j = i + 1 + rem;
             float acc = 0.f;
             for (int d = 0; d < D; ++d) acc = fmaf(e[i * D + d], e[j * D + d], acc);
-            out[b * P + p] = acc;
+            out[b * out_ld + p] = acc;
         }
         __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(256) void k_dot_interact_bwd(const float* emb, int64_t emb_ld,
-                                                          const float* g, int F, int D, int64_t B,
-                                                          float* demb, int64_t demb_ld) {
+                                                          const float* g, int64_t g_ld, int tail, int F,
+                                                          int D, int64_t B, float* demb,
+                                                          int64_t demb_ld) {
     __shared__ float e[FX_DOT_MAX_FD];
     __shared__ float gs[FX_DOT_MAX_FD];
     const int P = F * (F - 1) / 2;
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         for (int t = threadIdx.x; t < F * D; t += 256) e[t] = emb[b * emb_ld + t];
-        for (int t = threadIdx.x; t < P; t += 256) gs[t] = g[b * P + t];
+        for (int t = threadIdx.x; t < P; t += 256) gs[t] = g[b * g_ld + t];
         __syncthreads();
         for (int t = threadIdx.x; t < F * D; t += 256) {
             const int i = t / D, d = t - i * D;
@@ -604,6 +610,7 @@ __global__ __launch_bounds__(256) void k_dot_interact_bwd(const float* emb, int6
                 const int p = j > i ? fx_pair_index(i, j, F) : fx_pair_index(j, i, F);
                 acc = fmaf(gs[p], e[j * D + d], acc);
             }
+            if (tail && i == F - 1) acc += g[b * g_ld + P + d];      // the concatenated copy's gradient
             demb[b * demb_ld + t] = acc;
         }
         __syncthreads();
@@ -619,7 +626,8 @@ typedef float fx_dot_f32x16 __attribute__((ext_vector_type(16)));
 #define FX_DOT_LD 33
 
 __global__ __launch_bounds__(256) void k_dot_interact_fwd_mfma(const float* emb, int64_t emb_ld,
-                                                               int F, int D, int64_t B, float* out) {
+                                                               int F, int D, int64_t B, float* out,
+                                                               int64_t out_ld, int tail) {
     __shared__ float Es_[4][32 * FX_DOT_LD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
     float* Es = Es_[wave];
@@ -641,14 +649,16 @@ __global__ __launch_bounds__(256) void k_dot_interact_fwd_mfma(const float* emb,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (i < j && j < F) out[b * P + fx_pair_index(i, j, F)] = acc[r];
+            if (i < j && j < F) out[b * out_ld + fx_pair_index(i, j, F)] = acc[r];
         }
+        for (int t = lane; t < tail; t += 64)
+            out[b * out_ld + P + t] = t < D ? Es[(F - 1) * FX_DOT_LD + t] : 0.f;
     }
 }
 
 __global__ __launch_bounds__(256) void k_dot_interact_bwd_mfma(const float* emb, int64_t emb_ld,
-                                                               const float* g, int F, int D,
-                                                               int64_t B, float* demb,
+                                                               const float* g, int64_t g_ld, int tail,
+                                                               int F, int D, int64_t B, float* demb,
                                                                int64_t demb_ld) {
     __shared__ float Es_[4][32 * FX_DOT_LD];
     __shared__ float Gs_[4][32 * FX_DOT_LD];
@@ -674,7 +684,7 @@ __global__ __launch_bounds__(256) void k_dot_interact_bwd_mfma(const float* emb,
             Es[i * FX_DOT_LD + (t - i * D)] = emb[b * emb_ld + t];
         }
         for (int p = lane; p < P; p += 64) {
-            const float v = g[b * P + p];
+            const float v = g[b * g_ld + p];
             const int i = pi_[p], j = pj_[p];
             Gs[i * FX_DOT_LD + j] = v;
             Gs[j * FX_DOT_LD + i] = v;
@@ -692,7 +702,8 @@ __global__ __launch_bounds__(256) void k_dot_interact_bwd_mfma(const float* emb,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (i < F && d < D) demb[b * demb_ld + i * D + d] = acc[r];
+            if (i < F && d < D)
+                demb[b * demb_ld + i * D + d] = (tail && i == F - 1) ? acc[r] + g[b * g_ld + P + d] : acc[r];
         }
     }
 }
@@ -706,29 +717,32 @@ static bool fx_dot_mfma_ok(int F, int D) {
 }
 
 extern "C" int fx_dot_interact_fwd(const float* emb, int64_t emb_ld, int32_t F, int32_t D,
-                                   int64_t B, float* out, fx_stream_t stream) {
+                                   int64_t B, float* out, int64_t out_ld, int32_t tail,
+                                   fx_stream_t stream) {
     FX_CHECK_ARG(F >= 2 && D >= 1 && F * D <= FX_DOT_MAX_FD && F * (F - 1) / 2 <= FX_DOT_MAX_FD,
                  "fx_dot_interact_fwd: F=%d D=%d outside the supported range", F, D);
     if (B <= 0) return FX_OK;
     FX_CHECK_ARG(emb && out, "fx_dot_interact_fwd: null pointer");
+    FX_CHECK_ARG(tail == 0 || tail >= D, "fx_dot_interact_fwd: tail must be 0 or >= D");
+    FX_CHECK_ARG(out_ld >= (int64_t)F * (F - 1) / 2 + tail, "fx_dot_interact_fwd: out_ld too small");
     if (fx_dot_mfma_ok(F, D)) {
         int64_t wgs = fx_ceil_div(B, 4);
         if (wgs > 2048) wgs = 2048;
         hipLaunchKernelGGL(k_dot_interact_fwd_mfma, dim3((unsigned)wgs), dim3(256), 0,
-                           fx_hip_stream(stream), emb, emb_ld, (int)F, (int)D, B, out);
+                           fx_hip_stream(stream), emb, emb_ld, (int)F, (int)D, B, out, out_ld, (int)tail);
         FX_CHECK_LAUNCH();
         return FX_OK;
     }
     int64_t blocks = B < 8192 ? B : 8192;
     hipLaunchKernelGGL(k_dot_interact_fwd, dim3((unsigned)blocks), dim3(256), 0,
-                       fx_hip_stream(stream), emb, emb_ld, (int)F, (int)D, B, out);
+                       fx_hip_stream(stream), emb, emb_ld, (int)F, (int)D, B, out, out_ld, (int)tail);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }
 
-extern "C" int fx_dot_interact_bwd(const float* emb, int64_t emb_ld, const float* g, int32_t F,
-                                   int32_t D, int64_t B, float* demb, int64_t demb_ld,
-                                   fx_stream_t stream) {
+extern "C" int fx_dot_interact_bwd(const float* emb, int64_t emb_ld, const float* g, int64_t g_ld,
+                                   int32_t tail, int32_t F, int32_t D, int64_t B, float* demb,
+                                   int64_t demb_ld, fx_stream_t stream) {
     FX_CHECK_ARG(F >= 2 && D >= 1 && F * D <= FX_DOT_MAX_FD && F * (F - 1) / 2 <= FX_DOT_MAX_FD,
                  "fx_dot_interact_bwd: F=%d D=%d outside the supported range", F, D);
     if (B <= 0) return FX_OK;
@@ -737,13 +751,15 @@ extern "C" int fx_dot_interact_bwd(const float* emb, int64_t emb_ld, const float
         int64_t wgs = fx_ceil_div(B, 4);
         if (wgs > 2048) wgs = 2048;
         hipLaunchKernelGGL(k_dot_interact_bwd_mfma, dim3((unsigned)wgs), dim3(256), 0,
-                           fx_hip_stream(stream), emb, emb_ld, g, (int)F, (int)D, B, demb, demb_ld);
+                           fx_hip_stream(stream), emb, emb_ld, g, g_ld, (int)tail, (int)F, (int)D, B, demb,
+                           demb_ld);
         FX_CHECK_LAUNCH();
         return FX_OK;
     }
     int64_t blocks = B < 8192 ? B : 8192;
     hipLaunchKernelGGL(k_dot_interact_bwd, dim3((unsigned)blocks), dim3(256), 0,
-                       fx_hip_stream(stream), emb, emb_ld, g, (int)F, (int)D, B, demb, demb_ld);
+                       fx_hip_stream(stream), emb, emb_ld, g, g_ld, (int)tail, (int)F, (int)D, B, demb,
+                       demb_ld);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

@@ -252,7 +252,7 @@ class _TableGroup(object):
         return self.scal
 
     # -- plans ------------------------------------------------------------------------------
-    def plan_for(self, ordered_features, pooled=None, tail=None, holes=()):
+    def plan_for(self, ordered_features, pooled=None, tail=None, holes=(), tail_slots=0):
         """ordered_features: features of this group to embed, in feature_map order.
         pooled: {sequence feature: ops.POOL_SUM | ops.POOL_MEAN} — reduced inside the gather to ONE
         slot each (fx_emb_seq_pool_fwd); their id columns go last so that the plain gather takes
@@ -265,7 +265,8 @@ class _TableGroup(object):
         pooled = pooled or {}
         last = set(pooled) | set(tail or ())
         holes = tuple(f for f in holes if f in self.widths and f not in pooled)
-        key = (tuple(ordered_features), tuple(sorted(pooled.items())), tuple(sorted(last)), holes)
+        key = (tuple(ordered_features), tuple(sorted(pooled.items())), tuple(sorted(last)), holes,
+               int(tail_slots))
         plan = self.plans.get(key)
         if plan is not None:
             return plan
@@ -315,6 +316,10 @@ class _TableGroup(object):
             if f not in pooled:
                 assert p.C_main == len(row_base) - w, "pooled id columns must come last"
                 p.C_main = len(row_base)
+        # tail_slots: slots behind the last feature that the gather leaves alone (DLRM writes the bottom
+        # tower's vector there: the interaction then reads ONE record, no concatenation)
+        p.tail0 = slot if tail_slots else None
+        slot += int(tail_slots)
         p.n_slots = slot
         p.C = len(row_base)
         p.n_seq = len(seq_col0)
@@ -361,6 +366,21 @@ class _TableGroup(object):
         if cache is not None:
             cache[ckey] = (ids, dense)
         return ids, dense
+
+    def pack_dense(self, inputs, names):
+        """Numeric input columns that are NOT features of this group as one fp32 [B, len(names)] block,
+        through the same cast launch / cache as the group's own inputs (a captured step fills the
+        block together with the id matrix, outside the graph).  DLRM's bottom-tower input."""
+        key = tuple(names)
+        plan = self._dense_plans.get(key) if hasattr(self, "_dense_plans") else None
+        if plan is None:
+            if not hasattr(self, "_dense_plans"):
+                self._dense_plans = {}
+            plan = _Plan()
+            plan.id_feats, plan.num_feats, plan.C, plan.Fd = [], list(names), 0, len(names)
+            plan.pack_sig = ((), key)
+            self._dense_plans[key] = plan
+        return self.pack_inputs(plan, inputs)[1]
 
     def row_state(self, G=None):
         return ops.RowState(self.table, self.m, self.v, self.last_step, self.D, G)
@@ -855,6 +875,7 @@ class FeatureEmbeddingDict(nn.Module):
         self._groups = OrderedDict()   # D -> _TableGroup
         self._feat_group = {}          # feature -> D
         self._pooled_holes = set()     # raw sequence features with a reserved slot in front (DIN)
+        self._tail_slots = 0           # reserved slots behind the last feature (DLRM)
         self._torch_feats = set()      # features served by stock torch modules ("embedding" type)
         self._stock_feats = set()      # id features delegated to the reference's PretrainedEmbedding
         lr_mode = (not (use_pretrain and use_sharing)) and embedding_dim == 1
@@ -1056,7 +1077,8 @@ class FeatureEmbeddingDict(nn.Module):
             if not feats:
                 continue
             plan = grp.plan_for(feats, self._fused_pooling(grp, feats),
-                                holes=tuple(f for f in feats if f in self._pooled_holes))
+                                holes=tuple(f for f in feats if f in self._pooled_holes),
+                                tail_slots=self._tail_slots if len(self._groups) == 1 else 0)
             ids, dense = grp.pack_inputs(plan, inputs)
             track = torch.is_grad_enabled() and self.training
             anchor = self._anchor(grp)
@@ -1093,6 +1115,8 @@ class FeatureEmbeddingDict(nn.Module):
             # views in slot order; a reserved slot is one more (unnamed) view so that they tile the record
             entries = [(plan.slot[f][0], plan.slot[f][1] if r else None, f)
                        for f, r in zip(feats, raw_seq)] + [(h, None, None) for h in plan.hole.values()]
+            if plan.tail0 is not None:
+                entries += [(k, None, None) for k in range(plan.tail0, plan.n_slots)]
             entries.sort(key=lambda t: t[0])
             bounds = tuple((lo, w) for lo, w, _ in entries)
             if rec.requires_grad:
@@ -1121,6 +1145,11 @@ class FeatureEmbeddingDict(nn.Module):
         """Native extension: keep one record slot free in front of the positions of the raw sequence
         `feature`; a model that replaces the sequence by a pooled vector (DIN) writes it there."""
         self._pooled_holes.add(feature)
+
+    def reserve_tail_slots(self, n):
+        """Native extension: n record slots behind the last feature that the gather does not write (a
+        model appends its own vectors to the field list there: DLRM's bottom-tower output)."""
+        self._tail_slots = int(n)
 
     fuse_pooling = True     # class switch for A/B measurements (scripts/seqpool_bench.py)
     fuse_front = True       # class switch: the fused front / back end of csrc/fx_fused.hip
@@ -1329,7 +1358,9 @@ class FeatureEmbedding(nn.Module):
     def forward(self, X, feature_source=[], feature_type=[], flatten_emb=False):
         feature_emb_dict = self.embedding_layer(X, feature_source=feature_source,
                                                 feature_type=feature_type)
-        return self.embedding_layer.dict2tensor(feature_emb_dict, flatten_emb=flatten_emb)
+        out = self.embedding_layer.dict2tensor(feature_emb_dict, flatten_emb=flatten_emb)
+        out._fx_records = getattr(feature_emb_dict, "_records", None)   # (record, plan) pairs behind it
+        return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1445,6 +1476,37 @@ class _DotInteractFn(torch.autograd.Function):
         demb = torch.empty_like(emb)
         ops.dot_interact_bwd(emb.view(B, F * D), g.contiguous(), F, D, demb.view(B, F * D))
         return demb
+
+
+class _DlrmMixFn(torch.autograd.Function):
+    """DLRM's `dot` interaction with the bottom tower's vector as the LAST field of the gather record
+    (native fast path of zoo.DLRM, DLRM.py:110-121): rec [B, F, D] = [embeddings.. | dense vector], the
+    dense vector having been written into the record's reserved slot by the bottom tower's last GEMM.
+      forward : ONE launch -> [pairwise dots | dense vector | zero padding] = the top tower's (aligned)
+                input: no cat of the fields, no cat of the products with the dense vector, no padding cat;
+      backward: ONE launch -> the record's gradient, the dense vector's direct share added to its slot;
+                the slot's view is the bottom tower's gradient, the rest the embedding backward's.
+    `dense_vec` is an argument only so that its gradient has somewhere to go (its values are in rec)."""
+
+    @staticmethod
+    def forward(ctx, rec, dense_vec, pad):
+        B, F, D = rec.shape
+        P = F * (F - 1) // 2
+        out = torch.empty(B, P + D + pad, dtype=torch.float32, device=rec.device)
+        ops.dot_interact_fwd(rec.view(B, F * D), F, D, out, tail=D + pad)
+        ctx.save_for_backward(rec)
+        ctx.pad = pad
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (rec,) = ctx.saved_tensors
+        B, F, D = rec.shape
+        if g.stride(-1) != 1:
+            g = g.contiguous()
+        demb = torch.empty(B, F, D, dtype=torch.float32, device=rec.device)
+        ops.dot_interact_bwd(rec.view(B, F * D), g, F, D, demb.view(B, F * D), tail=D + ctx.pad)
+        return demb, demb[:, F - 1, :], None
 
 
 class InnerProductInteraction(nn.Module):
@@ -1602,11 +1664,14 @@ class _MLPFn(torch.autograd.Function):
     epilogue, split-K dW GEMM, column-sum db.  args = (x, acts, W0, b0, W1, b1, ...)."""
 
     @staticmethod
-    def forward(ctx, x, acts, out_add, dx_into, *wb):
+    def forward(ctx, x, acts, out_add, dx_into, out_into, *wb):
         """out_add: optional [B, N_last] tensor added to the last layer's output in its epilogue (DeepFM:
         logit = fm + mlp, DeepFM.py:87 — one ATen add launch less); its gradient is dy.
         dx_into: optional callable -> a [B, K0] tensor (unit inner stride) the input's gradient is
-        written into (DIN: the head of the gather record's gradient)."""
+        written into (DIN: the head of the gather record's gradient).
+        out_into: optional [B, N_last] tensor (unit inner stride) the LAST layer writes its result into and
+        that is returned (DLRM: a slot of the gather record).
+        An input that is already zero-padded to the aligned width (K0 + pad columns) is taken as it is."""
         need_dx = x.requires_grad
         if x.stride(-1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
             x = x.contiguous()       # a 16-byte aligned row-strided view (record prefix) is read in place
@@ -1615,11 +1680,13 @@ class _MLPFn(torch.autograd.Function):
         # columns) leaves the rows of x and W0 4-byte aligned: the GEMMs would take the unpipelined
         # kernel (55 us instead of 28 for 4096 x 1024 x 367, and no dW + dX pair).  One zero column
         # more on both operands changes no sum and keeps every row 16-byte aligned.
-        K0 = x.shape[1]
+        K0 = wb[0].shape[1]
         pad = (-K0) % 4 if (K0 >= 64 and _MLP_PAD) else 0
         W0p = None
+        pre_padded = pad > 0 and x.shape[1] == K0 + pad
         if pad:
-            x = torch.cat([x, _zero_cols(x.shape[0], pad, x.device)], dim=1)          # one launch each
+            if not pre_padded:
+                x = torch.cat([x, _zero_cols(x.shape[0], pad, x.device)], dim=1)      # one launch each
             W0p = torch.cat([wb[0], _zero_cols(wb[0].shape[0], pad, x.device)], dim=1)
         hs = [x]
         h = x
@@ -1627,7 +1694,10 @@ class _MLPFn(torch.autograd.Function):
             W, b = wb[2 * i], wb[2 * i + 1]
             if i == 0 and W0p is not None:
                 W = W0p
-            y = torch.empty(h.shape[0], W.shape[0], dtype=torch.float32, device=h.device)
+            if i == n - 1 and out_into is not None:
+                y = out_into
+            else:
+                y = torch.empty(h.shape[0], W.shape[0], dtype=torch.float32, device=h.device)
             ops.gemm(h, W, y, transa=False, transb=True, bias=b, act=1 if acts[i] else 0,
                      add=out_add if (i == n - 1 and out_add is not None) else None)
             hs.append(y)
@@ -1637,7 +1707,7 @@ class _MLPFn(torch.autograd.Function):
         ctx.wb = wb
         ctx.hs = hs
         ctx.need_dx = need_dx
-        ctx.K0, ctx.W0p = K0, W0p
+        ctx.K0, ctx.W0p, ctx.pre_padded = K0, W0p, pre_padded
         ctx.dx_into = dx_into if (need_dx and W0p is None) else None
         return h
 
@@ -1670,9 +1740,10 @@ class _MLPFn(torch.autograd.Function):
                 dW, db = linear_weight_grads(dz, h_in, W.shape, b is not None)
             if i == 0 and ctx.W0p is not None:        # drop the zero column again (views)
                 dW = dW[:, :ctx.K0]
-                dx = dx[:, :ctx.K0] if dx is not None else None
+                if dx is not None and not ctx.pre_padded:
+                    dx = dx[:, :ctx.K0]
             grads[2 * i], grads[2 * i + 1] = dW, db
-        return (dx, None, dy if ctx.has_add else None, None) + tuple(grads)
+        return (dx, None, dy if ctx.has_add else None, None, None) + tuple(grads)
 
 
 class FxLinear(nn.Linear):
@@ -1684,7 +1755,7 @@ class FxLinear(nn.Linear):
         x2 = x.reshape(-1, x.shape[-1])
         fuse = out_add is not None and out_add.is_contiguous() \
             and out_add.shape == (x2.shape[0], self.out_features)
-        y = _MLPFn.apply(x2, (False,), out_add if fuse else None, None, self.weight, self.bias)
+        y = _MLPFn.apply(x2, (False,), out_add if fuse else None, None, None, self.weight, self.bias)
         y = y.reshape(*lead, self.out_features)
         return y + out_add if (out_add is not None and not fuse) else y
 
@@ -1849,10 +1920,11 @@ class MLP_Block(nn.Module):
             return None
         return stack, mods[i:]
 
-    def forward(self, inputs, out_add=None, dx_into=None):
+    def forward(self, inputs, out_add=None, dx_into=None, out_into=None):
         """out_add (native extension, not in the reference's signature): a tensor the caller would add
         to the result anyway; when the whole stack is the fused Linear / ReLU node it rides in the last
-        GEMM's epilogue.  dx_into: see _MLPFn (ignored on the unfused path)."""
+        GEMM's epilogue.  dx_into / out_into: see _MLPFn (ignored on the unfused path; out_into only
+        when the fused stack is the whole block)."""
         if self._fused is None or inputs.dim() != 2:
             out = self.mlp(inputs)
             return out if out_add is None else out + out_add
@@ -1863,7 +1935,8 @@ class MLP_Block(nn.Module):
             wb += [lin.weight, lin.bias]
         fuse_add = out_add is not None and not tail and not acts[-1] and out_add.is_contiguous() \
             and out_add.shape == (inputs.shape[0], stack[-1][0].weight.shape[0])
-        out = _MLPFn.apply(inputs, acts, out_add if fuse_add else None, dx_into, *wb)
+        out = _MLPFn.apply(inputs, acts, out_add if fuse_add else None, dx_into,
+                           out_into if not tail else None, *wb)
         for mod in tail:
             out = mod(out)
         if out_add is not None and not fuse_add:

@@ -797,17 +797,18 @@ def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, mask, a_logit, d
           "fx_din_attn_bwd")
 
 
-def dot_interact_fwd(emb, F, D, out):
+def dot_interact_fwd(emb, F, D, out, tail=0):
+    """out[:, :P] = pairwise dots (rows of out may be wider: out.stride(0)); tail: see fx_dot_interact_fwd."""
     B = emb.shape[0]
-    check(_lib.load().fx_dot_interact_fwd(ptr(emb), emb.stride(0), F, D, B, ptr(out),
+    check(_lib.load().fx_dot_interact_fwd(ptr(emb), emb.stride(0), F, D, B, ptr(out), out.stride(0), tail,
                                           stream_ptr(emb.device)), "fx_dot_interact_fwd")
     return out
 
 
-def dot_interact_bwd(emb, g, F, D, demb):
+def dot_interact_bwd(emb, g, F, D, demb, tail=0):
     B = emb.shape[0]
-    check(_lib.load().fx_dot_interact_bwd(ptr(emb), emb.stride(0), ptr(g), F, D, B, ptr(demb),
-                                          demb.stride(0), stream_ptr(emb.device)),
+    check(_lib.load().fx_dot_interact_bwd(ptr(emb), emb.stride(0), ptr(g), g.stride(0), tail, F, D, B,
+                                          ptr(demb), demb.stride(0), stream_ptr(emb.device)),
           "fx_dot_interact_bwd")
     return demb
 

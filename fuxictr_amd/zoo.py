@@ -14,7 +14,8 @@ from torch import nn
 
 from .layers import (CompressedInteractionNet, CrossNetV2, DIN_Attention, Dice,
                      FactorizationMachine, FeatureEmbedding, FeatureEmbeddingDict, FxLinear,
-                     InnerProductInteraction, LogisticRegression, MLP_Block, _RecordGradSlot)
+                     InnerProductInteraction, LogisticRegression, MLP_Block, _DlrmMixFn, _MLP_PAD,
+                     _RecordGradSlot)
 from .rank_model import BaseModel
 
 
@@ -254,11 +255,43 @@ class DLRM(_ZooModel):
             top_in = n_fields * embedding_dim
         self.top_mlp = self._tower(top_in, top_mlp_units, top_mlp_activations, top_mlp_dropout,
                                    batch_norm, output_activation=self.output_activation)
+        # native fast path of the reference's configuration (dot interaction + numeric features): the
+        # bottom tower's vector becomes the last field of the gather record (layers._DlrmMixFn)
+        self._in_record = False
+        if (_os.environ.get("FX_DLRM_INPLACE", "1") != "0" and has_dense and interaction_op == "dot"
+                and n_fields <= 32 and embedding_dim <= 32 and embedding_dim % 2 == 0):
+            self._in_record = True
+            self.embedding_layer.embedding_layer.reserve_tail_slots(1)
         self._ready(kwargs, learning_rate)
+
+    def _forward_in_record(self, X, fields):
+        """-> the top tower's input, or None when this forward cannot take the in-record path."""
+        records = getattr(fields, "_fx_records", None)
+        if not self._in_record or not records or len(records) != 1:
+            return None
+        rec, plan = records[0]
+        B, n_slots, D = rec.shape
+        if plan.tail0 != n_slots - 1 or fields.shape[1] != n_slots - 1 \
+                or getattr(self.bottom_mlp, "_fused", None) is None or self.bottom_mlp._fused[1] \
+                or self.bottom_mlp._fused[0][-1][0].out_features != D:
+            return None
+        groups = list(self.embedding_layer.embedding_layer._groups.values())
+        dense_in = groups[0].pack_dense(X, self.dense_feats)     # one cast launch (none in a captured step)
+        dest = rec.detach()[:, n_slots - 1, :]
+        dense_vec = self.bottom_mlp(dense_in, out_into=dest)       # written into the record's last slot
+        assert dense_vec.data_ptr() == dest.data_ptr()
+        P = n_slots * (n_slots - 1) // 2
+        # the top tower pads an unaligned input width itself (one cat): hand it the padded row instead
+        fused_top = getattr(self.top_mlp, "_fused", None) is not None
+        pad = (-(P + D)) % 4 if (fused_top and P + D >= 64 and _MLP_PAD) else 0
+        return _DlrmMixFn.apply(rec, dense_vec, pad)
 
     def forward(self, inputs):
         X = self.get_inputs(inputs)
         fields = self.embedding_layer(X)                    # [B, Fs, D]
+        mixed = self._forward_in_record(X, fields)
+        if mixed is not None:
+            return {"y_pred": self.top_mlp(mixed)}
         dense_vec = None
         if self.dense_feats:
             dense_in = torch.cat([X[name].float().view(-1, 1) for name in self.dense_feats], dim=-1)

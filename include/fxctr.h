@@ -318,11 +318,16 @@ int fx_fm_fwd(const float* emb, int64_t emb_ld, int32_t F, int32_t D, const floa
 int fx_fm_bwd(const float* emb, int64_t emb_ld, int32_t F, int32_t D, const float* g,
               float* demb, int64_t demb_ld, int32_t accumulate, int64_t B, fx_stream_t stream);
 /* DLRM "dot" interaction: out[b, p] = <e[b,i,:], e[b,j,:]> for the pairs i < j in row-major
- * upper-triangle order (inner_product.py:63-66: bmm + triu masked_select), and its backward. */
+ * upper-triangle order (inner_product.py:63-66: bmm + triu masked_select), and its backward.
+ * Rows of out / g have out_ld / g_ld floats.  tail (0, or >= D): the LAST field is also appended to the
+ * products (DLRM.py:117-120 concatenates the bottom tower's vector): out[b, P .. P+D) = e[b, F-1, :],
+ * out[b, P+D .. P+tail) = 0 — the row is then the top tower's (padded) input — and the backward adds
+ * g[b, P .. P+D) to demb[b, F-1, :]. */
 int fx_dot_interact_fwd(const float* emb, int64_t emb_ld, int32_t F, int32_t D, int64_t B,
-                        float* out, fx_stream_t stream);
-int fx_dot_interact_bwd(const float* emb, int64_t emb_ld, const float* g, int32_t F, int32_t D,
-                        int64_t B, float* demb, int64_t demb_ld, fx_stream_t stream);
+                        float* out, int64_t out_ld, int32_t tail, fx_stream_t stream);
+int fx_dot_interact_bwd(const float* emb, int64_t emb_ld, const float* g, int64_t g_ld, int32_t tail,
+                        int32_t F, int32_t D, int64_t B, float* demb, int64_t demb_ld,
+                        fx_stream_t stream);
 int fx_lr_fwd(const float* table1, const int32_t* ids, int64_t ids_ld,
               const int64_t* col_row_base, const int32_t* col_vocab, int32_t C,
               const float* dense, int64_t dense_ld, const float* num_w1, int32_t Fd,

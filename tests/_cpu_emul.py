@@ -613,23 +613,30 @@ def din_attn_bwd(q, K, W1, b1, alpha, eps, training, stats, W2, mask, a_logit, d
     dK.copy_(d[:, :, 1] - d[:, :, 2] + d[:, :, 3] * q.unsqueeze(1) + wm.unsqueeze(-1) * dout.unsqueeze(1))
 
 
-def dot_interact_fwd(emb, F, D, out):
-    e = emb.view(-1, F, D)
+def dot_interact_fwd(emb, F, D, out, tail=0):
+    e = emb.reshape(emb.shape[0], -1)[:, :F * D].reshape(-1, F, D)
+    P = F * (F - 1) // 2
     ipm = torch.bmm(e, e.transpose(1, 2))
     mask = torch.triu(torch.ones(F, F), 1).bool()
-    out.copy_(torch.masked_select(ipm, mask).view(-1, F * (F - 1) // 2))
+    out[:, :P] = torch.masked_select(ipm, mask).view(-1, P)
+    if tail:
+        out[:, P:P + D] = e[:, F - 1, :]
+        out[:, P + D:P + tail] = 0
     return out
 
 
-def dot_interact_bwd(emb, g, F, D, demb):
-    e = emb.view(-1, F, D)
+def dot_interact_bwd(emb, g, F, D, demb, tail=0):
+    e = emb.reshape(emb.shape[0], -1)[:, :F * D].reshape(-1, F, D)
+    P = F * (F - 1) // 2
     G = torch.zeros(e.shape[0], F, F)
     iu = torch.triu_indices(F, F, 1)
-    G[:, iu[0], iu[1]] = g
+    G[:, iu[0], iu[1]] = g[:, :P]
     G = G + G.transpose(1, 2)
-    demb.copy_(torch.bmm(G, e).reshape(demb.shape))
+    d = torch.bmm(G, e)
+    if tail:
+        d[:, F - 1, :] += g[:, P:P + D]
+    demb.copy_(d.reshape(demb.shape))
     return demb
-
 
 def cin_workgroups():
     return 4

@@ -747,6 +747,26 @@ def test_dot_interaction_matches_bmm_triu(F, D):
     assert (demb.cpu().view(B, F, D) - e.grad).abs().max().item() <= 2e-5 * max(1.0, e.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("F,D,pad", [(27, 16, 1), (15, 8, 3), (5, 4, 0), (27, 16, 0), (40, 40, 2)])
+def test_dot_interaction_with_the_last_field_appended(F, D, pad):
+    """tail mode of fx_dot_interact_fwd / _bwd (DLRM's [dots | dense vector | zero padding] row and its
+    gradient, both kernels' MFMA and workgroup-per-sample forms): == the unfused composition."""
+    g = torch.Generator().manual_seed(F + D + pad)
+    B, P = 333, F * (F - 1) // 2
+    emb = torch.randn(B, F, D, generator=g)
+    out = torch.full((B, P + D + pad), float("nan"), device=DEV)
+    ops.dot_interact_fwd(_dev(emb).view(B, F * D), F, D, out, tail=D + pad)
+    e = emb.clone().requires_grad_(True)
+    ref = torch.cat([O.dot_interaction(e), e[:, F - 1, :], torch.zeros(B, pad)], dim=1)
+    assert (out.cpu() - ref.detach()).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(out.cpu()[:, P:P + D], emb[:, F - 1, :]) and (out.cpu()[:, P + D:] == 0).all()
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    demb = torch.full((B, F * D), float("nan"), device=DEV)
+    ops.dot_interact_bwd(_dev(emb).view(B, F * D), _dev(gy), F, D, demb, tail=D + pad)
+    assert (demb.cpu().view(B, F, D) - e.grad).abs().max().item() <= 2e-5 * max(1.0, e.grad.abs().max().item())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("F0,D,units,B", [(39, 16, [16, 16, 16], 700), (9, 8, [12, 6, 5], 130),
                                           (5, 10, [7], 3), (26, 40, [8, 4], 260),

@@ -426,3 +426,37 @@ def test_din_record_with_a_reserved_slot_also_serves_the_general_composition(tmp
     sd = {k: v.numpy() for k, v in model.state_dict().items()}
     for name, got, ref in g.final_weights(sd):
         assert_weights_close(got, ref, g.meta["lr"], g.meta["steps"], name)
+
+
+@pytest.mark.parametrize("case", ["dlrm_adam", "dlrm_sparse_only", "dlrm_cat"])
+def test_dlrm_bottom_vector_lives_in_the_gather_record(case, tmp_path, monkeypatch):
+    """DLRM with numeric features and the dot interaction: the bottom tower writes its vector into the
+    record's reserved last slot, one launch produces [dots | vector | padding] for the top tower and one
+    its gradient.  Same trajectory as the concatenating composition (FX_DLRM_INPLACE=0); models without
+    numeric features / with the `cat` interaction keep the general path."""
+    from conftest import Golden
+    from fuxictr_amd import layers as L
+    g = Golden(case)
+    calls = {"n": 0}
+    fwd0 = L._DlrmMixFn.forward
+
+    def fwd(ctx, *a):
+        calls["n"] += 1
+        return fwd0(ctx, *a)
+    monkeypatch.setattr(L._DlrmMixFn, "forward", staticmethod(fwd))
+    model = _build(g, tmp_path, monkeypatch)
+    model.train()
+    losses = [float(model.train_step(tb(g.batches[i])).item()) for i in range(g.meta["steps"])]
+    np.testing.assert_allclose(losses, g.expect["loss"], atol=5e-6)
+    expect_fast = case == "dlrm_adam"
+    assert model._in_record == expect_fast and calls["n"] == (g.meta["steps"] if expect_fast else 0)
+    model.eval()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    for name, got, ref in g.final_weights(sd):
+        assert_weights_close(got, ref, g.meta["lr"], g.meta["steps"], name)
+    if expect_fast:
+        monkeypatch.setenv("FX_DLRM_INPLACE", "0")
+        other = _build(g, tmp_path, monkeypatch)
+        other.train()
+        losses0 = [float(other.train_step(tb(g.batches[i])).item()) for i in range(g.meta["steps"])]
+        np.testing.assert_allclose(losses, losses0, atol=1e-6)
