@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, second full visit (after CIN on the matrix cores and DIN in the record): the whole GPU suite,
 # the default bench line, rocprofv3 stats of the same command, one-step timelines + bench lines of every model.
-TAG=${1:-r03y}
+TAG=${1:-r03final3}
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 S=$OUT/summary_$TAG.txt
 echo "== smoke" | tee $S
