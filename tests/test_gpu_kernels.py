@@ -814,6 +814,9 @@ def test_cin_stack_matches_einsum_conv1d(F0, D, units, B):
 def test_cin_packed_weight_image_is_only_a_layout(F0, Mi, O, B):
     """fx_cin_pack_w's image vs the kernels gathering W themselves (w_img = NULL): identical bits, in
     the forward, dX0 (accumulating), dXi and the dW partials."""
+    import os
+    if os.environ.get("FX_CIN_MFMA") == "0":
+        pytest.skip("FX_CIN_MFMA=0: the fp32 VALU kernels take every shape, there is no image")
     g = torch.Generator().manual_seed(F0 + Mi + O)
     x0 = _dev(torch.randn(B, F0, 16, generator=g))
     xi = _dev(torch.randn(B, Mi, 16, generator=g))
