@@ -38,6 +38,7 @@ VARIANTS = {
     "no_pipe": {"FX_GEMM_PIPE": "0"},          # the unpipelined GEMM kernel everywhere
     "splitk1": {"FX_DW_SPLITK": "1"},          # weight gradients without split-K (one k-ordered chain)
     "lazy": {"FX_PROBE_SPARSE": "lazy"},       # (not parity: SparseAdam semantics; scale reference)
+    "no_inplace": {"FX_DIN_INPLACE": "0", "FX_DLRM_INPLACE": "0"},   # the concatenating compositions of DIN / DLRM
 }
 
 
