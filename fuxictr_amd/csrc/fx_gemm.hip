@@ -1216,6 +1216,76 @@ __global__ __launch_bounds__(256) void k_gemm_small_m_v4(GemmArgs a) {
     }
 }
 
+// Backward of a Linear(hidden -> 1) head in ONE pass over the hidden activations: the weight gradient
+// dW[1, N] = sum_k dz[k] x[k, :] (k_gemm_small_m_v4 with M = 1: same loop, same slab order -> same bits)
+// and the input gradient dX[k, :] = dz[k] W[:] with the ReLU mask x[k, :] > 0 — x IS the mask, so the
+// row that was just loaded for dW also decides and the product leaves as one 16-byte store.  Two
+// launches (k_gemm_small_m_v4 + k_gemm_small_k_v4: x streamed twice) become one.
+struct HeadBwdArgs {
+    GemmArgs dw;          // A = dz [K, 1] (lda), B = x [K, N] (ldb), ws slabs, rowsum
+    float* dx;            // [K, N] (ldx)
+    int64_t ldx;
+    const float* w;       // [N]
+    int32_t use_mask;
+};
+
+template <int CG_LOG2>
+__global__ __launch_bounds__(256) void k_head_bwd_v4(HeadBwdArgs h) {
+    const GemmArgs& a = h.dw;
+    constexpr int CG = 1 << CG_LOG2, RL = 256 / CG;
+    __shared__ float4 red[256];
+    const int tx = threadIdx.x & (CG - 1), ty = threadIdx.x >> CG_LOG2;
+    const int64_t n = ((int64_t)blockIdx.x * CG + tx) * 4;
+    const int z = blockIdx.y;
+    const int64_t kbeg = (int64_t)z * a.k_chunk;
+    const int64_t kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
+    if (a.epi.rowsum && blockIdx.x == 0) fx_small_m_rowsum(a, z, kbeg, kend);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < a.N) {
+        const float4 wv = *reinterpret_cast<const float4*>(h.w + n);
+        const bool um = h.use_mask != 0;
+        auto row = [&](const float4& b, int64_t k) {
+            const float d = a.A[k * a.lda];
+            acc.x = fmaf(d, b.x, acc.x);
+            acc.y = fmaf(d, b.y, acc.y);
+            acc.z = fmaf(d, b.z, acc.z);
+            acc.w = fmaf(d, b.w, acc.w);
+            float4 o = make_float4(d * wv.x, d * wv.y, d * wv.z, d * wv.w);
+            if (um) {
+                o.x = b.x > 0.f ? o.x : 0.f;
+                o.y = b.y > 0.f ? o.y : 0.f;
+                o.z = b.z > 0.f ? o.z : 0.f;
+                o.w = b.w > 0.f ? o.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(h.dx + k * h.ldx + n) = o;
+        };
+        int64_t k = kbeg + ty;
+        for (; k + RL < kend; k += 2 * RL) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.B + k * a.ldb + n);
+            const float4 b1 = *reinterpret_cast<const float4*>(a.B + (k + RL) * a.ldb + n);
+            row(b0, k);
+            row(b1, k + RL);
+        }
+        for (; k < kend; k += RL) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.B + k * a.ldb + n);
+            row(b0, k);
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (ty == 0 && n < a.N) {
+        float4 r = red[tx];
+        for (int y = 1; y < RL; ++y) {          // fixed order over the row lanes
+            const float4 q = red[tx + y * CG];
+            r.x += q.x;
+            r.y += q.y;
+            r.z += q.z;
+            r.w += q.w;
+        }
+        *reinterpret_cast<float4*>(a.ws + (int64_t)z * a.N + n) = r;
+    }
+}
+
 // N <= 4, A stored [M,K] with K <= 256, K % 4 == 0, 16-B aligned rows (the 64 -> 1 attention output
 // layer over B*L rows): K/4 lanes read one row as float4s, 64/(K/4) rows per wave instruction
 template <int LPR_LOG2>
@@ -1696,6 +1766,55 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
                     fx_launch_splitk_reduce(a[i], s);
                     FX_CHECK_LAUNCH();
                 }
+            return FX_OK;
+        }
+    }
+    // The two gradients of a Linear(hidden -> 1) head in one pass over the hidden activations
+    // (k_head_bwd_v4).  FX_HEAD_FUSE=0: the two skinny launches.
+    static const bool head_on = []() {
+        const char* e = getenv("FX_HEAD_FUSE");
+        return !(e && atoi(e) == 0);
+    }();
+    if (n == 2 && head_on && p[0].transa && !p[0].transb && p[0].M == 1 && p[0].workspace && p[0].split_k >= 1 &&
+        !p[1].transa && !p[1].transb && p[1].K == 1 && p[1].M == p[0].K && p[1].N == p[0].N &&
+        p[1].A == p[0].A && p[1].lda == p[0].lda && p[0].N >= 16 && p[0].N % 4 == 0) {
+        const fx_gemm_problem& q0 = p[0];
+        const fx_gemm_problem& q1 = p[1];
+        const fx_gemm_epilogue* e1 = q1.epilogue;
+        const bool plain = !e1 || (!e1->bias && !e1->zout && e1->act == 0 && !e1->mul && !e1->add && !e1->rowsum &&
+                                   (!e1->mask || (e1->mask == q0.B && e1->ldmask == q0.ldb)));
+        const bool al = q0.ldb % 4 == 0 && q1.ldc % 4 == 0 &&
+                        (((uintptr_t)q0.B | (uintptr_t)q0.workspace | (uintptr_t)q1.C | (uintptr_t)q1.B) & 15) == 0;
+        if (plain && al && q0.B && q0.C && q1.B && q1.C) {
+            HeadBwdArgs h;
+            int bm = 0, bn = 0;
+            const int rc = fx_gemm_prepare(q0.transa, q0.transb, q0.M, q0.N, q0.K, q0.A, q0.lda, q0.B, q0.ldb,
+                                           q0.C, q0.ldc, q0.epilogue, q0.split_k, q0.workspace, h.dw, bm, bn);
+            if (rc != FX_OK) return rc;
+            // (the K split of the skinny weight-gradient kernel: a column-parallel reduction)
+            const int64_t want = q0.split_k > 1 ? q0.split_k : 1;
+            int64_t kc2 = fx_ceil_div(q0.K, want);
+            if (kc2 < 1) kc2 = 1;
+            h.dw.k_chunk = kc2;
+            h.dw.split_k = (int32_t)fx_ceil_div(q0.K, kc2);
+            h.dx = q1.C;
+            h.ldx = q1.ldc;
+            h.w = q1.B;
+            h.use_mask = (e1 && e1->mask) ? 1 : 0;
+            int cg_log2 = 2;
+            while ((4 << cg_log2) < q0.N && cg_log2 < 6) ++cg_log2;
+            hipStream_t s = fx_hip_stream(stream);
+            dim3 g((unsigned)fx_ceil_div(q0.N, 4 << cg_log2), (unsigned)h.dw.split_k);
+            switch (cg_log2) {
+                case 2: hipLaunchKernelGGL(k_head_bwd_v4<2>, g, dim3(256), 0, s, h); break;
+                case 3: hipLaunchKernelGGL(k_head_bwd_v4<3>, g, dim3(256), 0, s, h); break;
+                case 4: hipLaunchKernelGGL(k_head_bwd_v4<4>, g, dim3(256), 0, s, h); break;
+                case 5: hipLaunchKernelGGL(k_head_bwd_v4<5>, g, dim3(256), 0, s, h); break;
+                default: hipLaunchKernelGGL(k_head_bwd_v4<6>, g, dim3(256), 0, s, h); break;
+            }
+            FX_CHECK_LAUNCH();
+            fx_launch_splitk_reduce(h.dw, s);
+            FX_CHECK_LAUNCH();
             return FX_OK;
         }
     }
