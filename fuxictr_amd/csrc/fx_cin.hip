@@ -8,7 +8,8 @@
 //   pool[b,o]         = sum_d Xn[b,o,d]
 // Persistent workgroups (one per CU) keep the layer's W (O x F0*Mi fp32, 97 KB for 16 x 39*39) in
 // LDS and walk the samples; a sample's X0 / Xi tiles are staged in LDS too.  All reductions are in a
-// fixed order.  fp32 VALU FMAs: the per-sample products are 39x39x16 — far below an MFMA tile.
+// fixed order.  These are the fp32 VALU kernels: they take every shape; D = 16 with O <= 16 and
+// F0, Mi <= 40 (the BASELINE xDeepFM) runs on the matrix cores instead (fx_cin_mfma.hip).
 #include "fx_cin.h"
 
 #include <stdlib.h>
