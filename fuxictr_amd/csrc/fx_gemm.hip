@@ -1791,8 +1791,9 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
             const int rc = fx_gemm_prepare(q0.transa, q0.transb, q0.M, q0.N, q0.K, q0.A, q0.lda, q0.B, q0.ldb,
                                            q0.C, q0.ldc, q0.epilogue, q0.split_k, q0.workspace, h.dw, bm, bn);
             if (rc != FX_OK) return rc;
-            // (the K split of the skinny weight-gradient kernel: a column-parallel reduction)
-            const int64_t want = q0.split_k > 1 ? q0.split_k : 1;
+            // (the K split of the skinny weight-gradient kernel, derived exactly as fx_gemm_f32 does — from
+            // the slab count fx_gemm_prepare settled on — so that both paths sum the same slabs)
+            const int64_t want = h.dw.split_k > 1 ? h.dw.split_k : 1;
             int64_t kc2 = fx_ceil_div(q0.K, want);
             if (kc2 < 1) kc2 = 1;
             h.dw.k_chunk = kc2;

@@ -451,6 +451,40 @@ def test_gemm_batch_of_four_problems_in_one_grid():
         assert (db.double() - dz.double().sum(0)).abs().max().item() <= 1e-5 * dz.abs().double().sum(0).max().item()
 
 
+@pytest.mark.parametrize("B,K,masked", [(4096, 1024, True), (1000, 64, True), (333, 256, False), (4096, 368, True)])
+def test_head_backward_in_one_pass_is_the_two_skinny_launches(B, K, masked):
+    """gemm_dw_dx for a Linear(hidden -> 1) head (k_head_bwd_v4: dW, db and the masked dX in one pass over
+    the activations) == the two skinny launches it replaces, bit for bit (same slab order for dW, exact
+    single products for dX)."""
+    g = torch.Generator().manual_seed(B + K)
+    h = _dev(torch.relu(torch.randn(B, K, generator=g)))          # a ReLU layer's output: its own mask
+    dz = _dev(torch.randn(B, 1, generator=g))
+    W = _dev(torch.randn(1, K, generator=g))
+    sk = 16
+    res = []
+    for fused in (True, False):
+        dW = torch.full((1, K), float("nan"), device=DEV)
+        dx = torch.full((B, K), float("nan"), device=DEV)
+        db = torch.full((1,), float("nan"), device=DEV)
+        ws = torch.empty(ops.gemm_workspace_floats(1, K, sk), device=DEV)
+        mask = h if masked else None
+        if fused:
+            ops.gemm_dw_dx(dz, h, W, dW, dx, split_k=sk, workspace=ws, rowsum=db, mask=mask)
+        else:
+            ops.gemm(dz, h, dW, transa=True, transb=False, split_k=sk, workspace=ws, rowsum=db)
+            ops.gemm(dz, W, dx, transa=False, transb=False, mask=mask)
+        torch.cuda.synchronize()
+        res.append((dW.cpu(), dx.cpu(), db.cpu()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    ref_w = dz.double().t() @ h.double()
+    assert (res[0][0].double() - ref_w.cpu()).abs().max().item() <= 1e-5 * (dz.abs().double().t() @ h.abs().double()).max().item()
+    ref_x = dz.double() @ W.double()
+    if masked:
+        ref_x = ref_x * (h > 0).double()
+    assert (res[0][1].double() - ref_x.cpu()).abs().max().item() <= 1e-6 * ref_x.abs().max().item()
+
+
 @pytest.mark.parametrize("M", [4096, 1000])
 def test_gemm_batch_of_two_forward_problems_is_the_two_launches(M):
     """fx_gemm_f32_batch with the cross layer and the deep layer of one DCNv2 depth FORWARD (x W^T with the
