@@ -68,6 +68,8 @@ def parse():
                          "number of ranks (tests/test_gpu_dist.py)")
     ap.add_argument("--probe-world", type=int, default=0,
                     help="with --probe-loss on fewer ranks: the world size whose global batch to probe")
+    ap.add_argument("--no-step-events", action="store_true",
+                    help="skip the second pass that records one HIP event per step (step_us)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the step eagerly instead of replaying a captured hipGraph")
     return ap.parse_args()
@@ -358,7 +360,7 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
     if args.probe_loss:
         probe = probe_losses(args, model, cards, spec, rank, world, dev, dist,
                              sharded=(world > 1 or world1) and not args.replicas)
-    n_pool = min(args.pool, max(8, args.warmup + args.steps + 40))
+    n_pool = min(args.pool, max(8, max(args.warmup, 12) + 2 * args.steps + 40))
     pool = make_pool(args, rank, cards, spec, dev, n_pool)
 
     loader_iter = None
@@ -393,7 +395,10 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
     step_i = 0
     launch_note = None
     try:
-        for _ in range(max(args.warmup, 5 if model._use_graph else 0)):   # >= 5: 3 eager + capture
+        # graph mode: 3 eager steps + the capture + at least 8 replays before the clock starts (the first
+        # replays of a fresh hipGraph upload it and ramp the clocks; `warmup_steps_run` in the line)
+        warm_run = max(args.warmup, 12 if model._use_graph else 0)
+        for _ in range(warm_run):
             model.train_step(next_batch(step_i))
             step_i += 1
         sync()
@@ -404,17 +409,49 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         print("[bench] " + launch_note, file=sys.stderr, flush=True)
         model._use_graph = False
         model._graph_state = None
+        warm_run = args.warmup
         for _ in range(args.warmup):
             model.train_step(pool[step_i % n_pool])
             step_i += 1
         sync()
+    if model._use_graph and getattr(model, "_graph_state", None) is not None and loader_iter is None \
+            and not args.host_inputs:
+        # host side of the input cast of every pool batch (pointer blocks of the one pack launch),
+        # once per batch object: what an epoch over HBM-resident batches pays on its first pass only
+        for b in pool:
+            model.prepare_batch(b)
+        sync()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()                 # on the launch stream (torch's current stream): first launch ...
     for _ in range(args.steps):
         model.train_step(next_batch(step_i))
         step_i += 1
+    ev1.record()                 # ... to the end of the last kernel, without the host's sync latency
     sync()
     dt = time.perf_counter() - t0
+    dt_events = 1e-3 * ev0.elapsed_time(ev1)
     model.optimizer.check_errors()
+    # per-step spread: a SECOND pass of the same number of steps with one event per step (the events
+    # cost a few us of launch boundary each, so this pass is not the headline; it shows whether the
+    # mean hides a ramp or outliers)
+    step_us = None
+    if not args.no_step_events:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        sync()
+        evs[0].record()
+        for j in range(args.steps):
+            model.train_step(next_batch(step_i))
+            step_i += 1
+            evs[j + 1].record()
+        sync()
+        us = sorted(1e3 * evs[j].elapsed_time(evs[j + 1]) for j in range(args.steps))
+        step_us = {"min": us[0], "median": us[len(us) // 2], "p90": us[min(len(us) - 1, int(0.9 * len(us)))],
+                   "max": us[-1], "mean": sum(us) / len(us),
+                   "first3": [1e3 * evs[j].elapsed_time(evs[j + 1]) for j in range(min(3, args.steps))],
+                   "note": "second pass of %d steps, one HIP event per step on the launch stream "
+                           "(events add launch boundaries: not the headline)" % args.steps}
     timing_mode, ktimes = None, {}
     if not args.no_kernel_timing:
         # Per-kernel durations cannot be observed inside a replayed hipGraph, and an event pair around
@@ -458,16 +495,17 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
                        "launch, so the GEMM figure is a few per cent below the k_gemm_f32_* rows of the "
                        "rocprofv3 summary under profiles/" % (n_rec, n_rec, n_rec - 1))
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, dt_events], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_events = float(t[0].item()), float(t[1].item())
     launch = launch_note or ("hipGraph replay" if model._use_graph else "eager")
     rows = sum(cards) + len(cards)
     del model, pool
     import gc
     gc.collect()
     torch.cuda.empty_cache()
-    return {"dt": dt, "ktimes": ktimes, "launch": launch, "parallelism": parallelism,
+    return {"dt": dt, "dt_events": dt_events, "step_us": step_us, "warmup_run": warm_run,
+            "ktimes": ktimes, "launch": launch, "parallelism": parallelism,
             "cards": cards, "timing_mode": timing_mode, "rows": rows, "n_pool": n_pool,
             "probe": probe}
 
@@ -633,6 +671,24 @@ def rooflines(m, args, world):
     return out
 
 
+def timing_detail(m, args):
+    """Where the wall clock of the timed region goes: the same region between one HIP-event pair on the
+    launch stream, the per-step spread of a second pass, and the sum of the step's kernels (replayed
+    per launch group by ops.KernelTimer; DeepFM / DCNv2, whose every entry point is recorded)."""
+    out = {"ms_per_step_events": 1e3 * m["dt_events"] / args.steps,
+           "warmup_steps_run": m["warmup_run"]}
+    if m.get("step_us"):
+        out["step_us"] = {k: (round(v, 1) if isinstance(v, float) else
+                              [round(x, 1) for x in v] if isinstance(v, list) else v)
+                          for k, v in m["step_us"].items()}
+    tot = (m.get("ktimes") or {}).get("__step__")
+    if tot and args.model in ("DeepFM", "DCNv2"):
+        out["kernel_sum_us"] = round(1e3 * tot["total_ms"], 1)
+        out["kernel_sum_launches"] = round(tot["launches"], 1)
+        out["wall_minus_kernel_sum_us"] = round(1e3 * m["dt"] / args.steps * 1e3 - 1e3 * tot["total_ms"], 1)
+    return out
+
+
 def workload_name(args, rows):
     if args.model == "DIN":
         return ("configs[3]: DIN on synthetic Taobao-shape sequences (14 categorical + "
@@ -724,6 +780,7 @@ def main():
                        "256 MB Infinity Cache)" % m["n_pool"],
                        "parallelism": m["parallelism"]},
         }
+        out.update(timing_detail(m, args))
         out.update(rooflines(m, args, world))
         if m.get("probe") is not None:
             out["probe_loss"] = m["probe"]
@@ -732,6 +789,7 @@ def main():
             sub = {"workload": workload_name(args2, m2["rows"]),
                    "value": args.batch * args.steps / m2["dt"], "unit": "samples/sec",
                    "ms_per_step": 1e3 * m2["dt"] / args.steps, "launch": m2["launch"]}
+            sub.update(timing_detail(m2, args2))
             sub.update(rooflines(m2, args2, world))
             out["dcnv2"] = sub
         if world == 1 and not args.no_cpu_baseline and args.model in ("DeepFM", "DCNv2"):

@@ -226,6 +226,8 @@ class _GraphStep(object):
         static[label] = self.y.view(-1)
         self.static = static
         self._pack_keys = {k for k, *_ in self.packs}
+        self._fill_names = sorted({f for _, ids_n, num_n, _, _ in self.packs for f in ids_n + num_n})
+        self._fill_cache = {}
         self.fill(batch)
         torch.cuda.synchronize(dev)
         if model._dist is None:
@@ -256,24 +258,51 @@ class _GraphStep(object):
         # the capture only recorded the step; drop per-batch caches created while recording
         static.cache = {k: v for k, v in static.cache.items() if k in self._pack_keys}
 
-    def fill(self, batch):
+    FILL_CACHE_MAX = 512
+
+    def fill(self, batch, launch=True):
+        """Cast the batch's columns + label into the static input buffers (one launch).  The host
+        side of that launch (40 tensor look-ups, the ctypes argument blocks) is kept per batch OBJECT
+        whose columns are device-resident: a batch seen before (an epoch over resident batches,
+        bench.py's pool, anything handed to BaseModel.prepare_batch) costs one call, as long as the
+        dict still holds the very same tensors."""
+        ent = self._fill_cache.get(id(batch))
+        if ent is not None:
+            if ent[0] is batch and all(batch.get(f) is t for f, t in ent[1]):
+                self.model._staged_labels = (None, None)
+                if launch:
+                    ent[2]()
+                return
+            del self._fill_cache[id(batch)]
         dev = self.model.device
-        names = sorted({f for _, ids_n, num_n, _, _ in self.packs for f in ids_n + num_n})
-        staged = self.model._stage_host_columns(batch, names)     # one async H2D copy per dtype
+        staged = self.model._stage_host_columns(batch, self._fill_names)   # one async H2D copy per dtype
         key, y = self.model._staged_labels
 
         def col(f):
             return staged[f] if f in staged else batch[f].to(dev)
-        items = []
+        items, srcs = [], []
         for _, id_names, num_names, s_ids, s_dense in self.packs:
             for dst, cols_ in ((s_ids, id_names), (s_dense, num_names)):
                 c0 = 0
                 for f in cols_ if dst is not None else ():
                     t = col(f)
                     items.append((t, dst, c0))
+                    srcs.append((f, t))
                     c0 += 1 if t.dim() == 1 else t.shape[1]
-        items.append((y if key == id(batch) else batch[self.label].to(dev), self.y, 0))
-        ops.pack_columns_multi(items)      # ids + numerics + label of the batch: one launch
+        yt = y if key == id(batch) else batch[self.label].to(dev)
+        items.append((yt, self.y, 0))
+        srcs.append((self.label, yt))
+        if (not staged and type(batch) is dict
+                and all(batch.get(f) is t and t.is_contiguous() for f, t in srcs)):
+            call = ops.pack_columns_multi_prepare(items)
+            if len(self._fill_cache) >= self.FILL_CACHE_MAX:       # oldest entry out
+                self._fill_cache.pop(next(iter(self._fill_cache)))
+            self._fill_cache[id(batch)] = (batch, srcs, call)
+            if launch:
+                call()
+            return
+        if launch:
+            ops.pack_columns_multi(items)      # ids + numerics + label of the batch: one launch
 
 
 class BaseModel(nn.Module):
@@ -636,6 +665,16 @@ class BaseModel(nn.Module):
         st.fill(batch_data)
         st.graph.replay()
         return st.loss
+
+    def prepare_batch(self, batch_data):
+        """Optional: do the host side of a captured step's input cast for a device-resident batch
+        ahead of time (the first train_step on a batch object does it otherwise).  No launch, no
+        effect on results; a no-op before the step has been captured or for host batches."""
+        st = self._graph_state
+        if (st is not None and type(batch_data) is dict
+                and all(getattr(v, "is_cuda", False) for v in batch_data.values())
+                and batch_data[self.feature_map.labels[0]].shape[0] == st.B):
+            st.fill(batch_data, launch=False)
 
     def _progress(self, iterable):
         if self._verbose > 0:
