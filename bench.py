@@ -360,7 +360,7 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
     if args.probe_loss:
         probe = probe_losses(args, model, cards, spec, rank, world, dev, dist,
                              sharded=(world > 1 or world1) and not args.replicas)
-    n_pool = min(args.pool, max(8, max(args.warmup, 12) + 2 * args.steps + 40))
+    n_pool = min(args.pool, max(8, max(args.warmup, 20) + 2 * args.steps + 40))
     pool = make_pool(args, rank, cards, spec, dev, n_pool)
 
     loader_iter = None
@@ -394,11 +394,23 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
 
     step_i = 0
     launch_note = None
+
+    def prepare_pool():
+        # host side of the input cast of every pool batch (pointer blocks of the one pack launch),
+        # once per batch object: what an epoch over HBM-resident batches pays on its first pass only
+        if getattr(model, "_graph_state", None) is not None and loader_iter is None \
+                and not args.host_inputs:
+            for b in pool:
+                model.prepare_batch(b)
     try:
-        # graph mode: 3 eager steps + the capture + at least 8 replays before the clock starts (the first
-        # replays of a fresh hipGraph upload it and ramp the clocks; `warmup_steps_run` in the line)
-        warm_run = max(args.warmup, 12 if model._use_graph else 0)
-        for _ in range(warm_run):
+        # graph mode: 3 eager steps + the capture, then the host side of the pool's input casts, then at
+        # least 16 replays back to back right up to the clock: the chip's power management needs
+        # ~20 ms of sustained load to settle (profiles/r04_step_spread.txt: the 20 steps after an idle
+        # gap of a few ms ran 1.057 ms, the 20 after those 1.013) — `warmup_steps_run` in the line
+        warm_run = max(args.warmup, 20 if model._use_graph else 0)
+        for i in range(warm_run):
+            if i == 4 and model._use_graph:
+                prepare_pool()
             model.train_step(next_batch(step_i))
             step_i += 1
         sync()
@@ -413,13 +425,6 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         for _ in range(args.warmup):
             model.train_step(pool[step_i % n_pool])
             step_i += 1
-        sync()
-    if model._use_graph and getattr(model, "_graph_state", None) is not None and loader_iter is None \
-            and not args.host_inputs:
-        # host side of the input cast of every pool batch (pointer blocks of the one pack launch),
-        # once per batch object: what an epoch over HBM-resident batches pays on its first pass only
-        for b in pool:
-            model.prepare_batch(b)
         sync()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)

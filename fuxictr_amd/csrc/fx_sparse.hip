@@ -669,28 +669,39 @@ __global__ __launch_bounds__(FX_PLAN_BLOCK) void k_shard_count(const uint32_t* u
     if ((int)threadIdx.x < N) blk_cnt[(int64_t)blockIdx.x * N + threadIdx.x] = cnt[threadIdx.x];
 }
 
-// one thread per owner: exclusive scan of that owner's counts over the blocks (in place), totals
-__global__ void k_shard_scan_blocks(int32_t* blk_cnt, int nblk, int N, int cap, int32_t* total,
-                                    fx_scalars* scal) {
-    const int o = threadIdx.x;
-    if (o >= N) return;
-    int32_t acc = 0;
-    for (int b = 0; b < nblk; ++b) {
-        const int32_t c = blk_cnt[(int64_t)b * N + o];
-        blk_cnt[(int64_t)b * N + o] = acc;
-        acc += c;
-    }
-    total[o] = acc;
-    if (acc > cap) atomicOr(&scal->err_flag, FX_FLAG_A2A_OVERFLOW);
-}
-
-__global__ __launch_bounds__(FX_PLAN_BLOCK) void k_shard_assign(const uint32_t* uniq_key,
-                                                                const int32_t* n_unique, int N,
-                                                                int cap, int64_t n_max,
-                                                                const int32_t* blk_base,
-                                                                int32_t* uniq_slot, int32_t* send_idx) {
+// launch 2 of the plan.  Every block first turns the per-block owner histograms into ITS exclusive
+// base per owner and the per-owner totals (<= a few hundred words, read by all blocks: the separate
+// one-thread-per-owner scan launch of round 2 — 10 us — is gone), then
+//   assigns      unique key u -> slot (owner, rank inside the owner's bucket); send_idx, uniq_slot, and
+//                slot_uniq (slot -> u, the inverse map the gradient exchange fills its block by)
+//   pads         bucket tails: send_idx = the owner's pad row, slot_uniq = -1
+//   fills        lookup_slot with the pad slot (valid lookups are overwritten by launch 3)
+//   zeroes       `zero_row` (the pad row of the block the received rows land in), flags overflow
+// Round 2 did this in five launches (scan, assign, pad tails, fill, ...) of ~4.6 us each.
+__global__ __launch_bounds__(FX_PLAN_BLOCK) void k_shard_route(const uint32_t* uniq_key,
+                                                               const int32_t* n_unique, int N,
+                                                               int cap, int64_t n_max,
+                                                               const int32_t* blk_cnt, int nblk,
+                                                               int32_t pad_row, int32_t* uniq_slot,
+                                                               int32_t* send_idx, int32_t* slot_uniq,
+                                                               int32_t* lookup_slot, float* zero_row,
+                                                               int zero_w, fx_scalars* scal) {
     __shared__ int32_t wave_cnt[FX_PLAN_BLOCK / 64][FX_PLAN_MAX_SHARDS];
+    __shared__ int32_t base_s[FX_PLAN_MAX_SHARDS], total_s[FX_PLAN_MAX_SHARDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)threadIdx.x < N) {
+        int32_t before = 0, all = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const int32_t c = blk_cnt[(int64_t)b * N + threadIdx.x];
+            if (b < (int)blockIdx.x) before += c;
+            all += c;
+        }
+        base_s[threadIdx.x] = before;
+        total_s[threadIdx.x] = all;
+        if (blockIdx.x == 0 && all > cap) atomicOr(&scal->err_flag, FX_FLAG_A2A_OVERFLOW);
+    }
+    if (blockIdx.x == 0 && zero_row != nullptr)
+        for (int i = threadIdx.x; i < zero_w; i += FX_PLAN_BLOCK) zero_row[i] = 0.f;
     const int64_t u = (int64_t)blockIdx.x * FX_PLAN_BLOCK + threadIdx.x;
     const bool on = u < *n_unique;
     const uint32_t g = on ? uniq_key[u] : 0u;
@@ -703,32 +714,36 @@ __global__ __launch_bounds__(FX_PLAN_BLOCK) void k_shard_assign(const uint32_t* 
     }
     __syncthreads();
     if (on) {
-        int base = blk_base[(int64_t)blockIdx.x * N + my_o];
+        int base = base_s[my_o];
         for (int w = 0; w < wave; ++w) base += wave_cnt[w][my_o];
         const int j = base + my_rank;
         int32_t slot = N * cap;                             // pad slot on overflow
         if (j < cap) {
             slot = my_o * cap + j;
             send_idx[slot] = (int32_t)(g / (uint32_t)N);
+            if (slot_uniq) slot_uniq[slot] = (int32_t)u;
         }
         uniq_slot[u] = slot;
     } else if (u < n_max) {
         uniq_slot[u] = N * cap;
     }
-}
-
-// bucket tails: slots past an owner's count carry the owner's pad row
-__global__ __launch_bounds__(256) void k_shard_pad_tails(const int32_t* total, int N, int cap,
-                                                         int32_t pad_row, int32_t* send_idx) {
-    const int64_t n = (int64_t)N * cap;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    // bucket tails and the lookup-slot fill: grid-stride over the whole launch
+    const int64_t total = (int64_t)N * cap;
+    const int64_t tid = (int64_t)blockIdx.x * FX_PLAN_BLOCK + threadIdx.x;
+    const int64_t nthr = (int64_t)gridDim.x * FX_PLAN_BLOCK;
+    for (int64_t e = tid; e < total; e += nthr) {
         const int o = (int)(e / cap), j = (int)(e - (int64_t)o * cap);
-        if (j >= total[o]) send_idx[e] = pad_row;
+        if (j >= total_s[o]) {
+            send_idx[e] = pad_row;
+            if (slot_uniq) slot_uniq[e] = -1;
+        }
     }
+    if (lookup_slot)
+        for (int64_t i = tid; i < n_max; i += nthr) lookup_slot[i] = (int32_t)total;
 }
 
 // lookups whose id was padding / out of range have no position in the fast path's sorted arrays:
-// every lookup slot starts at the pad slot, valid positions are overwritten
+// every lookup slot starts at the pad slot (k_shard_route), valid positions are overwritten
 __global__ __launch_bounds__(256) void k_shard_lookup_slot_g(const uint32_t* sorted_pos,
                                                              const uint32_t* sorted_uid,
                                                              const int32_t* uniq_slot, int64_t n,
@@ -754,11 +769,13 @@ extern "C" int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique,
                              int64_t n_lookups, int32_t n_shards, int64_t total_rows, int32_t cap,
                              int32_t* send_idx, int32_t* uniq_slot, int32_t* lookup_slot,
                              fx_scalars* scal, int32_t global_keys, int32_t* workspace,
+                             int32_t* slot_uniq, float* zero_row, int32_t zero_w,
                              fx_stream_t stream) {
     FX_CHECK_ARG(n_shards >= 1 && cap >= 1 && n_lookups >= 0, "fx_shard_plan: bad sizes");
     FX_CHECK_ARG(uniq_key && n_unique && sorted_pos && sorted_uid && send_idx && uniq_slot &&
                      lookup_slot && scal,
                  "fx_shard_plan: null pointer");
+    FX_CHECK_ARG(zero_w >= 0 && (zero_w == 0 || zero_row), "fx_shard_plan: zero_w without zero_row");
     const int64_t rps = fx_ceil_div(total_rows, n_shards);
     hipStream_t s = fx_hip_stream(stream);
     const int64_t total = (int64_t)n_shards * cap;
@@ -768,28 +785,24 @@ extern "C" int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique,
                      FX_PLAN_MAX_SHARDS);
         const int nblk = (int)fx_ceil_div(n_lookups > 0 ? n_lookups : 1, FX_PLAN_BLOCK);
         int32_t* blk_cnt = workspace;
-        int32_t* tot = workspace + (int64_t)nblk * n_shards;
         hipLaunchKernelGGL(k_shard_count, dim3((unsigned)nblk), dim3(FX_PLAN_BLOCK), 0, s, uniq_key,
                            n_unique, (int)n_shards, blk_cnt);
-        hipLaunchKernelGGL(k_shard_scan_blocks, dim3(1), dim3(64), 0, s, blk_cnt, nblk,
-                           (int)n_shards, (int)cap, tot, scal);
-        hipLaunchKernelGGL(k_shard_assign, dim3((unsigned)nblk), dim3(FX_PLAN_BLOCK), 0, s, uniq_key,
-                           n_unique, (int)n_shards, (int)cap, n_lookups, blk_cnt, uniq_slot,
-                           send_idx);
-        int64_t bp = fx_ceil_div(total, 256);
-        if (bp > 4096) bp = 4096;
-        hipLaunchKernelGGL(k_shard_pad_tails, dim3((unsigned)bp), dim3(256), 0, s, tot, (int)n_shards,
-                           (int)cap, (int32_t)rps, send_idx);
+        hipLaunchKernelGGL(k_shard_route, dim3((unsigned)nblk), dim3(FX_PLAN_BLOCK), 0, s, uniq_key,
+                           n_unique, (int)n_shards, (int)cap, n_lookups, blk_cnt, nblk, (int32_t)rps,
+                           uniq_slot, send_idx, slot_uniq, lookup_slot, zero_row, (int)zero_w, scal);
         if (n_lookups > 0) {
             int64_t b2 = fx_ceil_div(n_lookups, 256);
             if (b2 > 4096) b2 = 4096;
-            hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)b2), dim3(256), 0, s, lookup_slot,
-                               n_lookups, (int32_t)total);
             hipLaunchKernelGGL(k_shard_lookup_slot_g, dim3((unsigned)b2), dim3(256), 0, s,
                                sorted_pos, sorted_uid, uniq_slot, n_lookups, lookup_slot);
         }
         FX_CHECK_LAUNCH();
         return FX_OK;
+    }
+    FX_CHECK_ARG(slot_uniq == nullptr, "fx_shard_plan: slot_uniq needs global_keys = 1");
+    if (zero_w > 0) {
+        hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(256), 0, s, reinterpret_cast<int32_t*>(zero_row),
+                           (int64_t)zero_w, 0);
     }
     int64_t b1 = fx_ceil_div(total, 256);
     if (b1 > 4096) b1 = 4096;
