@@ -346,11 +346,7 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         model, fmap, spec = build_model(args, local_rank, cards, shard="row")
         parallelism = ("tables row-sharded over %d ranks (RCCL all-to-all of ids / rows / row "
                        "gradients), towers data-parallel (one flat all-reduce carrying the clip "
-                       "norm); %s" % (world, "eager launches" if args.no_graph else
-                                      "one hipGraph per step with the RCCL collectives recorded in it "
-                                      "(FX_GRAPH_COLLECTIVES=1)"
-                                      if os.environ.get("FX_GRAPH_COLLECTIVES") == "1" else
-                                      "hipGraph segments with the collectives launched between them"))
+                       "norm partials); " % world)
     else:
         model, fmap, spec = build_model(args, local_rank, cards)
         if world > 1:
@@ -504,6 +500,12 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_events = float(t[0].item()), float(t[1].item())
     launch = launch_note or ("hipGraph replay" if model._use_graph else "eager")
+    if parallelism.endswith("; "):
+        # which of the two captured forms of the sharded step actually ran (fuxictr_amd/dist.py)
+        parallelism += ("eager launches" if not model._use_graph else
+                        (getattr(model._dist, "graph_mode", None) or "hipGraph"))
+    if model._dist is not None:
+        model.release_graphs()       # recorded RCCL kernels must be gone before the communicator
     rows = sum(cards) + len(cards)
     del model, pool
     import gc
@@ -803,15 +805,14 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        if os.environ.get("FX_GRAPH_COLLECTIVES") == "1" and dist.get_backend() == "nccl":
-            # opt-in mode (collectives recorded into the step's hipGraph): ProcessGroupNCCL's shutdown
-            # never returns once RCCL kernels were captured (torch 2.10 / ROCm 7.0: the traceback of
-            # profiles/r03_graph_collectives_teardown.txt ends in destroy_process_group).  The line
-            # is out and every rank passed the barrier: leave without the destructor chain.
-            sys.stdout.flush()
-            sys.stderr.flush()
-            os._exit(0)
-        dist.destroy_process_group()
+        # the captured steps (and the RCCL kernels recorded in them) were released in measure(); the
+        # helper destroys the process group and ends the process itself should that still not return
+        # (round 3: destroy_process_group hung while a graph with recorded collectives was alive,
+        # profiles/r03_graph_collectives_teardown.txt)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        from fuxictr_amd.dist import DistContext
+        DistContext.shutdown(timeout_s=20.0)
 
 
 if __name__ == "__main__":

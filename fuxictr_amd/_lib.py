@@ -71,7 +71,13 @@ SIGNATURES = {
     "fx_dedup_sorted_runs": (i32, [vp, i32, i64, i32, i32, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
                                    vp]),
     "fx_shard_plan_workspace_ints": (i64, [i64, i32]),
-    "fx_shard_plan": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "fx_shard_plan": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp]),
+    "fx_fill_grad_block": (i32, [C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), i32, vp, i64, vp, i64, vp]),
+    "fx_owner_grad_reduce_partials": (i64, [i64]),
+    "fx_owner_grad_reduce": (i32, [vp, i64, vp, vp, vp, i64, C.POINTER(vp), C.POINTER(i32),
+                                   C.POINTER(i32), i32, vp, vp]),
+    "fx_owner_fetch_rows": (i32, [C.POINTER(RowState), C.POINTER(i32), i32, vp, vp, vp, vp, i64, vp, i64,
+                                  i32, i32, vp, vp, i32, vp]),
     "fx_scatter_rows": (i32, [vp, vp, vp, i64, i32, vp, i64, vp]),
     "fx_split_rows": (i32, [vp, i64, i64, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), i32, vp]),
     "fx_sum_parts": (i32, [C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
@@ -139,7 +145,7 @@ SIGNATURES = {
     "fx_dedup_catchup": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
                                vp, C.POINTER(RowState), i32, i32, vp, vp]),
     "fx_emb_fm_fwd": (i32, [vp, i32, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, vp, i32, vp, i64, i64,
-                            vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+                            vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]),
     "fx_emb_fm_bwd_partials": (i64, [i64, i32]),
     "fx_emb_fm_bwd_workspace_floats": (i64, [i64, i32, i32]),
     "fx_emb_fm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp, vp,

@@ -521,6 +521,8 @@ struct EmbFmArgs {
     float* S;
     fx_scalars* scal;
     int32_t D, C, Fd, lanes_log2, bf16;
+    int64_t table_ld, table1_ld;     // row strides in elements (D and 1 for packed tables; the block of
+                                     // rows a row-sharded exchange delivered is read in place)
 };
 
 template <int VEC>
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(256) void k_emb_fm_fwd(EmbFmArgs a) {
                 off = a.col_out_off[r];
                 if (id >= 0 && id < a.col_vocab[r]) {
                     if (lane_on)
-                        fx_tab_load<VEC>(a.table, a.bf16, (a.col_row_base[r] + id) * a.D + d0, val);
+                        fx_tab_load<VEC>(a.table, a.bf16, (a.col_row_base[r] + id) * a.table_ld + d0, val);
                 } else if (sub == 0) {
                     atomicOr(&a.scal->err_flag, FX_FLAG_BAD_ID);
                 }
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(256) void k_emb_fm_fwd(EmbFmArgs a) {
         if (a.lr_out != nullptr || a.fm_lr_out != nullptr) {
             for (int c = lane; c < a.C; c += 64) {
                 const int32_t id = a.ids[b * a.ids_ld + c];
-                if (id >= 0 && id < a.col_vocab[c]) lr += a.table1[a.col_row_base[c] + id];
+                if (id >= 0 && id < a.col_vocab[c]) lr += a.table1[(a.col_row_base[c] + id) * a.table1_ld];
             }
             for (int j = lane; j < a.Fd; j += 64)
                 lr = fmaf(a.dense[b * a.dense_ld + j], a.num_w1[j], lr);
@@ -615,8 +617,11 @@ extern "C" int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, 
                              int32_t Fd, float* out, int64_t out_ld, int64_t B,
                              const float* table1, const float* num_w1, const float* bias1,
                              float* lr_out, float* fm_out, float* fm_lr_out, float* S,
-                             fx_scalars* scal, fx_stream_t stream) {
+                             fx_scalars* scal, int64_t table_ld, int64_t table1_ld,
+                             fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256, "fx_emb_fm_fwd: D=%d not in [1,256]", D);
+    if (table_ld <= 0) table_ld = D;
+    if (table1_ld <= 0) table1_ld = 1;
     FX_CHECK_ARG(table_dtype == FX_F32 || table_dtype == FX_BF16,
                  "fx_emb_fm_fwd: table_dtype must be FX_F32 or FX_BF16");
     FX_CHECK_ARG(C >= 0 && Fd >= 0 && B >= 0, "fx_emb_fm_fwd: negative size");
@@ -632,11 +637,15 @@ extern "C" int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, 
                  "fx_emb_fm_fwd: first-order term requested without its D=1 table / numeric weights");
     FX_CHECK_ARG(out_ld % g.vec == 0, "fx_emb_fm_fwd: out_ld=%lld not a multiple of %d",
                  (long long)out_ld, g.vec);
+    FX_CHECK_ARG(table_ld >= D && table_ld % g.vec == 0 &&
+                     (reinterpret_cast<uintptr_t>(table) % (g.vec * (table_dtype == FX_BF16 ? 2 : 4))) == 0,
+                 "fx_emb_fm_fwd: table_ld=%lld / table alignment does not allow %d-wide row loads",
+                 (long long)table_ld, g.vec);
     int ll = 0;
     while ((1 << ll) < g.lanes) ++ll;
     EmbFmArgs a{table, ids, ids_ld, col_row_base, col_vocab, col_out_off, dense, dense_ld, num_w,
                 num_out_off, out, out_ld, B, table1, num_w1, bias1, lr_out, fm_out, fm_lr_out, S,
-                scal, D, C, Fd, ll, table_dtype == FX_BF16 ? 1 : 0};
+                scal, D, C, Fd, ll, table_dtype == FX_BF16 ? 1 : 0, table_ld, table1_ld};
     int64_t blocks = fx_ceil_div(B, 4);
     if (blocks > 256 * 32) blocks = 256 * 32;
     dim3 grid((unsigned)blocks);
@@ -1392,6 +1401,146 @@ extern "C" int fx_adam_catchup_rows(const fx_row_state* tables_host, int32_t n_t
     int64_t blocks = fx_ceil_div(n_max, 256 >> gl);
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(k_catchup_rows, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fx_owner_fetch_rows: owner side of the row-sharded forward, ONE launch for every table group of the
+// exchange (round 2: a catch-up launch + a gather launch per group).  A lane group owns one unique
+// owned row of the de-dup of what the peers asked for: it brings the row up to date (exact mode: the
+// zero-gradient Adam replay of fx_adam_catchup_rows, `catchup` != 0) and writes the row into the send
+// block at EVERY position that asked for it (sorted_pos of its run: one entry per requesting rank), each
+// group in its own columns [off_t, off_t + D_t) of the [n_total, ld] block; pad columns and the
+// entries that asked for nothing (pad ids: the tail of the sorted array) are zeroed.  The rows are read
+// once — the round-2 sequence read them in the catch-up and again in the gather.
+// ---------------------------------------------------------------------------------------------
+struct OwnerFetchArgs {
+    FxTableDev t[FX_MAX_TABLES];
+    int32_t off[FX_MAX_TABLES];
+    const uint32_t* uniq_row;
+    const uint32_t* seg_start;
+    const uint32_t* sorted_pos;
+    const int32_t* n_unique;
+    float* send;
+    int64_t ld, n_total;
+    const fx_scalars* scal;
+    float* zero_row;             // zero_w floats cleared on the way (pad row of the block the rows land in)
+    int32_t n_tables, group_log2, upto_offset, catchup, used_w, zero_w;
+};
+
+template <int VEC>
+__device__ __forceinline__ void fx_owner_put(const OwnerFetchArgs& a, int ti, const FxRowRegs<VEC>& r,
+                                             int sub, uint32_t beg, uint32_t end) {
+    if (!r.on) return;
+    for (uint32_t i = beg; i < end; ++i)
+        fx_store<VEC>(a.send + (int64_t)a.sorted_pos[i] * a.ld + a.off[ti] + sub * VEC, r.p);
+}
+
+template <int VEC>
+__device__ __forceinline__ void fx_owner_one(const OwnerFetchArgs& a, int ti, int64_t row, int sub,
+                                             const fx_scalars& sc, int upto, double lb1, double lb2,
+                                             uint32_t beg, uint32_t end) {
+    FxRowRegs<VEC> r;
+    if (a.catchup) {
+        fx_row_load<VEC>(a.t[ti], row, sub, r);
+        fx_catchup_finish<VEC>(a.t[ti], row, sub, r, sc, upto, lb1, lb2);
+    } else {                                   // plain gather: only the row itself (no optimizer state)
+        const int lanes = 1 << a.t[ti].lanes_log2;
+        r.act = sub < lanes;
+        r.on = r.act && sub * VEC < a.t[ti].D;
+        if (r.on) fx_tab_load<VEC>(a.t[ti].table, 0, row * a.t[ti].D + sub * VEC, r.p);
+    }
+    fx_owner_put<VEC>(a, ti, r, sub, beg, end);
+}
+
+__global__ __launch_bounds__(256) void k_owner_fetch_rows(OwnerFetchArgs a) {
+    const int glanes = 1 << a.group_log2;
+    const int sub = threadIdx.x & (glanes - 1);
+    const int64_t rpb = 256 >> a.group_log2;
+    const int nu = *a.n_unique;
+    fx_scalars sc;
+    int upto = 0;
+    double lb1 = 0.0, lb2 = 0.0;
+    if (a.catchup) {
+        sc = *a.scal;
+        upto = sc.step + a.upto_offset;
+        lb1 = log2((double)sc.beta1);
+        lb2 = log2((double)sc.beta2);
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.zero_w; i += 256) a.zero_row[i] = 0.f;
+    const int64_t gid = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.group_log2);
+    const int64_t gstride = (int64_t)gridDim.x * rpb;
+    for (int64_t u = gid; u < nu; u += gstride) {
+        const int64_t row = a.uniq_row[u];
+        const uint32_t beg = a.seg_start[u], end = a.seg_start[u + 1];
+        if (a.catchup && a.n_tables == 2 && a.t[0].vec == 4 && a.t[1].vec == 1) {
+            // the D-float tables + the D=1 tables of LogisticRegression: all eight loads in flight
+            FxRowRegs<4> r0;
+            FxRowRegs<1> r1;
+            fx_row_load<4>(a.t[0], row, sub, r0);
+            fx_row_load<1>(a.t[1], row, sub, r1);
+            fx_catchup_finish<4>(a.t[0], row, sub, r0, sc, upto, lb1, lb2);
+            fx_catchup_finish<1>(a.t[1], row, sub, r1, sc, upto, lb1, lb2);
+            fx_owner_put<4>(a, 0, r0, sub, beg, end);
+            fx_owner_put<1>(a, 1, r1, sub, beg, end);
+        } else {
+            for (int ti = 0; ti < a.n_tables; ++ti) {
+                const int vec = a.t[ti].vec;
+                if (vec == 4) fx_owner_one<4>(a, ti, row, sub, sc, upto, lb1, lb2, beg, end);
+                else if (vec == 2) fx_owner_one<2>(a, ti, row, sub, sc, upto, lb1, lb2, beg, end);
+                else fx_owner_one<1>(a, ti, row, sub, sc, upto, lb1, lb2, beg, end);
+            }
+        }
+        if (sub == 0)                                          // pad columns of the block's rows
+            for (uint32_t i = beg; i < end; ++i)
+                for (int c = a.used_w; c < (int)a.ld; ++c)
+                    a.send[(int64_t)a.sorted_pos[i] * a.ld + c] = 0.f;
+    }
+    // entries that asked for nothing (pad ids sort to the tail): zero rows
+    const int64_t n_valid = a.seg_start[nu];
+    for (int64_t i = n_valid + (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_total;
+         i += (int64_t)gridDim.x * 256) {
+        float* dst = a.send + (int64_t)a.sorted_pos[i] * a.ld;
+        for (int c = 0; c < (int)a.ld; ++c) dst[c] = 0.f;
+    }
+}
+
+extern "C" int fx_owner_fetch_rows(const fx_row_state* tables_host, const int32_t* off_host,
+                                   int32_t n_tables, const uint32_t* uniq_row,
+                                   const uint32_t* seg_start, const uint32_t* sorted_pos,
+                                   const int32_t* n_unique, int64_t n_total, float* send, int64_t ld,
+                                   int32_t catchup, int32_t upto_offset, const fx_scalars* scal,
+                                   float* zero_row, int32_t zero_w, fx_stream_t stream) {
+    FX_CHECK_ARG(n_tables >= 1 && n_tables <= FX_MAX_TABLES,
+                 "fx_owner_fetch_rows: n_tables=%d not in [1,%d]", n_tables, FX_MAX_TABLES);
+    FX_CHECK_ARG(zero_w >= 0 && (zero_w == 0 || zero_row), "fx_owner_fetch_rows: zero_w without zero_row");
+    if (n_total <= 0) return FX_OK;
+    FX_CHECK_ARG(tables_host && off_host && uniq_row && seg_start && sorted_pos && n_unique && send,
+                 "fx_owner_fetch_rows: null pointer");
+    FX_CHECK_ARG(!catchup || scal, "fx_owner_fetch_rows: catch-up without scal");
+    OwnerFetchArgs a;
+    memset(&a, 0, sizeof(a));
+    int gl = 0;
+    const int st = fx_fill_tables(tables_host, n_tables, a.t, &gl, "fx_owner_fetch_rows", catchup != 0);
+    if (st != FX_OK) return st;
+    int used = 0;
+    for (int t = 0; t < n_tables; ++t) {
+        FX_CHECK_ARG(!a.t[t].bf16, "fx_owner_fetch_rows: bf16 tables are not supported here");
+        FX_CHECK_ARG(off_host[t] >= 0 && off_host[t] + a.t[t].D <= ld && off_host[t] % a.t[t].vec == 0 &&
+                         ld % a.t[t].vec == 0,
+                     "fx_owner_fetch_rows: table %d does not fit / align in the block", t);
+        a.off[t] = off_host[t];
+        if (off_host[t] + a.t[t].D > used) used = off_host[t] + a.t[t].D;
+    }
+    a.uniq_row = uniq_row; a.seg_start = seg_start; a.sorted_pos = sorted_pos; a.n_unique = n_unique;
+    a.send = send; a.ld = ld; a.n_total = n_total; a.scal = scal; a.n_tables = n_tables;
+    a.group_log2 = gl; a.upto_offset = upto_offset; a.catchup = catchup ? 1 : 0; a.used_w = used;
+    a.zero_row = zero_row; a.zero_w = zero_w;
+    int64_t blocks = fx_ceil_div(n_total, 256 >> gl);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_owner_fetch_rows, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), a);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

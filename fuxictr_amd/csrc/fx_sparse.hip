@@ -263,28 +263,37 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
 // — R-1 binary searches per element in ONE launch (the generic path's rocPRIM merge sort takes a
 // block sort + ~8 merge passes, ~55-75 us for 160 K keys; this is bound by L2 latency instead).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_merge_runs(const uint32_t* __restrict__ keys, int n_runs,
-                                                    int run_len, uint32_t* __restrict__ sorted_key,
+__device__ __forceinline__ uint32_t fx_run_key(const int32_t* __restrict__ ids, int64_t i,
+                                                int32_t vocab, int32_t pad) {
+    const int32_t id = ids[i];
+    return (id >= 0 && id < vocab && id != pad) ? (uint32_t)id : (uint32_t)vocab;
+}
+
+// (keys are formed on the fly from the ids — the sentinel `vocab` for pad / out-of-range entries: the
+// separate key-building launch of round 2 is gone)
+__global__ __launch_bounds__(256) void k_merge_runs(const int32_t* __restrict__ ids, int32_t vocab,
+                                                    int32_t pad, int n_runs, int run_len,
+                                                    uint32_t* __restrict__ sorted_key,
                                                     uint32_t* __restrict__ sorted_pos) {
     const int64_t n = (int64_t)n_runs * run_len;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / run_len);
-        const uint32_t k = keys[i];
+        const uint32_t k = fx_run_key(ids, i, vocab, pad);
         uint32_t rank = (uint32_t)(i - (int64_t)r * run_len);
         for (int q = 0; q < n_runs; ++q) {
             if (q == r) continue;
-            const uint32_t* run = keys + (int64_t)q * run_len;
+            const int64_t run0 = (int64_t)q * run_len;
             int lo = 0, hi = run_len;
             if (q < r) {                       // elements <= k come first (stable: earlier run wins)
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    if (run[mid] <= k) lo = mid + 1; else hi = mid;
+                    if (fx_run_key(ids, run0 + mid, vocab, pad) <= k) lo = mid + 1; else hi = mid;
                 }
             } else {                           // elements < k come first
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    if (run[mid] < k) lo = mid + 1; else hi = mid;
+                    if (fx_run_key(ids, run0 + mid, vocab, pad) < k) lo = mid + 1; else hi = mid;
                 }
             }
             rank += (uint32_t)lo;
@@ -329,12 +338,11 @@ extern "C" int fx_dedup_sorted_runs(const int32_t* ids, int32_t n_runs, int64_t 
     if (blocks > 4096) blocks = 4096;
     // keys: the id itself, sentinel for pad / out-of-range ids (each run stays ascending: its pad
     // entries sit at the tail and map to the largest key)
-    hipLaunchKernelGGL(k_keys_one_table, dim3((unsigned)blocks), dim3(256), 0, s, ids, n, vocab,
-                       pad, sentinel, keys_in);
-    hipLaunchKernelGGL(k_merge_runs, dim3((unsigned)blocks), dim3(256), 0, s, keys_in,
+    hipLaunchKernelGGL(k_merge_runs, dim3((unsigned)blocks), dim3(256), 0, s, ids, vocab, pad,
                        (int)n_runs, (int)run_len, sorted_key, sorted_pos);
     FX_CHECK_LAUNCH();
     (void)scan;
+    (void)keys_in;
     return fx_unique_from_sorted(sorted_key, n, sentinel, reinterpret_cast<uint32_t*>(temp), uniq_row,
                                  seg_start, n_unique, sorted_uid, s);
 }
@@ -676,7 +684,7 @@ __global__ __launch_bounds__(FX_PLAN_BLOCK) void k_shard_count(const uint32_t* u
 //                slot_uniq (slot -> u, the inverse map the gradient exchange fills its block by)
 //   pads         bucket tails: send_idx = the owner's pad row, slot_uniq = -1
 //   fills        lookup_slot with the pad slot (valid lookups are overwritten by launch 3)
-//   zeroes       `zero_row` (the pad row of the block the received rows land in), flags overflow
+//   flags        FX_FLAG_A2A_OVERFLOW when a bucket exceeds cap
 // Round 2 did this in five launches (scan, assign, pad tails, fill, ...) of ~4.6 us each.
 __global__ __launch_bounds__(FX_PLAN_BLOCK) void k_shard_route(const uint32_t* uniq_key,
                                                                const int32_t* n_unique, int N,
@@ -684,8 +692,7 @@ __global__ __launch_bounds__(FX_PLAN_BLOCK) void k_shard_route(const uint32_t* u
                                                                const int32_t* blk_cnt, int nblk,
                                                                int32_t pad_row, int32_t* uniq_slot,
                                                                int32_t* send_idx, int32_t* slot_uniq,
-                                                               int32_t* lookup_slot, float* zero_row,
-                                                               int zero_w, fx_scalars* scal) {
+                                                               int32_t* lookup_slot, fx_scalars* scal) {
     __shared__ int32_t wave_cnt[FX_PLAN_BLOCK / 64][FX_PLAN_MAX_SHARDS];
     __shared__ int32_t base_s[FX_PLAN_MAX_SHARDS], total_s[FX_PLAN_MAX_SHARDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -700,8 +707,6 @@ __global__ __launch_bounds__(FX_PLAN_BLOCK) void k_shard_route(const uint32_t* u
         total_s[threadIdx.x] = all;
         if (blockIdx.x == 0 && all > cap) atomicOr(&scal->err_flag, FX_FLAG_A2A_OVERFLOW);
     }
-    if (blockIdx.x == 0 && zero_row != nullptr)
-        for (int i = threadIdx.x; i < zero_w; i += FX_PLAN_BLOCK) zero_row[i] = 0.f;
     const int64_t u = (int64_t)blockIdx.x * FX_PLAN_BLOCK + threadIdx.x;
     const bool on = u < *n_unique;
     const uint32_t g = on ? uniq_key[u] : 0u;
@@ -769,13 +774,11 @@ extern "C" int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique,
                              int64_t n_lookups, int32_t n_shards, int64_t total_rows, int32_t cap,
                              int32_t* send_idx, int32_t* uniq_slot, int32_t* lookup_slot,
                              fx_scalars* scal, int32_t global_keys, int32_t* workspace,
-                             int32_t* slot_uniq, float* zero_row, int32_t zero_w,
-                             fx_stream_t stream) {
+                             int32_t* slot_uniq, fx_stream_t stream) {
     FX_CHECK_ARG(n_shards >= 1 && cap >= 1 && n_lookups >= 0, "fx_shard_plan: bad sizes");
     FX_CHECK_ARG(uniq_key && n_unique && sorted_pos && sorted_uid && send_idx && uniq_slot &&
                      lookup_slot && scal,
                  "fx_shard_plan: null pointer");
-    FX_CHECK_ARG(zero_w >= 0 && (zero_w == 0 || zero_row), "fx_shard_plan: zero_w without zero_row");
     const int64_t rps = fx_ceil_div(total_rows, n_shards);
     hipStream_t s = fx_hip_stream(stream);
     const int64_t total = (int64_t)n_shards * cap;
@@ -789,7 +792,7 @@ extern "C" int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique,
                            n_unique, (int)n_shards, blk_cnt);
         hipLaunchKernelGGL(k_shard_route, dim3((unsigned)nblk), dim3(FX_PLAN_BLOCK), 0, s, uniq_key,
                            n_unique, (int)n_shards, (int)cap, n_lookups, blk_cnt, nblk, (int32_t)rps,
-                           uniq_slot, send_idx, slot_uniq, lookup_slot, zero_row, (int)zero_w, scal);
+                           uniq_slot, send_idx, slot_uniq, lookup_slot, scal);
         if (n_lookups > 0) {
             int64_t b2 = fx_ceil_div(n_lookups, 256);
             if (b2 > 4096) b2 = 4096;
@@ -800,10 +803,6 @@ extern "C" int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique,
         return FX_OK;
     }
     FX_CHECK_ARG(slot_uniq == nullptr, "fx_shard_plan: slot_uniq needs global_keys = 1");
-    if (zero_w > 0) {
-        hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(256), 0, s, reinterpret_cast<int32_t*>(zero_row),
-                           (int64_t)zero_w, 0);
-    }
     int64_t b1 = fx_ceil_div(total, 256);
     if (b1 > 4096) b1 = 4096;
     hipLaunchKernelGGL(k_shard_send_idx, dim3((unsigned)b1), dim3(256), 0, s, uniq_key, n_unique,
@@ -863,6 +862,175 @@ extern "C" int fx_scatter_rows(const float* src, const int32_t* row_map, const i
     if (g.vec == 4) hipLaunchKernelGGL(k_scatter_rows<4>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst, dst_ld);
     else if (g.vec == 2) hipLaunchKernelGGL(k_scatter_rows<2>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst, dst_ld);
     else hipLaunchKernelGGL(k_scatter_rows<1>, grid, dim3(256), 0, s, src, row_map, n_rows, (int)D, ll, dst, dst_ld);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient exchange of the row-sharded path, one launch each side (round 2: a zero fill + one
+// scatter per table group before the all-to-all, three reduce launches per table group after it).
+//   fx_fill_grad_block    requester: block[e, off_t .. off_t + D_t) = G_t[slot_uniq[e]] for every slot e
+//                         of the [n_slots, ld] exchange block, zeros for empty slots / pad columns — the
+//                         block is written once, densely (no zero fill, no scatter)
+//   fx_owner_grad_reduce  owner: per unique owned row, the sum of the <= n_ranks received contributions
+//                         (ascending rank order) of every table group + the squared-norm partials of all
+//                         groups together (block b covers rows [b*256, (b+1)*256), fixed order)
+// ---------------------------------------------------------------------------------------------
+#define FX_GX_MAX_TABLES 4
+struct GradBlockArgs {
+    const float* G[FX_GX_MAX_TABLES];
+    int32_t D[FX_GX_MAX_TABLES], off[FX_GX_MAX_TABLES];
+    const int32_t* slot_uniq;
+    float* block;
+    int64_t ld, n_slots;
+    int32_t n_tables;
+};
+
+__global__ __launch_bounds__(256) void k_fill_grad_block(GradBlockArgs a) {
+    const int64_t n = a.n_slots * a.ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i / a.ld;
+        const int c = (int)(i - e * a.ld);
+        const int32_t u = a.slot_uniq[e];
+        float v = 0.f;
+        if (u >= 0) {
+#pragma unroll
+            for (int t = 0; t < FX_GX_MAX_TABLES; ++t) {
+                if (t < a.n_tables && a.G[t] != nullptr && c >= a.off[t] && c < a.off[t] + a.D[t])
+                    v = a.G[t][(int64_t)u * a.D[t] + (c - a.off[t])];
+            }
+        }
+        a.block[i] = v;
+    }
+}
+
+extern "C" int fx_fill_grad_block(const float* const* G_host, const int32_t* D_host,
+                                  const int32_t* off_host, int32_t n_tables,
+                                  const int32_t* slot_uniq, int64_t n_slots, float* block, int64_t ld,
+                                  fx_stream_t stream) {
+    FX_CHECK_ARG(n_tables >= 1 && n_tables <= FX_GX_MAX_TABLES, "fx_fill_grad_block: n_tables=%d not in [1,%d]",
+                 n_tables, FX_GX_MAX_TABLES);
+    FX_CHECK_ARG(n_slots >= 0 && ld >= 1, "fx_fill_grad_block: bad sizes");
+    if (n_slots == 0) return FX_OK;
+    FX_CHECK_ARG(G_host && D_host && off_host && slot_uniq && block, "fx_fill_grad_block: null pointer");
+    GradBlockArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int t = 0; t < n_tables; ++t) {
+        FX_CHECK_ARG(D_host[t] >= 1 && off_host[t] >= 0 && off_host[t] + D_host[t] <= ld,
+                     "fx_fill_grad_block: table %d does not fit the block", t);
+        a.G[t] = G_host[t];                 // NULL: this group has no gradient this step (zeros)
+        a.D[t] = D_host[t];
+        a.off[t] = off_host[t];
+    }
+    a.slot_uniq = slot_uniq; a.block = block; a.ld = ld; a.n_slots = n_slots; a.n_tables = n_tables;
+    int64_t blocks = fx_ceil_div(n_slots * ld, 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_fill_grad_block, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), a);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+#define FX_OGR_ROWS 32       // unique rows per workgroup (= per squared-norm partial)
+#define FX_OGR_PASSES 4      // rows a thread serves, their loads in flight together
+struct OwnerReduceArgs {
+    float* G[FX_GX_MAX_TABLES];
+    int32_t D[FX_GX_MAX_TABLES], off[FX_GX_MAX_TABLES];
+    const float* grecv;
+    int64_t ld;
+    const uint32_t* sorted_pos;
+    const uint32_t* seg_start;
+    const int32_t* n_unique;
+    float* sq_partials;
+    int32_t n_tables, width;     // width = floats of a row that carry gradients
+};
+
+// 32 lanes per unique row (lane c = column c of the row's gradient columns, all groups side by side;
+// rows wider than 32 floats take several column passes), 8 rows per pass of the workgroup, 4 passes
+// whose loads are issued together.  A row's run has at most n_ranks entries.
+__global__ __launch_bounds__(256) void k_owner_grad_reduce(OwnerReduceArgs a) {
+    __shared__ float red[4];
+    const int c_lane = threadIdx.x & 31, r_in = threadIdx.x >> 5;
+    const int nu = *a.n_unique;
+    float sq = 0.f;
+    uint32_t beg[FX_OGR_PASSES], len[FX_OGR_PASSES];
+    int64_t u[FX_OGR_PASSES];
+    uint32_t maxlen = 0;
+#pragma unroll
+    for (int p = 0; p < FX_OGR_PASSES; ++p) {
+        u[p] = (int64_t)blockIdx.x * FX_OGR_ROWS + p * 8 + r_in;
+        beg[p] = len[p] = 0;
+        if (u[p] < nu) {
+            beg[p] = a.seg_start[u[p]];
+            len[p] = a.seg_start[u[p] + 1] - beg[p];
+        }
+        maxlen = len[p] > maxlen ? len[p] : maxlen;
+    }
+    for (int c0 = 0; c0 < a.width; c0 += 32) {
+        const int c = c0 + c_lane;
+        int t = -1;
+#pragma unroll
+        for (int k = 0; k < FX_GX_MAX_TABLES; ++k)
+            if (k < a.n_tables && a.G[k] != nullptr && c >= a.off[k] && c < a.off[k] + a.D[k]) t = k;
+        float acc[FX_OGR_PASSES];
+#pragma unroll
+        for (int p = 0; p < FX_OGR_PASSES; ++p) acc[p] = 0.f;
+        if (t >= 0) {
+            for (uint32_t j = 0; j < maxlen; ++j) {            // ascending rank order: deterministic
+                float v[FX_OGR_PASSES];
+#pragma unroll
+                for (int p = 0; p < FX_OGR_PASSES; ++p) {
+                    v[p] = 0.f;
+                    if (j < len[p]) v[p] = a.grecv[(int64_t)a.sorted_pos[beg[p] + j] * a.ld + c];
+                }
+#pragma unroll
+                for (int p = 0; p < FX_OGR_PASSES; ++p) acc[p] += v[p];
+            }
+#pragma unroll
+            for (int p = 0; p < FX_OGR_PASSES; ++p)
+                if (u[p] < nu) a.G[t][u[p] * a.D[t] + (c - a.off[t])] = acc[p];
+        }
+#pragma unroll
+        for (int p = 0; p < FX_OGR_PASSES; ++p) sq = fmaf(acc[p], acc[p], sq);
+    }
+    const float tot = fx_block_sum_256(sq, red);
+    if (threadIdx.x == 0) a.sq_partials[blockIdx.x] = tot;
+}
+
+extern "C" int64_t fx_owner_grad_reduce_partials(int64_t n_max) {
+    return n_max <= 0 ? 1 : fx_ceil_div(n_max, FX_OGR_ROWS);
+}
+
+extern "C" int fx_owner_grad_reduce(const float* grecv, int64_t ld, const uint32_t* sorted_pos,
+                                    const uint32_t* seg_start, const int32_t* n_unique, int64_t n_max,
+                                    float* const* G_host, const int32_t* D_host,
+                                    const int32_t* off_host, int32_t n_tables, float* sq_partials,
+                                    fx_stream_t stream) {
+    FX_CHECK_ARG(n_tables >= 1 && n_tables <= FX_GX_MAX_TABLES,
+                 "fx_owner_grad_reduce: n_tables=%d not in [1,%d]", n_tables, FX_GX_MAX_TABLES);
+    FX_CHECK_ARG(sq_partials, "fx_owner_grad_reduce: null sq_partials");
+    if (n_max <= 0) {
+        hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(256), 0, fx_hip_stream(stream),
+                           reinterpret_cast<int32_t*>(sq_partials), (int64_t)1, 0);
+        FX_CHECK_LAUNCH();
+        return FX_OK;
+    }
+    FX_CHECK_ARG(grecv && sorted_pos && seg_start && n_unique && G_host && D_host && off_host,
+                 "fx_owner_grad_reduce: null pointer");
+    OwnerReduceArgs a;
+    memset(&a, 0, sizeof(a));
+    int width = 0;
+    for (int t = 0; t < n_tables; ++t) {
+        FX_CHECK_ARG(D_host[t] >= 1 && off_host[t] >= 0 && off_host[t] + D_host[t] <= ld,
+                     "fx_owner_grad_reduce: table %d does not fit the block", t);
+        a.G[t] = G_host[t];                 // NULL: no gradient for this group this step
+        a.D[t] = D_host[t];
+        a.off[t] = off_host[t];
+        if (off_host[t] + D_host[t] > width) width = off_host[t] + D_host[t];
+    }
+    a.grecv = grecv; a.ld = ld; a.sorted_pos = sorted_pos; a.seg_start = seg_start;
+    a.n_unique = n_unique; a.sq_partials = sq_partials; a.n_tables = n_tables; a.width = width;
+    const int64_t blocks = fx_ceil_div(n_max, FX_OGR_ROWS);
+    hipLaunchKernelGGL(k_owner_grad_reduce, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), a);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

@@ -77,6 +77,16 @@ class GraphSegments(object):
         self.items.append(self._cur)
         self._cur = None
 
+    def abort(self):
+        """End a capture that failed half way (best effort) and drop what was recorded."""
+        if self._cur is not None:
+            try:
+                self._cur.capture_end()
+            except Exception:   # noqa: BLE001 — the capture is already invalid
+                pass
+            self._cur = None
+        self.items = []
+
     def replay(self):
         if os.environ.get("FX_SEG_DEBUG"):
             for i, it in enumerate(self.items):
@@ -93,6 +103,7 @@ class GraphSegments(object):
 
 class DistContext(object):
     recorder = None      # a GraphSegments while a sharded step is being captured
+    graph_mode = None    # how the captured step launches its collectives (set by the capture)
 
     def __init__(self, group=None):
         if not dist.is_initialized():
@@ -102,18 +113,23 @@ class DistContext(object):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
-        # FX_GRAPH_COLLECTIVES=1 (opt-in, RCCL only): record the collectives INTO the step's hipGraph
-        # instead of cutting it into segments around them — one graph launch per step
+        # RCCL: the collectives are recorded INTO the step's hipGraph — one graph launch per step, no
+        # launch gaps around the four collectives (round 4 default; FX_GRAPH_COLLECTIVES=0 or a failed
+        # capture falls back to hipGraph segments with the collectives launched eagerly between them).
+        # A communicator must outlive no graph that recorded its kernels: see release_graphs().
         self.capture_collectives = (self.backend == "nccl"
-                                    and os.environ.get("FX_GRAPH_COLLECTIVES") == "1")
+                                    and os.environ.get("FX_GRAPH_COLLECTIVES", "1") != "0")
 
     def _stage(self, t):
         return self.backend == "gloo" and t.is_cuda
 
-    def all_to_all(self, send):
-        """send: [world * k, ...] -> recv of the same shape (chunk i goes to rank i)."""
+    def all_to_all(self, send, recv=None):
+        """send: [world * k, ...] -> recv of the same shape (chunk i goes to rank i); `recv`: a
+        contiguous buffer to receive into (e.g. the leading rows of a larger block)."""
         send = send.contiguous()
-        recv = torch.empty_like(send)
+        if recv is None:
+            recv = torch.empty_like(send)
+        assert recv.is_contiguous() and recv.shape == send.shape
         if self.recorder is not None and not self.capture_collectives:
             self.recorder.cut(lambda: self._a2a_into(recv, send))
         else:
@@ -175,6 +191,37 @@ class DistContext(object):
         if len(set(vals)) != 1:
             raise RuntimeError("row-sharded training needs the same %s on every rank, got %s "
                                "(per rank)" % (what, vals))
+
+    @staticmethod
+    def shutdown(models=(), timeout_s=30.0):
+        """Leave the process group cleanly after collectives were recorded into hipGraphs: RCCL's
+        communicator teardown waits until every graph that captured its kernels is destroyed
+        (ncclCommDestroy polls the graphs' references), so the captured steps go first — then
+        destroy_process_group().  A watchdog ends the process if the teardown still does not return
+        (the line a benchmark printed is already out)."""
+        import gc
+        import sys
+        import threading
+        for m in models:
+            if hasattr(m, "release_graphs"):
+                m.release_graphs()
+        from . import layers
+        layers._SHARD_PEERS.clear()
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if not dist.is_initialized():
+            return
+
+        def _bail():
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+        timer = threading.Timer(timeout_s, _bail)
+        timer.daemon = True
+        timer.start()
+        dist.destroy_process_group()
+        timer.cancel()
 
     def broadcast(self, t, src=0):
         if self._stage(t):

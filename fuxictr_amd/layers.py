@@ -144,7 +144,7 @@ class _Plan(object):
 
 class _ShardExchange(object):
     """Per-batch routing state of the row-sharded path (see _TableGroup.shard_exchange_ids)."""
-    gblock = None        # backward: the shared gradient block [N*cap + 1, width] (shard_send_grads)
+    grads = None         # backward: id(group) -> per-unique-key gradient waiting for the exchange
 
 
 # table groups that route with the same id plan (a model's D=16 tables and its D=1 LR tables):
@@ -541,14 +541,16 @@ class _TableGroup(object):
         sx.send_idx = torch.empty(N * cap, dtype=torch.int32, device=dev)
         sx.uniq_slot = torch.empty(n, dtype=torch.int32, device=dev)
         sx.lookup_slot = torch.empty(ids.shape[0], ids.shape[1], dtype=torch.int32, device=dev)
+        sx.slot_uniq = torch.empty(N * cap, dtype=torch.int32, device=dev)   # slot -> unique key (-1)
         wkey = ("plan_ws", n, N)
         pws = self._shard_consts.get(wkey)
         if pws is None:
             pws = self._shard_consts[wkey] = torch.empty(ops.shard_plan_workspace_ints(n, N),
                                                          dtype=torch.int32, device=dev)
         ops.shard_plan(dd, N, self.total_rows, cap, sx.send_idx, sx.uniq_slot, sx.lookup_slot,
-                       self.ensure_scal(), global_keys=True, workspace=pws)
+                       self.ensure_scal(), global_keys=True, workspace=pws, slot_uniq=sx.slot_uniq)
         sx.recv_idx = self.dist.all_to_all(sx.send_idx).view(N * cap, 1)
+        sx.grads = {}                                 # id(group) -> per-unique-key gradient (backward)
         if self.owner_ws is None or self.owner_ws[0] != N * cap:
             self.owner_ws = (N * cap, torch.empty(ops.dedup_workspace_bytes(N * cap),
                                                   dtype=torch.uint8, device=dev))
@@ -572,30 +574,29 @@ class _TableGroup(object):
         return sx
 
     def shard_fetch_rows(self, sx, track):
-        """Owner side: bring the requested rows up to date (exact mode), gather them, send them
-        back.  -> [N*cap + 1, D] rows in the slot order of sx.lookup_slot."""
+        """Owner side: bring the requested rows up to date (exact mode) and gather them — every table
+        group routed by this id plan in ONE launch, straight into its columns of one send block
+        ([N*cap, 16 + 1 (+3 pad)]) — then one all-to-all.  -> this group's columns of the received block
+        [N*cap + 1, width] (a strided view: the gather kernels read it in place; the last row is the
+        all-zero pad slot), in the slot order of sx.lookup_slot."""
         N, cap = self.n_shards, sx.cap
         got = sx.rows.pop(id(self), None)
         if got is not None:
             return got                                # fetched together with a peer group
         layout, width = self.shard_layout(sx)
-        # every group routed by this id plan gathers straight into its columns of ONE send block
-        # ([N*cap, 16 + 1 (+3 pad)]: no concatenation pass), one all-to-all, one launch that splits
-        # what arrived into the per-group row buffers the lookups read (+ their zero pad row)
         send = torch.empty(N * cap, width, dtype=torch.float32, device=self.device)
+        recv = torch.empty(N * cap + 1, width, dtype=torch.float32, device=self.device)
+        catchup = bool(track) and all(p.exact and p.opt_kind == "adam" for p, _ in layout)
+        if track and not catchup:
+            for p, _ in layout:                       # mixed optimizers: separate catch-up launches
+                if p.exact and p.opt_kind == "adam":
+                    ops.adam_catchup(p.table, p.m, p.v, p.last_step, p.D, sx.owner_dd,
+                                     p.rows_per_shard + 1, -1, p.scal)
+        ops.owner_fetch_rows([p.row_state() for p, _ in layout], [off for _, off in layout],
+                             sx.owner_dd, send, catchup, self.ensure_scal(), zero_row=recv[N * cap])
+        self.dist.all_to_all(send, recv=recv[:N * cap])
         for p, off in layout:
-            if track and p.exact and p.opt_kind == "adam":
-                ops.adam_catchup(p.table, p.m, p.v, p.last_step, p.D, sx.owner_dd,
-                                 p.rows_per_shard + 1, -1, p.scal)
-            ops.emb_gather_fwd(p.table, p.D, sx.recv_idx, sx.own_base, sx.own_vocab, sx.own_base,
-                               None, None, None, send[:, off:off + p.D], p.ensure_scal())
-        recv = self.dist.all_to_all(send)
-        parts = []
-        for p, off in layout:
-            rows = torch.empty(N * cap + 1, p.D, dtype=torch.float32, device=self.device)
-            parts.append((off, rows))
-            sx.rows[id(p)] = rows
-        ops.split_rows(recv, N * cap, parts, zero_tail_rows=1)     # the pad slot reads as a zero row
+            sx.rows[id(p)] = recv[:, off:off + p.D]
         return sx.rows.pop(id(self))
 
     def shard_layout(self, sx):
@@ -624,33 +625,16 @@ class _TableGroup(object):
         self.shard_send_grads(sx, G_loc)
 
     def shard_send_grads(self, sx, G_loc):
-        """Requester: per-unique-key gradients G_loc [n_max, D] into their bucket slots; the exchange
-        itself runs after autograd returns (finish_backward, called by the optimizer on the main
-        thread): collectives stay in one fixed program order on every rank."""
-        N, cap, D, dd = self.n_shards, sx.cap, self.D, sx.dd
-        layout, width = self.shard_layout(sx)
-        if sx.gblock is None:      # one zero-filled block for every group of this exchange
-            sx.gblock = torch.zeros(N * cap + 1, width, dtype=torch.float32, device=self.device)
-        off = next(o for p, o in layout if p is self)
-        ops.scatter_rows(G_loc, sx.uniq_slot, dd.n_unique, dd.n_max, D, sx.gblock[:, off:off + D])
-        self._await_exchange.append((sx, off))
+        """Requester: per-unique-key gradients G_loc [n_max, D] of this group; the exchange itself runs
+        after autograd returns (finish_shard_backward, called by the optimizer on the main thread):
+        collectives stay in one fixed program order on every rank."""
+        sx.grads[id(self)] = G_loc
+        self._await_exchange.append(sx)
 
     def finish_backward(self):
         """Owner side of the sharded backward: ship row gradients to their owners, reduce the
         contributions of all ranks per owned row."""
         finish_shard_backward([self])
-
-    def _finish_one(self, sx, grecv, ld):
-        """grecv: this group's columns of the received gradient block (row stride `ld`)."""
-        D = self.D
-        odd = sx.owner_dd
-        G_own = torch.empty(odd.n_max, D, dtype=torch.float32, device=self.device)
-        sq_own = torch.empty(ops.emb_grad_reduce_partials(odd.n_max, D), dtype=torch.float32,
-                             device=self.device)
-        ops.emb_grad_reduce(grecv, ld, sx.own_base, 1, D, odd, G_own, sq_own,
-                            self.reduce_scratch(odd.n_max))
-        self.pending.append(_PendingGrad(odd, G_own, sq_own))
-
 
     def flush(self):
         """exact mode: replay pending zero-gradient Adam steps for EVERY row (before eval/save)."""
@@ -664,20 +648,37 @@ class _TableGroup(object):
 
 
 def finish_shard_backward(groups):
-    """Row-gradient exchange of every table group that has one waiting: groups that were routed by
-    the same _ShardExchange scattered their rows side by side into ONE block ([N*cap, sum D]), which
-    goes out in one all-to-all; each owner then reduces its columns in place (row stride = width)."""
+    """Row-gradient exchange of every table group that has one waiting.  Groups that were routed by the
+    same _ShardExchange travel side by side in ONE block ([N*cap, sum D]): one launch writes it (every
+    slot: its unique key's gradient rows or zeros), one all-to-all ships it, one launch reduces what
+    arrived per owned row for all groups and emits the squared-norm partials of the clip."""
     by_sx = OrderedDict()
     for grp in groups:
         waiting, grp._await_exchange = grp._await_exchange, []
-        for sx, off in waiting:
-            by_sx.setdefault(id(sx), (sx, []))[1].append((grp, off))
-    for sx, items in by_sx.values():
-        n = items[0][0].n_shards * sx.cap
-        block, sx.gblock = sx.gblock, None
-        recv = items[0][0].dist.all_to_all(block[:n])
-        for grp, off in items:
-            grp._finish_one(sx, recv[:, off:off + grp.D], recv.shape[1])
+        for sx in waiting:
+            by_sx.setdefault(id(sx), (sx, []))[1].append(grp)
+    for sx, grps in by_sx.values():
+        first = grps[0]
+        layout, width = first.shard_layout(sx)
+        n = first.n_shards * sx.cap
+        dev = first.device
+        grads, sx.grads = sx.grads, {}
+        block = torch.empty(n, width, dtype=torch.float32, device=dev)
+        ops.fill_grad_block([(grads.get(id(p)), p.D, off) for p, off in layout], sx.slot_uniq, block)
+        recv = first.dist.all_to_all(block)
+        odd = sx.owner_dd
+        outs = []
+        for p, off in layout:
+            G_own = torch.empty(odd.n_max, p.D, dtype=torch.float32, device=dev) \
+                if id(p) in grads else None
+            outs.append((G_own, p.D, off))
+        sq = torch.empty(ops.owner_grad_reduce_partials(odd.n_max), dtype=torch.float32, device=dev)
+        ops.owner_grad_reduce(recv, odd, outs, sq)
+        for (p, _), (G_own, _, _) in zip(layout, outs):
+            if G_own is not None:
+                # (the partials cover every group of the block: they ride with the first one)
+                p.pending.append(_PendingGrad(odd, G_own, sq))
+                sq = None
 
 
 class _EmbGatherFn(torch.autograd.Function):
@@ -694,7 +695,9 @@ class _EmbGatherFn(torch.autograd.Function):
             # row-sharded: ids -> owners, rows <- owners, then the same kernels read the received
             # rows through the per-lookup slot matrix
             sx = group.shard_exchange_ids(plan, ids, inputs, track)
-            table = group.shard_fetch_rows(sx, track)
+            # (these kernels read packed [rows, D] tables: this group's columns of the received block
+            # are copied out; the fused front end — _EmbFMFn — reads the block in place)
+            table = group.shard_fetch_rows(sx, track).contiguous()
             src, base, vocab = sx.lookup_slot, sx.slot_base, sx.slot_vocab
         else:
             table, src, base, vocab = group.table, ids, plan.col_row_base, plan.col_vocab
@@ -1377,7 +1380,7 @@ class _LRFn(torch.autograd.Function):
         sx = None
         if group.sharded and plan.C:
             sx = group.shard_exchange_ids(plan, ids, inputs, track)
-            rows = group.shard_fetch_rows(sx, track)
+            rows = group.shard_fetch_rows(sx, track).contiguous()
             ops.lr_fwd(rows, sx.lookup_slot, sx.slot_base, sx.slot_vocab, dense, num_w1, bias,
                        out, group.ensure_scal())
         else:

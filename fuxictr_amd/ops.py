@@ -289,13 +289,46 @@ def shard_plan_workspace_ints(n_lookups, n_shards):
     return int(_lib.load().fx_shard_plan_workspace_ints(n_lookups, n_shards))
 
 
+@_timed("shard_plan", "other")
 def shard_plan(dd, n_shards, total_rows, cap, send_idx, uniq_slot, lookup_slot, scal,
-               global_keys=False, workspace=None):
+               global_keys=False, workspace=None, slot_uniq=None):
+    """slot_uniq [n_shards * cap] (out, optional): unique index held by every exchange slot, -1 = empty."""
     check(_lib.load().fx_shard_plan(ptr(dd.uniq_row), ptr(dd.n_unique), ptr(dd.sorted_pos),
                                     ptr(dd.sorted_uid), dd.n_max, n_shards, total_rows, cap,
                                     ptr(send_idx), ptr(uniq_slot), ptr(lookup_slot), ptr(scal),
-                                    1 if global_keys else 0, ptr(workspace),
+                                    1 if global_keys else 0, ptr(workspace), ptr(slot_uniq),
                                     stream_ptr(send_idx.device)), "fx_shard_plan")
+
+
+def _gx_arrays(tables):
+    """tables: [(tensor or None, D, column offset)] -> host arrays of the exchange-block entry points."""
+    n = len(tables)
+    ptrs = _lib.ptr_array([t for t, _, _ in tables])
+    return ptrs, (C.c_int32 * n)(*[int(d) for _, d, _ in tables]), \
+        (C.c_int32 * n)(*[int(o) for _, _, o in tables]), n
+
+
+@_timed("fill_grad_block", "other")
+def fill_grad_block(tables, slot_uniq, block):
+    """tables: [(G [n_max, D] or None, D, column offset)]; block [n_slots, ld] is written densely."""
+    ptrs, ds, offs, n = _gx_arrays(tables)
+    check(_lib.load().fx_fill_grad_block(ptrs, ds, offs, n, ptr(slot_uniq), block.shape[0], ptr(block),
+                                         block.stride(0), stream_ptr(block.device)),
+          "fx_fill_grad_block")
+
+
+def owner_grad_reduce_partials(n_max):
+    return int(_lib.load().fx_owner_grad_reduce_partials(n_max))
+
+
+@_timed("owner_grad_reduce", "other")
+def owner_grad_reduce(grecv, dd, tables, sq_partials):
+    """tables: [(G_out [n_max, D] or None, D, column offset)] of the received block grecv [n, ld]."""
+    ptrs, ds, offs, n = _gx_arrays(tables)
+    check(_lib.load().fx_owner_grad_reduce(ptr(grecv), grecv.stride(0), ptr(dd.sorted_pos),
+                                           ptr(dd.seg_start), ptr(dd.n_unique), dd.n_max, ptrs, ds,
+                                           offs, n, ptr(sq_partials), stream_ptr(grecv.device)),
+          "fx_owner_grad_reduce")
 
 
 @_timed("scatter_rows", "other")
@@ -967,7 +1000,9 @@ def _emb_fm_bytes(table, D, ids, col_row_base, col_vocab, col_out_off, dense, nu
 def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w, num_out_off, out,
                scal, table1=None, num_w1=None, bias1=None, lr_out=None, fm_out=None, fm_lr_out=None,
                S=None):
-    """Gather + numeric expansion (+ first-order term) (+ FM second-order term), one launch."""
+    """Gather + numeric expansion (+ first-order term) (+ FM second-order term), one launch.
+    table / table1 may be column ranges of a wider block (their row stride is passed on): the rows a
+    row-sharded exchange delivered are read in place."""
     lib = _lib.load()
     B = out.shape[0]
     C_ = 0 if ids is None else ids.shape[1]
@@ -978,6 +1013,8 @@ def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w
                             0 if dense is None else dense.stride(0), ptr(num_w), ptr(num_out_off),
                             Fd, ptr(out), out.stride(0), B, ptr(table1), ptr(num_w1), ptr(bias1),
                             ptr(lr_out), ptr(fm_out), ptr(fm_lr_out), ptr(S), ptr(scal),
+                            0 if table is None else table.stride(0),
+                            0 if table1 is None else table1.stride(0),
                             stream_ptr(out.device)), "fx_emb_fm_fwd")
     return out
 
@@ -1024,6 +1061,20 @@ def adam_catchup_rows(states, dd, upto_offset, scal):
         check(lib.fx_adam_catchup_rows(_row_states(part), len(part), ptr(dd.uniq_row),
                                        ptr(dd.n_unique), dd.n_max, upto_offset, ptr(scal),
                                        stream_ptr(scal.device)), "fx_adam_catchup_rows")
+
+
+@_timed("owner_fetch_rows", "sparse_path")
+def owner_fetch_rows(states, offs, dd, send, catchup, scal, upto_offset=-1, zero_row=None):
+    """Owner side of the row-sharded forward: (exact-mode catch-up +) gather of every table group in
+    `states` (RowState list) into its columns `offs` of the send block [n, ld]; one launch.
+    zero_row: a 1-D fp32 view cleared on the way (the pad row of the received-rows block)."""
+    arr = (C.c_int32 * len(offs))(*[int(o) for o in offs])
+    check(_lib.load().fx_owner_fetch_rows(_row_states(states), arr, len(states), ptr(dd.uniq_row),
+                                          ptr(dd.seg_start), ptr(dd.sorted_pos), ptr(dd.n_unique),
+                                          send.shape[0], ptr(send), send.stride(0),
+                                          1 if catchup else 0, upto_offset, ptr(scal), ptr(zero_row),
+                                          0 if zero_row is None else zero_row.numel(),
+                                          stream_ptr(send.device)), "fx_owner_fetch_rows")
 
 
 @_timed("sparse_update_multi", "sparse_path")

@@ -275,10 +275,11 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 if len(grp.pending) > 1:
                     raise NotImplementedError("several lookups of one table group per step")
             # ONE all-reduce per step: every dense gradient (losses were pre-scaled by 1/world)
-            # followed by one float — this rank's table part of the squared gradient norm (table
-            # rows are disjoint across ranks, so the SUM is the global table part)
-            tsq = torch.zeros(1, dtype=torch.float32, device=self.device)
-            tparts = [rec.sq for grp in self._groups for rec in grp.pending]
+            # followed by this rank's partial sums of the table part of the squared gradient norm (table
+            # rows are disjoint across ranks, so the element-wise SUM of the partial arrays still adds
+            # up to the global table part; no reduction launch before the collective)
+            tparts = [rec.sq.reshape(-1) for grp in self._groups for rec in grp.pending
+                      if rec.sq is not None]
             if self.dense_reg:
                 # |G + r|^2 over this rank's rows = sum r^2 + sum G^2 + sum 2 G.r (see fx_reg_*)
                 for grp in self._groups:
@@ -291,8 +292,6 @@ class _NativeOptimizer(torch.optim.Optimizer):
                     for rec in grp.pending:
                         ops.reg_cross(grp.table, grp.D, rec.dd, rec.G, self.scal, grp.reg_cross)
                         tparts.append(grp.reg_cross.clone())
-            if tparts:
-                ops.sum_parts(tparts, tsq)
             # every gradient starts on a 16-byte boundary of the flat buffer (a 1-element bias in the
             # middle would otherwise push everything after it onto the scalar path of the
             # multi-tensor norm / update kernels: 36 us instead of 19 us for k_mt_adam)
@@ -306,10 +305,11 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 if off % 4:
                     pieces.append(self._flat_pad[:4 - off % 4])
                     off += 4 - off % 4
-            flat = torch.cat(pieces + [tsq])
+            n_t = sum(t.numel() for t in tparts)
+            flat = torch.cat(pieces + tparts)
             self.dist.all_reduce_sum(flat)
             gs = [flat[o:o + g.numel()].view_as(g) for o, g in zip(offs, gs)]
-            tsq = flat[off:off + 1]
+            tsq = flat[off:off + n_t]
         parts = []
         if ps:
             need = len(ps) * _lib.FX_MT_BLOCKS
@@ -324,7 +324,8 @@ class _NativeOptimizer(torch.optim.Optimizer):
                     "sparse gradients per step is not implemented" % len(grp.pending))
             if tsq is None:
                 for rec in grp.pending:
-                    parts.append(rec.sq)
+                    if rec.sq is not None:
+                        parts.append(rec.sq)
             if self.dense_reg and grp.table is not None and tsq is None:
                 if not grp.reg_fresh:
                     ops.reg_stats(grp.table, self.scal, grp.reg_partials)
@@ -333,7 +334,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 for rec in grp.pending:
                     ops.reg_cross(grp.table, grp.D, rec.dd, rec.G, self.scal, grp.reg_cross)
                     parts.append(grp.reg_cross)
-        if tsq is not None:
+        if tsq is not None and tsq.numel():
             # global norm^2 = dense part (identical on every rank after the all-reduce) + the
             # all-reduced table part
             parts.append(tsq)

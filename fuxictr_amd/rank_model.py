@@ -239,22 +239,43 @@ class _GraphStep(object):
             import gc
             from .dist import GraphSegments
             nccl = model._dist.backend == "nccl"
-            self.graph = GraphSegments(comm_stream=torch.cuda.Stream(dev) if nccl else None,
-                                       settle_s=0.25 if nccl else 0.0)
-            gc.collect()
-            torch.cuda.empty_cache()
-            cur = torch.cuda.current_stream(dev)
-            model._graph_stream.wait_stream(cur)
-            with torch.cuda.stream(model._graph_stream):
-                model._dist.recorder = self.graph
-                try:
-                    self.graph.begin()
-                    self.loss = model._step_body(static)
-                    self.graph.finish()
-                finally:
-                    model._dist.recorder = None
-            cur.wait_stream(model._graph_stream)
-            torch.cuda.synchronize(dev)
+
+            def record():
+                self.graph = GraphSegments(comm_stream=torch.cuda.Stream(dev) if nccl else None,
+                                           settle_s=0.25 if nccl else 0.0)
+                gc.collect()
+                torch.cuda.empty_cache()
+                cur = torch.cuda.current_stream(dev)
+                model._graph_stream.wait_stream(cur)
+                with torch.cuda.stream(model._graph_stream):
+                    model._dist.recorder = self.graph
+                    try:
+                        self.graph.begin()
+                        self.loss = model._step_body(static)
+                        self.graph.finish()
+                    finally:
+                        model._dist.recorder = None
+                cur.wait_stream(model._graph_stream)
+                torch.cuda.synchronize(dev)
+            try:
+                record()
+            except Exception as exc:   # noqa: BLE001 — a stack that cannot record RCCL kernels
+                if not model._dist.capture_collectives:
+                    raise
+                logging.warning("recording the collectives into the step's hipGraph failed (%s: %s); "
+                                "hipGraph segments with eager collectives instead",
+                                type(exc).__name__, exc)
+                model._dist.capture_collectives = False
+                self.graph.abort()
+                model.optimizer._begun = False
+                model.optimizer._begin_pending = False
+                for grp in model.optimizer._groups:
+                    grp.pending, grp.num_grad, grp._await_exchange = [], None, []
+                torch.cuda.synchronize(dev)
+                record()
+            model._dist.graph_mode = ("one hipGraph per step with the RCCL collectives recorded in it"
+                                      if model._dist.capture_collectives else
+                                      "hipGraph segments with the collectives launched between them")
         # the capture only recorded the step; drop per-batch caches created while recording
         static.cache = {k: v for k, v in static.cache.items() if k in self._pack_keys}
 
@@ -665,6 +686,12 @@ class BaseModel(nn.Module):
         st.fill(batch_data)
         st.graph.replay()
         return st.loss
+
+    def release_graphs(self):
+        """Destroy the captured step (and with it every recorded RCCL kernel's hold on the
+        communicator); the next train_step captures again."""
+        self._graph_state = None
+        self._graph_warm = 0
 
     def prepare_batch(self, batch_data):
         """Optional: do the host side of a captured step's input cast for a device-resident batch

@@ -177,11 +177,34 @@ int fx_dedup_sorted_runs(const int32_t* ids, int32_t n_runs, int64_t run_len, in
  *   row order; needs `workspace` of fx_shard_plan_workspace_ints(n_lookups, n_shards) int32 words;
  *   positions whose id was padding / out of range get the pad slot. */
 int64_t fx_shard_plan_workspace_ints(int64_t n_lookups, int32_t n_shards);
+/*   slot_uniq (global_keys = 1 only; may be NULL): the inverse map, slot_uniq[o*cap + j] = u of the
+ *   unique key in that slot, -1 for empty slots — fx_fill_grad_block writes the gradient exchange block
+ *   by it.  Three launches (histograms; slots + bucket tails + fills; lookup slots). */
 int fx_shard_plan(const uint32_t* uniq_key, const int32_t* n_unique, const uint32_t* sorted_pos,
                   const uint32_t* sorted_uid, int64_t n_lookups, int32_t n_shards,
                   int64_t total_rows, int32_t cap, int32_t* send_idx, int32_t* uniq_slot,
                   int32_t* lookup_slot, fx_scalars* scal, int32_t global_keys, int32_t* workspace,
-                  fx_stream_t stream);
+                  int32_t* slot_uniq, fx_stream_t stream);
+/* Gradient exchange of the row-sharded backward, one launch each side.
+ * fx_fill_grad_block (requester): block[e, off_t .. off_t + D_t) = G_t[slot_uniq[e], :] for every slot
+ *   e < n_slots of the [n_slots, ld] exchange block, zeros for empty slots (slot_uniq < 0), for table
+ *   groups without a gradient this step (G_host[t] = NULL) and for pad columns: the block is written
+ *   once, densely.  G_host / D_host / off_host are HOST arrays (<= 4 table groups).
+ * fx_owner_grad_reduce (owner): for every unique owned row u of the owner-side de-dup (sorted_pos /
+ *   seg_start / n_unique of fx_dedup_sorted_runs over the received ids), G_t[u, :] = sum over the row's
+ *   run — one entry per requesting rank, ascending rank order — of grecv[sorted_pos[i], off_t + :], for
+ *   every table group in one launch, and sq_partials[b] = sum of G^2 of all groups over rows
+ *   [32 b, 32 b + 32) in a fixed order (fx_owner_grad_reduce_partials(n_max) entries; the table part of
+ *   clip_grad_norm_, rank_model.py:321).  Replaces aten::embedding_dense_backward's accumulation
+ *   across what would be one device in the reference (rank_model.py:320). */
+int fx_fill_grad_block(const float* const* G_host, const int32_t* D_host, const int32_t* off_host,
+                       int32_t n_tables, const int32_t* slot_uniq, int64_t n_slots, float* block,
+                       int64_t ld, fx_stream_t stream);
+int64_t fx_owner_grad_reduce_partials(int64_t n_max);
+int fx_owner_grad_reduce(const float* grecv, int64_t ld, const uint32_t* sorted_pos,
+                         const uint32_t* seg_start, const int32_t* n_unique, int64_t n_max,
+                         float* const* G_host, const int32_t* D_host, const int32_t* off_host,
+                         int32_t n_tables, float* sq_partials, fx_stream_t stream);
 int fx_scatter_rows(const float* src, const int32_t* row_map, const int32_t* n_rows, int64_t n_max,
                     int32_t D, float* dst, int64_t dst_ld, fx_stream_t stream);
 /* The received row block of an exchange, [n_rows, src_ld] with one column range (off, width) per
@@ -677,7 +700,25 @@ int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, const int32
                   int32_t C, const float* dense, int64_t dense_ld, const float* num_w,
                   const int64_t* num_out_off, int32_t Fd, float* out, int64_t out_ld, int64_t B,
                   const float* table1, const float* num_w1, const float* bias1, float* lr_out,
-                  float* fm_out, float* fm_lr_out, float* S, fx_scalars* scal, fx_stream_t stream);
+                  float* fm_out, float* fm_lr_out, float* S, fx_scalars* scal,
+                  int64_t table_ld /* row stride of `table` in elements; <= 0: D */,
+                  int64_t table1_ld /* row stride of `table1`; <= 0: 1 */, fx_stream_t stream);
+/* fx_owner_fetch_rows: owner side of the row-sharded forward for every table group of one exchange
+ *   (<= 4) in ONE launch.  For each unique owned row u of the owner-side de-dup (uniq_row / seg_start /
+ *   sorted_pos / n_unique of fx_dedup_sorted_runs over the n_total received ids): catchup != 0 replays
+ *   the row's missed zero-gradient Adam steps up to step + upto_offset exactly as fx_adam_catchup_rows
+ *   (tables need m, v, last_step), then the row is written into send[sorted_pos[i], off_t .. off_t + D_t)
+ *   for every entry i of its run (one per requesting rank); entries that asked for nothing (pad ids)
+ *   and the pad columns of the [n_total, ld] block are zeroed; zero_row / zero_w: a row of zero_w
+ *   floats cleared in the same launch (the pad row of the block the received rows will land in; NULL /
+ *   0 = none).  Replaces, on the owning rank, the
+ *   row reads of aten::embedding (feature_embedding.py:283-291) and dense Adam's step on untouched
+ *   rows (torch_utils.py:76).  fp32 tables only. */
+int fx_owner_fetch_rows(const fx_row_state* tables_host, const int32_t* off_host, int32_t n_tables,
+                        const uint32_t* uniq_row, const uint32_t* seg_start,
+                        const uint32_t* sorted_pos, const int32_t* n_unique, int64_t n_total,
+                        float* send, int64_t ld, int32_t catchup, int32_t upto_offset,
+                        const fx_scalars* scal, float* zero_row, int32_t zero_w, fx_stream_t stream);
 int64_t fx_emb_fm_bwd_partials(int64_t n_lookups, int32_t D);
 int64_t fx_emb_fm_bwd_workspace_floats(int64_t n_lookups, int32_t D, int32_t Fd);
 int fx_emb_fm_bwd(const float* drec, int64_t drec_ld, const float* rec, int64_t rec_ld,

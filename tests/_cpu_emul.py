@@ -111,12 +111,14 @@ def shard_plan_workspace_ints(n_lookups, n_shards):
 
 
 def shard_plan(dd, n_shards, total_rows, cap, send_idx, uniq_slot, lookup_slot, scal,
-               global_keys=False, workspace=None):
+               global_keys=False, workspace=None, slot_uniq=None):
     rps = -(-total_rows // n_shards)
     nu = int(dd.n_unique)
     keys = dd.uniq_row[:nu].long()
     send_idx.fill_(rps)
     uniq_slot.fill_(n_shards * cap)
+    if slot_uniq is not None:
+        slot_uniq.fill_(-1)
     for o in range(n_shards):
         if global_keys:      # keys are global rows: owner = g % N, local row = g // N
             sel = (keys % n_shards == o).nonzero().reshape(-1)
@@ -129,11 +131,59 @@ def shard_plan(dd, n_shards, total_rows, cap, send_idx, uniq_slot, lookup_slot, 
             sel, local = sel[:cap], local[:cap]
         send_idx[o * cap:o * cap + len(sel)] = local.int()
         uniq_slot[sel] = (o * cap + torch.arange(len(sel))).int()
+        if slot_uniq is not None:
+            slot_uniq[o * cap:o * cap + len(sel)] = sel.int()
     flat = lookup_slot.view(-1)
     uid = dd.sorted_uid.long()
     slots = torch.where(uid >= 0, uniq_slot[uid.clamp(min=0)].long(),
                         torch.full_like(uid, n_shards * cap))
     flat[dd.sorted_pos.long()] = slots.int()
+
+
+def fill_grad_block(tables, slot_uniq, block):
+    block.zero_()
+    on = (slot_uniq >= 0).nonzero().reshape(-1)
+    for G, D, off in tables:
+        if G is not None:
+            block[on, off:off + D] = G[slot_uniq[on].long()]
+
+
+def owner_grad_reduce_partials(n_max):
+    return max(1, -(-n_max // 32))
+
+
+def owner_grad_reduce(grecv, dd, tables, sq_partials):
+    nu = int(dd.n_unique)
+    sq_partials.zero_()
+    seg = dd.seg_start.long()
+    pos = dd.sorted_pos.long()
+    for G, D, off in tables:
+        if G is None:
+            continue
+        for u in range(nu):
+            acc = torch.zeros(D)
+            for i in range(int(seg[u]), int(seg[u + 1])):      # ascending rank order, like the kernel
+                acc = acc + grecv[pos[i], off:off + D]
+            G[u] = acc
+            sq_partials[u // 32] += float((acc * acc).sum())
+
+
+def owner_fetch_rows(states, offs, dd, send, catchup, scal, upto_offset=-1, zero_row=None):
+    if zero_row is not None:
+        zero_row.zero_()
+    send.zero_()
+    nu = int(dd.n_unique)
+    seg = dd.seg_start.long()
+    pos = dd.sorted_pos.long()
+    rows = dd.uniq_row[:nu].long()
+    # position -> unique row index of its run
+    owner = torch.repeat_interleave(torch.arange(nu), (seg[1:nu + 1] - seg[:nu]))
+    for st, off in zip(states, offs):
+        if catchup:
+            adam_catchup(st.table, st.m, st.v, st.last_step, st.D, dd, st.table.shape[0],
+                         upto_offset, scal)
+        if nu:
+            send[pos[:int(seg[nu])], off:off + st.D] = st.table[rows[owner]].float()
 
 
 def scatter_rows(src, row_map, n_rows, n_max, D, dst):
@@ -851,7 +901,8 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "dice_local_sums", "dice_fwd_from_sums", "dice_bwd_local_sums", "dice_bwd_from_sums",
          "din_attn_workspace_floats", "din_attn_stats", "dice_stats_from_sums", "din_attn_fwd",
          "din_attn_bwd_sums", "din_attn_bwd", "gemm_dw_dx", "split_rows", "gemm_problem", "gemm_batch",
-         "gemm_workspace_floats"]
+         "gemm_workspace_floats", "fill_grad_block", "owner_grad_reduce", "owner_grad_reduce_partials",
+         "owner_fetch_rows"]
 
 
 def install_plain():

@@ -14,6 +14,12 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
+
+def _shutdown(model):
+    """Captured steps go before the communicator (RCCL kernels recorded into a hipGraph keep it alive)."""
+    from fuxictr_amd.dist import DistContext
+    DistContext.shutdown([model])
+
 def run_c5(rank, world, port, out_path):
     """configs[4] in miniature: the c5 DLRM (bottom [512,256,16], dot, top [1024,1024,512,256],
     26 tables with the Criteo-skewed split) row-sharded over `world` ranks, each rank on its slice of
@@ -62,7 +68,7 @@ def run_c5(rank, world, port, out_path):
         np.savez(out_path, losses=np.asarray(losses), ref_losses=np.asarray(ref_losses),
                  pred=torch.cat(gp).numpy(), ref_pred=ref_p, wdiff=np.asarray([wdiff]))
     dist.barrier()
-    dist.destroy_process_group()
+    _shutdown(model)
 
 
 def run(rank, world, case, port, out_path, use_gpu):
@@ -152,7 +158,7 @@ def run(rank, world, case, port, out_path, use_gpu):
             np.savez(out_path, fit=torch.stack([t.cpu() for t in allv]).numpy(),
                      pred=torch.cat([t.cpu() for t in gp]).numpy())
         dist.barrier()
-        dist.destroy_process_group()
+        _shutdown(model)
         return
     model.eval()
     with torch.no_grad():
@@ -191,7 +197,7 @@ def run(rank, world, case, port, out_path, use_gpu):
                  losses=np.asarray(losses), pred0=torch.cat(gp0).numpy(),
                  pred1=torch.cat(gp1).numpy(), **{"state/" + k: v for k, v in full.items()})
     dist.barrier()
-    dist.destroy_process_group()
+    _shutdown(model)
 
 
 if __name__ == "__main__":

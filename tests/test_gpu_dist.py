@@ -77,14 +77,15 @@ def test_bench_launch_with_two_ranks_reports_two_gpus_and_the_one_rank_losses():
 
 
 def test_collectives_recorded_into_the_graph_run_and_exit_on_one_rccl_rank():
-    """FX_GRAPH_COLLECTIVES=1 (opt-in): the sharded step as ONE hipGraph with the RCCL collectives recorded
-    in it.  Round 2 hung at teardown (ProcessGroupNCCL's shutdown never returns once RCCL kernels were
-    captured); the bench now leaves after its final barrier.  One rank, real RCCL: the line comes out, the
-    process ends by itself, and the probe losses equal those of the segmented step (same kernels, same
-    order)."""
+    """Round-4 default on RCCL: the sharded step as ONE hipGraph with the collectives recorded in it
+    (FX_GRAPH_COLLECTIVES=0 = the hipGraph segments with eager collectives between them).  Rounds 2 / 3 hung at
+    teardown — RCCL's communicator waits for every graph that recorded its kernels — so the captured step
+    is released before destroy_process_group (DistContext.shutdown).  One rank, real RCCL: the line comes
+    out, the process ends by itself with exit code 0, the line says which form ran, and the probe losses
+    equal those of the segmented step (same kernels, same order)."""
     common = ["--vocab-scale", "0.01", "--steps", "3", "--warmup", "5", "--no-cpu-baseline",
               "--no-kernel-timing", "--no-dcnv2", "--probe-loss"]
     seg = _bench_line(common, env={"FX_SHARD_WORLD1": "1", "FX_GRAPH_COLLECTIVES": "0"})
-    rec = _bench_line(common, env={"FX_SHARD_WORLD1": "1", "FX_GRAPH_COLLECTIVES": "1"}, timeout=240)
+    rec = _bench_line(common, env={"FX_SHARD_WORLD1": "1"}, timeout=240)
     assert "recorded" in rec["config"]["parallelism"] and "segments" in seg["config"]["parallelism"]
     assert rec["probe_loss"] == seg["probe_loss"]
