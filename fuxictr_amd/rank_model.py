@@ -596,7 +596,9 @@ class BaseModel(nn.Module):
             self.optimizer.flush()
         return super().train(mode)
 
-    def _step_body(self, batch_data):
+    def _forward_backward(self, batch_data):
+        """zero_grad; forward; loss; backward (rank_model.py:308-320) -> loss.  Afterwards the dense
+        gradients sit in .grad, the table gradients (unique rows) in the table groups' `pending`."""
         opt = self.optimizer
         opt.zero_grad()                  # also opens the step: t += 1, Adam bias corrections
         act = self.output_activation
@@ -619,7 +621,11 @@ class BaseModel(nn.Module):
                 loss.backward(gradient=_scaled_grad(loss.device, self._dist.world))
         else:
             loss.backward(gradient=_unit_grad(loss.device))
-        opt.step()  # global-norm clip (rank_model.py:321) is fused into the update kernels
+        return loss
+
+    def _step_body(self, batch_data):
+        loss = self._forward_backward(batch_data)
+        self.optimizer.step()  # global-norm clip (rank_model.py:321) is fused into the update kernels
         return loss
 
     def load_full_state_dict(self, full_state):

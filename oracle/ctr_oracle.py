@@ -404,6 +404,43 @@ class OracleTrainer(object):
                     p.add_(g, alpha=-self.lr)               # torch.optim.SGD defaults
         return float(loss.detach()), total
 
+    def gradients(self, X, y, double=False):
+        """The gradients loss.backward() (rank_model.py:320) leaves in .grad for batch (X, y) at the
+        current weights, BEFORE clip_grad_norm_ — {state key: dense gradient} — evaluated in fp32
+        (double=False: what train_step uses) or with the forward / backward in float64 (the yardstick
+        of OracleTrainer64).  The weights are not touched."""
+        X, y = self._to_dev(X), y.to(self.device)
+        state = self.state
+        if double:
+            twin = {}
+            state = OrderedDict()
+            for k, t in self.state.items():
+                if id(t) not in twin:
+                    twin[id(t)] = (t.detach().double().requires_grad_(t.requires_grad)
+                                   if t.is_floating_point() else t.clone())
+                state[k] = twin[id(t)]
+            X = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v)
+                 for k, v in X.items()}
+            y = y.double()
+        else:
+            state = OrderedDict((k, (t.detach().clone().requires_grad_(True) if t.requires_grad else
+                                     t.clone())) for k, t in self.state.items())
+            # share_embedding aliases stay aliases
+            first = {}
+            for k, t in self.state.items():
+                if id(t) in first:
+                    state[k] = state[first[id(t)]]
+                else:
+                    first[id(t)] = k
+        prob = torch.sigmoid(model_logit(self.cfg, state, self.features, X, training=True))
+        loss = bce_mean(prob, y.to(prob.dtype).view(-1, 1))
+        loss.backward()
+        out = OrderedDict()
+        for k, t in state.items():
+            if torch.is_tensor(t) and t.requires_grad:
+                out[k] = (t.grad if t.grad is not None else torch.zeros_like(t)).detach().cpu()
+        return out
+
     def regularization_loss(self):
         """BaseModel.regularization_loss, rank_model.py:95-118."""
         reg_term = 0

@@ -132,6 +132,47 @@ def logits_of(model, batch):
     return p._fx_logit.reshape(-1).float().cpu().numpy(), p.reshape(-1).float().cpu().numpy()
 
 
+def native_gradients(model, batch):
+    """One forward / backward of the native model on `batch` WITHOUT the optimizer step ->
+    {state_dict key: dense fp32 gradient on the CPU}, the layout the reference's autograd leaves in
+    .grad (rank_model.py:320): dense-tower gradients as they are, the unique-row gradients of every
+    table group scattered into dense [V_f, D] arrays per feature, numeric weights [D, 1]."""
+    from fuxictr_amd.layers import FeatureEmbeddingDict
+    model.train()
+    model.optimizer.set_max_norm(0.0)
+    model._forward_backward(batch)
+    torch.cuda.synchronize()
+    out = {}
+    table_keys = set()
+    for prefix, mod in model.named_modules():
+        if not isinstance(mod, FeatureEmbeddingDict):
+            continue
+        pre = prefix + "." if prefix else ""
+        for grp in mod._groups.values():
+            dense = None
+            if grp.table is not None:
+                dense = torch.zeros(grp.total_rows, grp.D, dtype=torch.float32)
+                assert len(grp.pending) <= 1
+                for rec in grp.pending:
+                    nu = int(rec.dd.n_unique.item())
+                    rows = rec.dd.uniq_row[:nu].cpu().long()
+                    dense[rows] = rec.G[:nu].float().cpu()
+            for feature, (base, V, _) in grp.tables.items():
+                key = pre + "embedding_layers.%s.weight" % feature
+                table_keys.add(key)
+                out[key] = dense[base:base + V].clone()
+            for j, feature in enumerate(grp.numeric):
+                key = pre + "embedding_layers.%s.weight" % feature
+                table_keys.add(key)
+                g = grp.num_grad[j] if grp.num_grad is not None else torch.zeros(grp.D)
+                out[key] = g.detach().float().cpu().reshape(grp.D, 1).clone()
+    for name, p in model.named_parameters():
+        if name in table_keys or name in out:
+            continue
+        out[name] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().float().cpu().clone()
+    return out
+
+
 def run_parity(case, dist, model, features, cfg, spec, cards, oracle_mod, B=4096, steps=10,
                holdout=65536, logit_tol=1e-4, loss_tol=1e-4, metric_tol=5e-5, slack=3.0,
                gpu_yardstick=None):
