@@ -609,6 +609,158 @@ __global__ __launch_bounds__(256) void k_emb_fm_fwd(EmbFmArgs a) {
     }
 }
 
+// Round 4: the same work with every load of a sample in flight at once.  The first version walked
+// id -> col_vocab -> col_row_base -> row -> store three times in sequence per lane group and started the
+// 26 scattered 4-byte loads of the first-order term only after the record loop: 3 - 4 dependent HBM
+// round trips per sample, 10.8 us at B = 4096 (0.18 of the HBM roofline).  Here
+//   * the per-column constants (vocabulary, row base, record offset, the numeric weight rows) of the
+//     NI items a lane group serves are loaded ONCE per wave, outside the sample loop;
+//   * lane l loads id l / numeric l of the sample — one coalesced 104-byte + 52-byte request per
+//     sample — and the lane groups fetch "their" ids by shuffle;
+//   * all NI row loads of the record AND the lane's D = 1 row of the first-order term are issued
+//     before the first use, the stores follow;
+//   * SPW samples per wave and iteration (2 at large B) double the rows in flight.
+// Shapes: C <= 64 id columns, Fd <= 64 numerics, C + Fd <= NI * (64 / lanes), NI <= 4 — every schema
+// of the BASELINE configs; anything else keeps k_emb_fm_fwd.  Same sums in the same order: bit-identical
+// outputs (tests/test_gpu_fused.py::test_emb_fm_fwd_equals_the_three_unfused_kernels and the strided /
+// two-sample tests).
+template <int VEC, int NI, int SPW>
+__global__ __launch_bounds__(256) void k_emb_fm_fwd2(EmbFmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int lanes = 1 << a.lanes_log2;
+    const int sub = lane & (lanes - 1);
+    const int grp = lane >> a.lanes_log2;
+    const int ngrp = 64 >> a.lanes_log2;
+    const int d0 = sub * VEC;
+    const bool lane_on = d0 < a.D;
+    const int R = a.C + a.Fd;
+    const bool want_fm = a.fm_out != nullptr || a.fm_lr_out != nullptr || a.S != nullptr;
+    const bool want_lr = a.lr_out != nullptr || a.fm_lr_out != nullptr;
+    // ---- per-wave constants of this lane group's items
+    int kind[NI];                 // 0: none, 1: id column, 2: numeric column
+    int32_t vocab[NI];
+    int64_t base[NI], off[NI];
+    float wnum[NI][VEC];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int r = grp + j * ngrp;
+        kind[j] = r < a.C ? 1 : (r < R ? 2 : 0);
+        vocab[j] = 0;
+        base[j] = off[j] = 0;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) wnum[j][k] = 0.f;
+        if (kind[j] == 1) {
+            vocab[j] = a.col_vocab[r];
+            base[j] = a.col_row_base[r];
+            off[j] = a.col_out_off[r];
+        } else if (kind[j] == 2) {
+            off[j] = a.num_out_off[r - a.C];
+            if (lane_on) fx_load<VEC>(a.num_w + (int64_t)(r - a.C) * a.D + d0, wnum[j]);
+        }
+    }
+    // ... and of the lane's own column (ids of the sample, first-order term)
+    const bool has_id = lane < a.C, has_x = lane < a.Fd;
+    int32_t my_vocab = 0;
+    int64_t my_base = 0;
+    float my_w1 = 0.f;
+    if (has_id) {
+        my_vocab = a.col_vocab[lane];
+        my_base = a.col_row_base[lane];
+    }
+    if (want_lr && has_x) my_w1 = a.num_w1[lane];
+    const float bias1 = (want_lr && a.bias1) ? a.bias1[0] : 0.f;
+    const int64_t wstride = (int64_t)gridDim.x * 4 * SPW;
+    for (int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SPW; b0 < a.B; b0 += wstride) {
+        int32_t idl[SPW];
+        float xl[SPW];
+        bool live[SPW];
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const int64_t b = b0 + s;
+            live[s] = b < a.B;                                            // wave-uniform
+            idl[s] = -1;
+            xl[s] = 0.f;
+            if (live[s] && has_id) idl[s] = a.ids[b * a.ids_ld + lane];
+            if (live[s] && has_x) xl[s] = a.dense[b * a.dense_ld + lane];
+        }
+        // ---- all row loads of the sample(s)
+        float val[SPW][NI][VEC];
+        float t1[SPW];
+        bool bad = false;
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const bool ok_l = has_id && idl[s] >= 0 && idl[s] < my_vocab;
+            t1[s] = 0.f;
+            if (live[s] && has_id && !ok_l) bad = true;
+            if (want_lr && live[s] && ok_l) t1[s] = a.table1[(my_base + idl[s]) * a.table1_ld];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int r = grp + j * ngrp;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) val[s][j][k] = 0.f;
+                // (the shuffles are executed by every lane: the source lane index is r or r - C)
+                const int32_t id = __shfl(idl[s], r < a.C ? r : 0, 64);
+                const float x = __shfl(xl[s], r >= a.C && r < R ? r - a.C : 0, 64);
+                if (!live[s]) continue;
+                if (kind[j] == 1) {
+                    if (id >= 0 && id < vocab[j] && lane_on)
+                        fx_tab_load<VEC>(a.table, a.bf16, (base[j] + id) * a.table_ld + d0, val[s][j]);
+                } else if (kind[j] == 2) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) val[s][j][k] = x * wnum[j][k];
+                }
+            }
+        }
+        if (bad) atomicOr(&a.scal->err_flag, FX_FLAG_BAD_ID);
+        // ---- record stores, field sums, first-order term
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            if (!live[s]) continue;
+            const int64_t b = b0 + s;
+            float sm[VEC], q = 0.f;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) sm[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                if (kind[j] != 0 && lane_on) {
+                    fx_store<VEC>(a.out + b * a.out_ld + off[j] + d0, val[s][j]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        sm[k] += val[s][j][k];
+                        q = fmaf(val[s][j][k], val[s][j][k], q);
+                    }
+                }
+            }
+            float lr = 0.f;
+            if (want_lr) {
+                // (the first version summed ids, then numerics, per lane: lane l holds column l of both)
+                lr = t1[s];
+                if (has_x) lr = fmaf(xl[s], my_w1, lr);
+                lr = fx_wave_sum(lr) + bias1;
+            }
+            float fm = 0.f;
+            if (want_fm) {
+                for (int o = lanes; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) sm[k] += __shfl_xor(sm[k], o, 64);
+                }
+                float t = -q;
+                if (grp == 0 && lane_on) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) t = fmaf(sm[k], sm[k], t);
+                }
+                fm = 0.5f * fx_wave_sum(t);
+                if (a.S && grp == 0 && lane_on) fx_store<VEC>(a.S + b * a.D + d0, sm);
+            }
+            if (lane == 0) {
+                if (a.lr_out) a.lr_out[b] = lr;
+                if (a.fm_out) a.fm_out[b] = fm;
+                if (a.fm_lr_out) a.fm_lr_out[b] = fm + lr;
+            }
+        }
+    }
+}
+
 extern "C" int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, const int32_t* ids,
                              int64_t ids_ld,
                              const int64_t* col_row_base, const int32_t* col_vocab,
@@ -646,10 +798,40 @@ extern "C" int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, 
     EmbFmArgs a{table, ids, ids_ld, col_row_base, col_vocab, col_out_off, dense, dense_ld, num_w,
                 num_out_off, out, out_ld, B, table1, num_w1, bias1, lr_out, fm_out, fm_lr_out, S,
                 scal, D, C, Fd, ll, table_dtype == FX_BF16 ? 1 : 0, table_ld, table1_ld};
+    hipStream_t s = fx_hip_stream(stream);
+    // A/B switch, read per call so that a test can compare the two forms in one process:
+    // FX_EMB_FWD2=0 = the first version for every shape
+    const char* e2 = getenv("FX_EMB_FWD2");
+    const bool v2 = !(e2 && atoi(e2) == 0);
+    const int ngrp = 64 / g.lanes;
+    const int ni = (int)fx_ceil_div(C + Fd, ngrp);
+    if (v2 && C <= 64 && Fd <= 64 && ni <= 4) {
+        // two samples per wave once the batch alone fills the chip twice over (8192 resident waves)
+        const int spw = B >= 16384 ? 2 : 1;
+        int64_t blocks = fx_ceil_div(B, 4 * spw);
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        dim3 grid((unsigned)blocks);
+#define FX_FWD2(V, N)                                                                              \
+        do {                                                                                       \
+            if (spw == 2) hipLaunchKernelGGL((k_emb_fm_fwd2<V, N, 2>), grid, dim3(256), 0, s, a);  \
+            else hipLaunchKernelGGL((k_emb_fm_fwd2<V, N, 1>), grid, dim3(256), 0, s, a);           \
+        } while (0)
+#define FX_FWD2_NI(V)                                                                              \
+        do {                                                                                       \
+            if (ni <= 1) FX_FWD2(V, 1); else if (ni == 2) FX_FWD2(V, 2);                           \
+            else if (ni == 3) FX_FWD2(V, 3); else FX_FWD2(V, 4);                                   \
+        } while (0)
+        if (g.vec == 4) FX_FWD2_NI(4);
+        else if (g.vec == 2) FX_FWD2_NI(2);
+        else FX_FWD2_NI(1);
+#undef FX_FWD2_NI
+#undef FX_FWD2
+        FX_CHECK_LAUNCH();
+        return FX_OK;
+    }
     int64_t blocks = fx_ceil_div(B, 4);
     if (blocks > 256 * 32) blocks = 256 * 32;
     dim3 grid((unsigned)blocks);
-    hipStream_t s = fx_hip_stream(stream);
     if (g.vec == 4) hipLaunchKernelGGL(k_emb_fm_fwd<4>, grid, dim3(256), 0, s, a);
     else if (g.vec == 2) hipLaunchKernelGGL(k_emb_fm_fwd<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_emb_fm_fwd<1>, grid, dim3(256), 0, s, a);

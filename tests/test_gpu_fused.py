@@ -154,6 +154,60 @@ def test_emb_fm_fwd_equals_the_three_unfused_kernels(D, with_lr, with_fm):
     assert int(scal.view(torch.int32)[_lib.SC_ERR]) == 0
 
 
+@pytest.mark.parametrize("C,Fd,D,B", [(26, 13, 16, 4096), (26, 13, 16, 32769), (64, 0, 16, 2049),
+                                      (5, 3, 8, 1000), (5, 3, 10, 513), (7, 2, 1, 300), (6, 2, 40, 257),
+                                      (0, 9, 16, 100), (70, 3, 16, 500), (26, 13, 16, 1)])
+@pytest.mark.parametrize("with_lr,with_fm", [(True, True), (False, False)])
+def test_emb_fm_fwd_round4_kernel_is_bit_identical_to_the_first_version(C, Fd, D, B, with_lr, with_fm):
+    """k_emb_fm_fwd2 (per-wave constants, ids by shuffle, every row load of a sample in flight, two
+    samples per wave at large B) == k_emb_fm_fwd (FX_EMB_FWD2=0), every output bit for bit: the record,
+    the first-order term, the FM term, their sum, the field sums; bad / padding ids included; shapes
+    outside the new kernel's range (C > 64) take the first version either way."""
+    import os
+    rng = np.random.default_rng(C * 1000 + D + B)
+    g = torch.Generator().manual_seed(C + D + B)
+    vocabs = [int(v) for v in rng.integers(3, 5000, C)]
+    bases, R = _schema(vocabs) if C else (np.zeros(0, np.int64), 1)
+    table, num_w = torch.randn(max(R, 1), D, generator=g), torch.randn(max(Fd, 1), D, generator=g)
+    table1, num_w1 = torch.randn(max(R, 1), 1, generator=g), torch.randn(max(Fd, 1), 1, generator=g)
+    bias1 = torch.randn(1, generator=g)
+    ids = _ids(rng, B, vocabs, "power") if C else None
+    if C and B > 10:
+        ids[3, 0] = vocabs[0] + 7                                # a bad id: zeros + the error flag
+        ids[5, C - 1] = -1
+    dense = torch.rand(B, max(Fd, 1), generator=g)[:, :Fd].contiguous() if Fd else None
+    perm = rng.permutation(C + Fd)
+    slots_c, slots_n = perm[:C], perm[C:]
+    F = C + Fd
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["FX_EMB_FWD2"] = flag
+        scal = ops.new_scalars(DEV)
+        rec = torch.full((B, F * D), 5.0, device=DEV)
+        lr = torch.empty(B, 1, device=DEV) if with_lr else None
+        fm = torch.empty(B, 1, device=DEV) if with_fm else None
+        fml = torch.empty(B, 1, device=DEV) if (with_lr and with_fm) else None
+        S = torch.empty(B, D, device=DEV) if with_fm else None
+        ops.emb_fm_fwd(_dev(table) if C else None, D, _dev(ids, torch.int32) if C else None,
+                       _dev(bases, torch.int64) if C else None, _dev(vocabs, torch.int32) if C else None,
+                       _dev([s * D for s in slots_c], torch.int64) if C else None,
+                       _dev(dense) if Fd else None, _dev(num_w[:Fd]) if Fd else None,
+                       _dev([s * D for s in slots_n], torch.int64) if Fd else None, rec, scal,
+                       table1=_dev(table1) if (with_lr and C) else None,
+                       num_w1=_dev(num_w1[:Fd]) if (with_lr and Fd) else None,
+                       bias1=_dev(bias1) if with_lr else None, lr_out=lr, fm_out=fm, fm_lr_out=fml, S=S)
+        torch.cuda.synchronize()
+        outs.append([rec, lr, fm, fml, S, int(scal.view(torch.int32)[_lib.SC_ERR])])
+    os.environ.pop("FX_EMB_FWD2")
+    for x, y in zip(outs[0][:5], outs[1][:5]):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert torch.equal(x, y)
+    assert outs[0][5] == outs[1][5]
+    if C and B > 10:
+        assert outs[1][5] & _lib.FX_FLAG_BAD_ID
+
+
 def _bwd_reference(drec, rec, S, g_fm, g_lr, ids, bases, pads, vocabs, slots_c, slots_n, dense, D):
     """float64 restatement: the dense [R, D] gradient autograd would build, then the unique rows."""
     B, C = ids.shape
