@@ -68,6 +68,11 @@ def parse():
                          "number of ranks (tests/test_gpu_dist.py)")
     ap.add_argument("--probe-world", type=int, default=0,
                     help="with --probe-loss on fewer ranks: the world size whose global batch to probe")
+    ap.add_argument("--zoo", default="native", choices=["native", "reference"],
+                    help="reference: time the reference's OWN unmodified model_zoo classes behind "
+                         "fuxictr_amd.patch.install() (needs a reference checkout: FX_REFERENCE_ROOT, "
+                         "default <repo>/.ref_checkout or /root/reference) - the true drop-in; native: "
+                         "fuxictr_amd.zoo's mirrors of the same classes (what travels to the GPU box)")
     ap.add_argument("--no-step-events", action="store_true",
                     help="skip the second pass that records one HIP event per step (step_us)")
     ap.add_argument("--no-graph", action="store_true",
@@ -75,8 +80,35 @@ def parse():
     return ap.parse_args()
 
 
+def _reference_zoo():
+    """The reference's own model_zoo classes on the native layers."""
+    import types
+    root = os.environ.get("FX_REFERENCE_ROOT")
+    if not root:
+        for cand in (os.path.join(ROOT, ".ref_checkout"), "/root/reference"):
+            if os.path.isdir(os.path.join(cand, "fuxictr")):
+                root = cand
+                break
+    if not root or not os.path.isdir(os.path.join(root, "fuxictr")):
+        sys.exit("bench.py --zoo reference: no reference checkout (set FX_REFERENCE_ROOT)")
+    for name in ["polars", "h5py", "keras_preprocessing", "keras_preprocessing.sequence"]:
+        sys.modules.setdefault(name, types.ModuleType(name))     # import-time only (SURVEY.md 8c)
+    sys.modules["keras_preprocessing.sequence"].pad_sequences = lambda *a, **k: None
+    sys.dont_write_bytecode = True
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from fuxictr_amd import patch
+    patch.install()
+    import model_zoo
+    from model_zoo.DeepFM.DeepFM_torch.src import DeepFM as RefDeepFM
+    return types.SimpleNamespace(DeepFM=RefDeepFM, DCNv2=model_zoo.DCNv2, DIN=model_zoo.DIN,
+                                 DLRM=model_zoo.DLRM, xDeepFM=model_zoo.xDeepFM)
+
+
 def build_model(args, device_index, cards, shard=None):
     from fuxictr_amd import synthetic, zoo
+    if args.zoo == "reference":
+        zoo = _reference_zoo()
     if args.model == "DIN":
         fmap, spec = synthetic.taobao_feature_map(embedding_dim=16, scale=args.vocab_scale)
     else:
@@ -776,6 +808,9 @@ def main():
                                                       "configuration)" if args.emb_dtype != "fp32"
                                                       else ""),
                        "launch": m["launch"],
+                       "model_classes": ("the reference's own model_zoo classes behind "
+                                         "fuxictr_amd.patch.install()" if args.zoo == "reference" else
+                                         "fuxictr_amd.zoo (mirrors of the reference's model_zoo classes)"),
                        "distinct_batches": m["n_pool"],
                        "inputs": ("host tensors per step (DataLoader-style; one pinned staging "
                                   "copy per dtype) - PCIe-inclusive, NOT the headline number")

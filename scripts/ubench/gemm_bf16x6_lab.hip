@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ x, int
 #define PLANE_B (128 * ROWB)     // one plane of one operand tile
 #define OPER_B (3 * PLANE_B)
 
-template <int NTERMS>
+template <int NTERMS, bool EARLY>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(const uint16_t* __restrict__ A3,
                                                        const uint16_t* __restrict__ B3,
                                                        float* __restrict__ C, int M, int N, int K,
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(const uint16_t* __restric
             ra[i] = *reinterpret_cast<const u32x4*>(A3 + pl * planeA + (m0 + row) * K + kn * BK + c * 8);
             rb[i] = *reinterpret_cast<const u32x4*>(B3 + pl * planeB + (n0 + row) * K + kn * BK + c * 8);
         }
+        if (EARLY) __builtin_amdgcn_sched_barrier(0);      // keep the prefetch in front of the MFMAs
 #pragma unroll
         for (int s = 0; s < 2; ++s) {          // two k16 steps per tile
             bf16x8 fa[3][2], fb[3][2];
@@ -187,15 +188,15 @@ __global__ void k_fill(float* p, int64_t n, uint32_t seed, float scale) {
     }
 }
 
-template <int NT>
+template <int NT, bool EARLY>
 static float run(const uint16_t* A3, const uint16_t* B3, float* C, int M, int N, int K, int reps) {
     dim3 grid((M / BM) * (N / BN));
-    hipLaunchKernelGGL((k_gemm_bf16x<NT>), grid, dim3(256), 0, 0, A3, B3, C, M, N, K, (int64_t)N);
+    hipLaunchKernelGGL((k_gemm_bf16x<NT, EARLY>), grid, dim3(256), 0, 0, A3, B3, C, M, N, K, (int64_t)N);
     HC(hipDeviceSynchronize());
     hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
     HC(hipEventRecord(e0, 0));
     for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL((k_gemm_bf16x<NT>), grid, dim3(256), 0, 0, A3, B3, C, M, N, K, (int64_t)N);
+        hipLaunchKernelGGL((k_gemm_bf16x<NT, EARLY>), grid, dim3(256), 0, 0, A3, B3, C, M, N, K, (int64_t)N);
     HC(hipEventRecord(e1, 0));
     HC(hipDeviceSynchronize());
     float ms; HC(hipEventElapsedTime(&ms, e0, e1));
@@ -221,7 +222,7 @@ static void bench(int M, int N, int K, const char* what) {
     HC(hipDeviceSynchronize());
     float ms_split; HC(hipEventElapsedTime(&ms_split, e0, e1));
     const double flop = 2.0 * M * N * K;
-    const float t6 = run<6>(A3, B3, C, M, N, K, 20);
+    const float t6 = run<6, true>(A3, B3, C, M, N, K, 20);
     // accuracy of the 6-term result on every 37th row
     const int step = 37;
     const int64_t rows = (M + step - 1) / step;
@@ -243,10 +244,11 @@ static void bench(int M, int N, int K, const char* what) {
             if (fabs(d32) > m32) m32 = fabs(d32);
             if (fabs(ref) > mx) mx = fabs(ref);
         }
-    const float t3 = run<3>(A3, B3, C, M, N, K, 20);
-    const float t1 = run<1>(A3, B3, C, M, N, K, 20);
-    printf("%-34s %4dx%4dx%4d  x6 %7.2f us %6.1f TF-eq  | x3 %7.2f us | x1 (plain bf16) %7.2f us %6.1f TF | split A %6.2f us\n",
-           what, M, N, K, t6, flop / t6 * 1e-6, t3, t1, flop / t1 * 1e-6, 1e3f * ms_split / 10);
+    const float t3 = run<3, true>(A3, B3, C, M, N, K, 20);
+    const float t6l = run<6, false>(A3, B3, C, M, N, K, 20);
+    const float t1 = run<1, true>(A3, B3, C, M, N, K, 20);
+    printf("%-34s %4dx%4dx%4d  x6 %7.2f us %6.1f TF-eq (loads sunk by the compiler: %7.2f us) | x3 %7.2f us | x1 (plain bf16) %7.2f us %6.1f TF | split A %6.2f us\n",
+           what, M, N, K, t6, flop / t6 * 1e-6, t6l, t3, t1, flop / t1 * 1e-6, 1e3f * ms_split / 10);
     printf("%-34s rel L2 error vs fp64: x6 %.3e   fp32 fma chain %.3e   | max |err| / max |c|: x6 %.3e   chain %.3e\n",
            "", sqrt(e6 / nrm), sqrt(e32 / nrm), m6 / mx, m32 / mx);
     hipFree(A); hipFree(B); hipFree(C); hipFree(A3); hipFree(B3); hipFree(C64); hipFree(C32);
