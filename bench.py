@@ -277,6 +277,11 @@ def make_pool(args, rank, cards, spec, dev, n_pool):
             b = synthetic.taobao_batch(rng, args.batch, spec, dist=args.dist)
         else:
             b = synthetic.criteo_batch(rng, args.batch, cards=cards, dist=args.dist)
+        if args.zoo == "reference" and args.model == "DLRM":
+            # the reference's DLRM.forward concatenates the numeric columns on dim -1 (DLRM.py:115): they
+            # must arrive as [B, 1], which is how its own data loader shapes them
+            b = {k: (v.reshape(-1, 1) if (v.dtype == np.float32 and k != "label") else v)
+                 for k, v in b.items()}
         if args.host_inputs:
             # what the reference's DataLoader yields: host tensors, int64 ids / float64 numerics
             pool.append({k: torch.from_numpy(v.astype(np.float64) if v.dtype == np.float32 else v)

@@ -1142,6 +1142,9 @@ class FeatureEmbeddingDict(nn.Module):
             feature_emb_dict[f] = e
         feature_emb_dict._records = [v for k, v in emb.items() if isinstance(k, tuple)]
         feature_emb_dict._orig = {f: id(t) for f, t in feature_emb_dict.items()}
+        if self._pooled_holes:
+            # a linked DIN_Attention (link_fusion) finds the record and the packed ids of THIS forward here
+            self.__dict__["_fx_last"] = (inputs, feature_emb_dict)
         return feature_emb_dict
 
     def reserve_pooled_slot(self, feature):
@@ -1233,6 +1236,19 @@ class FeatureEmbeddingDict(nn.Module):
                 continue
             if feature in embedding_dict:
                 names.append(feature)
+        handed = getattr(embedding_dict, "_fx_flat", None)
+        if handed is not None and flatten_emb and not (feature_list or feature_source or feature_type):
+            # the attention already ran inside the gather record (DIN_Attention._try_in_record): the
+            # tower's input [fields.., attended vector] IS the record's prefix, provided the caller put
+            # exactly that attended vector into the dict in place of the sequence (DIN.py:127-130)
+            flat, seq, hole, D = handed
+            t = embedding_dict.get(seq)
+            same = (t is not None and t.dim() == 2 and t.shape[1] == D and t.stride(-1) == 1
+                    and t.data_ptr() == flat.data_ptr() + hole * D * flat.element_size()
+                    and names and names[-1] == seq and len(names) == hole + 1
+                    and all(embedding_dict._orig.get(f) == id(embedding_dict[f]) for f in names[:-1]))
+            if same:
+                return flat
         fast = self._record_slice(embedding_dict, names)
         if fast is not None:
             return fast.flatten(start_dim=1) if flatten_emb else fast
@@ -1509,7 +1525,10 @@ class _DlrmMixFn(torch.autograd.Function):
             g = g.contiguous()
         demb = torch.empty(B, F, D, dtype=torch.float32, device=rec.device)
         ops.dot_interact_bwd(rec.view(B, F * D), g, F, D, demb.view(B, F * D), tail=D + ctx.pad)
-        return demb, demb[:, F - 1, :], None
+        # (the dense vector's gradient is a COPY of its slot, B x D floats: handing out a view of demb
+        # would let autograd's in-place gradient accumulation corrupt it once rec gains a second
+        # consumer — ADVICE r3)
+        return demb, demb[:, F - 1, :].clone(), None
 
 
 class InnerProductInteraction(nn.Module):
@@ -1928,6 +1947,13 @@ class MLP_Block(nn.Module):
         to the result anyway; when the whole stack is the fused Linear / ReLU node it rides in the last
         GEMM's epilogue.  dx_into / out_into: see _MLPFn (ignored on the unfused path; out_into only
         when the fused stack is the whole block)."""
+        handed = self.__dict__.pop("_fx_dx_into", None)
+        if handed is not None and handed[0] is inputs and dx_into is None:
+            dx_into = handed[1]           # the record-shaped gradient buffer of the in-record attention
+        pending = self.__dict__.pop("_fx_pending", None)
+        if pending is not None and pending[0] is inputs and out_add is None and dx_into is None \
+                and out_into is None:
+            return pending[1]             # computed together with the linked CrossNetV2 (see there)
         if self._fused is None or inputs.dim() != 2:
             out = self.mlp(inputs)
             return out if out_add is None else out + out_add
@@ -2136,6 +2162,24 @@ class _DinRecordFn(torch.autograd.Function):
         return drec, None, dW1, db1, dalpha, dW2, db2, None, None, None, None
 
 
+def din_record_layout(emb, target, seq):
+    """(rec, tslot, hole) when the embedding dict `emb` is ONE gather record laid out
+    [single-slot fields.. | reserved | the positions of sequence `seq`]; None otherwise."""
+    records = getattr(emb, "_records", None)
+    if not records or len(records) != 1 or emb._encoded:
+        return None
+    rec, plan = records[0]
+    hole = plan.hole.get(seq)
+    if hole is None or target not in plan.slot or plan.slot[target][1] != 1 \
+            or list(emb)[-1] != seq or len(emb) != hole + 1 \
+            or plan.slot[seq][0] + plan.slot[seq][1] != plan.n_slots:
+        return None
+    for i, f in enumerate(emb):
+        if f != seq and plan.slot.get(f) != (i, 1):
+            return None
+    return rec, plan.slot[target][0], hole
+
+
 class DIN_Attention(nn.Module):
     """fuxictr/pytorch/layers/attentions/target_attention.py:26-92."""
 
@@ -2169,6 +2213,35 @@ class DIN_Attention(nn.Module):
             self._fx_plan = plan
         return plan
 
+    def _try_in_record(self, inrec, target_item, history_sequence):
+        """The reference's own DIN.forward (model_zoo/DIN/src/DIN.py:118-133) reaching the in-record
+        path: it calls this layer with the dict entries of the target and the sequence, replaces the
+        sequence's entry by what comes back, flattens the dict and feeds the tower.  When target and
+        history ARE the views of one gather record laid out [fields | reserved | positions] (link_fusion
+        reserved the slot), the attention runs inside the record; the attended vector is returned as the
+        view of its slot, dict2tensor hands the record's prefix to the tower and the tower writes its
+        input gradient into the record-shaped gradient buffer.  -> pooled [B, D] or None (generic path)."""
+        target, seq, emb_layer, dnn = inrec
+        last = emb_layer.__dict__.get("_fx_last")
+        if last is None:
+            return None
+        X, emb = last
+        if emb.get(target) is not target_item or emb.get(seq) is not history_sequence:
+            return None
+        layout = din_record_layout(emb, target, seq)
+        if layout is None:
+            return None
+        rec, tslot, hole = layout
+        B, n_slots, D = rec.shape
+        slot = _RecordGradSlot(B, n_slots, D, hole + 1, rec.device) if rec.requires_grad else None
+        flat = self.forward_in_record(rec, emb_layer.packed_ids(X, seq), tslot, hole, slot)
+        if flat is None:
+            return None
+        emb._fx_flat = (flat, seq, hole, D)
+        if slot is not None:
+            dnn.__dict__["_fx_dx_into"] = (flat, slot)
+        return flat[:, hole * D:(hole + 1) * D]
+
     def forward_in_record(self, rec, mask_i32, tslot, hole, grad_slot):
         """Native fast path (see _DinRecordFn): rec [B, n_slots, D] = [fields | reserved | positions];
         -> the tower's input [B, (hole + 1) * D] as a view of the record, or None when this
@@ -2182,6 +2255,11 @@ class DIN_Attention(nn.Module):
                                   lin2.bias, dice, tslot, hole, grad_slot)
 
     def forward(self, target_item, history_sequence, mask=None):
+        inrec = self.__dict__.get("_fx_inrec")
+        if inrec is not None:
+            out = self._try_in_record(inrec, target_item, history_sequence)
+            if out is not None:
+                return out
         seq_len = history_sequence.size(1)
         plan = self._fused_plan()
         if plan is not None and 4 * history_sequence.size(2) == plan[0].in_features \
@@ -2362,7 +2440,9 @@ def _dw_problem(dz, x, W, need_bias):
     K_in = x.shape[1]
     dW = torch.empty(N_out, K_in, dtype=torch.float32, device=dz.device)
     sk = max(_split_k_for(N_out, K_in, Bsz), 1 if _FORCE_SPLITK else min(8, Bsz // 256), 1)
-    ws = torch.empty(ops.gemm_workspace_floats(N_out, K_in, sk), dtype=torch.float32, device=dz.device)
+    # one grow-only workspace per weight shape: the problems of ONE batch have distinct shapes (a cross
+    # layer and the deep layer of its depth), launches follow each other on the stream
+    ws = _Workspace.get(dz.device, ops.gemm_workspace_floats(N_out, K_in, sk), tag=("dw", N_out, K_in))
     db = torch.empty(N_out, dtype=torch.float32, device=dz.device) if need_bias else None
     return ops.gemm_problem(dz, x, dW, transa=True, transb=False, split_k=sk, workspace=ws,
                             rowsum=db), dW, db
@@ -2381,6 +2461,10 @@ class _CrossDeepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, n_cross, acts, *wb):
+        # n_cross < 0: hand the two results out as TWO outputs (views of the one buffer) — the form the
+        # reference's own DCNv2.forward consumes (cross_out, dnn_out, then torch.cat), see CrossNetV2
+        ctx.two = n_cross < 0
+        n_cross = abs(n_cross)
         x0 = x0.contiguous()
         B, D0 = x0.shape
         cwb, dwb = wb[:2 * n_cross], wb[2 * n_cross:]
@@ -2410,19 +2494,35 @@ class _CrossDeepFn(torch.autograd.Function):
             ops.gemm_batch(probs)
         ctx.n_cross, ctx.acts, ctx.wb = n_cross, acts, wb
         ctx.xs, ctx.zs, ctx.hs, ctx.D0 = xs, zs, hs, D0
+        if ctx.two:
+            return out[:, :D0], out[:, D0:]
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         n_cross, acts, wb = ctx.n_cross, ctx.acts, ctx.wb
         xs, zs, hs, D0 = ctx.xs, ctx.zs, ctx.hs, ctx.D0
         cwb, dwb = wb[:2 * n_cross], wb[2 * n_cross:]
         n_deep = len(acts)
         x0 = xs[0]
-        if dout.stride(-1) != 1:
-            dout = dout.contiguous()
-        dxn = dout[:, :D0]                                  # row-strided views, read in place
-        ddeep = dout[:, D0:]
+        if ctx.two:
+            # the two gradients a torch.cat backward hands out: row-strided slices of ONE buffer, read
+            # in place (unit inner stride); an unused output arrives as None
+            dxn, ddeep = douts
+            if dxn is None:
+                dxn = torch.zeros_like(x0)
+            if ddeep is None:
+                ddeep = torch.zeros_like(hs[n_deep])
+            if dxn.stride(-1) != 1:
+                dxn = dxn.contiguous()
+            if ddeep.stride(-1) != 1:
+                ddeep = ddeep.contiguous()
+        else:
+            dout = douts[0]
+            if dout.stride(-1) != 1:
+                dout = dout.contiguous()
+            dxn = dout[:, :D0]                              # row-strided views, read in place
+            ddeep = dout[:, D0:]
         if acts[n_deep - 1]:
             dz = ops.mask_mul(ddeep, hs[n_deep], torch.empty_like(hs[n_deep]))
         else:
@@ -2496,6 +2596,19 @@ class CrossNetV2(nn.Module):
         wb = []
         for lin in self.cross_layers:
             wb += [lin.weight, lin.bias]
+        partner = self.__dict__.get("_fx_partner")
+        if partner is not None and self.num_layers >= 1 and X_0.dim() == 2 and X_0.shape[1] % 4 == 0:
+            # the reference's DCNv2.forward (model_zoo/DCNv2/src/DCNv2.py:113-120, `parallel`): crossnet(x0),
+            # then parallel_dnn(x0), then torch.cat of the two.  Both towers are computed HERE as one
+            # node (cross layer i + deep layer i one grid, forward and backward); the deep tower's
+            # result waits on the partner module until it is called with the same x0 (link_fusion)
+            fz = partner._fused
+            if fz is not None and not fz[1] and all(lin.weight.shape[0] % 4 == 0 for lin, _ in fz[0]):
+                for lin, _ in fz[0]:
+                    wb += [lin.weight, lin.bias]
+                cross, deep = _CrossDeepFn.apply(X_0, -self.num_layers, tuple(r for _, r in fz[0]), *wb)
+                partner.__dict__["_fx_pending"] = (X_0, deep)
+                return cross
         return _CrossNetV2Fn.apply(X_0, *wb)
 
 
@@ -2505,6 +2618,33 @@ def link_fusion(model):
     and which FM-style interaction read the same batch, so that their work rides along in the
     embedding layer's launches (_EmbFMFn).  Only the unambiguous case is linked: ONE
     FeatureEmbeddingDict besides the one LogisticRegression owns."""
+    # the reference's DCNv2 with `model_structure: parallel` (DCNv2.py:86-100: attributes `crossnet`,
+    # `parallel_dnn`): its forward calls the two towers one after the other on the same input.  (The
+    # native mirror zoo.DCNv2 pairs them itself and keeps the concatenation out of the step as well.)
+    cross, deep = getattr(model, "crossnet", None), getattr(model, "parallel_dnn", None)
+    if (isinstance(cross, CrossNetV2) and isinstance(deep, MLP_Block)
+            and getattr(model, "model_structure", None) == "parallel"
+            and not hasattr(type(model), "_fused_parallel")
+            and os.environ.get("FX_DCN_HANDOFF", "1") != "0"):
+        cross.__dict__["_fx_partner"] = deep
+    # the reference's DIN (DIN.py:50-100: `attention_layers`, `din_target_field`, `din_sequence_field`,
+    # `embedding_layer` a FeatureEmbeddingDict, `dnn`) in its shipped configuration — one target field,
+    # one raw sequence that is the LAST feature: the attention runs inside the gather record, exactly as
+    # in the mirror zoo.DIN (which wires it itself: `_in_record`)
+    att = getattr(model, "attention_layers", None)
+    tf, sf = getattr(model, "din_target_field", None), getattr(model, "din_sequence_field", None)
+    emb_layer, dnn = getattr(model, "embedding_layer", None), getattr(model, "dnn", None)
+    if (att is not None and len(att) == 1 and isinstance(att[0], DIN_Attention)
+            and isinstance(emb_layer, FeatureEmbeddingDict) and isinstance(dnn, MLP_Block)
+            and isinstance(tf, list) and isinstance(sf, list) and len(tf) == 1 and len(sf) == 1
+            and isinstance(tf[0], str) and isinstance(sf[0], str)
+            and not hasattr(model, "_in_record") and os.environ.get("FX_DIN_INPLACE", "1") != "0"):
+        fmap = model.feature_map.features
+        names = list(fmap)
+        if (names and names[-1] == sf[0] and fmap[sf[0]]["type"] == "sequence"
+                and not fmap[sf[0]].get("feature_encoder")):
+            emb_layer.reserve_pooled_slot(sf[0])
+            att[0].__dict__["_fx_inrec"] = (tf[0], sf[0], emb_layer, dnn)
     lrs = [m for m in model.modules() if isinstance(m, LogisticRegression)]
     lr_layers = {id(lr.embedding_layer.embedding_layer) for lr in lrs}
     mains = [m for m in model.modules()

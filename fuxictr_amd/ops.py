@@ -531,9 +531,10 @@ def lr_fwd(table1, ids, col_row_base, col_vocab, dense, num_w1, bias, out, scal)
 
 
 def gemm_workspace_floats(M, N, split_k):
-    """Floats of split-K workspace for an [M, N] product: split_k slabs + the partial row sums of the fused
-    bias gradient (one vector per slab and 64-wide tile column, include/fxctr.h)."""
-    return split_k * M * (N + N // 64 + 2) + 64
+    """Floats of split-K workspace for an [M, N] product: split_k slabs of the product + split_k vectors of
+    M partial row sums (the fused bias gradient), as include/fxctr.h's fx_gemm_problem comment says
+    (ws[split_k * M * N + z * M + m]), + 64 floats of alignment slack."""
+    return split_k * M * (N + 1) + 64
 
 
 def gemm(A, B_, C_, transa=False, transb=False, bias=None, act=0, zout=None, mul=None, mask=None,

@@ -101,11 +101,18 @@ class _NativeOptimizer(torch.optim.Optimizer):
             grp.reg_fresh = False
 
     def set_max_norm(self, max_norm, _from_model=False):
-        """Global-norm clip applied inside the update kernels (0 / None: no clipping).  An explicit call
-        wins over the model's `_max_gradient_norm` (which step() only adopts while nobody has set one:
-        a train_step override that deliberately does not clip calls set_max_norm(0))."""
+        """Global-norm clip applied inside the update kernels (0: no clipping).  An explicit call wins
+        over the model's `_max_gradient_norm` (which step() only adopts while nobody has set one: a
+        train_step override that deliberately does not clip calls set_max_norm(0)); set_max_norm(None)
+        clears the explicit value and returns control to the model."""
         if not _from_model:
-            self._max_norm_explicit = True
+            if max_norm is None:
+                # hand control back to the model: step() adopts fit()'s max_gradient_norm again
+                self._max_norm_explicit = False
+                if self._model is not None and hasattr(self._model, "_max_gradient_norm"):
+                    max_norm = self._model._max_gradient_norm
+            else:
+                self._max_norm_explicit = True
         max_norm = float(max_norm) if max_norm else 0.0
         if max_norm != self._max_norm:
             self.scal[_lib.SC_MAX_NORM:_lib.SC_MAX_NORM + 1].fill_(max_norm)
@@ -256,7 +263,14 @@ class _NativeOptimizer(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError("closure is not supported by the native optimizer")
         if not self._begun:
-            self.begin_step()      # no training forward opened the step (no table lookups)
+            # no zero_grad() / training forward opened the step (a model without table lookups, or an
+            # accidental second step()): the step counter and the bias corrections advance
+            if self._groups and not getattr(self, "_warned_open", False):
+                import logging
+                logging.warning("native optimizer: step() had to open the step itself (no zero_grad() or "
+                                "training forward since the last step) - t advances once more")
+                self._warned_open = True
+            self.begin_step()
         self._begun = False
         self.flush_begin()
         if (not self._max_norm_explicit and self._model is not None

@@ -15,7 +15,7 @@ from torch import nn
 from .layers import (CompressedInteractionNet, CrossNetV2, DIN_Attention, Dice,
                      FactorizationMachine, FeatureEmbedding, FeatureEmbeddingDict, FxLinear,
                      InnerProductInteraction, LogisticRegression, MLP_Block, _DlrmMixFn, _MLP_PAD,
-                     _RecordGradSlot)
+                     _RecordGradSlot, din_record_layout)
 from .rank_model import BaseModel
 
 
@@ -176,20 +176,7 @@ class DIN(_ZooModel):
         [single-slot fields.. | reserved | the sequence's positions]; None otherwise."""
         if self._in_record is None:
             return None
-        records = getattr(emb, "_records", None)
-        if not records or len(records) != 1 or emb._encoded:
-            return None
-        rec, plan = records[0]
-        target, seq = self._in_record
-        hole = plan.hole.get(seq)
-        if hole is None or target not in plan.slot or plan.slot[target][1] != 1 \
-                or list(emb)[-1] != seq or len(emb) != hole + 1 \
-                or plan.slot[seq][0] + plan.slot[seq][1] != plan.n_slots:
-            return None
-        for i, f in enumerate(emb):
-            if f != seq and plan.slot.get(f) != (i, 1):
-                return None
-        return rec, plan.slot[target][0], hole
+        return din_record_layout(emb, *self._in_record)
 
     def get_embedding(self, field, feature_emb_dict):
         names = _fields(field)

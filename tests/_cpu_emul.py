@@ -410,7 +410,7 @@ def gemm_batch(problems):
 
 
 def gemm_workspace_floats(M, N, split_k):
-    return split_k * M * (N + N // 64 + 2) + 64
+    return split_k * M * (N + 1) + 64
 
 
 def gemm_dw_dx(dz, x, W, dW, dx, split_k=1, workspace=None, rowsum=None, mask=None, add=None):
