@@ -163,6 +163,121 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(const uint16_t* __restric
         }
 }
 
+// Second structure: 8 waves (2 x 4, a wave owns 64 x 32 of the tile: two waves per SIMD, so one can issue
+// MFMAs while its partner waits for LDS or the barrier), TWO LDS stages and ONE barrier per k tile:
+//   compute tile t from stage t & 1 | write the registers of tile t + 1 into the other stage | request
+//   tile t + 2 from memory | barrier
+template <int NTERMS>
+__global__ __launch_bounds__(512, 2) void k_gemm_bf16x_w8(const uint16_t* __restrict__ A3,
+                                                          const uint16_t* __restrict__ B3,
+                                                          float* __restrict__ C, int M, int N, int K,
+                                                          int64_t ldc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // 2 stages x 2 operands
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int tiles_n = N / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t planeA = (int64_t)M * K, planeB = (int64_t)N * K;
+    u32x4 ra[3], rb[3];
+    const int nk = K / BK;
+#define W8_GLOAD(KT)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                    \
+        const int q = tid + 512 * i;                                                                   \
+        const int c = q & 3, row = (q >> 2) & 127, pl = q >> 9;                                        \
+        ra[i] = *reinterpret_cast<const u32x4*>(A3 + pl * planeA + (m0 + row) * K + (KT) * BK + c * 8); \
+        rb[i] = *reinterpret_cast<const u32x4*>(B3 + pl * planeB + (n0 + row) * K + (KT) * BK + c * 8); \
+    }
+#define W8_LSTORE(ST)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                    \
+        const int q = tid + 512 * i;                                                                   \
+        const int c = q & 3, row = (q >> 2) & 127, pl = q >> 9;                                        \
+        *reinterpret_cast<u32x4*>(lds2 + (ST) * 2 * OPER_B + pl * PLANE_B + row * ROWB + c * 16) = ra[i]; \
+        *reinterpret_cast<u32x4*>(lds2 + (ST) * 2 * OPER_B + OPER_B + pl * PLANE_B + row * ROWB + c * 16) = rb[i]; \
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    W8_GLOAD(0)
+    W8_LSTORE(0)
+    {
+        const int k1 = nk > 1 ? 1 : 0;
+        W8_GLOAD(k1)
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char* st = lds2 + (kt & 1) * 2 * OPER_B;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fa[3][2], fb[3];
+            const int c = 2 * s + (lane >> 5);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int rowa = wm * 64 + b * 32 + (lane & 31);
+                    fa[p][b] = *reinterpret_cast<const bf16x8*>(st + p * PLANE_B + rowa * ROWB + c * 16);
+                }
+                const int rowb = wn * 32 + (lane & 31);
+                fb[p] = *reinterpret_cast<const bf16x8*>(st + OPER_B + p * PLANE_B + rowb * ROWB + c * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (NTERMS >= 6) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[2], fa[0][i], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1], fa[1][i], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0], fa[2][i], acc[i], 0, 0, 0);
+                }
+                if (NTERMS >= 3) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1], fa[0][i], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0], fa[1][i], acc[i], 0, 0, 0);
+                }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0], fa[0][i], acc[i], 0, 0, 0);
+            }
+        }
+        // the other stage was last read in iteration kt - 1, before the barrier that ended it
+        if (kt + 1 < nk) {
+            W8_LSTORE((kt + 1) & 1)
+        }
+        {
+            const int kn = kt + 2 < nk ? kt + 2 : kt;
+            W8_GLOAD(kn)
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (lane & 31);
+        const int64_t nb = n0 + wn * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = make_float4(acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2],
+                                         acc[i][4 * g + 3]);
+            *reinterpret_cast<float4*>(C + m * ldc + nb + 8 * g) = v;
+        }
+    }
+}
+
+template <int NT>
+static float run_w8(const uint16_t* A3, const uint16_t* B3, float* C, int M, int N, int K, int reps) {
+    dim3 grid((M / BM) * (N / BN));
+    const size_t smem = 4 * OPER_B;
+    HC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16x_w8<NT>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((k_gemm_bf16x_w8<NT>), grid, dim3(512), smem, 0, A3, B3, C, M, N, K, (int64_t)N);
+    HC(hipDeviceSynchronize());
+    hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
+    HC(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL((k_gemm_bf16x_w8<NT>), grid, dim3(512), smem, 0, A3, B3, C, M, N, K, (int64_t)N);
+    HC(hipEventRecord(e1, 0));
+    HC(hipDeviceSynchronize());
+    float ms; HC(hipEventElapsedTime(&ms, e0, e1));
+    return 1e3f * ms / reps;
+}
+
 // references on a sample of rows: fp64 sums and the k-ordered fp32 fmaf chain (what the fp32 MFMA computes)
 __global__ void k_ref(const float* A, const float* B, int M, int N, int K, int row_step, double* C64,
                       float* C32) {
@@ -247,6 +362,15 @@ static void bench(int M, int N, int K, const char* what) {
     const float t3 = run<3, true>(A3, B3, C, M, N, K, 20);
     const float t6l = run<6, false>(A3, B3, C, M, N, K, 20);
     const float t1 = run<1, true>(A3, B3, C, M, N, K, 20);
+    const float w6 = run_w8<6>(A3, B3, C, M, N, K, 20);
+    {   // the 8-wave kernel's result against the 4-wave one's (same products, same k order per element)
+        std::vector<float> hw((size_t)M * N);
+        HC(hipMemcpy(hw.data(), C, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t i = 0; i < hw.size(); ++i) bad += hw[i] != hc[i];
+        printf("%-34s 8 waves, 2 LDS stages: x6 %7.2f us %6.1f TF-eq, x1 %7.2f us; %zu elements differ from the 4-wave result\n",
+               "", w6, flop / w6 * 1e-6, run_w8<1>(A3, B3, C, M, N, K, 20), bad);
+    }
     printf("%-34s %4dx%4dx%4d  x6 %7.2f us %6.1f TF-eq (loads sunk by the compiler: %7.2f us) | x3 %7.2f us | x1 (plain bf16) %7.2f us %6.1f TF | split A %6.2f us\n",
            what, M, N, K, t6, flop / t6 * 1e-6, t6l, t3, t1, flop / t1 * 1e-6, 1e3f * ms_split / 10);
     printf("%-34s rel L2 error vs fp64: x6 %.3e   fp32 fma chain %.3e   | max |err| / max |c|: x6 %.3e   chain %.3e\n",

@@ -422,6 +422,12 @@ int main(int argc, char** argv) {
         run_mix("cross pair + deep pair 1024x1024", "w:4096,624,624;a:4096,624,624;w:4096,1024,1024;x:4096,1024,1024", 8);
         run_mix("cross pair + deep pair 1024x624", "w:4096,624,624;a:4096,624,624;w:4096,1024,624;a:4096,1024,624", 8);
     }
+    if (suite == "first") {   // the tower's first layer (K = N = 624 = 39 x 16): as it is, and padded to 640
+        run_case({"fwd 4096x1024x624 bias+relu", 0, 1, B, 1024, 624, 1, true, true, false, false, false, false, false});
+        run_case({"fwd 4096x1024x640 bias+relu", 0, 1, B, 1024, 640, 1, true, true, false, false, false, false, false});
+        run_mix("first-layer pair 624 (dW + dX)", "w:4096,1024,624;x:4096,1024,624", 8);
+        run_mix("first-layer pair 640 (dW + dX)", "w:4096,1024,640;x:4096,1024,640", 8);
+    }
     if (suite == "pairs") {
         run_pair("pair 4096x1024x1024 (dW + dX mask)", B, 1024, 1024, 8, true, false);
         run_pair("pair 4096x1024x624 (dW + dX)", B, 1024, 624, 8, false, false);
