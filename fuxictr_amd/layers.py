@@ -2618,6 +2618,14 @@ def link_fusion(model):
     and which FM-style interaction read the same batch, so that their work rides along in the
     embedding layer's launches (_EmbFMFn).  Only the unambiguous case is linked: ONE
     FeatureEmbeddingDict besides the one LogisticRegression owns."""
+    # stock nn.Linear layers the reference's model code creates itself (DCNv2's `fc` head, DCNv2.py:100;
+    # not one of the layer classes patch.install() re-binds) become FxLinear IN PLACE: same module object,
+    # same Parameters and state_dict keys, forward / backward on the native GEMM (the 1648 -> 1 head on the
+    # skinny kernels instead of three ATen launches).  Only the exact type, only floating-point fp32.
+    if os.environ.get("FX_LINEAR_SWAP", "1") != "0":
+        for mod in model.modules():
+            if type(mod) is nn.Linear and mod.weight.dtype == torch.float32:
+                mod.__class__ = FxLinear
     # the reference's DCNv2 with `model_structure: parallel` (DCNv2.py:86-100: attributes `crossnet`,
     # `parallel_dnn`): its forward calls the two towers one after the other on the same input.  (The
     # native mirror zoo.DCNv2 pairs them itself and keeps the concatenation out of the step as well.)
