@@ -130,6 +130,11 @@ class DistContext(object):
         if recv is None:
             recv = torch.empty_like(send)
         assert recv.is_contiguous() and recv.shape == send.shape
+        if (self.recorder is not None and self.capture_collectives
+                and os.environ.get("FX_TEST_CAPTURE_FAIL") == "1"):
+            # test hook: a stack that cannot record RCCL kernels (tests/test_gpu_dist.py checks that the
+            # step then falls back to hipGraph segments by itself)
+            raise RuntimeError("FX_TEST_CAPTURE_FAIL: simulated failure to record a collective")
         if self.recorder is not None and not self.capture_collectives:
             self.recorder.cut(lambda: self._a2a_into(recv, send))
         else:

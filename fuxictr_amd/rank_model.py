@@ -267,6 +267,8 @@ class _GraphStep(object):
                                 type(exc).__name__, exc)
                 model._dist.capture_collectives = False
                 self.graph.abort()
+                # per-batch entries the aborted recording left in the static batch's cache
+                static.cache = {k: v for k, v in static.cache.items() if k in self._pack_keys}
                 model.optimizer._begun = False
                 model.optimizer._begin_pending = False
                 for grp in model.optimizer._groups:

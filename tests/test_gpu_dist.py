@@ -89,3 +89,17 @@ def test_collectives_recorded_into_the_graph_run_and_exit_on_one_rccl_rank():
     rec = _bench_line(common, env={"FX_SHARD_WORLD1": "1"}, timeout=240)
     assert "recorded" in rec["config"]["parallelism"] and "segments" in seg["config"]["parallelism"]
     assert rec["probe_loss"] == seg["probe_loss"]
+
+
+def test_a_failed_capture_of_the_collectives_falls_back_to_segments():
+    """The recorded-collectives form is the default; a stack on which recording an RCCL kernel throws must
+    not take the run down: the step falls back to hipGraph segments with eager collectives by itself, the
+    line says so, and the probe losses are those of the recorded form."""
+    common = ["--vocab-scale", "0.01", "--steps", "3", "--warmup", "5", "--no-cpu-baseline",
+              "--no-kernel-timing", "--no-dcnv2", "--probe-loss"]
+    rec = _bench_line(common, env={"FX_SHARD_WORLD1": "1"}, timeout=240)
+    fb = _bench_line(common, env={"FX_SHARD_WORLD1": "1", "FX_TEST_CAPTURE_FAIL": "1"}, timeout=240)
+    assert "recorded" in rec["config"]["parallelism"]
+    assert "segments" in fb["config"]["parallelism"], fb["config"]["parallelism"]
+    assert fb["probe_loss"] == rec["probe_loss"]
+    assert fb["value"] > 0
