@@ -753,10 +753,31 @@ def workload_name(args, rows):
                 "xDeepFM": "MLP 4x1024, CIN [16,16,16]"}.get(args.model, "MLP 4x1024")))
 
 
+_JSON_FD = None
+
+
+def _own_stdout():
+    """ONE JSON line on stdout, whatever the libraries print: RCCL ("RCCL version : ..." at the flush of
+    its stdio buffer when the process ends), gloo ("[Gloo] Rank 0 is connected ...") and hipBLASLt-style
+    banners write to fd 1 from C code.  The line goes out through a private duplicate of the original
+    stdout; fd 1 itself is pointed at stderr for the rest of the process — on every rank (torchrun merges
+    the ranks' stdout into the launcher's)."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    os.write(_JSON_FD, (line + "\n").encode())
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _spawn_ranks(args)                                  # does not return
+    _own_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -849,7 +870,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model in ("DeepFM", "DCNv2"):
             out["cpu_baseline"] = cpu_baseline(args, m["cards"], args.cpu_baseline_steps)
         assert out["n_gpus"] == args.gpus
-        print(json.dumps(out), flush=True)
+        _emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         # the captured steps (and the RCCL kernels recorded in them) were released in measure(); the

@@ -253,6 +253,11 @@ class _GraphStep(object):
                         self.graph.begin()
                         self.loss = model._step_body(static)
                         self.graph.finish()
+                    except BaseException:
+                        # end the capture HERE, while the capturing stream is still the current one
+                        # (capture_end on another stream raises and leaves this one capturing for good)
+                        self.graph.abort()
+                        raise
                     finally:
                         model._dist.recorder = None
                 cur.wait_stream(model._graph_stream)
@@ -266,7 +271,6 @@ class _GraphStep(object):
                                 "hipGraph segments with eager collectives instead",
                                 type(exc).__name__, exc)
                 model._dist.capture_collectives = False
-                self.graph.abort()
                 # per-batch entries the aborted recording left in the static batch's cache
                 static.cache = {k: v for k, v in static.cache.items() if k in self._pack_keys}
                 model.optimizer._begun = False
