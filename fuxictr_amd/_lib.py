@@ -145,7 +145,7 @@ SIGNATURES = {
     "fx_dedup_catchup": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
                                vp, C.POINTER(RowState), i32, i32, vp, vp]),
     "fx_emb_fm_fwd": (i32, [vp, i32, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, vp, i32, vp, i64, i64,
-                            vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]),
+                            vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i64, i32, vp]),
     "fx_emb_fm_bwd_partials": (i64, [i64, i32]),
     "fx_emb_fm_bwd_workspace_floats": (i64, [i64, i32, i32]),
     "fx_emb_fm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp, vp,

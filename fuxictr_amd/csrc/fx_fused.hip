@@ -523,7 +523,16 @@ struct EmbFmArgs {
     int32_t D, C, Fd, lanes_log2, bf16;
     int64_t table_ld, table1_ld;     // row strides in elements (D and 1 for packed tables; the block of
                                      // rows a row-sharded exchange delivered is read in place)
+    int64_t zero_off[2];             // reserved slots of the record (a DIN hole, DLRM's tail): zero_n floats
+    int32_t zero_n[2];               // at zero_off of every sample's row are cleared (their producer writes
+                                     // them later in the step; nobody may ever read uninitialised memory)
 };
+
+__device__ __forceinline__ void fx_zero_reserved(const EmbFmArgs& a, int64_t b, int lane) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        for (int i = lane; i < a.zero_n[r]; i += 64) a.out[b * a.out_ld + a.zero_off[r] + i] = 0.f;
+}
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_emb_fm_fwd(EmbFmArgs a) {
@@ -606,6 +615,7 @@ __global__ __launch_bounds__(256) void k_emb_fm_fwd(EmbFmArgs a) {
             if (a.fm_out) a.fm_out[b] = fm;
             if (a.fm_lr_out) a.fm_lr_out[b] = fm + lr;
         }
+        fx_zero_reserved(a, b, lane);
     }
 }
 
@@ -757,6 +767,7 @@ __global__ __launch_bounds__(256) void k_emb_fm_fwd2(EmbFmArgs a) {
                 if (a.fm_out) a.fm_out[b] = fm;
                 if (a.fm_lr_out) a.fm_lr_out[b] = fm + lr;
             }
+            fx_zero_reserved(a, b, lane);
         }
     }
 }
@@ -770,6 +781,7 @@ extern "C" int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, 
                              const float* table1, const float* num_w1, const float* bias1,
                              float* lr_out, float* fm_out, float* fm_lr_out, float* S,
                              fx_scalars* scal, int64_t table_ld, int64_t table1_ld,
+                             int64_t zero_off0, int32_t zero_n0, int64_t zero_off1, int32_t zero_n1,
                              fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256, "fx_emb_fm_fwd: D=%d not in [1,256]", D);
     if (table_ld <= 0) table_ld = D;
@@ -797,7 +809,11 @@ extern "C" int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, 
     while ((1 << ll) < g.lanes) ++ll;
     EmbFmArgs a{table, ids, ids_ld, col_row_base, col_vocab, col_out_off, dense, dense_ld, num_w,
                 num_out_off, out, out_ld, B, table1, num_w1, bias1, lr_out, fm_out, fm_lr_out, S,
-                scal, D, C, Fd, ll, table_dtype == FX_BF16 ? 1 : 0, table_ld, table1_ld};
+                scal, D, C, Fd, ll, table_dtype == FX_BF16 ? 1 : 0, table_ld, table1_ld,
+                {zero_off0, zero_off1}, {zero_n0, zero_n1}};
+    FX_CHECK_ARG(zero_n0 >= 0 && zero_n1 >= 0 && zero_off0 >= 0 && zero_off1 >= 0 &&
+                     zero_off0 + zero_n0 <= out_ld && zero_off1 + zero_n1 <= out_ld,
+                 "fx_emb_fm_fwd: reserved-slot range outside the record row");
     hipStream_t s = fx_hip_stream(stream);
     // A/B switch, read per call so that a test can compare the two forms in one process:
     // FX_EMB_FWD2=0 = the first version for every shape

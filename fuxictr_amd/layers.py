@@ -321,6 +321,12 @@ class _TableGroup(object):
         p.tail0 = slot if tail_slots else None
         slot += int(tail_slots)
         p.n_slots = slot
+        # reserved slots (holes, tail) as (float offset, float count) ranges: the fused gather clears up to
+        # two of them per record row (nobody may read uninitialised slots)
+        rr = [(h * D, D) for h in sorted(p.hole.values())]
+        if tail_slots:
+            rr.append((p.tail0 * D, int(tail_slots) * D))
+        p.reserved_ranges = tuple(rr[:2])
         p.C = len(row_base)
         p.n_seq = len(seq_col0)
         p.Fd = len(p.num_feats)
@@ -764,7 +770,7 @@ class _EmbFMFn(torch.autograd.Function):
                        table1=table1,
                        num_w1=lr_group.select_num_w(lr_plan) if want_lr else None,
                        bias1=lr_bias if want_lr else None, lr_out=lr_out, fm_out=fm_out,
-                       fm_lr_out=fm_lr, S=S)
+                       fm_lr_out=fm_lr, S=S, zero_ranges=plan.reserved_ranges)
         ctx.group, ctx.plan, ctx.lr_group, ctx.lr_plan = group, plan, lr_group, lr_plan
         ctx.ids, ctx.dense, ctx.dd, ctx.out, ctx.S = ids, dense, dd, out, S
         ctx.sx = sx

@@ -1000,8 +1000,10 @@ def _emb_fm_bytes(table, D, ids, col_row_base, col_vocab, col_out_off, dense, nu
 @_timed("k_emb_fm_fwd", "sparse_path", _emb_fm_bytes, alone=True)
 def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w, num_out_off, out,
                scal, table1=None, num_w1=None, bias1=None, lr_out=None, fm_out=None, fm_lr_out=None,
-               S=None):
+               S=None, zero_ranges=()):
     """Gather + numeric expansion (+ first-order term) (+ FM second-order term), one launch.
+    zero_ranges: up to two (offset, floats) ranges of every record row that the launch clears (reserved
+    slots a later kernel of the step fills).
     table / table1 may be column ranges of a wider block (their row stride is passed on): the rows a
     row-sharded exchange delivered are read in place."""
     lib = _lib.load()
@@ -1016,6 +1018,7 @@ def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w
                             ptr(lr_out), ptr(fm_out), ptr(fm_lr_out), ptr(S), ptr(scal),
                             0 if table is None else table.stride(0),
                             0 if table1 is None else table1.stride(0),
+                            *[int(x) for r in (tuple(zero_ranges) + ((0, 0), (0, 0)))[:2] for x in r],
                             stream_ptr(out.device)), "fx_emb_fm_fwd")
     return out
 

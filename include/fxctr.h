@@ -702,7 +702,12 @@ int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, const int32
                   const float* table1, const float* num_w1, const float* bias1, float* lr_out,
                   float* fm_out, float* fm_lr_out, float* S, fx_scalars* scal,
                   int64_t table_ld /* row stride of `table` in elements; <= 0: D */,
-                  int64_t table1_ld /* row stride of `table1`; <= 0: 1 */, fx_stream_t stream);
+                  int64_t table1_ld /* row stride of `table1`; <= 0: 1 */,
+                  int64_t zero_off0, int32_t zero_n0, int64_t zero_off1, int32_t zero_n1
+                  /* two ranges of reserved floats per record row (offset, count; count 0 = none) that the
+                     launch clears: slots a later kernel of the step fills (DIN's attended vector, DLRM's
+                     bottom-tower vector) */,
+                  fx_stream_t stream);
 /* fx_owner_fetch_rows: owner side of the row-sharded forward for every table group of one exchange
  *   (<= 4) in ONE launch.  For each unique owned row u of the owner-side de-dup (uniq_row / seg_start /
  *   sorted_pos / n_unique of fx_dedup_sorted_runs over the n_total received ids): catchup != 0 replays

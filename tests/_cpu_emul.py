@@ -787,9 +787,11 @@ def dedup_catchup(ids, col_row_base, col_vocab, col_pad, workspace, states, scal
 
 def emb_fm_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w, num_out_off, out,
                scal, table1=None, num_w1=None, bias1=None, lr_out=None, fm_out=None, fm_lr_out=None,
-               S=None):
+               S=None, zero_ranges=()):
     emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w, num_out_off,
                    out, scal)
+    for off, n in zero_ranges:
+        out[:, off:off + n] = 0
     lr = None
     if lr_out is not None or fm_lr_out is not None:
         lr = torch.empty(out.shape[0], 1)

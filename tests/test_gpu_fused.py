@@ -208,6 +208,41 @@ def test_emb_fm_fwd_round4_kernel_is_bit_identical_to_the_first_version(C, Fd, D
         assert outs[1][5] & _lib.FX_FLAG_BAD_ID
 
 
+@pytest.mark.parametrize("fwd2", ["1", "0"])
+def test_emb_fm_fwd_clears_the_reserved_slots(fwd2):
+    """Reserved slots of the record (DIN's hole, DLRM's tail: filled by a later kernel of the step) are
+    cleared by the gather launch, by both forms of the kernel; every other float of the row is what the
+    launch without reserved ranges writes."""
+    import os
+    rng = np.random.default_rng(11)
+    g = torch.Generator().manual_seed(11)
+    vocabs = [50, 3, 1000, 7]
+    bases, R = _schema(vocabs)
+    B, C, Fd, D = 513, 4, 2, 16
+    table, num_w = torch.randn(R, D, generator=g), torch.randn(Fd, D, generator=g)
+    ids = _ids(rng, B, vocabs, "power")
+    dense = torch.rand(B, Fd, generator=g)
+    # slots: [n0, c0, c1, HOLE, c2, c3, n1, TAIL, TAIL]
+    slots_c, slots_n, n_slots = [1, 2, 4, 5], [0, 6], 9
+    os.environ["FX_EMB_FWD2"] = fwd2
+    outs = []
+    for ranges in ((), ((3 * D, D), (7 * D, 2 * D))):
+        scal = ops.new_scalars(DEV)
+        rec = torch.full((B, n_slots * D), 5.0, device=DEV)
+        ops.emb_fm_fwd(_dev(table), D, _dev(ids, torch.int32), _dev(bases, torch.int64),
+                       _dev(vocabs, torch.int32), _dev([s_ * D for s_ in slots_c], torch.int64), _dev(dense),
+                       _dev(num_w), _dev([s_ * D for s_ in slots_n], torch.int64), rec, scal,
+                       zero_ranges=ranges)
+        torch.cuda.synchronize()
+        outs.append(rec.view(B, n_slots, D).cpu())
+    os.environ.pop("FX_EMB_FWD2")
+    plain, cleared = outs
+    keep = [0, 1, 2, 4, 5, 6]
+    assert torch.equal(plain[:, keep], cleared[:, keep])
+    assert float(plain[:, [3, 7, 8]].min()) == 5.0                 # untouched without ranges
+    assert float(cleared[:, [3, 7, 8]].abs().max()) == 0.0
+
+
 def _bwd_reference(drec, rec, S, g_fm, g_lr, ids, bases, pads, vocabs, slots_c, slots_n, dense, D):
     """float64 restatement: the dense [R, D] gradient autograd would build, then the unique rows."""
     B, C = ids.shape
