@@ -260,6 +260,141 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x_w8(const uint16_t* __rest
     }
 }
 
+// Third structure: LDS-DMA (global_load_lds_dwordx4) into THREE dense LDS stages, prefetch distance two,
+// ONE raw s_barrier per k tile and a counted s_waitcnt vmcnt — the loads of tile t + 1 stay in flight across
+// the barrier that releases tile t.  The LDS image is dense ([row][64 B], what the DMA can write: wave-uniform
+// base + lane x 16 B); bank conflicts of the fragment reads are avoided by XOR-ing the 16-byte chunk index
+// with (row >> 2) & 3 on BOTH sides (the per-lane GLOBAL address picks the chunk, the ds_read address undoes it).
+#define G3_PLANE (128 * 64)
+#define G3_OPER (3 * G3_PLANE)
+#define G3_STAGE (2 * G3_OPER)
+template <int NTERMS>
+__global__ __launch_bounds__(512, 2) void k_gemm_bf16x_g3(const uint16_t* __restrict__ A3,
+                                                          const uint16_t* __restrict__ B3,
+                                                          float* __restrict__ C, int M, int N, int K,
+                                                          int64_t ldc) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds3[];      // 3 stages
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int tiles_n = N / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t planeA = (int64_t)M * K, planeB = (int64_t)N * K;
+    const int nk = K / BK;
+    // this wave's six DMA units of a tile: unit u = w * 6 + j -> operand u / 24, plane (u / 8) % 3, 16-row
+    // block u % 8; lane l -> row (l >> 2) of the block, LDS chunk slot l & 3, global chunk slot ^ swizzle
+    const uint16_t* gsrc[6];
+    uint32_t ldst[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int u = w * 6 + j;
+        const int oper = u / 24, pl = (u >> 3) % 3, blk = u & 7;
+        const int row = blk * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        gsrc[j] = (oper ? B3 + pl * planeB + (n0 + row) * K : A3 + pl * planeA + (m0 + row) * K) + c * 8;
+        ldst[j] = (uint32_t)(oper * G3_OPER + pl * G3_PLANE + blk * 1024);     // wave-uniform base
+    }
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds3);
+#define G3_ISSUE(KT, ST)                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                          \
+        __builtin_amdgcn_global_load_lds(                                                                \
+            (const __attribute__((address_space(1))) void*)(uintptr_t)(gsrc[j] + (int64_t)(KT) * BK),   \
+            (__attribute__((address_space(3))) void*)(uintptr_t)(lds_base + (uint32_t)(ST) * G3_STAGE + ldst[j]),  \
+            16, 0, 0);
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    G3_ISSUE(0, 0)
+    {
+        const int k1 = nk > 1 ? 1 : 0;
+        G3_ISSUE(k1, 1)
+    }
+    // fragment addresses (byte offsets inside a stage), constant over the k loop
+    uint32_t offa[2][2], offb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int c = 2 * s + (lane >> 5);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int r = wm * 64 + b * 32 + (lane & 31);
+            offa[s][b] = (uint32_t)(r * 64 + ((c ^ ((r >> 2) & 3)) * 16));
+        }
+        const int rb = wn * 32 + (lane & 31);
+        offb[s] = (uint32_t)(G3_OPER + rb * 64 + ((c ^ ((rb >> 2) & 3)) * 16));
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once at most the 6 DMAs of tile kt + 1 are still outstanding (per wave), and
+        // every wave has said so
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // stage (kt + 2) % 3 was read in iteration kt - 1: every wave is past those reads (it waited for
+            // them before its MFMAs) when it arrives at the barrier above
+            const int kn = kt + 2 < nk ? kt + 2 : nk - 1;
+            const int stn = (kt + 2) % 3;
+            G3_ISSUE(kn, stn)
+        }
+        const unsigned char* st = lds3 + (kt % 3) * G3_STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fa[3][2], fb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    fa[p][b] = *reinterpret_cast<const bf16x8*>(st + p * G3_PLANE + offa[s][b]);
+                fb[p] = *reinterpret_cast<const bf16x8*>(st + p * G3_PLANE + offb[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (NTERMS >= 6) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[2], fa[0][i], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1], fa[1][i], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0], fa[2][i], acc[i], 0, 0, 0);
+                }
+                if (NTERMS >= 3) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1], fa[0][i], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0], fa[1][i], acc[i], 0, 0, 0);
+                }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0], fa[0][i], acc[i], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (lane & 31);
+        const int64_t nb = n0 + wn * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = make_float4(acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2],
+                                         acc[i][4 * g + 3]);
+            *reinterpret_cast<float4*>(C + m * ldc + nb + 8 * g) = v;
+        }
+    }
+}
+
+template <int NT>
+static float run_g3(const uint16_t* A3, const uint16_t* B3, float* C, int M, int N, int K, int reps) {
+    dim3 grid((M / BM) * (N / BN));
+    const size_t smem = 3 * G3_STAGE;
+    HC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16x_g3<NT>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((k_gemm_bf16x_g3<NT>), grid, dim3(512), smem, 0, A3, B3, C, M, N, K, (int64_t)N);
+    HC(hipDeviceSynchronize());
+    hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
+    HC(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL((k_gemm_bf16x_g3<NT>), grid, dim3(512), smem, 0, A3, B3, C, M, N, K, (int64_t)N);
+    HC(hipEventRecord(e1, 0));
+    HC(hipDeviceSynchronize());
+    float ms; HC(hipEventElapsedTime(&ms, e0, e1));
+    return 1e3f * ms / reps;
+}
+
 template <int NT>
 static float run_w8(const uint16_t* A3, const uint16_t* B3, float* C, int M, int N, int K, int reps) {
     dim3 grid((M / BM) * (N / BN));
@@ -370,6 +505,15 @@ static void bench(int M, int N, int K, const char* what) {
         for (size_t i = 0; i < hw.size(); ++i) bad += hw[i] != hc[i];
         printf("%-34s 8 waves, 2 LDS stages: x6 %7.2f us %6.1f TF-eq, x1 %7.2f us; %zu elements differ from the 4-wave result\n",
                "", w6, flop / w6 * 1e-6, run_w8<1>(A3, B3, C, M, N, K, 20), bad);
+    }
+    {
+        const float g6 = run_g3<6>(A3, B3, C, M, N, K, 20);
+        std::vector<float> hw((size_t)M * N);
+        HC(hipMemcpy(hw.data(), C, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t i = 0; i < hw.size(); ++i) bad += hw[i] != hc[i];
+        printf("%-34s LDS-DMA, 3 stages, 1 raw barrier: x6 %7.2f us %6.1f TF-eq, x1 %7.2f us; %zu elements differ from the 4-wave result\n",
+               "", g6, flop / g6 * 1e-6, run_g3<1>(A3, B3, C, M, N, K, 20), bad);
     }
     printf("%-34s %4dx%4dx%4d  x6 %7.2f us %6.1f TF-eq (loads sunk by the compiler: %7.2f us) | x3 %7.2f us | x1 (plain bf16) %7.2f us %6.1f TF | split A %6.2f us\n",
            what, M, N, K, t6, flop / t6 * 1e-6, t6l, t3, t1, flop / t1 * 1e-6, 1e3f * ms_split / 10);
