@@ -75,7 +75,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(const uint16_t* __restric
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
     const int tiles_n = N / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 — give every XCD a contiguous range of tiles
+    // (whole tile rows), so that an A panel is read by one XCD's L2 only
+    const int nwg = gridDim.x;
+    const int bid = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t planeA = (int64_t)M * K, planeB = (int64_t)N * K;
     // this thread's 12 chunks of a k tile: q = tid + 256 i, i < 6 (A) and the same for B
@@ -176,7 +180,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x_w8(const uint16_t* __rest
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 2, wn = w & 3;
     const int tiles_n = N / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 — give every XCD a contiguous range of tiles
+    // (whole tile rows), so that an A panel is read by one XCD's L2 only
+    const int nwg = gridDim.x;
+    const int bid = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t planeA = (int64_t)M * K, planeB = (int64_t)N * K;
     u32x4 ra[3], rb[3];
@@ -277,7 +285,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x_g3(const uint16_t* __rest
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 2, wn = w & 3;
     const int tiles_n = N / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 — give every XCD a contiguous range of tiles
+    // (whole tile rows), so that an A panel is read by one XCD's L2 only
+    const int nwg = gridDim.x;
+    const int bid = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t planeA = (int64_t)M * K, planeB = (int64_t)N * K;
     const int nk = K / BK;
