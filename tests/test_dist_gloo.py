@@ -100,3 +100,13 @@ def test_c5_shaped_dlrm_sharded_equals_the_oracle(tmp_path):
     np.testing.assert_allclose(z["losses"], z["ref_losses"], atol=1e-5)
     np.testing.assert_allclose(z["pred"], z["ref_pred"], atol=2e-5)
     assert float(z["wdiff"][0]) <= 1e-3 * 4 + 2e-5       # (Adam's eps-conditioning, see conftest)
+
+
+@pytest.mark.parametrize("case", ["deepfm_adam_clip", "dlrm_adam"])
+def test_eight_ranks_like_c5(case, tmp_path):
+    """BASELINE configs[4]'s world size (8 ranks, owner = row % 8): every rank owns an eighth of
+    every table and trains on an eighth of each golden batch — routing, caps and the global clip at
+    the world size the N = 8 line of the driver runs at."""
+    g = Golden(case)
+    z = run_workers(case, tmp_path, use_gpu=False, world=8)
+    check_against_golden(z, g)
