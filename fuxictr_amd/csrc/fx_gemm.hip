@@ -36,6 +36,7 @@ struct GemmArgs {
     float* ws;
     int32_t split_k;
     int32_t tiles_m, tiles_n;
+    int32_t edge_plain;          // M / N edge tiles run the unmasked k-loop bodies (fx_gemm_pipe_tile)
 #ifdef FX_GEMM_LAB
     unsigned long long* trace;   // scripts/ubench/gemm_lab.hip: 8 words per workgroup (timestamps)
 #endif
@@ -633,10 +634,16 @@ __device__ __forceinline__ void fx_gemm_pipe_tile(const GemmArgs& a, const int64
         // "loads in flight" states at the back edge and the compiler then waits vmcnt(0) there
         using P0 = std::integral_constant<int, 0>;
         using P1 = std::integral_constant<int, 1>;
-        const bool rows_full = (m0 + BM <= a.M) && (n0 + BN <= a.N);
         const int64_t nk_full = (kend - kbeg) / FX_BK;           // tiles with all 32 k inside
-        // plain bodies: tile t+1 (written to LDS) and tile t+2 (loaded) are full tiles
-        const int64_t n_plain = rows_full ? nk_full - 2 : 0;
+        // plain bodies: tile t+1 (written to LDS) and tile t+2 (loaded) have all 32 k inside.  Tiles on
+        // the M / N edge take them too (round 4; FX_GEMM_EDGE_PLAIN=0 restores the masked bodies): the
+        // rows past the edge are loaded from clamped, in-range addresses (voff is built from rc) and
+        // reach the MFMAs unmasked, but a row m >= M of A only ever feeds row m of C and a column
+        // n >= N of B only column n — neither is stored (nor is its row sum).  Only the K tail has to
+        // be zero.  624-wide operands (the 39 x 16 record): 10 % of the tiles of a launch were running
+        // the masked bodies for their whole K loop and ended the launch late.
+        const bool rows_full = (m0 + BM <= a.M) && (n0 + BN <= a.N);
+        const int64_t n_plain = (rows_full || a.edge_plain) ? nk_full - 2 : 0;
         int64_t t = 0;
         for (; t + 1 < n_plain; t += 2) {
             body(t, P0{}, std::false_type{});
@@ -1405,6 +1412,13 @@ static int fx_gemm_prepare(int32_t transa, int32_t transb, int64_t M, int64_t N,
     }
     a.tiles_m = (int32_t)fx_ceil_div(M, bm);
     a.tiles_n = (int32_t)fx_ceil_div(N, bn);
+    {
+        static const int edge_plain = []() {   // FX_GEMM_EDGE_PLAIN=0: masked bodies on edge tiles (A/B)
+            const char* e = getenv("FX_GEMM_EDGE_PLAIN");
+            return e ? atoi(e) : 1;
+        }();
+        a.edge_plain = edge_plain;
+    }
 #ifdef FX_GEMM_LAB
     a.trace = fx_gemm_lab_trace;
 #endif
