@@ -902,6 +902,45 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a) {
 }
 
 
+// The same sums on 16-byte vectors (N % 4 == 0, everything 16-byte aligned: fx_gemm_tr_ok): the slab loads
+// of a vector are issued together (SK <= 8 of them: the split rules' range) and added in slab order, so the
+// result is bit for bit k_splitk_reduce's.  4096 x 1024 x 1024's weight gradient (8 slabs of 4 MB): 7.4 us
+// -> round 4's A/B in profiles/.
+template <int SK>
+__global__ __launch_bounds__(256) void k_splitk_reduce_v4(GemmArgs a) {
+    const int64_t total = a.M * a.N, nv = total >> 2, n4 = a.N >> 2;
+    const int sk = SK > 0 ? SK : a.split_k;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        const float4* w = reinterpret_cast<const float4*>(a.ws) + i;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (SK > 0) {
+            float4 v[SK];
+#pragma unroll
+            for (int z = 0; z < SK; ++z) v[z] = w[(int64_t)z * nv];
+#pragma unroll
+            for (int z = 0; z < SK; ++z) { s.x += v[z].x; s.y += v[z].y; s.z += v[z].z; s.w += v[z].w; }
+        } else {
+            for (int z = 0; z < sk; ++z) {
+                const float4 v = w[(int64_t)z * nv];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        const int64_t m = i / n4, n = (i - m * n4) << 2;
+        FxEpiOps4 o;
+        fx_epi_load4(a.epi, m, n, o);
+        *reinterpret_cast<float4*>(a.C + m * a.ldc + n) = fx_epi_apply4(a.epi, s, m, n, o);
+    }
+    if (a.epi.rowsum) {
+        const float* rs = a.ws + (int64_t)sk * total;
+        for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < a.M;
+             m += (int64_t)gridDim.x * 256) {
+            float r = 0.f;
+            for (int z = 0; z < sk; ++z) r += rs[(int64_t)z * a.M + m];
+            a.epi.rowsum[m] = r;
+        }
+    }
+}
+
 // many slabs over a small output (skinny weight gradients with K = B*L): EL elements x 256/EL slab
 // lanes per workgroup, fixed LDS tree over the slab lanes (deterministic)
 template <int EL>
@@ -965,6 +1004,14 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_wide(GemmArgs a) {
     }
 }
 
+static int fx_splitk_v4_mode() {     // FX_SPLITK_V4=0: the 4-byte slab reduce (A/B runs)
+    static const int mode = []() {
+        const char* e = getenv("FX_SPLITK_V4");
+        return e ? atoi(e) : 1;
+    }();
+    return mode;
+}
+
 static void fx_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
     const int64_t total = a.M * a.N;
     if (a.split_k >= 32 && total <= 65536 && a.M <= 256) {
@@ -974,6 +1021,16 @@ static void fx_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
         else
             hipLaunchKernelGGL(k_splitk_reduce_wide<32>, dim3((unsigned)fx_ceil_div(total, 32)),
                                dim3(256), 0, s, a);
+    } else if (fx_splitk_v4_mode() && fx_gemm_tr_ok(a) && (total & 3) == 0) {
+        int64_t blocks = fx_ceil_div(total >> 2, 256);      // one vector per thread up to 4096 workgroups
+        if (blocks > 4096) blocks = 4096;
+        const dim3 g((unsigned)blocks), b(256);
+        switch (a.split_k) {
+            case 2: hipLaunchKernelGGL(k_splitk_reduce_v4<2>, g, b, 0, s, a); break;
+            case 4: hipLaunchKernelGGL(k_splitk_reduce_v4<4>, g, b, 0, s, a); break;
+            case 8: hipLaunchKernelGGL(k_splitk_reduce_v4<8>, g, b, 0, s, a); break;
+            default: hipLaunchKernelGGL(k_splitk_reduce_v4<0>, g, b, 0, s, a); break;
+        }
     } else {
         int64_t blocks = fx_ceil_div(total, 256);
         if (blocks > 2048) blocks = 2048;

@@ -53,9 +53,10 @@ np.savez(sys.argv[1], **out)
 """
 
 
-def _run(mode, tmp_path):
-    out = str(tmp_path / ("edge_%s.npz" % mode))
-    env = dict(os.environ, FX_GEMM_EDGE_PLAIN=mode)
+def _run(mode, tmp_path, var="FX_GEMM_EDGE_PLAIN"):
+    out = str(tmp_path / ("%s_%s.npz" % (var, mode)))
+    env = dict(os.environ)
+    env[var] = mode
     p = subprocess.run([sys.executable, "-c", SCRIPT % ROOT, out], env=env, capture_output=True, text=True,
                        timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -69,3 +70,12 @@ def test_body_selection_is_bit_identical(tmp_path):
         assert sorted(z.files) == sorted(base.files)
         for k in base.files:
             assert np.array_equal(z[k].view(np.uint32), base[k].view(np.uint32)), (mode, k)
+
+
+def test_vector_slab_reduce_is_bit_identical(tmp_path):
+    """k_splitk_reduce_v4 (16-byte loads, all slabs of a vector in flight) adds the slabs in the order of
+    the 4-byte kernel it replaces (FX_SPLITK_V4=0): weight gradients and bias gradients bit for bit."""
+    base = _run("0", tmp_path, var="FX_SPLITK_V4")
+    z = _run("1", tmp_path, var="FX_SPLITK_V4")
+    for k in base.files:
+        assert np.array_equal(z[k].view(np.uint32), base[k].view(np.uint32)), k
