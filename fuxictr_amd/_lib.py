@@ -111,6 +111,9 @@ SIGNATURES = {
     "fx_mask_mul": (i32, [vp, i64, vp, i64, vp, i64, i64, vp]),
     "fx_cross_bwd_prep": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, vp]),
     "fx_sigmoid_bce": (i32, [vp, vp, i64, vp, vp, vp, vp]),
+    "fx_head_train_workspace": (i64, [i64, i64]),
+    "fx_head_train": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i64, i32, C.c_float, vp, vp, vp, i64, vp, vp,
+                            vp, vp, vp]),
     "fx_din_concat_fwd": (i32, [vp, i64, vp, i64, i64, i64, i32, i32, vp, vp]),
     "fx_din_concat_bwd": (i32, [vp, vp, i64, vp, i64, i64, i64, i32, i32, vp, vp, i64, i64, i32, vp]),
     "fx_din_pool_fwd": (i32, [vp, vp, i64, vp, i64, i64, i64, i32, i32, vp, vp]),

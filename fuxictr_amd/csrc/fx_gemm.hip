@@ -920,7 +920,15 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_v4(GemmArgs a) {
 #pragma unroll
             for (int z = 0; z < SK; ++z) { s.x += v[z].x; s.y += v[z].y; s.z += v[z].z; s.w += v[z].w; }
         } else {
-            for (int z = 0; z < sk; ++z) {
+            int z = 0;
+            for (; z + 4 <= sk; z += 4) {          // four independent loads at a time, added in slab order
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = w[(int64_t)(z + u) * nv];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            }
+            for (; z < sk; ++z) {
                 const float4 v = w[(int64_t)z * nv];
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
@@ -935,7 +943,15 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_v4(GemmArgs a) {
         for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < a.M;
              m += (int64_t)gridDim.x * 256) {
             float r = 0.f;
-            for (int z = 0; z < sk; ++z) r += rs[(int64_t)z * a.M + m];
+            int z = 0;
+            for (; z + 8 <= sk; z += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = rs[(int64_t)(z + u) * a.M + m];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r += v[u];
+            }
+            for (; z < sk; ++z) r += rs[(int64_t)z * a.M + m];
             a.epi.rowsum[m] = r;
         }
     }
@@ -1029,6 +1045,7 @@ static void fx_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
             case 2: hipLaunchKernelGGL(k_splitk_reduce_v4<2>, g, b, 0, s, a); break;
             case 4: hipLaunchKernelGGL(k_splitk_reduce_v4<4>, g, b, 0, s, a); break;
             case 8: hipLaunchKernelGGL(k_splitk_reduce_v4<8>, g, b, 0, s, a); break;
+            case 16: hipLaunchKernelGGL(k_splitk_reduce_v4<16>, g, b, 0, s, a); break;   // (the DIN tower)
             default: hipLaunchKernelGGL(k_splitk_reduce_v4<0>, g, b, 0, s, a); break;
         }
     } else {
@@ -2128,6 +2145,208 @@ extern "C" int fx_sigmoid_bce(const float* logit, const float* y, int64_t B, flo
     FX_CHECK_ARG(y || (!loss && !dlogit), "fx_sigmoid_bce: loss/dlogit need labels");
     hipLaunchKernelGGL(k_sigmoid_bce, dim3(1), dim3(1024), 0, fx_hip_stream(stream), logit, y, B,
                        prob, loss, dlogit);
+    FX_CHECK_LAUNCH();
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The training step's last mile in one pass over the top hidden layer (round 4): the Linear(K -> 1)
+// head forward (+ the term added to the logit), sigmoid + BCE, and the head's backward — dlogit, the
+// input gradient dz[m, :] = dlogit[m] w[:] (with the ReLU mask of the hidden layer: h IS the mask) and
+// the slabs of dW = sum_m dlogit[m] h[m, :], db = sum_m dlogit[m], loss = mean_m bce_m.  It replaces
+// k_gemm_small_n_wide + k_sigmoid_bce + k_head_bwd_v4 (h streamed twice, three launch boundaries) by
+// one launch; k_head_reduce then adds the G slabs in a fixed order (deterministic) instead of
+// k_splitk_reduce_wide.  One wave per row, a lane holds the row's float4s k = 4 lane + 256 u (u < NU):
+// the dot product is k_gemm_small_n_wide's fmaf chain + fx_wave_sum, so the logit is bit for bit the
+// unfused forward's (evaluate / predict run that one); dlogit is k_sigmoid_bce's expression.
+// ---------------------------------------------------------------------------------------------
+struct HeadTrainArgs {
+    const float* h;       // [M, K] hidden activations (row stride ldh)
+    int64_t ldh;
+    const float* w;       // [K]
+    const float* bias;    // [1] or null
+    const float* add;     // [M] (stride ldadd) or null: added to the logit after the bias
+    int64_t ldadd;
+    const float* y;       // [M] labels
+    float* logit;         // [M]
+    float* dlogit;        // [M]
+    float* dz;            // [M, K] (row stride lddz) or null
+    int64_t lddz;
+    float* ws;            // [G, K] dW slabs | [G] db partials | [G] loss partials
+    int64_t M, K;
+    float root_scale;     // the root gradient of loss.backward() (1, or 1 / world when sharded)
+    int32_t use_mask;
+};
+
+template <int NU>
+__global__ __launch_bounds__(256) void k_head_train(HeadTrainArgs a) {
+    __shared__ float red[4][NU * 256];
+    __shared__ float red2[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t G = gridDim.x;
+    const float invB = 1.f / (float)a.M;
+    float4 wv[NU], acc[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int64_t k = (int64_t)lane * 4 + 256 * u;
+        wv[u] = k < a.K ? *reinterpret_cast<const float4*>(a.w + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float b0 = a.bias ? a.bias[0] : 0.f;
+    float dbs = 0.f, ls = 0.f;
+    for (int64_t m = (int64_t)blockIdx.x * 4 + wave; m < a.M; m += G * 4) {
+        const float* row = a.h + m * a.ldh;
+        float4 x[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int64_t k = (int64_t)lane * 4 + 256 * u;
+            x[u] = k < a.K ? *reinterpret_cast<const float4*>(row + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float t = a.y[m];
+        const float ad = a.add ? a.add[m * a.ldadd] : 0.f;
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if ((int64_t)lane * 4 + 256 * u < a.K) {      // (k_gemm_small_n_wide adds nothing past K either)
+                s = fmaf(x[u].x, wv[u].x, s);
+                s = fmaf(x[u].y, wv[u].y, s);
+                s = fmaf(x[u].z, wv[u].z, s);
+                s = fmaf(x[u].w, wv[u].w, s);
+            }
+        }
+        float z = fx_wave_sum(s);
+        if (a.bias) z += b0;
+        if (a.add) z += ad;
+        const float p = 1.f / (1.f + expf(-z));
+        const float lp = fmaxf(logf(p), -100.f);
+        const float lq = fmaxf(logf(1.f - p), -100.f);
+        ls += -(t * lp + (1.f - t) * lq);
+        const float dp = (p - t) / fmaxf((1.f - p) * p, 1e-12f) * invB;
+        float d = dp * ((1.f - p) * p);
+        if (a.root_scale != 1.f) d *= a.root_scale;
+        dbs += d;
+        if (lane == 0) {
+            a.logit[m] = z;
+            a.dlogit[m] = d;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int64_t k = (int64_t)lane * 4 + 256 * u;
+            acc[u].x = fmaf(d, x[u].x, acc[u].x);
+            acc[u].y = fmaf(d, x[u].y, acc[u].y);
+            acc[u].z = fmaf(d, x[u].z, acc[u].z);
+            acc[u].w = fmaf(d, x[u].w, acc[u].w);
+            if (a.dz && k < a.K) {
+                float4 o = make_float4(d * wv[u].x, d * wv[u].y, d * wv[u].z, d * wv[u].w);
+                if (a.use_mask) {
+                    o.x = x[u].x > 0.f ? o.x : 0.f;
+                    o.y = x[u].y > 0.f ? o.y : 0.f;
+                    o.z = x[u].z > 0.f ? o.z : 0.f;
+                    o.w = x[u].w > 0.f ? o.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(a.dz + m * a.lddz + k) = o;
+            }
+        }
+    }
+    // the four waves' partial sums, added in wave order
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+        *reinterpret_cast<float4*>(&red[wave][lane * 4 + 256 * u]) = acc[u];
+    if (lane == 0) {
+        red2[wave] = dbs;
+        red2[4 + wave] = ls;
+    }
+    __syncthreads();
+    for (int64_t k = threadIdx.x; k < a.K; k += 256)
+        a.ws[(int64_t)blockIdx.x * a.K + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    if (threadIdx.x == 0) {
+        a.ws[G * a.K + blockIdx.x] = ((red2[0] + red2[1]) + red2[2]) + red2[3];
+        a.ws[G * a.K + G + blockIdx.x] = ((red2[4] + red2[5]) + red2[6]) + red2[7];
+    }
+}
+
+// dW[k] = sum over the G slabs (8 elements x 32 slab lanes per workgroup, 8 loads in flight, fixed LDS
+// tree); workgroup 0 also adds the G db / loss partials (G <= 256: one per thread, fixed tree).
+__global__ __launch_bounds__(256) void k_head_reduce(const float* ws, int64_t G, int64_t K, float invB,
+                                                     float* dW, float* db, float* loss) {
+    __shared__ float red[256];
+    const int ii = threadIdx.x & 7, zi = threadIdx.x >> 3;
+    const int64_t k = (int64_t)blockIdx.x * 8 + ii;
+    float s = 0.f;
+    if (k < K) {
+        int64_t z = zi;
+        for (; z + 7 * 32 < G; z += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(z + u * 32) * K + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < G; z += 32) s += ws[z * K + k];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 16; h > 0; h >>= 1) {
+        if (zi < h) red[threadIdx.x] += red[threadIdx.x + h * 8];
+        __syncthreads();
+    }
+    if (zi == 0 && k < K) dW[k] = red[ii];
+    if (blockIdx.x == 0) {                       // block-uniform
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+            red[threadIdx.x] = (int64_t)threadIdx.x < G ? ws[G * K + which * G + threadIdx.x] : 0.f;
+            __syncthreads();
+            for (int h = 128; h > 0; h >>= 1) {
+                if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                if (which == 0) { if (db) db[0] = red[0]; }
+                else if (loss) loss[0] = red[0] * invB;
+            }
+        }
+    }
+}
+
+static int64_t fx_head_train_groups(int64_t M) {
+    int64_t g = fx_ceil_div(M, 4);
+    return g > 256 ? 256 : (g < 1 ? 1 : g);
+}
+
+extern "C" int64_t fx_head_train_workspace(int64_t M, int64_t K) {
+    return fx_head_train_groups(M) * (K + 2);
+}
+
+extern "C" int fx_head_train(const float* h, int64_t ldh, const float* w, const float* bias,
+                             const float* add, int64_t ldadd, const float* y, int64_t M, int64_t K,
+                             int32_t use_mask, float root_scale, float* logit, float* dlogit, float* dz,
+                             int64_t lddz, float* dW, float* db, float* loss, float* workspace,
+                             fx_stream_t stream) {
+    FX_CHECK_ARG(M > 0 && K > 0, "fx_head_train: M and K must be positive");
+    FX_CHECK_ARG(h && w && y && logit && dlogit && dW && workspace, "fx_head_train: null argument");
+    FX_CHECK_ARG(K % 4 == 0 && K <= 2048, "fx_head_train: K must be a multiple of 4 and <= 2048 (K=%lld)",
+                 (long long)K);
+    FX_CHECK_ARG(ldh % 4 == 0 && (reinterpret_cast<uintptr_t>(h) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+                 "fx_head_train: h / w / workspace must be 16-byte aligned, ldh %% 4 == 0");
+    FX_CHECK_ARG(!dz || (lddz % 4 == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0),
+                 "fx_head_train: dz must be 16-byte aligned, lddz %% 4 == 0");
+    HeadTrainArgs a;
+    a.h = h; a.ldh = ldh; a.w = w; a.bias = bias; a.add = add; a.ldadd = ldadd; a.y = y;
+    a.logit = logit; a.dlogit = dlogit; a.dz = dz; a.lddz = lddz; a.ws = workspace;
+    a.M = M; a.K = K; a.root_scale = root_scale; a.use_mask = use_mask;
+    const int64_t G = fx_head_train_groups(M);
+    hipStream_t s = fx_hip_stream(stream);
+    const dim3 grid((unsigned)G), block(256);
+    const int64_t nu = fx_ceil_div(K, 256);
+    if (nu <= 1) hipLaunchKernelGGL(k_head_train<1>, grid, block, 0, s, a);
+    else if (nu <= 2) hipLaunchKernelGGL(k_head_train<2>, grid, block, 0, s, a);
+    else if (nu <= 4) hipLaunchKernelGGL(k_head_train<4>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_head_train<8>, grid, block, 0, s, a);
+    FX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_head_reduce, dim3((unsigned)fx_ceil_div(K, 8)), block, 0, s, workspace, G, K,
+                       1.f / (float)M, dW, db, loss);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

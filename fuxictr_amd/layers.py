@@ -1686,14 +1686,45 @@ def _zero_cols(rows, cols, device):
     return z
 
 
+class _HeadCtx(object):
+    """The labels of ONE training step, announced by BaseModel._forward_backward before the forward pass
+    (rank_model.py:307-323 runs forward -> compute_loss -> backward; nothing in between needs the loss
+    value): a tower that ends in Linear(K -> 1) can then run its head forward, the sigmoid + BCE and the
+    head's backward in one pass over its top hidden layer (ops.head_train).  Whether that output really
+    was the model's logit is only known later: the loss (rank_model._bce_loss) takes the fused result if
+    it is handed exactly this logit tensor, the tower's backward takes the fused gradients if the gradient
+    it receives is exactly the fused dlogit — anything else (the logit went through more arithmetic: the
+    reference's `y_pred += mlp(...)`, DeepFM.py:86-87) falls back to the separate kernels, and the module
+    stops asking (`_fx_head_off`)."""
+    __slots__ = ("y", "root_scale", "root_ptr", "result")
+
+    def __init__(self, y, root_scale, root_ptr):
+        self.y = y if y.is_contiguous() else y.contiguous()
+        self.root_scale, self.root_ptr = root_scale, root_ptr
+        self.result = None            # (logit, dlogit, loss) of the last head that took the offer
+
+
+_HEAD_CTX = None
+_HEAD_FUSED = os.environ.get("FX_HEAD_FUSED", "1") != "0"
+
+
+def _head_offer(module, rows, out_features):
+    """The step's _HeadCtx if `module` (a tower ending in `out_features` == 1 over `rows` samples) may use it."""
+    hc = _HEAD_CTX
+    if hc is None or out_features != 1 or rows != hc.y.numel() or module.__dict__.get("_fx_head_off"):
+        return None
+    return hc, module
+
+
 class _MLPFn(torch.autograd.Function):
     """Whole Linear(+ReLU) stack as ONE autograd node: forward = one GEMM per layer with
     bias+ReLU in the epilogue; backward = dX GEMM with the ReLU mask of the layer below in its
     epilogue, split-K dW GEMM, column-sum db.  args = (x, acts, W0, b0, W1, b1, ...)."""
 
     @staticmethod
-    def forward(ctx, x, acts, out_add, dx_into, out_into, *wb):
-        """out_add: optional [B, N_last] tensor added to the last layer's output in its epilogue (DeepFM:
+    def forward(ctx, x, acts, out_add, dx_into, out_into, head, *wb):
+        """head: None or _head_offer()'s (step context, asking module) — see _HeadCtx.
+        out_add: optional [B, N_last] tensor added to the last layer's output in its epilogue (DeepFM:
         logit = fm + mlp, DeepFM.py:87 — one ATen add launch less); its gradient is dy.
         dx_into: optional callable -> a [B, K0] tensor (unit inner stride) the input's gradient is
         written into (DIN: the head of the gather record's gradient).
@@ -1718,6 +1749,7 @@ class _MLPFn(torch.autograd.Function):
             W0p = torch.cat([wb[0], _zero_cols(wb[0].shape[0], pad, x.device)], dim=1)
         hs = [x]
         h = x
+        ctx.head = None
         for i in range(n):
             W, b = wb[2 * i], wb[2 * i + 1]
             if i == 0 and W0p is not None:
@@ -1726,8 +1758,25 @@ class _MLPFn(torch.autograd.Function):
                 y = out_into
             else:
                 y = torch.empty(h.shape[0], W.shape[0], dtype=torch.float32, device=h.device)
-            ops.gemm(h, W, y, transa=False, transb=True, bias=b, act=1 if acts[i] else 0,
-                     add=out_add if (i == n - 1 and out_add is not None) else None)
+            if (i == n - 1 and head is not None and not acts[i] and out_into is None
+                    and not (n == 1 and (W0p is not None or dx_into is not None))
+                    and ops.head_train_ok(h, W, out_add)):
+                hc, asker = head
+                rows, K = h.shape
+                dlogit = torch.empty(rows, 1, dtype=torch.float32, device=h.device)
+                dzp = torch.empty(rows, K, dtype=torch.float32, device=h.device) \
+                    if (n > 1 or need_dx) else None
+                dW = torch.empty(1, K, dtype=torch.float32, device=h.device)
+                db = torch.empty(1, dtype=torch.float32, device=h.device) if b is not None else None
+                loss = torch.empty((), dtype=torch.float32, device=h.device)
+                ws = _Workspace.get(h.device, ops.head_train_workspace_floats(rows, K), tag=("head", K))
+                ops.head_train(h, W, b, out_add, hc.y, n > 1 and bool(acts[n - 2]), hc.root_scale, y,
+                               dlogit, dzp, dW, db, loss, ws)
+                ctx.head = (dlogit, dzp, dW, db, asker)
+                hc.result = (y, dlogit, loss)
+            else:
+                ops.gemm(h, W, y, transa=False, transb=True, bias=b, act=1 if acts[i] else 0,
+                         add=out_add if (i == n - 1 and out_add is not None) else None)
             hs.append(y)
             h = y
         ctx.has_add = out_add is not None
@@ -1743,15 +1792,32 @@ class _MLPFn(torch.autograd.Function):
     def backward(ctx, dy):
         acts, wb, hs = ctx.acts, ctx.wb, ctx.hs
         n = len(acts)
-        if acts[n - 1]:
-            # (a column slice of the gradient of the torch.cat that joins the towers is read in place)
-            dz = ops.mask_mul(dy if dy.stride(-1) == 1 else dy.contiguous(), hs[n],
-                              torch.empty_like(hs[n]))
-        else:
-            dz = dy.contiguous()
         grads = [None] * (2 * n)
         dx = None
-        for i in range(n - 1, -1, -1):
+        top = n - 1
+        fused_head = ctx.head
+        if fused_head is not None:
+            dlogit, dzp, dWh, dbh, asker = fused_head
+            if dy.data_ptr() == dlogit.data_ptr() and dy.numel() == dlogit.numel():
+                # the gradient that arrives IS the fused dlogit: the head's own gradients and the
+                # gradient below it were formed in the forward pass (ops.head_train)
+                grads[2 * top], grads[2 * top + 1] = dWh, dbh
+                if n == 1:
+                    return (dzp if ctx.need_dx else None, None, dy if ctx.has_add else None, None, None,
+                            None) + tuple(grads)
+                dz = dzp
+                top = n - 2
+            else:
+                asker.__dict__["_fx_head_off"] = True        # this tower's output is not the logit
+                fused_head = None
+        if fused_head is None:
+            if acts[n - 1]:
+                # (a column slice of the gradient of the torch.cat that joins the towers is read in place)
+                dz = ops.mask_mul(dy if dy.stride(-1) == 1 else dy.contiguous(), hs[n],
+                                  torch.empty_like(hs[n]))
+            else:
+                dz = dy.contiguous()
+        for i in range(top, -1, -1):
             W, b = wb[2 * i], wb[2 * i + 1]
             if i == 0 and ctx.W0p is not None:
                 W = ctx.W0p
@@ -1771,7 +1837,7 @@ class _MLPFn(torch.autograd.Function):
                 if dx is not None and not ctx.pre_padded:
                     dx = dx[:, :ctx.K0]
             grads[2 * i], grads[2 * i + 1] = dW, db
-        return (dx, None, dy if ctx.has_add else None, None, None) + tuple(grads)
+        return (dx, None, dy if ctx.has_add else None, None, None, None) + tuple(grads)
 
 
 class FxLinear(nn.Linear):
@@ -1783,7 +1849,9 @@ class FxLinear(nn.Linear):
         x2 = x.reshape(-1, x.shape[-1])
         fuse = out_add is not None and out_add.is_contiguous() \
             and out_add.shape == (x2.shape[0], self.out_features)
-        y = _MLPFn.apply(x2, (False,), out_add if fuse else None, None, None, self.weight, self.bias)
+        head = _head_offer(self, x2.shape[0], self.out_features) \
+            if (_HEAD_CTX is not None and (out_add is None or fuse)) else None
+        y = _MLPFn.apply(x2, (False,), out_add if fuse else None, None, None, head, self.weight, self.bias)
         y = y.reshape(*lead, self.out_features)
         return y + out_add if (out_add is not None and not fuse) else y
 
@@ -1970,8 +2038,15 @@ class MLP_Block(nn.Module):
             wb += [lin.weight, lin.bias]
         fuse_add = out_add is not None and not tail and not acts[-1] and out_add.is_contiguous() \
             and out_add.shape == (inputs.shape[0], stack[-1][0].weight.shape[0])
+        head = None
+        if _HEAD_CTX is not None and (out_add is None or fuse_add):
+            # (the reference's DIN keeps the output activation INSIDE the tower, DIN.py:77-84: a deferring
+            # FxSigmoid as the whole tail hands the logit on untouched)
+            if not tail or (len(tail) == 1 and type(tail[0]).__name__ == "FxSigmoid"
+                            and getattr(tail[0], "defer", False) and tail[0].training):
+                head = _head_offer(self, inputs.shape[0], stack[-1][0].weight.shape[0])
         out = _MLPFn.apply(inputs, acts, out_add if fuse_add else None, dx_into,
-                           out_into if not tail else None, *wb)
+                           out_into if not tail else None, head, *wb)
         for mod in tail:
             out = mod(out)
         if out_add is not None and not fuse_add:

@@ -165,9 +165,32 @@ class _SigmoidBCEFn(torch.autograd.Function):
         return dlogit * g, None
 
 
+class _FusedHeadLossFn(torch.autograd.Function):
+    """The loss of a step whose tower head already evaluated it (layers._HeadCtx, ops.head_train): forward
+    hands out that value, backward the dlogit formed with it (already times the root gradient the step
+    announced — any other root gradient is an error, the tower's gradients below were built on it)."""
+
+    @staticmethod
+    def forward(ctx, logit, dlogit, loss, root_ptr):
+        ctx.dlogit, ctx.root_ptr = dlogit, root_ptr
+        return loss.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        if g.data_ptr() != ctx.root_ptr:
+            raise RuntimeError("fused training head: loss.backward() got a root gradient other than the one "
+                               "BaseModel._forward_backward announced (set FX_HEAD_FUSED=0 for custom loops "
+                               "that scale the loss)")
+        return ctx.dlogit, None, None, None
+
+
 def _bce_loss(y_pred, y_true, reduction="mean"):
     logit = getattr(y_pred, "_fx_logit", None)
     if logit is not None and reduction == "mean":
+        hc = layers._HEAD_CTX
+        if hc is not None and hc.result is not None and hc.result[0].data_ptr() == logit.data_ptr() \
+                and hc.result[0].numel() == logit.numel() and hc.y.data_ptr() == y_true.data_ptr():
+            return _FusedHeadLossFn.apply(logit, hc.result[1].view(logit.shape), hc.result[2], hc.root_ptr)
         return _SigmoidBCEFn.apply(logit, y_true)
     if getattr(y_pred, "_fx_deferred", False):
         y_pred = torch.sigmoid(logit)
@@ -610,23 +633,27 @@ class BaseModel(nn.Module):
         act = self.output_activation
         fused = (isinstance(act, FxSigmoid) and self.loss_fn is _bce_loss
                  and type(self).add_loss is BaseModel.add_loss)
+        y_true = self.get_labels(batch_data)
+        # the root gradient of this step: 1, or 1 / world when the batch is one rank's share (global-batch
+        # mean = mean of the ranks' local means: scale, then SUM-reduce the gradients)
+        if self._dist is not None and self._dist.world > 1:
+            root, root_scale = _scaled_grad(y_true.device, self._dist.world), 1.0 / self._dist.world
+        else:
+            root, root_scale = _unit_grad(y_true.device), 1.0
         if fused:
             act.defer = True        # nobody reads the probabilities of a training step
+            if layers._HEAD_FUSED:
+                # the labels are known before the forward pass: a tower ending in Linear(K -> 1) may
+                # evaluate head + loss + head backward in one pass (layers._HeadCtx)
+                layers._HEAD_CTX = layers._HeadCtx(y_true, root_scale, root.data_ptr())
         try:
             return_dict = self.forward(batch_data)
+            loss = self.compute_loss(return_dict, y_true)
         finally:
             if fused:
                 act.defer = False
-        y_true = self.get_labels(batch_data)
-        loss = self.compute_loss(return_dict, y_true)
-        if self._dist is not None:
-            # global-batch mean = mean of the ranks' local means: scale, then SUM-reduce grads
-            if self._dist.world == 1:
-                loss.backward(gradient=_unit_grad(loss.device))
-            else:
-                loss.backward(gradient=_scaled_grad(loss.device, self._dist.world))
-        else:
-            loss.backward(gradient=_unit_grad(loss.device))
+                layers._HEAD_CTX = None
+        loss.backward(gradient=root)
         return loss
 
     def _step_body(self, batch_data):

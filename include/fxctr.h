@@ -452,6 +452,27 @@ int fx_sigmoid_bce(const float* logit, const float* y, int64_t B, float* prob, f
                    float* dlogit, fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The last mile of a binary-classification training step in one pass over the top hidden layer:
+ * BaseModel.train_step (rank_model.py:307-323) runs forward -> compute_loss -> loss.backward(); for a
+ * tower that ends in Linear(K -> 1) (MLP_Block's output layer, blocks/mlp_block.py:44-45; DCNv2's `fc`,
+ * DCNv2.py:100) whose output IS the logit, these are
+ *     logit[m]  = h[m, :] . w + bias (+ add[m])                       (the head's forward)
+ *     loss      = mean_m BCE(sigmoid(logit[m]), y[m])                 (fx_sigmoid_bce's formulas)
+ *     dlogit[m] = dloss/dlogit[m] * root_scale
+ *     dz[m, :]  = dlogit[m] * w[:]   (zeroed where h[m, :] <= 0 if use_mask: the ReLU below the head)
+ *     dW[:]     = sum_m dlogit[m] h[m, :],   db = sum_m dlogit[m]
+ * h: [M, K] row stride ldh; add: NULL or [M] with stride ldadd (DeepFM: the FM + first-order term);
+ * dz: NULL or [M, K] row stride lddz; K % 4 == 0, K <= 2048, 16-byte aligned rows.  The logit is bit for
+ * bit fx_gemm_f32's (transb, N = 1, bias + add epilogue), so training and evaluate see one function; the
+ * sums over m are taken in a fixed order (deterministic).  workspace: fx_head_train_workspace(M, K) floats.
+ * ------------------------------------------------------------------------------------------ */
+int64_t fx_head_train_workspace(int64_t M, int64_t K);
+int fx_head_train(const float* h, int64_t ldh, const float* w, const float* bias, const float* add,
+                  int64_t ldadd, const float* y, int64_t M, int64_t K, int32_t use_mask, float root_scale,
+                  float* logit, float* dlogit, float* dz, int64_t lddz, float* dW, float* db, float* loss,
+                  float* workspace, fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * DIN target attention (fuxictr/pytorch/layers/attentions/target_attention.py:66-92) and Dice
  * (fuxictr/pytorch/layers/activations.py:24-51).  The attention MLP itself runs on fx_gemm_f32;
  * these are the pieces around it.  q: [B,E] (row stride q_ld); K: [B,L,E] addressed as

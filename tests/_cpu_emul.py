@@ -446,6 +446,39 @@ def sigmoid_bce(logit, y, prob=None, loss=None, dlogit=None):
         dlogit.copy_((p - y) / torch.clamp((1 - p) * p, min=1e-12) / logit.numel() * (p * (1 - p)))
 
 
+def head_train_workspace_floats(M, K):
+    return min(256, max(1, -(-M // 4))) * (K + 2)
+
+
+def head_train_ok(h, W, out_add=None):
+    K = W.shape[1]
+    return (W.shape[0] == 1 and K % 4 == 0 and K <= 2048 and h.dim() == 2 and h.stride(1) == 1
+            and (out_add is None or (out_add.numel() == h.shape[0] and out_add.dim() <= 2)))
+
+
+def head_train(h, W, bias, out_add, y, use_mask, root_scale, logit, dlogit, dz, dW, db, loss, workspace):
+    M = h.shape[0]
+    z = h @ W.reshape(-1)
+    if bias is not None:
+        z = z + bias.reshape(())
+    if out_add is not None:
+        z = z + out_add.reshape(-1)
+    yv = y.reshape(-1)
+    p = torch.sigmoid(z)
+    loss.copy_(torch.nn.functional.binary_cross_entropy(p, yv))
+    d = (p - yv) / torch.clamp((1 - p) * p, min=1e-12) / M * (p * (1 - p))
+    if root_scale != 1.0:
+        d = d * root_scale
+    logit.reshape(-1).copy_(z)
+    dlogit.reshape(-1).copy_(d)
+    if dz is not None:
+        o = d[:, None] * W.reshape(1, -1)
+        dz.copy_(torch.where(h > 0, o, torch.zeros(())) if use_mask else o)
+    dW.copy_((d[:, None] * h).sum(0).reshape(dW.shape))
+    if db is not None:
+        db.copy_(d.sum().reshape(db.shape))
+
+
 def din_concat_fwd(q, K, out):
     B, L, E = K.shape
     t = q.unsqueeze(1).expand(-1, L, -1)
@@ -904,7 +937,7 @@ NAMES = ["new_scalars", "pack_columns", "emb_gather_fwd", "dedup_workspace_bytes
          "din_attn_workspace_floats", "din_attn_stats", "dice_stats_from_sums", "din_attn_fwd",
          "din_attn_bwd_sums", "din_attn_bwd", "gemm_dw_dx", "split_rows", "gemm_problem", "gemm_batch",
          "gemm_workspace_floats", "fill_grad_block", "owner_grad_reduce", "owner_grad_reduce_partials",
-         "owner_fetch_rows"]
+         "owner_fetch_rows", "head_train", "head_train_ok", "head_train_workspace_floats"]
 
 
 def install_plain():

@@ -42,7 +42,7 @@ def test_mlp_tower_pads_an_unaligned_input_width(emulated):
     W0, b0 = torch.randn(H1, K, generator=g) * 0.1, torch.randn(H1, generator=g)
     W1, b1 = torch.randn(H2, H1, generator=g) * 0.1, torch.randn(H2, generator=g)
     ps = [t.clone().requires_grad_(True) for t in (W0, b0, W1, b1)]
-    y = nat._MLPFn.apply(x, (True, False), None, None, None, *ps)
+    y = nat._MLPFn.apply(x, (True, False), None, None, None, None, *ps)
     gy = torch.randn(B, H2, generator=g)
     y.backward(gy)
     xr = x.detach().clone().requires_grad_(True)
