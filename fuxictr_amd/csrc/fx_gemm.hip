@@ -2152,7 +2152,8 @@ extern "C" int fx_sigmoid_bce(const float* logit, const float* y, int64_t B, flo
 // ---------------------------------------------------------------------------------------------
 // The training step's last mile in one pass over the top hidden layer (round 4): the Linear(K -> 1)
 // head forward (+ the term added to the logit), sigmoid + BCE, and the head's backward — dlogit, the
-// input gradient dz[m, :] = dlogit[m] w[:] (with the ReLU mask of the hidden layer: h IS the mask) and
+// input gradient dz[m, :] = dlogit[m] w[:] (with the ReLU mask of the hidden layer: h IS the mask; from a
+// column on when only the tail of h went through a ReLU — DCNv2's [cross | deep] head input) and
 // the slabs of dW = sum_m dlogit[m] h[m, :], db = sum_m dlogit[m], loss = mean_m bce_m.  It replaces
 // k_gemm_small_n_wide + k_sigmoid_bce + k_head_bwd_v4 (h streamed twice, three launch boundaries) by
 // one launch; k_head_reduce then adds the G slabs in a fixed order (deterministic) instead of
@@ -2175,7 +2176,7 @@ struct HeadTrainArgs {
     float* ws;            // [G, K] dW slabs | [G] db partials | [G] loss partials
     int64_t M, K;
     float root_scale;     // the root gradient of loss.backward() (1, or 1 / world when sharded)
-    int32_t use_mask;
+    int32_t mask_from;    // < 0: no mask; else dz[m, k] = 0 where h[m, k] <= 0 for k >= mask_from (4 | mask_from)
 };
 
 template <int NU>
@@ -2238,7 +2239,7 @@ __global__ __launch_bounds__(256) void k_head_train(HeadTrainArgs a) {
             acc[u].w = fmaf(d, x[u].w, acc[u].w);
             if (a.dz && k < a.K) {
                 float4 o = make_float4(d * wv[u].x, d * wv[u].y, d * wv[u].z, d * wv[u].w);
-                if (a.use_mask) {
+                if (a.mask_from >= 0 && k >= a.mask_from) {
                     o.x = x[u].x > 0.f ? o.x : 0.f;
                     o.y = x[u].y > 0.f ? o.y : 0.f;
                     o.z = x[u].z > 0.f ? o.z : 0.f;
@@ -2319,12 +2320,13 @@ extern "C" int64_t fx_head_train_workspace(int64_t M, int64_t K) {
 
 extern "C" int fx_head_train(const float* h, int64_t ldh, const float* w, const float* bias,
                              const float* add, int64_t ldadd, const float* y, int64_t M, int64_t K,
-                             int32_t use_mask, float root_scale, float* logit, float* dlogit, float* dz,
+                             int32_t mask_from, float root_scale, float* logit, float* dlogit, float* dz,
                              int64_t lddz, float* dW, float* db, float* loss, float* workspace,
                              fx_stream_t stream) {
     FX_CHECK_ARG(M > 0 && K > 0, "fx_head_train: M and K must be positive");
     FX_CHECK_ARG(h && w && y && logit && dlogit && dW && workspace, "fx_head_train: null argument");
-    FX_CHECK_ARG(K % 4 == 0 && K <= 2048, "fx_head_train: K must be a multiple of 4 and <= 2048 (K=%lld)",
+    // (K <= 8: fx_gemm_f32 takes its one-thread-per-output kernel there — another summation order)
+    FX_CHECK_ARG(K % 4 == 0 && K > 8 && K <= 2048, "fx_head_train: K must be a multiple of 4 in (8, 2048] (K=%lld)",
                  (long long)K);
     FX_CHECK_ARG(ldh % 4 == 0 && (reinterpret_cast<uintptr_t>(h) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
@@ -2335,7 +2337,8 @@ extern "C" int fx_head_train(const float* h, int64_t ldh, const float* w, const 
     HeadTrainArgs a;
     a.h = h; a.ldh = ldh; a.w = w; a.bias = bias; a.add = add; a.ldadd = ldadd; a.y = y;
     a.logit = logit; a.dlogit = dlogit; a.dz = dz; a.lddz = lddz; a.ws = workspace;
-    a.M = M; a.K = K; a.root_scale = root_scale; a.use_mask = use_mask;
+    FX_CHECK_ARG(mask_from < 0 || mask_from % 4 == 0, "fx_head_train: mask_from must be a multiple of 4");
+    a.M = M; a.K = K; a.root_scale = root_scale; a.mask_from = mask_from;
     const int64_t G = fx_head_train_groups(M);
     hipStream_t s = fx_hip_stream(stream);
     const dim3 grid((unsigned)G), block(256);

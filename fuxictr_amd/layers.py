@@ -1696,16 +1696,44 @@ class _HeadCtx(object):
     it receives is exactly the fused dlogit — anything else (the logit went through more arithmetic: the
     reference's `y_pred += mlp(...)`, DeepFM.py:86-87) falls back to the separate kernels, and the module
     stops asking (`_fx_head_off`)."""
-    __slots__ = ("y", "root_scale", "root_ptr", "result")
+    __slots__ = ("_y", "_labels", "root_scale", "root_ptr", "result")
 
-    def __init__(self, y, root_scale, root_ptr):
-        self.y = y if y.is_contiguous() else y.contiguous()
+    def __init__(self, labels, root_scale, root_ptr):
+        # `labels`: a callable, asked at the first offer — i.e. inside the towers, AFTER the model's
+        # get_inputs() staged this batch (BaseModel.get_labels reads the labels out of that staging buffer;
+        # before it they are the previous batch's)
+        self._labels, self._y = labels, None
         self.root_scale, self.root_ptr = root_scale, root_ptr
         self.result = None            # (logit, dlogit, loss) of the last head that took the offer
+
+    @property
+    def y(self):
+        if self._y is None:
+            y = self._labels()
+            self._y = y if y.is_contiguous() else y.contiguous()
+        return self._y
+
+    @property
+    def labels_taken(self):
+        return self._y
 
 
 _HEAD_CTX = None
 _HEAD_FUSED = os.environ.get("FX_HEAD_FUSED", "1") != "0"
+
+
+class _ReluNote(object):
+    """Left by a node whose output buffer is [plain | ReLU'd] columns (_CrossDeepFn: [cross | deep]) for the
+    head that reads that buffer: the fused head applies the ReLU mask of the columns >= `col` to the gradient
+    it hands back (`masked` is set when that gradient really is used), the node then skips its own
+    mask launch."""
+    __slots__ = ("col", "masked")
+
+    def __init__(self, col):
+        self.col, self.masked = col, False
+
+
+_RELU_NOTES = {}      # data_ptr of such a buffer -> _ReluNote, for the duration of one step's forward
 
 
 def _head_offer(module, rows, out_features):
@@ -1713,7 +1741,7 @@ def _head_offer(module, rows, out_features):
     hc = _HEAD_CTX
     if hc is None or out_features != 1 or rows != hc.y.numel() or module.__dict__.get("_fx_head_off"):
         return None
-    return hc, module
+    return hc, module, None
 
 
 class _MLPFn(torch.autograd.Function):
@@ -1761,8 +1789,13 @@ class _MLPFn(torch.autograd.Function):
             if (i == n - 1 and head is not None and not acts[i] and out_into is None
                     and not (n == 1 and (W0p is not None or dx_into is not None))
                     and ops.head_train_ok(h, W, out_add)):
-                hc, asker = head
+                hc, asker, note = head
                 rows, K = h.shape
+                if n > 1:
+                    mask_from, note = (0 if acts[n - 2] else -1), None
+                else:
+                    mask_from = note.col if (note is not None and note.col % 4 == 0) else -1
+                    note = note if mask_from >= 0 else None
                 dlogit = torch.empty(rows, 1, dtype=torch.float32, device=h.device)
                 dzp = torch.empty(rows, K, dtype=torch.float32, device=h.device) \
                     if (n > 1 or need_dx) else None
@@ -1770,9 +1803,8 @@ class _MLPFn(torch.autograd.Function):
                 db = torch.empty(1, dtype=torch.float32, device=h.device) if b is not None else None
                 loss = torch.empty((), dtype=torch.float32, device=h.device)
                 ws = _Workspace.get(h.device, ops.head_train_workspace_floats(rows, K), tag=("head", K))
-                ops.head_train(h, W, b, out_add, hc.y, n > 1 and bool(acts[n - 2]), hc.root_scale, y,
-                               dlogit, dzp, dW, db, loss, ws)
-                ctx.head = (dlogit, dzp, dW, db, asker)
+                ops.head_train(h, W, b, out_add, hc.y, mask_from, hc.root_scale, y, dlogit, dzp, dW, db, loss, ws)
+                ctx.head = (dlogit, dzp, dW, db, asker, note)
                 hc.result = (y, dlogit, loss)
             else:
                 ops.gemm(h, W, y, transa=False, transb=True, bias=b, act=1 if acts[i] else 0,
@@ -1797,11 +1829,17 @@ class _MLPFn(torch.autograd.Function):
         top = n - 1
         fused_head = ctx.head
         if fused_head is not None:
-            dlogit, dzp, dWh, dbh, asker = fused_head
+            dlogit, dzp, dWh, dbh, asker, note = fused_head
+            # (no second owner of dW / db: AccumulateGrad takes over a gradient it holds alone and
+            # CLONES one somebody else still references — two copy launches per step)
+            ctx.head = fused_head = None
+            fused_head = True
             if dy.data_ptr() == dlogit.data_ptr() and dy.numel() == dlogit.numel():
                 # the gradient that arrives IS the fused dlogit: the head's own gradients and the
                 # gradient below it were formed in the forward pass (ops.head_train)
                 grads[2 * top], grads[2 * top + 1] = dWh, dbh
+                if note is not None:
+                    note.masked = True            # dzp carries the ReLU mask of the producer's columns
                 if n == 1:
                     return (dzp if ctx.need_dx else None, None, dy if ctx.has_add else None, None, None,
                             None) + tuple(grads)
@@ -1851,6 +1889,10 @@ class FxLinear(nn.Linear):
             and out_add.shape == (x2.shape[0], self.out_features)
         head = _head_offer(self, x2.shape[0], self.out_features) \
             if (_HEAD_CTX is not None and (out_add is None or fuse)) else None
+        if head is not None and _RELU_NOTES:
+            note = _RELU_NOTES.pop(x2.data_ptr(), None)
+            if note is not None and x2.shape[1] > note.col and x2.is_contiguous():
+                head = (head[0], head[1], note)
         y = _MLPFn.apply(x2, (False,), out_add if fuse else None, None, None, head, self.weight, self.bias)
         y = y.reshape(*lead, self.out_features)
         return y + out_add if (out_add is not None and not fuse) else y
@@ -2575,8 +2617,12 @@ class _CrossDeepFn(torch.autograd.Function):
             ops.gemm_batch(probs)
         ctx.n_cross, ctx.acts, ctx.wb = n_cross, acts, wb
         ctx.xs, ctx.zs, ctx.hs, ctx.D0 = xs, zs, hs, D0
+        ctx.relu_note = None
         if ctx.two:
             return out[:, :D0], out[:, D0:]
+        if _HEAD_CTX is not None and acts[n_deep - 1]:
+            # a fused head that reads this buffer masks the deep columns of the gradient itself
+            ctx.relu_note = _RELU_NOTES[out.data_ptr()] = _ReluNote(D0)
         return out
 
     @staticmethod
@@ -2604,7 +2650,10 @@ class _CrossDeepFn(torch.autograd.Function):
                 dout = dout.contiguous()
             dxn = dout[:, :D0]                              # row-strided views, read in place
             ddeep = dout[:, D0:]
-        if acts[n_deep - 1]:
+        note = ctx.relu_note
+        if note is not None and note.masked and ddeep.stride(0) % 4 == 0 and ddeep.data_ptr() % 16 == 0:
+            dz = ddeep                  # masked by the head that produced it; read in place (row-strided)
+        elif acts[n_deep - 1]:
             dz = ops.mask_mul(ddeep, hs[n_deep], torch.empty_like(hs[n_deep]))
         else:
             dz = ddeep.contiguous()

@@ -682,20 +682,21 @@ def head_train_workspace_floats(M, K):
 def head_train_ok(h, W, out_add=None):
     """The shapes / alignments fx_head_train takes (else the caller keeps the three-kernel path)."""
     K = W.shape[1]
-    return (W.shape[0] == 1 and K % 4 == 0 and K <= 2048 and h.dim() == 2 and h.stride(1) == 1
+    return (W.shape[0] == 1 and K % 4 == 0 and 8 < K <= 2048 and h.dim() == 2 and h.stride(1) == 1
             and h.stride(0) % 4 == 0 and h.data_ptr() % 16 == 0 and W.is_contiguous()
             and W.data_ptr() % 16 == 0
             and (out_add is None or (out_add.numel() == h.shape[0] and out_add.dim() <= 2)))
 
 
 @_timed("head_train", "other")
-def head_train(h, W, bias, out_add, y, use_mask, root_scale, logit, dlogit, dz, dW, db, loss, workspace):
+def head_train(h, W, bias, out_add, y, mask_from, root_scale, logit, dlogit, dz, dW, db, loss, workspace):
     """Head forward + sigmoid / BCE + head backward in one pass (fx_head_train).  h: [M, K]; W: [1, K];
-    out_add / y / logit / dlogit: M elements; dz: [M, K] or None; dW: [1, K]; db: [1] or None; loss: []."""
+    out_add / y / logit / dlogit: M elements; dz: [M, K] or None; dW: [1, K]; db: [1] or None; loss: [];
+    mask_from: -1 no ReLU mask on dz, else the first masked column (0: all of them)."""
     M, K = h.shape
     check(_lib.load().fx_head_train(ptr(h), h.stride(0), ptr(W), ptr(bias), ptr(out_add),
                                     (out_add.stride(0) if out_add is not None else 0), ptr(y), M, K,
-                                    1 if use_mask else 0, float(root_scale), ptr(logit), ptr(dlogit), ptr(dz),
+                                    int(mask_from), float(root_scale), ptr(logit), ptr(dlogit), ptr(dz),
                                     (dz.stride(0) if dz is not None else 0), ptr(dW), ptr(db), ptr(loss),
                                     ptr(workspace), stream_ptr(h.device)), "fx_head_train")
 

@@ -633,26 +633,31 @@ class BaseModel(nn.Module):
         act = self.output_activation
         fused = (isinstance(act, FxSigmoid) and self.loss_fn is _bce_loss
                  and type(self).add_loss is BaseModel.add_loss)
-        y_true = self.get_labels(batch_data)
         # the root gradient of this step: 1, or 1 / world when the batch is one rank's share (global-batch
         # mean = mean of the ranks' local means: scale, then SUM-reduce the gradients)
         if self._dist is not None and self._dist.world > 1:
-            root, root_scale = _scaled_grad(y_true.device, self._dist.world), 1.0 / self._dist.world
+            root, root_scale = _scaled_grad(self.device, self._dist.world), 1.0 / self._dist.world
         else:
-            root, root_scale = _unit_grad(y_true.device), 1.0
+            root, root_scale = _unit_grad(self.device), 1.0
+        hc = None
         if fused:
             act.defer = True        # nobody reads the probabilities of a training step
             if layers._HEAD_FUSED:
-                # the labels are known before the forward pass: a tower ending in Linear(K -> 1) may
-                # evaluate head + loss + head backward in one pass (layers._HeadCtx)
-                layers._HEAD_CTX = layers._HeadCtx(y_true, root_scale, root.data_ptr())
+                # the labels are part of the batch: a tower ending in Linear(K -> 1) may evaluate head +
+                # loss + head backward in one pass (layers._HeadCtx; it asks for the labels when it gets
+                # there, after get_inputs() staged the batch)
+                hc = layers._HEAD_CTX = layers._HeadCtx(lambda: self.get_labels(batch_data), root_scale,
+                                                        root.data_ptr())
         try:
             return_dict = self.forward(batch_data)
+            y_true = hc.labels_taken if (hc is not None and hc.labels_taken is not None) \
+                else self.get_labels(batch_data)
             loss = self.compute_loss(return_dict, y_true)
         finally:
             if fused:
                 act.defer = False
                 layers._HEAD_CTX = None
+                layers._RELU_NOTES.clear()
         loss.backward(gradient=root)
         return loss
 

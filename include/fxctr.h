@@ -459,16 +459,17 @@ int fx_sigmoid_bce(const float* logit, const float* y, int64_t B, float* prob, f
  *     logit[m]  = h[m, :] . w + bias (+ add[m])                       (the head's forward)
  *     loss      = mean_m BCE(sigmoid(logit[m]), y[m])                 (fx_sigmoid_bce's formulas)
  *     dlogit[m] = dloss/dlogit[m] * root_scale
- *     dz[m, :]  = dlogit[m] * w[:]   (zeroed where h[m, :] <= 0 if use_mask: the ReLU below the head)
+ *     dz[m, k]  = dlogit[m] * w[k]   (zeroed where h[m, k] <= 0 for k >= mask_from: the ReLU below the head;
+ *                                     mask_from < 0: no mask, 0: every column, 624: DCNv2's [cross | deep] input)
  *     dW[:]     = sum_m dlogit[m] h[m, :],   db = sum_m dlogit[m]
  * h: [M, K] row stride ldh; add: NULL or [M] with stride ldadd (DeepFM: the FM + first-order term);
- * dz: NULL or [M, K] row stride lddz; K % 4 == 0, K <= 2048, 16-byte aligned rows.  The logit is bit for
+ * dz: NULL or [M, K] row stride lddz; K % 4 == 0, 8 < K <= 2048, 16-byte aligned rows.  The logit is bit for
  * bit fx_gemm_f32's (transb, N = 1, bias + add epilogue), so training and evaluate see one function; the
  * sums over m are taken in a fixed order (deterministic).  workspace: fx_head_train_workspace(M, K) floats.
  * ------------------------------------------------------------------------------------------ */
 int64_t fx_head_train_workspace(int64_t M, int64_t K);
 int fx_head_train(const float* h, int64_t ldh, const float* w, const float* bias, const float* add,
-                  int64_t ldadd, const float* y, int64_t M, int64_t K, int32_t use_mask, float root_scale,
+                  int64_t ldadd, const float* y, int64_t M, int64_t K, int32_t mask_from, float root_scale,
                   float* logit, float* dlogit, float* dz, int64_t lddz, float* dW, float* db, float* loss,
                   float* workspace, fx_stream_t stream);
 

@@ -452,11 +452,11 @@ def head_train_workspace_floats(M, K):
 
 def head_train_ok(h, W, out_add=None):
     K = W.shape[1]
-    return (W.shape[0] == 1 and K % 4 == 0 and K <= 2048 and h.dim() == 2 and h.stride(1) == 1
+    return (W.shape[0] == 1 and K % 4 == 0 and 8 < K <= 2048 and h.dim() == 2 and h.stride(1) == 1
             and (out_add is None or (out_add.numel() == h.shape[0] and out_add.dim() <= 2)))
 
 
-def head_train(h, W, bias, out_add, y, use_mask, root_scale, logit, dlogit, dz, dW, db, loss, workspace):
+def head_train(h, W, bias, out_add, y, mask_from, root_scale, logit, dlogit, dz, dW, db, loss, workspace):
     M = h.shape[0]
     z = h @ W.reshape(-1)
     if bias is not None:
@@ -473,7 +473,9 @@ def head_train(h, W, bias, out_add, y, use_mask, root_scale, logit, dlogit, dz, 
     dlogit.reshape(-1).copy_(d)
     if dz is not None:
         o = d[:, None] * W.reshape(1, -1)
-        dz.copy_(torch.where(h > 0, o, torch.zeros(())) if use_mask else o)
+        if mask_from >= 0:
+            o[:, mask_from:] = torch.where(h[:, mask_from:] > 0, o[:, mask_from:], torch.zeros(()))
+        dz.copy_(o)
     dW.copy_((d[:, None] * h).sum(0).reshape(dW.shape))
     if db is not None:
         db.copy_(d.sum().reshape(db.shape))

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
     (4096, 1648, False, False, True, 1.0),      # DCNv2's fc over [cross | deep]
     (4096, 64, True, False, True, 0.125),       # DIN's tower, one rank of eight
     (1000, 256, True, True, False, 1.0),
-    (37, 8, False, True, True, 0.5),
+    (37, 12, False, True, True, 0.5),
     (3, 2048, True, False, True, 1.0),
 ])
 def test_head_train_equals_the_three_kernels(M, K, mask, use_add, use_bias, scale):
@@ -44,7 +44,7 @@ def test_head_train_equals_the_three_kernels(M, K, mask, use_add, use_bias, scal
     loss = torch.empty((), device=dev)
     ws = torch.empty(ops.head_train_workspace_floats(M, K), device=dev)
     assert ops.head_train_ok(h, W, add)
-    ops.head_train(h, W, b, add, y, mask, scale, logit, dl, dz, dW, db, loss, ws)
+    ops.head_train(h, W, b, add, y, 0 if mask else -1, scale, logit, dl, dz, dW, db, loss, ws)
     torch.cuda.synchronize()
     assert torch.equal(logit, logit0)
     assert torch.equal(dl, dl0)
@@ -74,8 +74,33 @@ def test_head_train_without_input_gradient():
     logit, dl, dW = torch.empty(M, 1, device=dev), torch.empty(M, 1, device=dev), torch.empty(1, K, device=dev)
     loss = torch.empty((), device=dev)
     ws = torch.empty(ops.head_train_workspace_floats(M, K), device=dev)
-    ops.head_train(h, W, None, None, y, False, 1.0, logit, dl, None, dW, None, loss, ws)
+    ops.head_train(h, W, None, None, y, -1, 1.0, logit, dl, None, dW, None, loss, ws)
     torch.cuda.synchronize()
     ref = (dl.double() * h.double()).sum(0, keepdim=True)
     assert float((dW.double() - ref).abs().max()) <= 1e-5
     assert np.isfinite(float(loss.item()))
+
+
+def test_head_train_masks_from_a_column_on():
+    """DCNv2's head reads [cross | deep]: only the deep part went through a ReLU (mask_from = 624)."""
+    from fuxictr_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    M, K, D0 = 2048, 1648, 624
+    h = torch.randn(M, K, generator=g).to(dev)
+    h[:, D0:] = torch.relu(h[:, D0:])
+    W = (torch.randn(1, K, generator=g) / K ** 0.5).to(dev)
+    y = (torch.rand(M, 1, generator=g) > 0.5).float().to(dev)
+    outs = []
+    for mf in (-1, D0):
+        logit, dl = torch.empty(M, 1, device=dev), torch.empty(M, 1, device=dev)
+        dz, dW = torch.empty(M, K, device=dev), torch.empty(1, K, device=dev)
+        loss = torch.empty((), device=dev)
+        ws = torch.empty(ops.head_train_workspace_floats(M, K), device=dev)
+        ops.head_train(h, W, None, None, y, mf, 1.0, logit, dl, dz, dW, None, loss, ws)
+        outs.append((dz.clone(), dW.clone(), dl.clone()))
+    torch.cuda.synchronize()
+    (dz0, dW0, dl0), (dz1, dW1, dl1) = outs
+    assert torch.equal(dl0, dl1) and torch.equal(dW0, dW1)
+    assert torch.equal(dz1[:, :D0], dz0[:, :D0])
+    assert torch.equal(dz1[:, D0:], torch.where(h[:, D0:] > 0, dz0[:, D0:], torch.zeros((), device=dev)))

@@ -523,7 +523,7 @@ def test_a_head_whose_output_is_not_the_logit_falls_back(monkeypatch):
         for p_ in mlp.parameters():
             p_.grad = None
         x.grad = None
-        layers._HEAD_CTX = layers._HeadCtx(y, 1.0, 0) if offer else None
+        layers._HEAD_CTX = layers._HeadCtx(lambda: y, 1.0, 0) if offer else None
         try:
             out = mlp(x)
         finally:
@@ -539,3 +539,37 @@ def test_a_head_whose_output_is_not_the_logit_falls_back(monkeypatch):
     monkeypatch.setattr(layers.ops, "head_train", lambda *a, **k: calls.append(1))
     run(True)
     assert not calls
+
+
+def test_dcnv2_head_masks_the_deep_columns_itself(tmp_path, monkeypatch):
+    """zoo.DCNv2 `parallel`: the head reads the [cross | deep] buffer of layers._CrossDeepFn; the one-pass
+    head (ops.head_train, mask_from = width of the cross part) hands back a gradient whose deep columns
+    already carry the top ReLU's mask, so _CrossDeepFn.backward launches no ops.mask_mul of its own
+    (layers._ReluNote).  With FX_HEAD_FUSED off the launch is there."""
+    import fuxictr_amd.ops as real
+    from fuxictr_amd import layers
+    g = Golden("dcnv2_adam")
+    counts = {}
+    for fused in (True, False):
+        monkeypatch.setattr(layers, "_HEAD_FUSED", fused)
+        model = _build(g, tmp_path, monkeypatch)
+        calls = {"mask": 0, "from": []}
+        emul_mask, emul_head = real.mask_mul, real.head_train
+
+        def mask(*a, **k):
+            calls["mask"] += 1
+            return emul_mask(*a, **k)
+
+        def head(*a, **k):
+            calls["from"].append(a[5])
+            return emul_head(*a, **k)
+        monkeypatch.setattr(real, "mask_mul", mask)
+        monkeypatch.setattr(real, "head_train", head)
+        model.train()
+        losses = [float(model.train_step(tb(g.batches[i])).item()) for i in range(g.meta["steps"])]
+        np.testing.assert_allclose(losses, g.expect["loss"], rtol=0, atol=1e-4)
+        counts[fused] = (calls["mask"], list(calls["from"]))
+        monkeypatch.setattr(real, "mask_mul", emul_mask)
+        monkeypatch.setattr(real, "head_train", emul_head)
+    assert counts[True][0] == 0 and all(f > 0 for f in counts[True][1]), counts
+    assert counts[False][0] == g.meta["steps"] and not counts[False][1], counts
