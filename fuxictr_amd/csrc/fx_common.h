@@ -196,7 +196,8 @@ __device__ __forceinline__ void fx_tab_store(void* base, int bf16, int64_t off, 
 // A dense torch.optim.Adam moves a row that no batch touches: with g = 0, step j after `last` does
 //     m *= beta1 ; v *= beta2 ; p -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps),  t = last + j.
 // Its magnitude decays like (beta1/sqrt(beta2))^j ~ 0.9^j: after FX_REPLAY_MAX steps the remaining
-// terms are below fp32 resolution of the accumulated update; the tail only decays m and v.
+// terms are below fp32 resolution of the accumulated update; the tail only decays m and v — and the loop
+// leaves as soon as the steps have stopped moving this lane's elements (see below).
 // The loop body is the hot spot of the catch-up kernels (a wave runs as long as its coldest row: up
 // to 256 iterations), so it carries no sqrt and no true division: sqrt(v_j) = sqrt(v_0) sqrt(beta2)^j
 // is advanced by one multiply, the two bias corrections use v_rcp_f32 / v_rsq_f32 (1 ulp), the
@@ -208,13 +209,26 @@ template <int VEC>
 __device__ __forceinline__ void fx_adam_replay(float (&p)[VEC], float (&m)[VEC], float (&v)[VEC],
                                                int last, int k_steps, const fx_scalars& sc,
                                                double lb1, double lb2) {
-    const int kk = k_steps < FX_REPLAY_MAX ? k_steps : FX_REPLAY_MAX;
+    int kk = k_steps < FX_REPLAY_MAX ? k_steps : FX_REPLAY_MAX;
+    // (round 4) The steps that cannot move p are not replayed.  A row that never had a gradient (m = 0: most
+    // first touches of a large table) does not move at all.  Otherwise |u_j| shrinks by >= 8 % per step once
+    // t >= 32 (beta1 / sqrt(beta2), over the ratio of the bias corrections), so after 8 steps in which none of
+    // this lane's elements changed none will change again — the reference's own fp32 `p -= u_j` is a no-op from
+    // there on; m and v take the remaining decay in closed form, as they do past FX_REPLAY_MAX.  With every
+    // touched row 256 steps behind, the loop was 100 us of VALU work per DeepFM step at step 300 (bench.py
+    // --warmup 300: 1.068 ms against 0.973 at step 50, profiles/r04_gpu_visit_final_summary.txt).
+    bool moving = false;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) moving |= (m[k] != 0.f);
+    if (!moving) kk = 0;
+    int done = kk;
     float pw1 = (float)exp2(lb1 * (double)last);       // beta1^last
     float pw2 = (float)exp2(lb2 * (double)last);
     const float sb2 = sqrtf(sc.beta2);
     float r[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) r[k] = sqrtf(v[k]);
+    bool changed = false;
     for (int j = 0; j < kk; ++j) {
         pw1 *= sc.beta1;
         pw2 *= sc.beta2;
@@ -224,14 +238,23 @@ __device__ __forceinline__ void fx_adam_replay(float (&p)[VEC], float (&m)[VEC],
         for (int k = 0; k < VEC; ++k) {
             m[k] *= sc.beta1;
             r[k] *= sb2;
-            p[k] = fmaf(-ss * m[k], __builtin_amdgcn_rcpf(fmaf(r[k], ib, sc.eps)), p[k]);
+            const float pn = fmaf(-ss * m[k], __builtin_amdgcn_rcpf(fmaf(r[k], ib, sc.eps)), p[k]);
+            changed |= (pn != p[k]);
+            p[k] = pn;
+        }
+        if ((j & 7) == 7) {
+            if (!changed && last + j >= 32) {
+                done = j + 1;
+                break;
+            }
+            changed = false;
         }
     }
     const float f2 = (float)exp2(lb2 * (double)k_steps);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) v[k] *= f2;
-    if (k_steps > kk) {
-        const float f1 = (float)exp2(lb1 * (double)(k_steps - kk));
+    if (k_steps > done) {
+        const float f1 = (float)exp2(lb1 * (double)(k_steps - done));
 #pragma unroll
         for (int k = 0; k < VEC; ++k) m[k] *= f1;
     }

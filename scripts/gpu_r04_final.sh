@@ -25,7 +25,8 @@ print("driver settings:", round(d["value"]), d["ms_per_step"], "events", d.get("
 x = d.get("dcnv2") or {}
 print("dcnv2 block:", {k: x.get(k) for k in ("value", "ms_per_step", "kernel_sum_us", "wall_minus_kernel_sum_us")})
 PY
-echo "== steady state of the exact-mode catch-up (300 warm-up steps)" | tee -a $S
+echo "== steady state of the exact-mode catch-up (300 / 1000 warm-up steps)" | tee -a $S
+timeout 600 python bench.py --steps 50 --warmup 1000 --no-cpu-baseline --no-kernel-timing --no-dcnv2 2>/dev/null | head -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('warm-up 1000:', round(d['value']), d['ms_per_step'], d['step_us']['median'])" | tee -a $S
 timeout 600 python bench.py --steps 50 --warmup 300 --no-cpu-baseline --no-kernel-timing --no-dcnv2 2>/dev/null | head -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('warm-up 300:', round(d['value']), d['ms_per_step'], d['step_us'])" | tee -a $S
 echo "== rocprofv3 kernel trace of the default command" | tee -a $S
 rm -rf /tmp/prof_$TAG
@@ -59,5 +60,7 @@ rm -rf /tmp/prof_${TAG}_shard
     python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-dcnv2 > /dev/null 2> $OUT/prof_${TAG}_shard.err)
 TR=$(find /tmp/prof_${TAG}_shard -name '*kernel_trace.csv' | head -1)
 python scripts/step_timeline.py $TR 3 > $OUT/timeline_deepfm_shard1_$TAG.txt; echo "sharded $(tail -1 $OUT/timeline_deepfm_shard1_$TAG.txt)" | tee -a $S
+if [ -z "$SKIP_PMC" ]; then
 echo "== PMC traffic" | tee -a $S
 bash scripts/pmc_traffic.sh $TAG 2>&1 | tail -25 | cut -c1-200 | tee -a $S
+fi
