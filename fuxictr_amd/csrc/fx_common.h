@@ -205,6 +205,7 @@ __device__ __forceinline__ void fx_tab_store(void* base, int bf16, int64_t off, 
 // step-by-step fp32 sequence of the reference this differs by O(j * 6e-8) relative in terms that
 // have decayed by 0.9^j (tests: exact mode == dense Adam to 5e-6 over 330 steps).
 #define FX_REPLAY_MAX 256
+#define FX_REPLAY_WINDOW 16
 template <int VEC>
 __device__ __forceinline__ void fx_adam_replay(float (&p)[VEC], float (&m)[VEC], float (&v)[VEC],
                                                int last, int k_steps, const fx_scalars& sc,
@@ -212,7 +213,7 @@ __device__ __forceinline__ void fx_adam_replay(float (&p)[VEC], float (&m)[VEC],
     int kk = k_steps < FX_REPLAY_MAX ? k_steps : FX_REPLAY_MAX;
     // (round 4) The steps that cannot move p are not replayed.  A row that never had a gradient (m = 0: most
     // first touches of a large table) does not move at all.  Otherwise |u_j| shrinks by >= 8 % per step once
-    // t >= 32 (beta1 / sqrt(beta2), over the ratio of the bias corrections), so after 8 steps in which none of
+    // t >= 32 (beta1 / sqrt(beta2), over the ratio of the bias corrections), so after a window of steps in which none of
     // this lane's elements changed none will change again — the reference's own fp32 `p -= u_j` is a no-op from
     // there on; m and v take the remaining decay in closed form, as they do past FX_REPLAY_MAX.  With every
     // touched row 256 steps behind, the loop was 100 us of VALU work per DeepFM step at step 300 (bench.py
@@ -228,26 +229,34 @@ __device__ __forceinline__ void fx_adam_replay(float (&p)[VEC], float (&m)[VEC],
     float r[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) r[k] = sqrtf(v[k]);
-    bool changed = false;
-    for (int j = 0; j < kk; ++j) {
-        pw1 *= sc.beta1;
-        pw2 *= sc.beta2;
-        const float ss = sc.lr * __builtin_amdgcn_rcpf(1.f - pw1);     // lr / (1 - beta1^t)
-        const float ib = __builtin_amdgcn_rsqf(1.f - pw2);              // 1 / sqrt(1 - beta2^t)
+    // (windows of FX_REPLAY_WINDOW steps; the test sits between them, the step loop itself has no exit: p at the
+    // window's start is compared once per window — every step moves an element the same way, the sign of m, so
+    // "equal after a window" is "never moved".  The window test costs ~25 instructions: 16 steps per window
+    // keep it at 5 % of the loop; with 8 the first 100 steps of a run — nobody is far enough behind to leave
+    // early — paid 4 us per step for it, profiles/r04_gpu_visit_final4_summary.txt.)
+    for (int j = 0; j < kk;) {
+        const int jend = j + FX_REPLAY_WINDOW < kk ? j + FX_REPLAY_WINDOW : kk;
+        float p0[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            m[k] *= sc.beta1;
-            r[k] *= sb2;
-            const float pn = fmaf(-ss * m[k], __builtin_amdgcn_rcpf(fmaf(r[k], ib, sc.eps)), p[k]);
-            changed |= (pn != p[k]);
-            p[k] = pn;
-        }
-        if ((j & 7) == 7) {
-            if (!changed && last + j >= 32) {
-                done = j + 1;
-                break;
+        for (int k = 0; k < VEC; ++k) p0[k] = p[k];
+        for (; j < jend; ++j) {
+            pw1 *= sc.beta1;
+            pw2 *= sc.beta2;
+            const float ss = sc.lr * __builtin_amdgcn_rcpf(1.f - pw1);     // lr / (1 - beta1^t)
+            const float ib = __builtin_amdgcn_rsqf(1.f - pw2);              // 1 / sqrt(1 - beta2^t)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                m[k] *= sc.beta1;
+                r[k] *= sb2;
+                p[k] = fmaf(-ss * m[k], __builtin_amdgcn_rcpf(fmaf(r[k], ib, sc.eps)), p[k]);
             }
-            changed = false;
+        }
+        bool changed = false;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) changed |= (p[k] != p0[k]);
+        if (!changed && last + j > 32 && j < kk) {
+            done = j;
+            break;
         }
     }
     const float f2 = (float)exp2(lb2 * (double)k_steps);
