@@ -1725,12 +1725,13 @@ _HEAD_FUSED = os.environ.get("FX_HEAD_FUSED", "1") != "0"
 class _ReluNote(object):
     """Left by a node whose output buffer is [plain | ReLU'd] columns (_CrossDeepFn: [cross | deep]) for the
     head that reads that buffer: the fused head applies the ReLU mask of the columns >= `col` to the gradient
-    it hands back (`masked` is set when that gradient really is used), the node then skips its own
-    mask launch."""
-    __slots__ = ("col", "masked")
+    it hands back (`masked_ptr`: that gradient tensor, set when it really is used); the node skips its own
+    mask launch if the gradient it receives is that very tensor — a sum with some other consumer's gradient
+    is a new tensor and is masked as always (the mask is idempotent)."""
+    __slots__ = ("col", "masked_ptr")
 
     def __init__(self, col):
-        self.col, self.masked = col, False
+        self.col, self.masked_ptr = col, None
 
 
 _RELU_NOTES = {}      # data_ptr of such a buffer -> _ReluNote, for the duration of one step's forward
@@ -1827,19 +1828,19 @@ class _MLPFn(torch.autograd.Function):
         grads = [None] * (2 * n)
         dx = None
         top = n - 1
-        fused_head = ctx.head
-        if fused_head is not None:
-            dlogit, dzp, dWh, dbh, asker, note = fused_head
+        head_used = False
+        if ctx.head is not None:
+            dlogit, dzp, dWh, dbh, asker, note = ctx.head
             # (no second owner of dW / db: AccumulateGrad takes over a gradient it holds alone and
             # CLONES one somebody else still references — two copy launches per step)
-            ctx.head = fused_head = None
-            fused_head = True
+            ctx.head = None
             if dy.data_ptr() == dlogit.data_ptr() and dy.numel() == dlogit.numel():
                 # the gradient that arrives IS the fused dlogit: the head's own gradients and the
                 # gradient below it were formed in the forward pass (ops.head_train)
+                head_used = True
                 grads[2 * top], grads[2 * top + 1] = dWh, dbh
-                if note is not None:
-                    note.masked = True            # dzp carries the ReLU mask of the producer's columns
+                if note is not None and dzp is not None:
+                    note.masked_ptr = dzp.data_ptr()   # THIS tensor carries the producer's ReLU mask
                 if n == 1:
                     return (dzp if ctx.need_dx else None, None, dy if ctx.has_add else None, None, None,
                             None) + tuple(grads)
@@ -1847,8 +1848,7 @@ class _MLPFn(torch.autograd.Function):
                 top = n - 2
             else:
                 asker.__dict__["_fx_head_off"] = True        # this tower's output is not the logit
-                fused_head = None
-        if fused_head is None:
+        if not head_used:
             if acts[n - 1]:
                 # (a column slice of the gradient of the torch.cat that joins the towers is read in place)
                 dz = ops.mask_mul(dy if dy.stride(-1) == 1 else dy.contiguous(), hs[n],
@@ -2651,7 +2651,9 @@ class _CrossDeepFn(torch.autograd.Function):
             dxn = dout[:, :D0]                              # row-strided views, read in place
             ddeep = dout[:, D0:]
         note = ctx.relu_note
-        if note is not None and note.masked and ddeep.stride(0) % 4 == 0 and ddeep.data_ptr() % 16 == 0:
+        if (note is not None and note.masked_ptr is not None and not ctx.two
+                and douts[0].data_ptr() == note.masked_ptr
+                and ddeep.stride(0) % 4 == 0 and ddeep.data_ptr() % 16 == 0):
             dz = ddeep                  # masked by the head that produced it; read in place (row-strided)
         elif acts[n_deep - 1]:
             dz = ops.mask_mul(ddeep, hs[n_deep], torch.empty_like(hs[n_deep]))

@@ -573,3 +573,55 @@ def test_dcnv2_head_masks_the_deep_columns_itself(tmp_path, monkeypatch):
         monkeypatch.setattr(real, "head_train", emul_head)
     assert counts[True][0] == 0 and all(f > 0 for f in counts[True][1]), counts
     assert counts[False][0] == g.meta["steps"] and not counts[False][1], counts
+
+
+def test_relu_note_is_ignored_when_the_buffer_has_a_second_consumer(monkeypatch):
+    """layers._ReluNote: the [cross | deep] node skips its own ReLU-mask launch only when the gradient it
+    receives is the very tensor the fused head produced.  With a second consumer of the buffer autograd hands it
+    the SUM of two gradients (a new tensor): the mask launch runs and the gradients equal the unfused ones."""
+    _cpu_emul.install(monkeypatch)
+    from fuxictr_amd import layers
+    import fuxictr_amd.rank_model as rm
+    import fuxictr_amd.ops as real
+    gen = torch.Generator().manual_seed(11)
+    B, D0, H = 16, 8, 12
+    x0 = torch.randn(B, D0, generator=gen, requires_grad=True)
+    Wc, bc = torch.randn(D0, D0, generator=gen, requires_grad=True), torch.randn(D0, generator=gen, requires_grad=True)
+    Wd, bd = torch.randn(H, D0, generator=gen, requires_grad=True), torch.randn(H, generator=gen, requires_grad=True)
+    fc = layers.FxLinear(D0 + H, 1)
+    y = (torch.rand(B, 1, generator=gen) > 0.5).float()
+    c = torch.randn(B, D0 + H, generator=gen)
+    leaves = [x0, Wc, bc, Wd, bd, fc.weight, fc.bias]
+    unit = rm._unit_grad(torch.device("cpu"))
+    masks = []
+    emul_mask = real.mask_mul
+    monkeypatch.setattr(real, "mask_mul", lambda *a, **k: (masks.append(1), emul_mask(*a, **k))[1])
+
+    def run(offer, second_consumer):
+        for t in leaves:
+            t.grad = None
+        del masks[:]
+        layers._HEAD_CTX = layers._HeadCtx(lambda: y, 1.0, unit.data_ptr()) if offer else None
+        try:
+            out = layers._CrossDeepFn.apply(x0, 1, (True,), Wc, bc, Wd, bd)
+            logit = fc(out)
+            pred = logit.view_as(logit)
+            pred._fx_logit = logit
+            loss = rm._bce_loss(pred, y)
+        finally:
+            layers._HEAD_CTX = None
+            layers._RELU_NOTES.clear()
+        if second_consumer:
+            loss = loss + (out * c).sum()
+        loss.backward(gradient=unit)        # (the root gradient the step announced; an add hands it on as it is)
+        return [t.grad.clone() for t in leaves], len(masks)
+    ref2, n_ref2 = run(False, True)
+    got2, n_got2 = run(True, True)
+    assert n_ref2 == 1 and n_got2 == 1                 # the node masked the summed gradient itself
+    for a_, b_ in zip(got2, ref2):
+        assert torch.allclose(a_, b_, atol=1e-6, rtol=1e-6)
+    ref1, n_ref1 = run(False, False)
+    got1, n_got1 = run(True, False)
+    assert n_ref1 == 1 and n_got1 == 0                 # sole consumer: the head's gradient is read in place
+    for a_, b_ in zip(got1, ref1):
+        assert torch.allclose(a_, b_, atol=1e-6, rtol=1e-6)
