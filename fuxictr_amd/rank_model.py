@@ -756,14 +756,21 @@ class BaseModel(nn.Module):
     def train_epoch(self, data_generator):
         """rank_model.py:325-348."""
         self.train()
-        window_loss, self._batch_index = 0.0, 0
+        # The reference adds `loss.item()` to a running sum every step (rank_model.py:333): a host round
+        # trip that drains the device before the next batch is even staged.  The sum is only ever LOGGED
+        # (every eval_steps), so it is kept on the device (float64, one tiny add behind each step) and
+        # read when it is printed; the host runs a step ahead of the GPU in between.
+        window_loss, self._batch_index = None, 0
         for self._batch_index, batch in enumerate(self._progress(data_generator)):
-            window_loss += self.train_step(batch).item()
+            loss = self.train_step(batch)
+            if window_loss is None:
+                window_loss = torch.zeros((), dtype=torch.float64, device=loss.device)
+            window_loss.add_(loss.detach())
             self._total_steps += 1
             if self._total_steps % self._eval_steps == 0:
                 logging.info("mean train loss over the last %d steps: %.6f", self._eval_steps,
-                             window_loss / self._eval_steps)
-                window_loss = 0.0
+                             float(window_loss.item()) / self._eval_steps)
+                window_loss.zero_()
                 self.eval_step()
             if self._stop_training:
                 break
