@@ -1704,7 +1704,7 @@ class _HeadCtx(object):
         # before it they are the previous batch's)
         self._labels, self._y = labels, None
         self.root_scale, self.root_ptr = root_scale, root_ptr
-        self.result = None            # (logit, dlogit, loss) of the last head that took the offer
+        self.result = None            # (logit, dlogit, loss, logit._version) of the last head that took the offer
 
     @property
     def y(self):
@@ -1805,8 +1805,11 @@ class _MLPFn(torch.autograd.Function):
                 loss = torch.empty((), dtype=torch.float32, device=h.device)
                 ws = _Workspace.get(h.device, ops.head_train_workspace_floats(rows, K), tag=("head", K))
                 ops.head_train(h, W, b, out_add, hc.y, mask_from, hc.root_scale, y, dlogit, dzp, dW, db, loss, ws)
-                ctx.head = (dlogit, dzp, dW, db, asker, note)
-                hc.result = (y, dlogit, loss)
+                # (the logit's version counter: a model that goes on to modify it IN PLACE — AutoInt.py:112-116
+                # `y_pred += self.lr_layer(X)` — hands the loss the same storage with another value; views share
+                # the counter with their base)
+                ctx.head = (dlogit, dzp, dW, db, asker, note, y, y._version)
+                hc.result = (y, dlogit, loss, y._version)
             else:
                 ops.gemm(h, W, y, transa=False, transb=True, bias=b, act=1 if acts[i] else 0,
                          add=out_add if (i == n - 1 and out_add is not None) else None)
@@ -1830,11 +1833,12 @@ class _MLPFn(torch.autograd.Function):
         top = n - 1
         head_used = False
         if ctx.head is not None:
-            dlogit, dzp, dWh, dbh, asker, note = ctx.head
+            dlogit, dzp, dWh, dbh, asker, note, y_head, y_ver = ctx.head
             # (no second owner of dW / db: AccumulateGrad takes over a gradient it holds alone and
             # CLONES one somebody else still references — two copy launches per step)
             ctx.head = None
-            if dy.data_ptr() == dlogit.data_ptr() and dy.numel() == dlogit.numel():
+            if (dy.data_ptr() == dlogit.data_ptr() and dy.numel() == dlogit.numel()
+                    and y_head._version == y_ver):
                 # the gradient that arrives IS the fused dlogit: the head's own gradients and the
                 # gradient below it were formed in the forward pass (ops.head_train)
                 head_used = True

@@ -188,8 +188,11 @@ def _bce_loss(y_pred, y_true, reduction="mean"):
     logit = getattr(y_pred, "_fx_logit", None)
     if logit is not None and reduction == "mean":
         hc = layers._HEAD_CTX
+        # (same storage AND same version: a logit that was modified in place after the head ran — the
+        # reference's AutoInt / DESTINE `y_pred += ...` — is not the value the fused loss was formed on)
         if hc is not None and hc.result is not None and hc.result[0].data_ptr() == logit.data_ptr() \
-                and hc.result[0].numel() == logit.numel() and hc.y.data_ptr() == y_true.data_ptr():
+                and hc.result[0].numel() == logit.numel() and hc.y.data_ptr() == y_true.data_ptr() \
+                and logit._version == hc.result[3] and hc.result[0]._version == hc.result[3]:
             return _FusedHeadLossFn.apply(logit, hc.result[1].view(logit.shape), hc.result[2], hc.root_ptr)
         return _SigmoidBCEFn.apply(logit, y_true)
     if getattr(y_pred, "_fx_deferred", False):
