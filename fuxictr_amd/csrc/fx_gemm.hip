@@ -14,89 +14,9 @@
 //   global->register prefetch of tile t+1 is issued before the MFMAs of tile t;
 //   blockIdx is remapped so the 8 n-tiles that share one A row-panel run on the same XCD (L2).
 #include "fx_common.h"
+#include "fx_gemm_int.h"
 
 #include <stdlib.h>
-
-#include <type_traits>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define FX_BK 32
-
-struct GemmArgs {
-    const float* A;
-    int64_t lda;
-    const float* B;
-    int64_t ldb;
-    float* C;
-    int64_t ldc;
-    int64_t M, N, K;
-    int64_t k_chunk;
-    fx_gemm_epilogue epi;
-    float* ws;
-    int32_t split_k;
-    int32_t tiles_m, tiles_n;
-    int32_t edge_plain;          // M / N edge tiles run the unmasked k-loop bodies (fx_gemm_pipe_tile)
-#ifdef FX_GEMM_LAB
-    unsigned long long* trace;   // scripts/ubench/gemm_lab.hip: 8 words per workgroup (timestamps)
-#endif
-};
-
-#ifdef FX_GEMM_LAB
-unsigned long long* fx_gemm_lab_trace = nullptr;   // set by the lab before a traced launch
-#define FX_LAB_STAMP(slot)                                                                    \
-    do {                                                                                      \
-        if (a.trace && threadIdx.x == 0)                                                      \
-            a.trace[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
-    } while (0)
-#else
-#define FX_LAB_STAMP(slot) do {} while (0)
-#endif
-
-__device__ __forceinline__ float fx_epilogue(const fx_gemm_epilogue& e, float z, int64_t m,
-                                             int64_t n) {
-    if (e.bias) z += e.bias[n];
-    if (e.zout) e.zout[m * e.ldz + n] = z;
-    if (e.act == 1) z = fmaxf(z, 0.f);
-    if (e.mul) z *= e.mul[m * e.ldmul + n];
-    if (e.mask) z = e.mask[m * e.ldmask + n] > 0.f ? z : 0.f;
-    if (e.add) z += e.add[m * e.ldadd + n];
-    return z;
-}
-
-// The same epilogue for 4 adjacent columns n .. n+3 of one row (every operand 16-byte aligned: checked
-// by the launcher), in two halves: the operand LOADS of a 32x32 accumulator tile are issued together,
-// one tile ahead of the arithmetic and the stores.  (Written as load -> use -> store per vector, each
-// of a lane's 16 vectors paid its own memory round trip — the compiler may not move a load above a
-// store to memory it cannot prove distinct: +6.7 us on a 128x128 tile with bias + ReLU.)  Element for
-// element the operation order of fx_epilogue.
-struct FxEpiOps4 {
-    float4 bias, mul, mask, add;
-};
-
-__device__ __forceinline__ void fx_epi_load4(const fx_gemm_epilogue& e, int64_t m, int64_t n,
-                                             FxEpiOps4& o) {
-    if (e.bias) o.bias = *reinterpret_cast<const float4*>(e.bias + n);
-    if (e.mul) o.mul = *reinterpret_cast<const float4*>(e.mul + m * e.ldmul + n);
-    if (e.mask) o.mask = *reinterpret_cast<const float4*>(e.mask + m * e.ldmask + n);
-    if (e.add) o.add = *reinterpret_cast<const float4*>(e.add + m * e.ldadd + n);
-}
-
-__device__ __forceinline__ float4 fx_epi_apply4(const fx_gemm_epilogue& e, float4 z, int64_t m,
-                                                int64_t n, const FxEpiOps4& o) {
-    if (e.bias) { z.x += o.bias.x; z.y += o.bias.y; z.z += o.bias.z; z.w += o.bias.w; }
-    if (e.zout) *reinterpret_cast<float4*>(e.zout + m * e.ldz + n) = z;
-    if (e.act == 1) {
-        z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f);
-    }
-    if (e.mul) { z.x *= o.mul.x; z.y *= o.mul.y; z.z *= o.mul.z; z.w *= o.mul.w; }
-    if (e.mask) {
-        z.x = o.mask.x > 0.f ? z.x : 0.f; z.y = o.mask.y > 0.f ? z.y : 0.f;
-        z.z = o.mask.z > 0.f ? z.z : 0.f; z.w = o.mask.w > 0.f ? z.w : 0.f;
-    }
-    if (e.add) { z.x += o.add.x; z.y += o.add.y; z.z += o.add.z; z.w += o.add.w; }
-    return z;
-}
 
 // Operand tile loader for an R x 32 tile (R = 64 or 128 rows of the non-contracted dimension).
 // KC: element (r,k) at P[r*ld + k] (k contiguous) else at P[k*ld + r] (r contiguous).
@@ -436,14 +356,6 @@ struct PipeLoader {
         }
     }
 };
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void fx_static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        fx_static_for<I + 1, N>(f);
-    }
-}
 
 template <int BM, int BN, bool A_KC, bool B_KC>
 struct PipeSmem {
@@ -785,14 +697,6 @@ void k_gemm_f32_pair(GemmArgs a1, GemmArgs a2) {
 // three more of the same — the dW and dX products of a layer (and, for DCNv2's parallel structure, the
 // cross and the deep layer of the same depth) fill each other's prologue / epilogue gaps.
 // cfg bit 0: A k-contiguous, bit 1: B k-contiguous, bit 2: 128x64 tile (else 128x128).
-#define FX_MULTI_MAX 4
-struct MultiArgs {
-    GemmArgs p[FX_MULTI_MAX];
-    int32_t start[FX_MULTI_MAX + 1];     // first workgroup of each problem
-    int32_t cfg[FX_MULTI_MAX];
-    int32_t n;
-};
-
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_gemm_f32_multi(MultiArgs a) {
     constexpr int F0 = PipeSmem<128, 128, false, false>::FLOATS, F1 = PipeSmem<128, 128, true, true>::FLOATS,
@@ -1513,6 +1417,34 @@ static bool fx_gemm_pipe_ok(int32_t transa, int32_t transb, const GemmArgs& a) {
     return fx_gemm_pipe_mode() && av && bv && small_offsets && a.k_chunk >= 4;
 }
 
+// The split-bf16 kernels (fx_gemm_x6.hip) take a prepared problem when its operands satisfy the pipelined
+// kernel's alignment rules and the 16-byte epilogue's, the output has at least a few 128x128 tiles per slab
+// and a fused row sum is asked of a row-contiguous op(A) only (the weight gradients' dZ^T).  Measured on one
+// box against the fp32-MFMA kernels (profiles/r05_gemm_x6s_lab_a.txt): 4096x1024x1024 forward 50.6 vs 86.6 us,
+// dX 52.4 vs 88.5, dW (4 slabs) 57.3 vs 91.7, 4096x624x624 29.3 vs 43.0; a 256x256x128 product loses
+// (8.4 vs 7.2 us): small outputs stay on the fp32 kernels' 64x64 tiles.
+#define FX_X6_MIN_WGS 144
+static bool fx_gemm_x6_shape(int64_t M, int64_t N, int64_t K) {
+    return fx_gemm_x6_enabled() && M >= 128 && N >= 128 && K >= 64;
+}
+
+static bool fx_gemm_x6_ok(int32_t transa, int32_t transb, const GemmArgs& a) {
+    if (!fx_gemm_x6_shape(a.M, a.N, a.K)) return false;
+    if (!fx_gemm_pipe_ok(transa, transb, a) || !fx_gemm_tr_ok(a)) return false;
+    if (a.epi.rowsum && !transa) return false;
+    // one 8-wave workgroup per CU at ~1.7x the fp32 kernels' per-CU rate: below ~144 tiles (0.56 of the CUs)
+    // the fp32 kernels' 64x64 tiles, which fill the chip with a quarter of the output, come out ahead
+    return fx_ceil_div(a.M, 128) * fx_ceil_div(a.N, 128) * a.split_k >= FX_X6_MIN_WGS;
+}
+
+// K slabs of a problem on the x6 kernels: about 1024 deep (fx_multi_plan's rule), within the caller's cap
+static int32_t fx_splitk_rule_x6(int64_t K, int32_t cap) {
+    if (cap <= 1) return 1;
+    int64_t sk = (K + 512) / 1024;
+    if (sk > cap) sk = cap;
+    return (int32_t)(sk < 1 ? 1 : sk);
+}
+
 extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N, int64_t K,
                            const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                            int64_t ldc, const fx_gemm_epilogue* epi_host, int32_t split_k,
@@ -1617,6 +1549,17 @@ extern "C" int fx_gemm_f32(int32_t transa, int32_t transb, int64_t M, int64_t N,
         return FX_OK;
     }
     const bool a_kc = !transa, b_kc = transb != 0;
+    if (fx_gemm_x6_ok(transa, transb, a)) {
+        a.tiles_m = (int32_t)fx_ceil_div(M, 128);
+        a.tiles_n = (int32_t)fx_ceil_div(N, 128);
+        const int rc = fx_gemm_x6_launch(a_kc, b_kc, a, s);
+        if (rc != FX_OK) return rc;
+        if (split_k > 1) {
+            fx_launch_splitk_reduce(a, s);
+            FX_CHECK_LAUNCH();
+        }
+        return FX_OK;
+    }
     const bool a_al = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_al = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
     const bool av = a_al && (a_kc ? (K % 4 == 0) : (M % 4 == 0));
@@ -1746,9 +1689,67 @@ static int fx_gemm_multi_mode() {     // FX_GEMM_MULTI=0: the 64x64 pair / per-p
 }
 
 // -> FX_OK and *launched = true when the problems went out as one k_gemm_f32_multi grid
+// The same on the split-bf16 kernels (one workgroup of 8 waves per CU, 128x128 tiles only): any 2 .. 4 problems
+// that all qualify, K-split or not — the tiles of the shorter problems fill the CUs the longest one leaves.
+static int fx_gemm_try_multi_x6(const fx_gemm_problem* p, int32_t n, fx_stream_t stream, bool* launched) {
+    *launched = false;
+    if (n < 2 || n > FX_MULTI_MAX || !fx_gemm_x6_enabled() || !fx_gemm_multi_mode()) return FX_OK;
+    for (int i = 0; i < n; ++i) {
+        const fx_gemm_problem& q = p[i];
+        if (fx_gemm_skinny(q) || !q.A || !q.B || !q.C || !fx_gemm_x6_shape(q.M, q.N, q.K)) return FX_OK;
+    }
+    MultiArgs ma;
+    memset(&ma, 0, sizeof(ma));
+    int order[FX_MULTI_MAX];
+    int32_t sk[FX_MULTI_MAX];
+    double wl[FX_MULTI_MAX];
+    for (int i = 0; i < n; ++i) {
+        order[i] = i;
+        sk[i] = (p[i].split_k > 1 && p[i].workspace) ? fx_splitk_rule_x6(p[i].K, p[i].split_k) : 1;
+        wl[i] = (double)fx_ceil_div(p[i].K, sk[i]) + (sk[i] == 1 ? 1.0 : 0.0);     // longest workgroups first
+    }
+    for (int a2 = 0; a2 < n; ++a2)
+        for (int b2 = a2 + 1; b2 < n; ++b2)
+            if (wl[order[b2]] > wl[order[a2]]) { const int t = order[a2]; order[a2] = order[b2]; order[b2] = t; }
+    int64_t wgs = 0;
+    for (int oi = 0; oi < n; ++oi) {
+        const fx_gemm_problem& q = p[order[oi]];
+        GemmArgs& a = ma.p[oi];
+        int bm = 0, bn = 0;
+        const int rc = fx_gemm_prepare(q.transa, q.transb, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc,
+                                       q.epilogue, sk[order[oi]], q.workspace, a, bm, bn);
+        if (rc != FX_OK) return rc;
+        a.tiles_m = (int32_t)fx_ceil_div(q.M, 128);
+        a.tiles_n = (int32_t)fx_ceil_div(q.N, 128);
+        if (!fx_gemm_pipe_ok(q.transa, q.transb, a) || !fx_gemm_tr_ok(a) || (a.epi.rowsum && !q.transa))
+            return FX_OK;
+        ma.cfg[oi] = (q.transa ? 0 : 1) | (q.transb ? 2 : 0);
+        ma.start[oi] = (int32_t)wgs;
+        wgs += (int64_t)a.tiles_m * a.tiles_n * a.split_k;
+    }
+    ma.start[n] = (int32_t)wgs;
+    for (int oi = n + 1; oi <= FX_MULTI_MAX; ++oi) ma.start[oi] = (int32_t)wgs;
+    ma.n = n;
+    if (wgs < FX_X6_MIN_WGS || wgs > 0x3FFFFFFF) return FX_OK;
+    hipStream_t s = fx_hip_stream(stream);
+    const int rc = fx_gemm_x6_launch_multi(ma, wgs, s);
+    if (rc != FX_OK) return rc;
+    for (int oi = 0; oi < n; ++oi)
+        if (ma.p[oi].split_k > 1) {
+            fx_launch_splitk_reduce(ma.p[oi], s);
+            FX_CHECK_LAUNCH();
+        }
+    *launched = true;
+    return FX_OK;
+}
+
 static int fx_gemm_try_multi(const fx_gemm_problem* p, int32_t n, fx_stream_t stream, bool* launched) {
     *launched = false;
     if (n < 2 || n > FX_MULTI_MAX || !fx_gemm_multi_mode()) return FX_OK;
+    {
+        const int rc = fx_gemm_try_multi_x6(p, n, stream, launched);
+        if (rc != FX_OK || *launched) return rc;
+    }
     // (two forward-type products — no K split anywhere — measured no better as one grid than as two
     // launches with their own tile shapes: 125 vs 122 us for DCNv2's cross + deep forward)
     bool any_split = false;
@@ -1949,6 +1950,7 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
         const int rc = fx_gemm_f32(q.transa, q.transb, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C,
                                    q.ldc, q.epilogue,
                                    fx_gemm_skinny(q) ? q.split_k
+                                   : fx_gemm_x6_shape(q.M, q.N, q.K) ? fx_splitk_rule_x6(q.K, q.workspace ? q.split_k : 1)
                                                      : fx_splitk_rule64(q.M, q.N, q.K, q.split_k),
                                    q.workspace, stream);
         if (rc != FX_OK) return rc;

@@ -56,6 +56,7 @@ np.savez(sys.argv[1], **out)
 def _run(mode, tmp_path, var="FX_GEMM_EDGE_PLAIN"):
     out = str(tmp_path / ("%s_%s.npz" % (var, mode)))
     env = dict(os.environ)
+    env["FX_GEMM_BF16X6"] = "0"       # these switches select among the fp32-MFMA kernels' forms
     env[var] = mode
     p = subprocess.run([sys.executable, "-c", SCRIPT % ROOT, out], env=env, capture_output=True, text=True,
                        timeout=600)

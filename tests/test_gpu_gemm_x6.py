@@ -1,0 +1,190 @@
+"""The split-bf16 GEMM (fx_gemm_x6.hip: every fp32 operand split into three exact bf16 planes inside the kernel,
+six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulate) behind fx_gemm_f32 / fx_gemm_f32_batch.
+
+It computes the products of mlp_block.py:96 and cross_net.py:126-129 (and their autograd, rank_model.py:320) the
+reference gets from aten::addmm in fp32; the claim is "fp32 accuracy", so every check is against float64 with
+a bound TIGHTER than the one the fp32-MFMA kernels are held to (tests/test_gpu_kernels.py: 2e-6 x bound):
+all four operand layouts, the M / N edges and K tails of the 624-wide record, K slabs with the fused bias
+gradient, every epilogue operand, the multi-problem grid.  A subprocess pair (FX_GEMM_BF16X6=0 / 1) shows that
+the switch selects different kernels (different bits on the large shapes) whose results agree to fp32 rounding.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = torch.device("cuda:0") if torch.cuda.is_available() else None
+
+
+def _ops():
+    from fuxictr_amd import ops
+    return ops
+
+
+def _dev(t):
+    return t.to(DEV)
+
+
+# (M, N, K): >= 144 tiles of 128 x 128 (x slabs) so that fx_gemm_f32 takes the split-bf16 kernels
+X6_SHAPES = [(4096, 1024, 1024), (4096, 1024, 624), (4096, 624, 624), (4096, 624, 1024), (2000, 1160, 200),
+             (4099 - 3, 628, 68), (1536, 1536, 100)]
+
+
+@pytest.mark.parametrize("M,N,K", X6_SHAPES)
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+def test_x6_all_layouts_against_float64(M, N, K, ta, tb):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g) * 0.1
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(_dev(A), _dev(Bm), C, transa=ta, transb=tb)
+    a = A.t() if ta else A
+    b = Bm.t() if tb else Bm
+    ref = a.double() @ b.double()
+    bound = (a.abs().double() @ b.abs().double()).max().item()
+    err = (C.cpu().double() - ref).abs().max().item()
+    assert err <= 1e-6 * bound, (err, bound)
+    rel = ((C.cpu().double() - ref).norm() / ref.norm()).item()
+    assert rel <= 1.5e-6, rel
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(1024, 1024, 4096, 4), (1024, 624, 4096, 8), (624, 624, 4096, 8),
+                                      (1024, 1024, 4000, 5), (640, 1024, 4100, 3)])
+def test_x6_weight_gradient_slabs_and_bias_gradient(M, N, K, sk):
+    """dW[M, N] = dz^T x with K slabs and the fused row sums of dz^T (the bias gradient), ragged K included."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + K + sk)
+    dz = torch.randn(K, M, generator=g)
+    x = torch.randn(K, N, generator=g)
+    dW = torch.full((M, N), float("nan"), device=DEV)
+    db = torch.full((M,), float("nan"), device=DEV)
+    ws = torch.empty(ops.gemm_workspace_floats(M, N, sk), device=DEV)
+    ops.gemm(_dev(dz), _dev(x), dW, transa=True, split_k=sk, workspace=ws, rowsum=db)
+    ref = dz.double().t() @ x.double()
+    bound = (dz.abs().double().t() @ x.abs().double()).max().item()
+    assert (dW.cpu().double() - ref).abs().max().item() <= 1e-6 * bound
+    refb = dz.double().sum(0)
+    assert (db.cpu().double() - refb).abs().max().item() <= 1e-6 * dz.abs().double().sum(0).max().item()
+
+
+def test_x6_epilogues():
+    """bias, pre-activation output, ReLU, Hadamard operand, mask, residual — into a strided output."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 4096, 624, 624
+    x, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias, mul, add, msk = (torch.randn(N, generator=g), torch.randn(M, N, generator=g),
+                           torch.randn(M, N, generator=g), torch.randn(M, N, generator=g))
+    z_ref = x.double() @ W.double().t() + bias.double()
+    tol = 1.5e-6 * (x.abs().double() @ W.abs().double().t()).max().item()
+    wide = torch.full((M, N + 1024), float("nan"), device=DEV)
+    C, Z = wide[:, :N], torch.empty(M, N, device=DEV)
+    ops.gemm(_dev(x), _dev(W), C, transb=True, bias=_dev(bias), act=1)
+    assert (C.cpu().double() - z_ref.clamp(min=0)).abs().max().item() <= tol
+    ops.gemm(_dev(x), _dev(W), C, transb=True, bias=_dev(bias), zout=Z, mul=_dev(mul), add=_dev(add))
+    assert (Z.cpu().double() - z_ref).abs().max().item() <= tol
+    assert (C.cpu().double() - (z_ref * mul.double() + add.double())).abs().max().item() <= 4 * tol
+    ops.gemm(_dev(x), _dev(W), C, transb=True, mask=_dev(msk))
+    ref = torch.where(msk > 0, x.double() @ W.double().t(), torch.zeros((), dtype=torch.float64))
+    assert (C.cpu().double() - ref).abs().max().item() <= tol
+    assert torch.isnan(wide[:, N:]).all()                    # nothing past the output's columns was touched
+
+
+def test_x6_exact_cases():
+    """Products that are exact in fp32 must come out exact: the three planes of an operand add up to it bit
+    for bit (A = I picks single elements of an asymmetric B: also catches a transposed fragment mapping), and
+    small integers stay integers."""
+    ops = _ops()
+    n = 2048
+    Bm = (torch.arange(n * n, dtype=torch.float32).view(n, n) * 1.000123 - 999.5)
+    C = torch.empty(n, n, device=DEV)
+    ops.gemm(_dev(torch.eye(n)), _dev(Bm), C)
+    assert torch.equal(C.cpu(), Bm)
+    g = torch.Generator().manual_seed(1)
+    A = torch.randint(-8, 9, (2048, 256), generator=g).float()
+    W = torch.randint(-8, 9, (1536, 256), generator=g).float()
+    C = torch.empty(2048, 1536, device=DEV)
+    ops.gemm(_dev(A), _dev(W), C, transb=True)
+    assert torch.equal(C.cpu(), A @ W.t())
+
+
+def test_x6_multi_problem_grid_equals_single_launches():
+    """fx_gemm_f32_batch: DCNv2's four backward products of one depth in ONE grid — the same tile function,
+    k order and (for the un-split dX) the same bits as single launches; dW against float64."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    M = 4096
+    probs, outs, singles, keep = [], [], [], []
+    for N, K in ((624, 624), (1024, 624)):
+        dz, x = _dev(torch.randn(M, N, generator=g)), _dev(torch.randn(M, K, generator=g))
+        W = _dev(torch.randn(N, K, generator=g) * 0.1)
+        dW, dx = torch.full((N, K), float("nan"), device=DEV), torch.full((M, K), float("nan"), device=DEV)
+        db = torch.full((N,), float("nan"), device=DEV)
+        ws = torch.empty(ops.gemm_workspace_floats(N, K, 8), device=DEV)
+        probs.append(ops.gemm_problem(dz, x, dW, transa=True, transb=False, split_k=8, workspace=ws, rowsum=db))
+        probs.append(ops.gemm_problem(dz, W, dx, transa=False, transb=False))
+        dx1 = torch.empty(M, K, device=DEV)
+        ops.gemm(dz, W, dx1, transa=False, transb=False)
+        outs.append((dz, x, W, dW, dx, db))
+        singles.append(dx1)
+        keep.append(ws)
+    ops.gemm_batch(probs)
+    torch.cuda.synchronize()
+    for (dz, x, W, dW, dx, db), dx1 in zip(outs, singles):
+        assert torch.equal(dx, dx1)
+        ref_w = dz.double().t() @ x.double()
+        assert (dW.double() - ref_w).abs().max().item() <= 1e-6 * (dz.abs().double().t() @ x.abs().double()).max().item()
+        assert (db.double() - dz.double().sum(0)).abs().max().item() <= 1e-6 * dz.abs().double().sum(0).max().item()
+
+
+SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, %r)
+from fuxictr_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(7)
+def rnd(*s):
+    return torch.randn(*s, generator=g).to(dev)
+out = {}
+for tag, (M, N, K) in {"first": (4096, 1024, 624), "cross": (4096, 624, 624), "tower": (4096, 1024, 1024)}.items():
+    x, W, b, dz = rnd(M, K), rnd(N, K) * 0.1, rnd(N), rnd(M, N)
+    y = torch.empty(M, N, device=dev)
+    ops.gemm(x, W, y, transb=True, bias=b, act=1)
+    out[tag + "/y"] = y.cpu().numpy()
+    dW, dx, rs = torch.empty(N, K, device=dev), torch.empty(M, K, device=dev), torch.empty(N, device=dev)
+    ws = torch.empty(ops.gemm_workspace_floats(N, K, 8), device=dev)
+    ops.gemm_dw_dx(dz, x, W, dW, dx, split_k=8, workspace=ws, rowsum=rs)
+    out[tag + "/dW"], out[tag + "/dx"], out[tag + "/db"] = dW.cpu().numpy(), dx.cpu().numpy(), rs.cpu().numpy()
+    out[tag + "/ref_y"] = torch.relu(x.double() @ W.double().t() + b.double()).cpu().numpy()
+    out[tag + "/ref_dW"] = (dz.double().t() @ x.double()).cpu().numpy()
+    out[tag + "/ref_dx"] = (dz.double() @ W.double()).cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_x6_switch_selects_other_kernels_with_the_same_results(tmp_path):
+    res = {}
+    for mode in ("0", "1"):
+        out = str(tmp_path / ("x6_%s.npz" % mode))
+        env = dict(os.environ)
+        env["FX_GEMM_BF16X6"] = mode
+        p = subprocess.run([sys.executable, "-c", SCRIPT % ROOT, out], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[mode] = np.load(out)
+    for tag in ("first", "cross", "tower"):
+        for k in ("y", "dW", "dx"):
+            a, b, ref = res["0"]["%s/%s" % (tag, k)], res["1"]["%s/%s" % (tag, k)], res["1"]["%s/ref_%s" % (tag, k)]
+            assert not np.array_equal(a, b), (tag, k, "FX_GEMM_BF16X6 made no difference: which kernel ran?")
+            e0 = np.linalg.norm(a - ref) / np.linalg.norm(ref)
+            e1 = np.linalg.norm(b - ref) / np.linalg.norm(ref)
+            print("[x6 a/b] %s/%s relative L2 error vs float64: fp32-MFMA %.3e  split-bf16 %.3e" % (tag, k, e0, e1))
+            assert e1 <= 1.2e-6 and e1 <= 1.25 * e0 + 1e-8, (tag, k, e0, e1)

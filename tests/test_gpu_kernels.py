@@ -507,11 +507,16 @@ def test_gemm_batch_of_two_forward_problems_is_the_two_launches(M):
             ops.gemm(xi, Wd, out[:, D0:], transb=True, bias=bd, act=1)
         torch.cuda.synchronize()
         res.append((out.cpu(), z.cpu()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    if M == 4096:
+        # (both forms on the same kernels — round 5: the split-bf16 ones, every problem has >= 144 tiles)
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # M = 1000: the batch (104 tiles of 128x128) leaves on the split-bf16 kernels, the single launches (40 and
+    # 64 tiles) stay on the fp32-MFMA ones — same products, different rounding: compared through fp64 below
     zr = xi.double() @ Wc.double().t() + bc.double()
     ref = torch.cat([zr * x0.double() + xi.double(),
                      torch.relu(xi.double() @ Wd.double().t() + bd.double())], dim=1).cpu()
-    assert (res[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    for r in res:
+        assert (r[0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("widths", [(16, 1), (16,), (8, 4, 1), (3,)])
