@@ -102,6 +102,7 @@ class GraphSegments(object):
 
 
 class DistContext(object):
+    TEARDOWN_EXIT = 75   # exit status of shutdown()'s watchdog (EX_TEMPFAIL): the teardown hung
     recorder = None      # a GraphSegments while a sharded step is being captured
     graph_mode = None    # how the captured step launches its collectives (set by the capture)
 
@@ -219,9 +220,13 @@ class DistContext(object):
             return
 
         def _bail():
+            # a stuck communicator teardown is a failure, and it must read as one: distinct non-zero exit
+            # status, after saying so on stderr
+            sys.stderr.write("[fuxictr_amd.dist] destroy_process_group() did not return within %.0f s: "
+                             "leaving the process with exit status %d\n" % (timeout_s, DistContext.TEARDOWN_EXIT))
             sys.stdout.flush()
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(DistContext.TEARDOWN_EXIT)
         timer = threading.Timer(timeout_s, _bail)
         timer.daemon = True
         timer.start()

@@ -2561,15 +2561,17 @@ class _CrossNetV2Fn(torch.autograd.Function):
         return (dxn,) + tuple(grads)
 
 
-def _dw_problem(dz, x, W, need_bias):
-    """-> (problem, dW, db) for dW[N_out, K_in] = dz^T x with the fused bias gradient."""
+def _dw_problem(dz, x, W, need_bias, kind):
+    """-> (problem, dW, db) for dW[N_out, K_in] = dz^T x with the fused bias gradient.  kind: which tower of
+    the batch ("cross" / "deep") — the two dW problems of one gemm_batch run in ONE grid and must not share
+    their K-slab workspace even when their shapes coincide (a deep layer as wide as the record: ADVICE r4)."""
     Bsz, N_out = dz.shape
     K_in = x.shape[1]
     dW = torch.empty(N_out, K_in, dtype=torch.float32, device=dz.device)
     sk = max(_split_k_for(N_out, K_in, Bsz), 1 if _FORCE_SPLITK else min(8, Bsz // 256), 1)
-    # one grow-only workspace per weight shape: the problems of ONE batch have distinct shapes (a cross
-    # layer and the deep layer of its depth), launches follow each other on the stream (ADVICE r3)
-    ws = _Workspace.get(dz.device, ops.gemm_workspace_floats(N_out, K_in, sk), tag=("dw", N_out, K_in))
+    # one grow-only workspace per (tower, weight shape): launches follow each other on the stream
+    # (ADVICE r3), the problems of one launch differ in `kind`
+    ws = _Workspace.get(dz.device, ops.gemm_workspace_floats(N_out, K_in, sk), tag=("dw", kind, N_out, K_in))
     db = torch.empty(N_out, dtype=torch.float32, device=dz.device) if need_bias else None
     return ops.gemm_problem(dz, x, dW, transa=True, transb=False, split_k=sk, workspace=ws,
                             rowsum=db), dW, db
@@ -2675,7 +2677,7 @@ class _CrossDeepFn(torch.autograd.Function):
                 W, b = cwb[2 * ic], cwb[2 * ic + 1]
                 ops.cross_bwd_prep(dxn, x0, zs[ic], t, dx0, init=(ic == n_cross - 1),
                                    add_dxn=(ic == 0))
-                pw, dW, db = _dw_problem(t, xs[ic], W, b is not None)
+                pw, dW, db = _dw_problem(t, xs[ic], W, b is not None, "cross")
                 dxi = torch.empty_like(x0)
                 add = dx0 if ic == 0 else dxn
                 probs += [pw, ops.gemm_problem(t, W, dxi, add=add)]
@@ -2683,7 +2685,7 @@ class _CrossDeepFn(torch.autograd.Function):
                 post.append(("c", dxi))
             if idp >= 0:
                 W, b = dwb[2 * idp], dwb[2 * idp + 1]
-                pw, dW, db = _dw_problem(dz, hs[idp], W, b is not None)
+                pw, dW, db = _dw_problem(dz, hs[idp], W, b is not None, "deep")
                 dh = torch.empty_like(hs[idp])
                 mask = hs[idp] if (idp > 0 and acts[idp - 1]) else None
                 add = g_cross if (idp == 0 and ic < 0 and g_cross is not None) else None

@@ -254,6 +254,7 @@ class _GraphStep(object):
         self._pack_keys = {k for k, *_ in self.packs}
         self._fill_names = sorted({f for _, ids_n, num_n, _, _ in self.packs for f in ids_n + num_n})
         self._fill_cache = {}
+        self._fill_stream = []       # ids of the cache entries that came in through train_step, oldest first
         self.fill(batch)
         torch.cuda.synchronize(dev)
         if model._dist is None:
@@ -311,9 +312,12 @@ class _GraphStep(object):
         # the capture only recorded the step; drop per-batch caches created while recording
         static.cache = {k: v for k, v in static.cache.items() if k in self._pack_keys}
 
-    FILL_CACHE_MAX = 512
+    FILL_CACHE_MAX = 512       # batches registered through BaseModel.prepare_batch (bench.py's pool, epochs
+    #                            over device-resident batches): the caller keeps those alive anyway
+    FILL_CACHE_STREAM = 4      # batches first seen by train_step: a loop that streams fresh device-resident
+    #                            batches must not pin hundreds of them — a short LRU
 
-    def fill(self, batch, launch=True):
+    def fill(self, batch, launch=True, registered=False):
         """Cast the batch's columns + label into the static input buffers (one launch).  The host
         side of that launch (40 tensor look-ups, the ctypes argument blocks) is kept per batch OBJECT
         whose columns are device-resident: a batch seen before (an epoch over resident batches,
@@ -321,6 +325,8 @@ class _GraphStep(object):
         dict still holds the very same tensors."""
         ent = self._fill_cache.get(id(batch))
         if ent is not None:
+            if registered and id(batch) in self._fill_stream:
+                self._fill_stream.remove(id(batch))        # promoted: prepare_batch() vouches for it
             if ent[0] is batch and all(batch.get(f) is t for f, t in ent[1]):
                 self.model._staged_labels = (None, None)
                 if launch:
@@ -348,8 +354,13 @@ class _GraphStep(object):
         if (not staged and type(batch) is dict
                 and all(batch.get(f) is t and t.is_contiguous() for f, t in srcs)):
             call = ops.pack_columns_multi_prepare(items)
-            if len(self._fill_cache) >= self.FILL_CACHE_MAX:       # oldest entry out
-                self._fill_cache.pop(next(iter(self._fill_cache)))
+            if registered:
+                if len(self._fill_cache) >= self.FILL_CACHE_MAX:       # oldest entry out
+                    self._fill_cache.pop(next(iter(self._fill_cache)))
+            else:
+                self._fill_stream.append(id(batch))
+                if len(self._fill_stream) > self.FILL_CACHE_STREAM:
+                    self._fill_cache.pop(self._fill_stream.pop(0), None)
             self._fill_cache[id(batch)] = (batch, srcs, call)
             if launch:
                 call()
@@ -748,7 +759,7 @@ class BaseModel(nn.Module):
         if (st is not None and type(batch_data) is dict
                 and all(getattr(v, "is_cuda", False) for v in batch_data.values())
                 and batch_data[self.feature_map.labels[0]].shape[0] == st.B):
-            st.fill(batch_data, launch=False)
+            st.fill(batch_data, launch=False, registered=True)
 
     def _progress(self, iterable):
         if self._verbose > 0:
