@@ -30,7 +30,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0           # HBM3E spec (6.3 TB/s measured streaming ceiling)
+# The tower / CrossNet GEMMs run on the split-bf16 kernels (fuxictr_amd/csrc/fx_gemm_x6.hip, round 5): six bf16
+# MFMA products per fp32 product, so the matrix-core peak for the ALGORITHMIC (fp32) flops is a sixth of the
+# bf16 peak.  FX_GEMM_BF16X6=0 restores the fp32-MFMA kernels (peak 157.3).
+X6_ON = os.environ.get("FX_GEMM_BF16X6", "1") != "0"
+PEAK_GEMM_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0 if X6_ON else PEAK_FP32_MFMA_TFLOPS
 
 
 def parse():
@@ -77,6 +83,16 @@ def parse():
                     help="skip the second pass that records one HIP event per step (step_us)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the step eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--age-steps", type=int, default=300,
+                    help="training steps (on distinct batches) before the clock starts: the exact-mode Adam "
+                         "catch-up replays the steps a row missed, so a young run is faster than the rate a "
+                         "training run sustains (round 4: 0.981 vs 1.035-1.046 ms); `value` is the steady state, "
+                         "the young-run figure is reported beside it (`young_run`)")
+    ap.add_argument("--no-uniform", action="store_true",
+                    help="skip the uniform-id measurement (`value_uniform`, SURVEY 8d: both distributions)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the full-vocabulary parity leg (`parity_full_vocab`: the native step against the "
+                         "oracle at 33.76 M rows, same weights, same batches)")
     return ap.parse_args()
 
 
@@ -243,6 +259,90 @@ def cpu_baseline(args, cards, n_steps):
                                             "box")}
 
 
+def parity_full_vocab(case, gpu_index, steps=6, B=4096, dist="powerlaw"):
+    """the native step against the oracle AT THE FULL VOCABULARY the metric is quoted on
+    (33 762 603 rows; the parity tests of tests/baseline_shapes.py scale the tables x 0.01).  The native
+    model's own initial state_dict is copied to the host and handed to the oracle (the reference's
+    dense-gradient, dense-Adam algorithm on ATen's CPU kernels) and to a second oracle on ATen's GPU kernels
+    (the yardstick: how far the reference's own two back ends drift apart); `steps` teacher-labelled batches go
+    through all three — the native model through its real train_step (3 eager steps, the hipGraph capture,
+    replays).  Batch 1 carries ids at the very top of every table (rows V-1, V-2, ...: the packed-row offsets
+    and 32-bit keys of the 5-10 M row columns C3 / C12 / C16 / C21).
+    Same weights -> logits within 1e-4 (before training, and at the oracle's trained weights loaded back
+    into the native model); independent training -> per-step loss against the oracle, with the yardstick's
+    own difference beside it.  The oracle is the CHECKER here, never the thing measured."""
+    import tempfile
+    from fuxictr_amd import zoo
+    from oracle import ctr_oracle as O
+    from tests import baseline_shapes as bs
+    t_begin = time.perf_counter()
+    model, features, cfg, spec, cards = bs.build(case, zoo, gpu_index, tempfile.mkdtemp(prefix="fx_parity_"),
+                                                 vocab_scale=1.0, hip_graph=True)
+    dev = model.device
+    state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tr = O.OracleTrainer(cfg, state0, features, lr=1e-3, max_norm=10.0)
+    yard = O.OracleTrainer(cfg, state0, features, lr=1e-3, max_norm=10.0, device=dev)
+    rows = int(sum(cards) + len(cards))
+    del state0
+    teacher = bs.Teacher(features)
+    rng = np.random.default_rng(2025)
+    raw = bs.make_batches(case, spec, cards, rng, B, steps + 1, dist, teacher)
+    # ids at the top of every table in batch 1 (ids are 1-based with 0 = padding: the largest id is V - 1)
+    top = {}
+    for name, fs in features.items():
+        if fs["type"] == "categorical":
+            V = int(fs["vocab_size"])
+            n = min(256, V - 1)
+            raw[1][name] = raw[1][name].copy()
+            raw[1][name][:n] = (V - 1 - np.arange(n)).astype(raw[1][name].dtype)
+            top[name] = V - 1
+    hold = raw[steps]
+    raw = raw[:steps]
+    res = {"rows": rows, "steps": steps, "batch": B, "id_distribution": dist,
+           "largest_table_rows": int(max(cards)), "top_ids_in_batch_1": True}
+    torch.set_num_threads(min(_host_cores(), 32))
+
+    def native_logits(b):
+        return bs.logits_of(model, {k: v.to(dev) for k, v in bs.tb(b).items()})[0]
+    model.eval()
+    d0 = max(float(np.abs(native_logits(b) - tr.logits(bs.tb(b)).numpy()).max()) for b in (raw[0], raw[1]))
+    res["max_dlogit_before"] = d0
+    model.train()
+    model._max_gradient_norm = 10.0
+    ln, lo, ly = [], [], []
+    for b in raw:
+        t = bs.tb(b)
+        ln.append(float(model.train_step({k: v.to(dev) for k, v in t.items()}).item()))
+        lo.append(tr.train_step(t, t["label"])[0])
+        ly.append(yard.train_step(t, t["label"])[0])
+    model.optimizer.check_errors()
+    res["loss_native"], res["loss_oracle"] = ln, lo
+    res["max_dloss"] = float(np.abs(np.asarray(ln) - np.asarray(lo)).max())
+    res["max_dloss_yardstick"] = float(np.abs(np.asarray(ly) - np.asarray(lo)).max())
+    res["launch"] = "3 eager steps, hipGraph capture, %d replays" % max(steps - 4, 0)
+    # independent trajectories: hold-out logits (how far apart two fp32 evaluations of the reference's
+    # algorithm are after `steps` Adam steps is the yardstick's column)
+    model.eval()
+    ref = tr.logits(bs.tb(hold)).numpy()
+    res["independent_training"] = {
+        "mean_dlogit_native": float(np.abs(native_logits(hold) - ref).mean()),
+        "mean_dlogit_yardstick": float(np.abs(yard.logits(bs.tb(hold)).numpy() - ref).mean())}
+    # the oracle's TRAINED weights loaded into the native model (reference checkpoint keys): forward parity
+    # at weights that have been through Adam, including the touched top rows
+    del yard
+    model.load_state_dict({k: v.detach().cpu() for k, v in tr.state.items()})
+    model.eval()
+    d1 = max(float(np.abs(native_logits(b) - tr.logits(bs.tb(b)).numpy()).max()) for b in (hold, raw[1]))
+    res["max_dlogit_after"] = d1
+    res["max_dlogit"] = max(d0, d1)
+    res["seconds"] = round(time.perf_counter() - t_begin, 1)
+    del model, tr
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def _spawn_ranks(args):
     """`bench.py --gpus N` launched plainly: start N ranks of this script with torch.distributed.run
     (what the driver does for N > 1) and pass its exit code on."""
@@ -393,7 +493,9 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
     if args.probe_loss:
         probe = probe_losses(args, model, cards, spec, rank, world, dev, dist,
                              sharded=(world > 1 or world1) and not args.replicas)
-    n_pool = min(args.pool, max(8, max(args.warmup, 20) + 2 * args.steps + 40))
+    age = max(args.age_steps, args.warmup, 20) if (not args.no_graph and not args.loader
+                                                   and not args.host_inputs) else max(args.warmup, 20)
+    n_pool = min(args.pool, max(8, age + 3 * args.steps + 40))
     pool = make_pool(args, rank, cards, spec, dev, n_pool)
 
     loader_iter = None
@@ -435,17 +537,36 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
                 and not args.host_inputs:
             for b in pool:
                 model.prepare_batch(b)
+    young = None
     try:
-        # graph mode: 3 eager steps + the capture, then the host side of the pool's input casts, then at
-        # least 16 replays back to back right up to the clock: the chip's power management needs
-        # ~20 ms of sustained load to settle (profiles/r04_step_spread.txt: the 20 steps after an idle
-        # gap of a few ms ran 1.057 ms, the 20 after those 1.013) — `warmup_steps_run` in the line
-        warm_run = max(args.warmup, 20 if model._use_graph else 0)
-        for i in range(warm_run):
+        # graph mode: 3 eager steps + the capture, then the host side of the pool's input casts, then replays
+        # back to back right up to the clock (the chip's power management needs ~20 ms of sustained load to
+        # settle, profiles/r04_step_spread.txt).  The run is AGED before the clock: `age` steps on distinct
+        # batches, so that the rows a timed step touches carry the revisit distances of a long run (the
+        # exact-mode catch-up replays missed steps: k_catchup_rows ran 11.6 us at step 20 and 55 us at
+        # step 300 in round 4).  The same number of steps timed right after step 20 is kept as `young_run`.
+        warm_run = age if model._use_graph else max(args.warmup, 0)
+        for i in range(min(20, warm_run)):
             if i == 4 and model._use_graph:
                 prepare_pool()
             model.train_step(next_batch(step_i))
             step_i += 1
+        if warm_run > 20 + args.steps:
+            sync()
+            y0 = torch.cuda.Event(enable_timing=True)
+            y1 = torch.cuda.Event(enable_timing=True)
+            y0.record()
+            for _ in range(args.steps):
+                model.train_step(next_batch(step_i))
+                step_i += 1
+            y1.record()
+            sync()
+            young = {"ms_per_step": y0.elapsed_time(y1) / args.steps, "steps_before": 20,
+                     "steps": args.steps}
+        while step_i < warm_run:
+            model.train_step(next_batch(step_i))
+            step_i += 1
+        warm_run = step_i
         sync()
     except Exception as exc:   # noqa: BLE001 — e.g. a capture problem on a software stack not seen
         if not model._use_graph:                      # in development: keep the run, launch eagerly
@@ -548,7 +669,7 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
     import gc
     gc.collect()
     torch.cuda.empty_cache()
-    return {"dt": dt, "dt_events": dt_events, "step_us": step_us, "warmup_run": warm_run,
+    return {"dt": dt, "dt_events": dt_events, "step_us": step_us, "warmup_run": warm_run, "young": young,
             "ktimes": ktimes, "launch": launch, "parallelism": parallelism,
             "cards": cards, "timing_mode": timing_mode, "rows": rows, "n_pool": n_pool,
             "probe": probe}
@@ -622,11 +743,20 @@ def rooflines(m, args, world):
     if g and g["total_ms"] > 0:
         ach = g["work"] / (g["total_ms"] * 1e-3) / 1e12
         traffic, src = _traffic(args.model, args.batch, world)
-        out["roofline"] = {"kernel": "k_gemm_f32_pipe / k_gemm_f32_pair (fp32 MFMA GEMM, MLP/CrossNet "
+        out["roofline"] = {"kernel": ("k_gemm_x6 / k_gemm_x6_multi (split-bf16 GEMM: operands split into three "
+                                      "exact bf16 planes in the kernel, six v_mfma_f32_32x32x16_bf16 products "
+                                      "per fp32 product, fp32 accumulate; MLP / CrossNet forward, dW + dX "
+                                      "grids backward)") if X6_ON else
+                                     "k_gemm_f32_pipe / k_gemm_f32_pair (fp32 MFMA GEMM, MLP/CrossNet "
                                      "fwd; dW+dX pairs bwd)",
-                           "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                           "traffic": traffic,
+                           "bound": "mfma", "achieved": ach, "peak": PEAK_GEMM_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_GEMM_TFLOPS,
+                           "peak_note": ("algorithmic (fp32) flops 2MNK per product; the kernel executes 6 bf16 "
+                                         "MFMA flops per algorithmic flop, so its matrix-core peak is the dense "
+                                         "bf16 peak / 6 = %.1f TFLOP/s; against the fp32-MFMA peak (%.1f) the "
+                                         "same figure is %.3f" % (PEAK_GEMM_TFLOPS, PEAK_FP32_MFMA_TFLOPS,
+                                                                  ach / PEAK_FP32_MFMA_TFLOPS)) if X6_ON else None,
+                           "traffic": traffic if not X6_ON else None,
                            "traffic_unit": "bytes per launch (L2 fabric requests incl. Infinity-"
                                            "Cache hits; profiles/%s)" % src if src else None,
                            "launches": g["launches"], "avg_launch_us": g["avg_us"],
@@ -643,7 +773,7 @@ def rooflines(m, args, world):
                 shapes[label] = {"launches_per_step": v["launches"] / n_inst,
                                  "avg_launch_us": round(v["avg_us"], 2),
                                  "tflops": round(tf, 1),
-                                 "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 3)}
+                                 "frac": round(tf / PEAK_GEMM_TFLOPS, 3)}
         out["roofline"]["by_shape_MxNxK"] = shapes
     sp = kt.get("sparse_path")
     if sp and sp["total_ms"] > 0:
@@ -662,8 +792,8 @@ def rooflines(m, args, world):
             "algorithmic_bytes_per_sample": per_sample, "us_per_step": us_step,
             "launches_per_step": sp["launches"] / n_inst,
             "distinct_batches_replayed": sp.get("steps", 1),
-            "per_kernel": "profiles/r03_step_timeline_deepfm_head.txt (rocprofv3 kernel trace of one "
-                          "step of the timed region)"}
+            "per_kernel": "profiles/r05_step_timeline_%s_final.txt (rocprofv3 kernel trace of one "
+                          "step of the timed region)" % args.model}
         tr = _sparse_traffic(args.model, args.batch, world)
         if tr is not None:
             out["roofline_sparse"]["traffic"] = tr[0]
@@ -728,6 +858,14 @@ def timing_detail(m, args):
     per launch group by ops.KernelTimer; DeepFM / DCNv2, whose every entry point is recorded)."""
     out = {"ms_per_step_events": 1e3 * m["dt_events"] / args.steps,
            "warmup_steps_run": m["warmup_run"]}
+    if m.get("young"):
+        y = m["young"]
+        out["young_run"] = {"ms_per_step": round(y["ms_per_step"], 4),
+                            "value": args.batch * 1e3 / y["ms_per_step"],
+                            "note": "%d steps timed right after step %d of the same run (HIP events): rows "
+                                    "have few missed Adam steps to catch up yet — NOT the headline; `value` "
+                                    "is measured after %d steps" % (y["steps"], y["steps_before"],
+                                                                    m["warmup_run"])}
     if m.get("step_us"):
         out["step_us"] = {k: (round(v, 1) if isinstance(v, float) else
                               [round(x, 1) for x in v] if isinstance(v, list) else v)
@@ -823,6 +961,13 @@ def main():
         args2.model = "DCNv2"
         m2 = measure(args2, rank, local_rank, world, world1, dev, dist)
         second = (args2, m2)
+    third = None
+    if (args.model == "DeepFM" and world == 1 and not world1 and not args.no_uniform and args.dist == "powerlaw"
+            and not args.loader and not args.host_inputs):
+        import copy
+        args3 = copy.copy(args)
+        args3.dist, args3.no_kernel_timing, args3.no_step_events = "uniform", True, True
+        third = measure(args3, rank, local_rank, world, world1, dev, dist)
 
     if rank == 0:
         global_batch = args.batch * world
@@ -830,8 +975,10 @@ def main():
         out = {
             "metric": "samples/sec at batch 4096, Criteo-shape DeepFM/DCNv2, 1/2/4/8 MI355X",
             "value": value, "unit": "samples/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * m["dt"] / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "warmup": m["warmup_run"], "warmup_requested": args.warmup,
+            "ms_per_step": 1e3 * m["dt"] / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (bf16x6 split operands, fp32 accumulate)" if X6_ON else "f32",
             "data": "synthetic",
             "config": {"workload": workload_name(args, m["rows"]),
                        "global_batch": global_batch, "per_gpu_batch": args.batch,
@@ -867,6 +1014,21 @@ def main():
             sub.update(timing_detail(m2, args2))
             sub.update(rooflines(m2, args2, world))
             out["dcnv2"] = sub
+        if third is not None:
+            m3 = third
+            out["value_uniform"] = args.batch * args.steps / m3["dt"]
+            out["uniform"] = {"value": out["value_uniform"], "unit": "samples/sec",
+                              "ms_per_step": 1e3 * m3["dt"] / args.steps,
+                              "warmup_steps_run": m3["warmup_run"],
+                              "note": "the same DeepFM step on UNIFORM ids (SURVEY 8d: both distributions): "
+                                      "~106 K unique rows per batch instead of ~25 K"}
+        if world == 1 and not args.no_parity and not world1 and args.model in ("DeepFM", "DCNv2") \
+                and args.vocab_scale == 1.0 and args.zoo == "native":
+            out["parity_full_vocab"] = {}
+            for case in (("c2_deepfm", "c3_dcnv2") if args.model == "DeepFM" and not args.no_dcnv2 else
+                         ("c2_deepfm",) if args.model == "DeepFM" else ("c3_dcnv2",)):
+                out["parity_full_vocab"][case] = parity_full_vocab(case, local_rank)
+            out["parity_full_vocab"]["max_dlogit"] = max(v["max_dlogit"] for v in out["parity_full_vocab"].values())
         if world == 1 and not args.no_cpu_baseline and args.model in ("DeepFM", "DCNv2"):
             out["cpu_baseline"] = cpu_baseline(args, m["cards"], args.cpu_baseline_steps)
         assert out["n_gpus"] == args.gpus

@@ -113,11 +113,17 @@ struct X6Opnd {
     __device__ __forceinline__ void load_piece(int32_t t, float (&r)[8]) const {
         if constexpr (!MASK) {
             const char* b = P + (int64_t)t * tstride;
+            // (the per-lane offset is "touched" inside the loop: hoisted out of it, its zero-extension to 64
+            // bits lands in another basic block and the instruction selector no longer sees the
+            // saddr + 32-bit voffset form — it then builds a 64-bit address per load in VGPRs that alias
+            // in-flight fragment registers: lgkmcnt waits in front of address arithmetic)
+            uint32_t vo = voff[KC ? I : 0];
+            asm volatile("" : "+v"(vo));
             if constexpr (KC) {
-                const float4 v = *reinterpret_cast<const float4*>(b + voff[I]);
+                const float4 v = *reinterpret_cast<const float4*>(b + vo);
                 r[4 * I + 0] = v.x; r[4 * I + 1] = v.y; r[4 * I + 2] = v.z; r[4 * I + 3] = v.w;
             } else {
-                r[I] = *reinterpret_cast<const float*>(b + I * kstride + voff[0]);
+                r[I] = *reinterpret_cast<const float*>(b + I * kstride + vo);
             }
         } else {
             if constexpr (KC) {
@@ -138,22 +144,23 @@ struct X6Opnd {
     }
 
     // split sub-op S (0..11): pair j = S / 3, plane step st = S % 3; r is overwritten by the residuals.
-    // The empty asm statements are scheduling anchors: these are pure VALU operations that the instruction
-    // selector is free to place anywhere between the load and the LDS write (it floated all of them to the
-    // top of the half in the first cut); asm volatile statements keep their order relative to each other and
-    // to sched_barrier, so the work stays in the slot it was written in.
+    // The conversion is issued as a volatile asm statement: these are pure VALU operations that the instruction
+    // selector is otherwise free to place anywhere between the global load and the LDS write (the first cut
+    // floated all of them to the top of the half; a later one copied the freshly loaded registers right behind
+    // their load — s_waitcnt vmcnt(0) there drains the prefetch, scripts/check_x6_isa.py).  asm volatile
+    // statements keep their order relative to each other and to sched_barrier, the shifts / subtractions hang
+    // off the conversion's result, so the work stays in the slot it was written in and the raw registers are
+    // read where they are.  (s_nop 0: gfx950 wants one wait state between a VALU write and v_cvt_pk_bf16_f32
+    // reading it — the compiler inserts it for its own conversions.)
     template <int S>
     static __device__ __forceinline__ void split_piece(float (&r)[8], uint32_t (&pl)[3][4]) {
         constexpr int j = S / 3, st = S % 3;
-        asm volatile("" : "+v"(r[2 * j]), "+v"(r[2 * j + 1]));
-        const uint32_t p = x6_pk_bf16(r[2 * j], r[2 * j + 1]);
+        uint32_t p;
+        asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(r[2 * j]), "v"(r[2 * j + 1]));
         pl[st][j] = p;
         if constexpr (st < 2) {
             r[2 * j] = r[2 * j] - __uint_as_float(p << 16);                    // exact
             r[2 * j + 1] = r[2 * j + 1] - __uint_as_float(p & 0xffff0000u);    // exact
-            asm volatile("" : "+v"(r[2 * j]), "+v"(r[2 * j + 1]));
-        } else {
-            asm volatile("" : "+v"(pl[st][j]));
         }
     }
 
@@ -198,11 +205,17 @@ __device__ __forceinline__ void fx_gemm_x6_tile(const GemmArgs& a, const int64_t
     const bool do_rowsum = !A_KC && (a.epi.rowsum != nullptr) && (n0 == 0);
     float rs = 0.f;
 
-    f32x16 acc[2];
+    // Two accumulators per 32x32 block: the leading product a0 b0 on its own chain, the five correction
+    // products (2^-8 and 2^-16 of it) on a second one.  Every MFMA rounds its accumulator once; with one chain
+    // per block all six products of a k16 step rounded at the size of the full sum (6 K / 16 roundings: relative
+    // L2 error 4.8e-7 at K = 1024, and the first-step gradients of c3's lower tower layers 3 x further from
+    // fp64 than the fp32 chain's, tests/test_gpu_grad_parity.py) — now K / 16 roundings at full size and 5 K / 16
+    // at 2^-8 of it; the chains meet in one addition at the end.  Four independent MFMA chains per wave.
+    f32x16 acc[2], accs[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accs[i][r] = 0.f; }
 
     if (nk > 0) {
         OA oa;
@@ -238,7 +251,10 @@ __device__ __forceinline__ void fx_gemm_x6_tile(const GemmArgs& a, const int64_t
             constexpr int bp = p == 0 ? 2 : (p == 1 || p == 3) ? 1 : 0;
             constexpr int ap = p == 0 ? 0 : p == 1 ? 1 : p == 2 ? 2 : p == 3 ? 0 : p == 4 ? 1 : 0;
             asm volatile("" : "+v"(fa[S][ap][i]));
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][bp], fa[S][ap][i], acc[i], 0, 0, 0);
+            if constexpr (p == 5)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][bp], fa[S][ap][i], acc[i], 0, 0, 0);
+            else
+                accs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][bp], fa[S][ap][i], accs[i], 0, 0, 0);
         };
 
         // one k tile; kt = -1 (DO = false) is the pipeline's fill: everything but the MFMAs and step-1 reads
@@ -321,6 +337,11 @@ __device__ __forceinline__ void fx_gemm_x6_tile(const GemmArgs& a, const int64_t
         }
         if (kt < nk) body(kt, P0{}, TT{}, TT{});
     }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] += accs[i][r];
 
     if (a.epi.rowsum != nullptr && n0 == 0 && !A_KC) {        // workgroup-uniform
         float* const red = reinterpret_cast<float*>(lds);

@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out
+O=gpurun_out/r05_gemm_prod_${1:-k}.txt; : > $O
+FX_GEMM_BF16X6=1 timeout 120 ./scripts/ubench/gemm_x6s_lab fuxictr_amd/libfxctr.so ${2:-quick} >> $O 2>&1
+grep -E "==|us " $O | sed -e 's/ta[01] tb[01] sk[0-9] epi[01] //' -e 's/| max.max.*//' | cut -c1-200

@@ -341,11 +341,12 @@ __global__ void k_ref(const float* A, int64_t sa_m, int64_t sa_k, const float* B
     }
 }
 
-__global__ void k_fill(float* p, int64_t n, uint32_t seed, float scale) {
+static float g_fill_shift = 0.5f;      // 0.5: zero-mean data; 0: all positive (accumulators grow monotonically)
+__global__ void k_fill(float* p, int64_t n, uint32_t seed, float scale, float shift) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         uint32_t x = (uint32_t)i * 2654435761u + seed;
         x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-        p[i] = ((float)(x >> 8) * (1.0f / 16777216.0f) - 0.5f) * scale;
+        p[i] = ((float)(x >> 8) * (1.0f / 16777216.0f) - shift) * scale;
     }
 }
 
@@ -377,9 +378,9 @@ static void bench(int M, int N, int K, int ta, int tb, int split_k, int epi, con
     HC(hipMalloc(&A, (size_t)M * K * 4)); HC(hipMalloc(&B, (size_t)N * K * 4));
     HC(hipMalloc(&C, (size_t)M * N * 4)); HC(hipMalloc(&C2, (size_t)M * N * 4)); HC(hipMalloc(&bias, (size_t)N * 4));
     HC(hipMalloc(&ws, (size_t)(split_k > 1 ? split_k : 1) * M * (N + 1) * 4));
-    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, A, (int64_t)M * K, 17u, 2.f);
-    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, B, (int64_t)N * K, 91u, 0.1f);
-    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, bias, (int64_t)N, 5u, 0.5f);
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, A, (int64_t)M * K, 17u, 2.f, g_fill_shift);
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, B, (int64_t)N * K, 91u, 0.1f, g_fill_shift);
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, bias, (int64_t)N, 5u, 0.5f, 0.5f);
     X6Args a;
     memset(&a, 0, sizeof(a));
     a.A = A; a.lda = ta ? M : K; a.B = B; a.ldb = tb ? K : N; a.C = C; a.ldc = N;
@@ -412,12 +413,13 @@ static void bench(int M, int N, int K, int ta, int tb, int split_k, int epi, con
     } else {
         HC(hipMemcpy(hc.data(), C, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     }
-    double e6 = 0, nrm = 0, m6 = 0, mx = 0;
+    double e6 = 0, nrm = 0, m6 = 0, mx = 0, sgn6 = 0, sgnf = 0, sabs = 0;
     for (int64_t r = 0; r < rows; ++r)
         for (int n = 0; n < N; ++n) {
             double ref = h64[r * N + n];
             if (epi && split_k == 1) { ref += hb[n]; if (ref < 0) ref = 0; }
             const double d6 = hc[(size_t)(r * step) * N + n] - ref;
+            sgn6 += d6 * (ref >= 0 ? 1.0 : -1.0); sabs += fabs(ref);
             e6 += d6 * d6; nrm += ref * ref;
             if (fabs(d6) > m6) m6 = fabs(d6);
             if (fabs(ref) > mx) mx = fabs(ref);
@@ -455,6 +457,7 @@ static void bench(int M, int N, int K, int ta, int tb, int split_k, int epi, con
                 double ref = h64[r * N + n];
                 if (epi) { ref += hb[n]; if (ref < 0) ref = 0; }
                 const double d = hf[(size_t)(r * step) * N + n] - ref;
+                sgnf += d * (ref >= 0 ? 1.0 : -1.0);
                 ef += d * d;
                 if (fabs(d) > mf) mf = fabs(d);
             }
@@ -463,12 +466,27 @@ static void bench(int M, int N, int K, int ta, int tb, int split_k, int epi, con
     printf("%-30s %4dx%4dx%4d ta%d tb%d sk%d epi%d | x6s %7.2f us %6.1f TF-eq | fp32-mfma %7.2f us %6.1f TF%s | relL2 x6s %.3e fp32 %.3e | max/max x6s %.3e fp32 %.3e\n",
            what, M, N, K, ta, tb, split_k, epi, t, flop / t * 1e-6, tf, tf > 0 ? flop / tf * 1e-6 : 0.0,
            split_k > 1 ? " (+reduce)" : "", sqrt(e6 / nrm), sqrt(ef / nrm), m6 / mx, mf / mx);
+    printf("    signed error toward larger |c| (sum d sign(c) / sum |c|): x6s %+.3e   fx_gemm_f32 %+.3e\n", sgn6 / sabs, sgnf / sabs);
     fflush(stdout);
     hipFree(A); hipFree(B); hipFree(C); hipFree(C2); hipFree(bias); hipFree(ws); hipFree(C64);
 }
 
 int main(int argc, char** argv) {
     const char* so = argc > 1 ? argv[1] : "fuxictr_amd/libfxctr.so";
+    void* h = dlopen(so, RTLD_NOW | RTLD_LOCAL);
+    if (h) g_fx_gemm = (fx_gemm_f32_t)dlsym(h, "fx_gemm_f32");
+    if (!g_fx_gemm) fprintf(stderr, "no libfxctr (%s): fp32-mfma column skipped\n", dlerror());
+    if (argc > 2 && !strcmp(argv[2], "bias")) {
+        for (int pass = 0; pass < 2; ++pass) {
+            g_fill_shift = pass ? 0.f : 0.5f;
+            printf("== data %s\n", pass ? "all positive" : "zero mean");
+            bench(4096, 1024, 1024, 0, 1, 1, 0, "fwd 1024");
+            bench(4096, 1024, 1024, 0, 0, 1, 0, "dX 1024");
+            bench(1024, 1024, 4096, 1, 0, 4, 0, "dW 1024 sk4");
+            bench(4096, 1024, 128, 0, 1, 1, 0, "K 128");
+        }
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "prof")) {
         bench(4096, 4096, 4096, 0, 1, 1, 0, "4096^3");
         return 0;
@@ -480,9 +498,6 @@ int main(int argc, char** argv) {
         bench(4096, 4096, 4096, 0, 1, 1, 0, "4096^3");
         return 0;
     }
-    void* h = dlopen(so, RTLD_NOW | RTLD_LOCAL);
-    if (h) g_fx_gemm = (fx_gemm_f32_t)dlsym(h, "fx_gemm_f32");
-    if (!g_fx_gemm) fprintf(stderr, "no libfxctr (%s): fp32-mfma column skipped\n", dlerror());
     bench(256, 256, 128, 0, 1, 1, 0, "small KC/KC");
     bench(256, 256, 128, 0, 0, 1, 0, "small KC/row");
     bench(256, 256, 128, 1, 0, 1, 0, "small row/row");
