@@ -107,8 +107,10 @@ struct X6Opnd {
     }
 
     // load instruction I of tile t.  MASK = false: the tile lies fully inside [kbeg, kend) — uniform tile base +
-    // constant per-lane byte offset; MASK = true (the slab's last tiles, the pipeline fill): elements past kend
-    // are read from clamped addresses and zeroed.
+    // 32-bit per-lane byte offset (the saddr form); MASK = true (the slab's last tiles, the pipeline fill):
+    // elements past kend are read from clamped in-range addresses here and zeroed WHERE THEY ARE CONSUMED
+    // (split_piece<S, true>) — a select on the loaded registers right behind the load would wait for it and
+    // drain the prefetch in the last iterations of every slab.
     template <int I, bool MASK>
     __device__ __forceinline__ void load_piece(int32_t t, float (&r)[8]) const {
         if constexpr (!MASK) {
@@ -128,17 +130,13 @@ struct X6Opnd {
         } else {
             if constexpr (KC) {
                 const int32_t k = kbeg + t * FX_BK + kl;
-                const bool ok = k < kend;                    // (K % 4 == 0: a float4 is in or out as a whole)
-                const int32_t kc = ok ? k : kend - 4;
+                const int32_t kc = k < kend ? k : kend - 4;    // (K % 4 == 0: a float4 is in or out as a whole)
                 const float4 v = *reinterpret_cast<const float4*>(P + (int64_t)(rc[I] + kc) * 4);
-                r[4 * I + 0] = ok ? v.x : 0.f; r[4 * I + 1] = ok ? v.y : 0.f;
-                r[4 * I + 2] = ok ? v.z : 0.f; r[4 * I + 3] = ok ? v.w : 0.f;
+                r[4 * I + 0] = v.x; r[4 * I + 1] = v.y; r[4 * I + 2] = v.z; r[4 * I + 3] = v.w;
             } else {
                 const int32_t k = kbeg + t * FX_BK + kl + I;
-                const bool ok = k < kend;
-                const int32_t kc = ok ? k : kend - 1;
-                const float v = *reinterpret_cast<const float*>(P + ((int64_t)kc * ld + rc[0]) * 4);
-                r[I] = ok ? v : 0.f;
+                const int32_t kc = k < kend ? k : kend - 1;
+                r[I] = *reinterpret_cast<const float*>(P + ((int64_t)kc * ld + rc[0]) * 4);
             }
         }
     }
@@ -152,9 +150,20 @@ struct X6Opnd {
     // off the conversion's result, so the work stays in the slot it was written in and the raw registers are
     // read where they are.  (s_nop 0: gfx950 wants one wait state between a VALU write and v_cvt_pk_bf16_f32
     // reading it — the compiler inserts it for its own conversions.)
-    template <int S>
-    static __device__ __forceinline__ void split_piece(float (&r)[8], uint32_t (&pl)[3][4]) {
+    // MASK: the staged tile was tile t of the slab and may cross kend: its elements past kend become zero
+    // before the first conversion (see load_piece).
+    template <int S, bool MASK = false>
+    __device__ __forceinline__ void split_piece(float (&r)[8], uint32_t (&pl)[3][4], int32_t t = 0) const {
         constexpr int j = S / 3, st = S % 3;
+        if constexpr (MASK && st == 0) {
+            const int32_t k0 = kbeg + t * FX_BK + kl;
+            if constexpr (KC) {
+                if (!(k0 < kend)) { r[2 * j] = 0.f; r[2 * j + 1] = 0.f; }
+            } else {
+                if (!(k0 + 2 * j < kend)) r[2 * j] = 0.f;
+                if (!(k0 + 2 * j + 1 < kend)) r[2 * j + 1] = 0.f;
+            }
+        }
         uint32_t p;
         asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(r[2 * j]), "v"(r[2 * j + 1]));
         pl[st][j] = p;
@@ -264,7 +273,8 @@ __device__ __forceinline__ void fx_gemm_x6_tile(const GemmArgs& a, const int64_t
             constexpr bool MASK = decltype(msk)::value;      // tile kt + 2 (loaded here) may cross kend
             unsigned char* const st_cur = lds + P * X6_STAGE;            // tile kt
             unsigned char* const st_nxt = lds + (P ^ 1) * X6_STAGE;      // tile kt + 1
-            const int32_t tl = kt + 2 < nk ? kt + 2 : nk - 1;
+            const int32_t tl = kt + 2 < nk ? kt + 2 : nk - 1;       // B is loaded and split in this iteration
+            const int32_t tsa = kt + 1 < nk ? kt + 1 : nk - 1;      // the tile whose A is split here
             constexpr int NLB = OB::NL, NLA = OA::NL, NWB = OB::NW, NWA = OA::NW;
             // first half's list: [B loads][A loads][B plane writes][A split 0..5][A writes of float4 0 (KC)]
             //                    [A split 6..11][remaining A writes]
@@ -283,9 +293,9 @@ __device__ __forceinline__ void fx_gemm_x6_tile(const GemmArgs& a, const int64_t
                             rs += ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
                         }
                     }
-                    OA::template split_piece<I - X3>(ra[P ^ 1], pa);
+                    oa.template split_piece<I - X3, MASK>(ra[P ^ 1], pa, tsa);
                 } else if constexpr (I < X5) oa.template write_piece<I - X4>(st_nxt, pa);
-                else if constexpr (I < X6) OA::template split_piece<6 + I - X5>(ra[P ^ 1], pa);
+                else if constexpr (I < X6) oa.template split_piece<6 + I - X5, MASK>(ra[P ^ 1], pa, tsa);
                 else oa.template write_piece<I - X6 + NWA1>(st_nxt, pa);
             };
             fx_static_for<0, 12>([&](auto mm) {
@@ -306,7 +316,7 @@ __device__ __forceinline__ void fx_gemm_x6_tile(const GemmArgs& a, const int64_t
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (DO) mfma(mm, std::integral_constant<int, 1>{});
-                OB::template split_piece<m>(rb, pb);
+                ob.template split_piece<m, MASK>(rb, pb, tl);
                 if constexpr (m >= 2 && m < 11)
                     frag_read(std::integral_constant<int, m - 2>{}, std::integral_constant<int, 0>{}, st_nxt);
                 __builtin_amdgcn_sched_barrier(0);
@@ -320,7 +330,7 @@ __device__ __forceinline__ void fx_gemm_x6_tile(const GemmArgs& a, const int64_t
         using FF = std::false_type;
         fx_static_for<0, OB::NL>([&](auto ii) { ob.template load_piece<decltype(ii)::value, true>(0, rb); });
         fx_static_for<0, OA::NL>([&](auto ii) { oa.template load_piece<decltype(ii)::value, true>(0, ra[0]); });
-        fx_static_for<0, 12>([&](auto ss) { OB::template split_piece<decltype(ss)::value>(rb, pb); });
+        fx_static_for<0, 12>([&](auto ss) { ob.template split_piece<decltype(ss)::value, true>(rb, pb, 0); });
         body(-1, P1{}, FF{}, TT{});
         // tile kt + 2 is loaded in iteration kt: plain bodies while it has all 32 k inside the slab.  Pairs in
         // the loops, the odd tail outside (a skip path inside a loop would join two "loads in flight" states
