@@ -103,10 +103,169 @@ __device__ __forceinline__ void fx_catchup_row(const FxTableDev& t, int64_t row,
     fx_catchup_finish<VEC>(t, row, sub, r, sc, upto, lb1, lb2);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The DeepFM / xDeepFM shape of the catch-up — a 16-float row (4 lanes x 4 floats) and the D = 1 row of
+// LogisticRegression under the same id — as ONE replay by the row's quad of lanes (round 5).
+//
+// Step i after `last` moves an element by  u_i = lr/(1-b1^(t+i)) . m b1^i / (sqrt(v) b2^(i/2) / sqrt(1-b2^(t+i)) + eps)
+// (fx_adam_replay).  Factored:  u_i = (lr m / sqrt(v)) . w_i / (g_i + eps / sqrt(v))  with
+//     w_i = b1^i / (1 - b1^(t+i)),   g_i = b2^(i/2) / sqrt(1 - b2^(t+i))
+// the same for every element of the row: an element costs  acc += w_i . rcp(g_i + c)  per step (3 instructions,
+// fx_adam_replay: 6), the sum is applied to p once.  (w_i, g_i) cost 10 instructions with two
+// transcendentals: lane s of the quad computes them for step 4q + s + 1 of round q and the quad reads each
+// other's pair through DPP quad broadcasts — 2.5 + 2 instructions a step instead of 10 on every lane.  The D = 1
+// row rides as a fifth element (lane 0; zeros elsewhere) instead of a second pass with a quarter of the
+// lanes.  19.75 instructions per step where the two passes of fx_adam_replay issued ~49 (k_catchup_rows
+// is VALU-bound: a wave runs as long as its coldest row).
+// The terms shrink by >= 5 % a step (b1 / sqrt(b2) over the ratio of the bias corrections), so once a
+// step's terms are below 2^-29 of every sum of the quad the rest cannot change them in fp32: the quad is
+// done; the wave leaves when all its quads are (no lane leaves the loop alone: there is no divergence).
+// Against the reference's step-by-step `p -= u_i` this sums the same terms in the same order in fp32 and
+// rounds p once instead of k times; what it drops is below 2^-29 of the move (tests: exact mode == dense
+// torch Adam stepped k times).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fx_quad_bcast(float x, int u) {      // lane u of this lane's quad
+    const int v = __float_as_int(x);
+    int r;
+    switch (u) {
+        case 0: r = __builtin_amdgcn_mov_dpp(v, 0x00, 0xF, 0xF, true); break;      // quad_perm [0,0,0,0]
+        case 1: r = __builtin_amdgcn_mov_dpp(v, 0x55, 0xF, 0xF, true); break;
+        case 2: r = __builtin_amdgcn_mov_dpp(v, 0xAA, 0xF, 0xF, true); break;
+        default: r = __builtin_amdgcn_mov_dpp(v, 0xFF, 0xF, 0xF, true); break;
+    }
+    return __int_as_float(r);
+}
+
+__device__ __forceinline__ bool fx_quad_any(bool x) {
+    const unsigned long long b = __ballot(x);
+    const int q4 = (threadIdx.x & 63) & ~3;
+    return ((b >> q4) & 0xFull) != 0ull;
+}
+
+// LR = false: the D = 16 table alone (DCNv2, DLRM, ...: models without a first-order term).
+template <bool LR>
+__device__ __forceinline__ void fx_catchup_quad(const FxTableDev& t0, const FxTableDev& t1, int64_t row, int sub,
+                                                const fx_scalars& sc, int upto, double lb1, double lb2) {
+    FxRowRegs<4> r0;
+    FxRowRegs<1> r1;
+    fx_row_load<4, false>(t0, row, sub, r0);
+    if constexpr (LR) fx_row_load<1, false>(t1, row, sub, r1);
+    else { r1.p[0] = r1.m[0] = r1.v[0] = 0.f; r1.on = r1.act = false; r1.last = 0; }
+    const int last = t0.last_step[row];               // (same address in the four lanes: one access)
+    const int last1 = LR ? t1.last_step[row] : last;
+    const int k0 = upto - last, k1 = upto - last1;
+    if (last1 != last) {
+        // the two tables were not touched together (cannot happen under one id plan): the plain replays
+        r0.last = last; r1.last = last1;
+        fx_catchup_finish<4>(t0, row, sub, r0, sc, upto, lb1, lb2);
+        fx_catchup_finish<1>(t1, row, sub, r1, sc, upto, lb1, lb2);
+        return;
+    }
+    if (k0 <= 0) return;                               // (the whole quad: `last` is the row's)
+    (void)k1;
+    // this lane's five elements: 4 of the D-float row + the D = 1 row (lane 0)
+    float pe[5], me[5], ve[5];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pe[e] = r0.p[e]; me[e] = r0.m[e]; ve[e] = r0.v[e]; }
+    pe[4] = r1.p[0]; me[4] = r1.m[0]; ve[4] = r1.v[0];
+    bool any_state = false, moving = false;
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        any_state |= (me[e] != 0.f) || (ve[e] != 0.f);
+        moving |= (me[e] != 0.f);
+    }
+    const int kk = k0 < FX_REPLAY_MAX ? k0 : FX_REPLAY_MAX;
+    if (fx_quad_any(moving)) {
+        float c[5], sc_e[5], acc[5];
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            const float r = sqrtf(ve[e]);
+            const bool live = (me[e] != 0.f) && (r > 0.f);
+            const float inv = live ? 1.f / r : 0.f;
+            c[e] = live ? sc.eps * inv : 1.f;          // (a dead element: acc grows harmlessly, scale 0)
+            sc_e[e] = sc.lr * me[e] * inv;
+            acc[e] = 0.f;
+        }
+        // lane `sub` owns the steps 4 q + sub + 1
+        const float b1 = sc.beta1, b2 = sc.beta2, sb2 = sqrtf(sc.beta2);
+        const float b1_2 = b1 * b1, b2_2 = b2 * b2, sb2_2 = sb2 * sb2;
+        const float b1_4 = b1_2 * b1_2, b2_4 = b2_2 * b2_2, sb2_4 = sb2_2 * sb2_2;
+        float bi = sub == 0 ? b1 : sub == 1 ? b1_2 : sub == 2 ? b1_2 * b1 : b1_4;          // b1^(sub+1)
+        float sb = sub == 0 ? sb2 : sub == 1 ? sb2_2 : sub == 2 ? sb2_2 * sb2 : sb2_4;
+        float a1 = (float)exp2(lb1 * (double)(last + sub + 1));                             // b1^(t+i)
+        float a2 = (float)exp2(lb2 * (double)(last + sub + 1));
+        const int nr = (kk + 3) >> 2;
+        for (int q = 0; q < nr; ++q) {
+            const int i = 4 * q + sub + 1;
+            float w = bi * __builtin_amdgcn_rcpf(1.f - a1);
+            const float g = sb * __builtin_amdgcn_rsqf(1.f - a2);
+            w = i <= kk ? w : 0.f;
+            bi *= b1_4; sb *= sb2_4; a1 *= b1_4; a2 *= b2_4;
+            float term[5];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float wu = fx_quad_bcast(w, u), gu = fx_quad_bcast(g, u);
+#pragma unroll
+                for (int e = 0; e < 5; ++e) {
+                    term[e] = wu * __builtin_amdgcn_rcpf(gu + c[e]);
+                    acc[e] += term[e];
+                }
+            }
+            // (term[] = the round's last step.)  Done when it can no longer change any live sum of the quad.
+            bool small = true;
+#pragma unroll
+            for (int e = 0; e < 5; ++e) small &= (sc_e[e] == 0.f) || (term[e] <= acc[e] * 1.862645e-9f);   // 2^-29
+            // (quads that have counted all their steps have left the loop and do not vote; the ones still
+            // here leave together)
+            if (__all(!fx_quad_any(!small))) break;
+        }
+#pragma unroll
+        for (int e = 0; e < 5; ++e) pe[e] = fmaf(-sc_e[e], acc[e], pe[e]);
+    }
+    // the decay of the moments over ALL missed steps, in closed form
+    if (any_state) {
+        const float f1 = (float)exp2(lb1 * (double)k0), f2 = (float)exp2(lb2 * (double)k0);
+#pragma unroll
+        for (int e = 0; e < 5; ++e) { me[e] *= f1; ve[e] *= f2; }
+    }
+    if (r0.on) {
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) any |= (r0.m[e] != 0.f) || (r0.v[e] != 0.f);
+        if (any) {
+            float po[4] = {pe[0], pe[1], pe[2], pe[3]}, mo[4] = {me[0], me[1], me[2], me[3]},
+                  vo[4] = {ve[0], ve[1], ve[2], ve[3]};
+            const int64_t o = row * t0.D + sub * 4;
+            fx_tab_store<4>(t0.table, t0.bf16, o, po);
+            fx_store<4>(t0.m + o, mo);
+            fx_store<4>(t0.v + o, vo);
+        }
+    }
+    if (r1.on && ((r1.m[0] != 0.f) || (r1.v[0] != 0.f))) {
+        float po[1] = {pe[4]}, mo[1] = {me[4]}, vo[1] = {ve[4]};
+        fx_tab_store<1>(t1.table, t1.bf16, row, po);
+        fx_store<1>(t1.m + row, mo);
+        fx_store<1>(t1.v + row, vo);
+    }
+    if (sub == 0) {
+        t0.last_step[row] = upto;
+        if constexpr (LR) t1.last_step[row] = upto;
+    }
+}
+
+static const bool fx_catchup_quad_on = []() {     // FX_CATCHUP_QUAD=0: the two plain replays (A/B runs)
+    const char* e = getenv("FX_CATCHUP_QUAD");
+    return !(e && atoi(e) == 0);
+}();
+
 // one unique row of a de-dup result, in every table group that shares the id plan
 __device__ __forceinline__ void fx_catchup_tables(const FxTableDev* t, int n_tables, int64_t row,
                                                   int sub, const fx_scalars& sc, int upto, double lb1,
-                                                  double lb2) {
+                                                  double lb2, bool quad = false) {
+    if (quad) {
+        fx_catchup_quad<true>(t[0], t[1], row, sub, sc, upto, lb1, lb2);
+        return;
+    }
     if (n_tables == 2 && t[0].vec == 4 && t[1].vec == 1) {
         // the D-float tables + the D=1 tables of LogisticRegression: all eight loads in flight
         FxRowRegs<4> r0;
@@ -1542,7 +1701,7 @@ struct CatchRowsArgs {
     const uint32_t* uniq_row;
     const int32_t* n_unique;
     const fx_scalars* scal;
-    int32_t n_tables, group_log2, upto_offset;
+    int32_t n_tables, group_log2, upto_offset, quad;
 };
 
 __global__ __launch_bounds__(256) void k_catchup_rows(CatchRowsArgs a) {
@@ -1553,6 +1712,17 @@ __global__ __launch_bounds__(256) void k_catchup_rows(CatchRowsArgs a) {
     const fx_scalars sc = *a.scal;
     const int upto = sc.step + a.upto_offset;
     const double lb1 = log2((double)sc.beta1), lb2 = log2((double)sc.beta2);
+    if (a.quad) {
+        // (the votes inside fx_catchup_quad run over the lanes that are in it: quads past the end of the list
+        // simply are not)
+        if (a.quad == 1)
+            for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> 2); u < nu; u += (int64_t)gridDim.x * rpb)
+                fx_catchup_quad<true>(a.t[0], a.t[1], (int64_t)a.uniq_row[u], sub, sc, upto, lb1, lb2);
+        else
+            for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> 2); u < nu; u += (int64_t)gridDim.x * rpb)
+                fx_catchup_quad<false>(a.t[0], a.t[0], (int64_t)a.uniq_row[u], sub, sc, upto, lb1, lb2);
+        return;
+    }
     for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.group_log2); u < nu;
          u += (int64_t)gridDim.x * rpb)
         fx_catchup_tables(a.t, a.n_tables, (int64_t)a.uniq_row[u], sub, sc, upto, lb1, lb2);
@@ -1570,6 +1740,8 @@ static int fx_launch_catchup_rows(const FxTableDev* t, int n_tables, int gl, con
     a.n_tables = n_tables;
     a.group_log2 = gl;
     a.upto_offset = upto_offset;
+    a.quad = !fx_catchup_quad_on || gl != 2 || t[0].vec != 4 || t[0].D != 16 ? 0
+             : (n_tables == 2 && t[1].vec == 1 && t[1].D == 1) ? 1 : n_tables == 1 ? 2 : 0;
     int64_t blocks = fx_ceil_div(n_max, 256 >> gl);
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(k_catchup_rows, dim3((unsigned)blocks), dim3(256), 0, s, a);
@@ -1596,6 +1768,8 @@ extern "C" int fx_adam_catchup_rows(const fx_row_state* tables_host, int32_t n_t
     a.n_tables = n_tables;
     a.group_log2 = gl;
     a.upto_offset = upto_offset;
+    a.quad = !fx_catchup_quad_on || gl != 2 || a.t[0].vec != 4 || a.t[0].D != 16 ? 0
+             : (n_tables == 2 && a.t[1].vec == 1 && a.t[1].D == 1) ? 1 : n_tables == 1 ? 2 : 0;
     int64_t blocks = fx_ceil_div(n_max, 256 >> gl);
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(k_catchup_rows, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), a);
