@@ -413,6 +413,8 @@ def probe_losses(args, model, cards, spec, rank, world, dev, dist, sharded):
     use_graph, model._use_graph = model._use_graph, False
     lo, n_loc = rank * G // max(world, 1), G // max(world, 1)
     out = []
+    from fuxictr_amd import layers as _layers
+    _layers.A2A_FILL_PROBE.update(on=sharded, max_used=0)
     for _ in range(2):
         b = synthetic.taobao_batch(rng, G, spec, dist=args.dist) if args.model == "DIN" \
             else synthetic.criteo_batch(rng, G, cards=cards, dist=args.dist)
@@ -432,9 +434,22 @@ def probe_losses(args, model, cards, spec, rank, world, dev, dist, sharded):
             loss = loss / world
         out.append(float(loss.item()))
     model._use_graph = use_graph
+    _layers.A2A_FILL_PROBE["on"] = False
+    if sharded and _layers.A2A_FILL_PROBE["cap"]:
+        used = torch.tensor([float(_layers.A2A_FILL_PROBE["max_used"])], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(used, op=dist.ReduceOp.MAX)
+        PROBE_EXTRA["a2a_bucket"] = {
+            "fullest_bucket_rows": int(used.item()), "capacity_rows": int(_layers.A2A_FILL_PROBE["cap"]),
+            "even_share_of_lookups": int(_layers.A2A_FILL_PROBE["even_share"]),
+            "fill": float(used.item()) / _layers.A2A_FILL_PROBE["cap"],
+            "note": "unique keys one rank sends to one owner in the probe steps (max over ranks, owners, "
+                    "steps) against the fixed per-owner capacity of the all-to-all blocks; FX_FLAG_A2A_OVERFLOW "
+                    "would abort the run (optimizer.check_errors)"}
     return out
 
 
+PROBE_EXTRA = {}
 SPARSE_RECORD_STEPS = 32
 C5_BATCH = 32768
 
@@ -1006,6 +1021,7 @@ def main():
         out.update(rooflines(m, args, world))
         if m.get("probe") is not None:
             out["probe_loss"] = m["probe"]
+            out.update(PROBE_EXTRA)
         if second is not None:
             args2, m2 = second
             sub = {"workload": workload_name(args2, m2["rows"]),

@@ -555,6 +555,13 @@ class _TableGroup(object):
                                                          dtype=torch.int32, device=dev)
         ops.shard_plan(dd, N, self.total_rows, cap, sx.send_idx, sx.uniq_slot, sx.lookup_slot,
                        self.ensure_scal(), global_keys=True, workspace=pws, slot_uniq=sx.slot_uniq)
+        if A2A_FILL_PROBE["on"]:
+            # diagnostic (bench.py --probe-loss, eager steps only: this reads the device): how full the fullest
+            # per-owner bucket of the exchange is, against its fixed capacity (a2a_factor x the even share)
+            used = int((sx.slot_uniq.view(N, cap) >= 0).sum(dim=1).max().item())
+            A2A_FILL_PROBE["max_used"] = max(A2A_FILL_PROBE["max_used"], used)
+            A2A_FILL_PROBE["cap"] = cap
+            A2A_FILL_PROBE["even_share"] = -(-n // N)
         sx.recv_idx = self.dist.all_to_all(sx.send_idx).view(N * cap, 1)
         sx.grads = {}                                 # id(group) -> per-unique-key gradient (backward)
         if self.owner_ws is None or self.owner_ws[0] != N * cap:
@@ -1720,6 +1727,7 @@ class _HeadCtx(object):
 
 _HEAD_CTX = None
 _HEAD_FUSED = os.environ.get("FX_HEAD_FUSED", "1") != "0"
+A2A_FILL_PROBE = {"on": False, "max_used": 0, "cap": 0, "even_share": 0}     # see _TableGroup.shard_exchange_ids
 
 
 class _ReluNote(object):

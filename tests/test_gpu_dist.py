@@ -103,3 +103,29 @@ def test_a_failed_capture_of_the_collectives_falls_back_to_segments():
     assert "segments" in fb["config"]["parallelism"], fb["config"]["parallelism"]
     assert fb["probe_loss"] == rec["probe_loss"]
     assert fb["value"] > 0
+
+
+@pytest.mark.parametrize("dist", ["powerlaw", "uniform"])
+def test_eight_ranks_on_one_gpu_at_the_real_c5_shapes(dist):
+    """the first real 8-GPU run, rehearsed on the one GPU there is.  configs[4] as BASELINE.json
+    states it — DLRM bottom [512,256] / top [1024,1024,512,256], tables scaled x 3.7 (124.9 M rows: 8 GB of
+    embeddings + 16 GB of Adam state over the 8 ranks), global batch 32 768 — with EIGHT ranks sharing cuda:0 (the
+    real kernels, the collectives staged through gloo: RCCL refuses two ranks on one device).  Same seeded model
+    (weights by parameter name and global row), same seeded global batch: the two probe losses equal those of the
+    one-rank run on the whole batch, the per-owner buckets of the all-to-all never overflow (the run would abort
+    through optimizer.check_errors) and their fullest fill against the fixed 1.5 x capacity is printed — power-law
+    and uniform ids."""
+    common = ["--model", "DLRM", "--vocab-scale", "3.7", "--dist", dist, "--steps", "2", "--warmup", "3",
+              "--age-steps", "0", "--no-cpu-baseline", "--no-kernel-timing", "--no-step-events", "--no-parity",
+              "--no-uniform", "--probe-loss"]
+    one = _bench_line(["--gpus", "1", "--probe-world", "8"] + common, timeout=1200)
+    eight = _bench_line(["--gpus", "8"] + common, env={"FX_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert eight["n_gpus"] == 8 and eight["config"]["global_batch"] == 32768
+    assert "row-sharded over 8 ranks" in eight["config"]["parallelism"]
+    for a, b in zip(one["probe_loss"], eight["probe_loss"]):
+        assert abs(a - b) <= 2e-5, (one["probe_loss"], eight["probe_loss"])
+    fill = eight["a2a_bucket"]
+    print("[8 ranks, c5 shapes, %s] probe losses %s | fullest all-to-all bucket %d of %d rows (%.2f of capacity; "
+          "even share of the lookups %d)" % (dist, eight["probe_loss"], fill["fullest_bucket_rows"],
+                                             fill["capacity_rows"], fill["fill"], fill["even_share_of_lookups"]))
+    assert 0.0 < fill["fill"] < 1.0
