@@ -1689,6 +1689,118 @@ static int fx_gemm_multi_mode() {     // FX_GEMM_MULTI=0: the 64x64 pair / per-p
 }
 
 // -> FX_OK and *launched = true when the problems went out as one k_gemm_f32_multi grid
+// K slabs of the problems of one split-bf16 multi-problem launch.  One 8-wave workgroup per CU: the launch is a
+// list-scheduling problem on 256 machines — a workgroup costs a fixed part (pipeline fill + epilogue: ~9 us) plus
+// ~1.2 us per k tile, workgroups start in grid order (longest first) as CUs free up — and the slab count of the
+// weight gradients is the one free parameter: 1024 x 624 x 4096 (dW) beside 4096 x 624 x 1024 (dX) is 160 + 160
+// workgroups of 32 k tiles at 4 slabs — a full round and a quarter-full one, 64 k tiles of wall time — but
+// 320 + 160 workgroups that pack into ~48 at 8 slabs.  Every combination of {1,2,3,4,6,8,12,16} slabs (within
+// the caller's workspace cap, slabs >= 256 deep) is simulated, plus what its slab reduces cost; the best one is
+// kept per shape set (the simulation runs once per distinct launch).
+struct FxX6PlanKey {
+    int64_t d[FX_MULTI_MAX][4];
+    int n;
+    bool operator==(const FxX6PlanKey& o) const { return n == o.n && memcmp(d, o.d, sizeof(d)) == 0; }
+};
+
+static double fx_x6_makespan(const int64_t* tiles, const int64_t* ktiles, const int32_t* sk, const int* order,
+                             int n) {
+    double cu[256];
+    for (int i = 0; i < 256; ++i) cu[i] = 0.0;
+    // CUs as a binary min-heap on their free time (all zero: already a heap)
+    auto sift = [&](int i) {
+        for (;;) {
+            int l = 2 * i + 1, r = l + 1, m = i;
+            if (l < 256 && cu[l] < cu[m]) m = l;
+            if (r < 256 && cu[r] < cu[m]) m = r;
+            if (m == i) return;
+            const double t = cu[i]; cu[i] = cu[m]; cu[m] = t;
+            i = m;
+        }
+    };
+    double end = 0.0;
+    for (int oi = 0; oi < n; ++oi) {
+        const int i = order[oi];
+        const double len = 9.0 + 1.2 * (double)fx_ceil_div(ktiles[i], sk[i]);
+        const int64_t jobs = tiles[i] * sk[i];
+        for (int64_t j = 0; j < jobs; ++j) {
+            cu[0] += len;
+            if (cu[0] > end) end = cu[0];
+            sift(0);
+        }
+    }
+    return end;
+}
+
+static void fx_x6_plan_splits(const fx_gemm_problem* p, int n, int32_t* sk_out) {
+    static FxX6PlanKey keys[16];
+    static int32_t plans[16][FX_MULTI_MAX];
+    static int n_cached = 0;
+    FxX6PlanKey key;
+    memset(&key, 0, sizeof(key));
+    key.n = n;
+    int64_t tiles[FX_MULTI_MAX], ktiles[FX_MULTI_MAX];
+    int32_t cap[FX_MULTI_MAX];
+    for (int i = 0; i < n; ++i) {
+        cap[i] = (p[i].split_k > 1 && p[i].workspace) ? p[i].split_k : 1;
+        key.d[i][0] = p[i].M; key.d[i][1] = p[i].N; key.d[i][2] = p[i].K; key.d[i][3] = cap[i];
+        tiles[i] = fx_ceil_div(p[i].M, 128) * fx_ceil_div(p[i].N, 128);
+        ktiles[i] = fx_ceil_div(p[i].K, FX_BK);
+    }
+    for (int c = 0; c < n_cached; ++c)
+        if (keys[c] == key) {
+            for (int i = 0; i < n; ++i) sk_out[i] = plans[c][i];
+            return;
+        }
+    static const bool planner_on = []() {     // FX_X6_PLAN=0: ~1024-deep slabs (round 5's first cut)
+        const char* e = getenv("FX_X6_PLAN");
+        return !(e && atoi(e) == 0);
+    }();
+    static const int cand[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+    int32_t best[FX_MULTI_MAX], cur[FX_MULTI_MAX];
+    for (int i = 0; i < n; ++i) best[i] = cur[i] = fx_splitk_rule_x6(p[i].K, cap[i]);
+    if (planner_on) {
+        double best_t = 1e30;
+        int idx[FX_MULTI_MAX] = {0, 0, 0, 0};
+        for (;;) {
+            bool ok = true;
+            for (int i = 0; i < n && ok; ++i) {
+                cur[i] = cap[i] > 1 ? cand[idx[i]] : 1;
+                ok = cur[i] <= cap[i] && (cur[i] == 1 || p[i].K / cur[i] >= 256);
+            }
+            if (ok) {
+                int order[FX_MULTI_MAX];
+                for (int i = 0; i < n; ++i) order[i] = i;
+                for (int a2 = 0; a2 < n; ++a2)
+                    for (int b2 = a2 + 1; b2 < n; ++b2) {
+                        const double wa = (double)fx_ceil_div(p[order[a2]].K, cur[order[a2]]);
+                        const double wb = (double)fx_ceil_div(p[order[b2]].K, cur[order[b2]]);
+                        if (wb > wa) { const int t = order[a2]; order[a2] = order[b2]; order[b2] = t; }
+                    }
+                double t = fx_x6_makespan(tiles, ktiles, cur, order, n);
+                for (int i = 0; i < n; ++i)        // the slab reduce launches that follow (k_splitk_reduce_v4)
+                    if (cur[i] > 1) t += 2.5 + (double)cur[i] * (double)p[i].M * (double)p[i].N * 4.0 / 5.0e6;
+                if (t < best_t - 1e-9) {
+                    best_t = t;
+                    for (int i = 0; i < n; ++i) best[i] = cur[i];
+                }
+            }
+            int i = 0;
+            for (; i < n; ++i) {
+                if (cap[i] > 1 && ++idx[i] < 8) break;
+                idx[i] = 0;
+            }
+            if (i == n) break;
+        }
+    }
+    for (int i = 0; i < n; ++i) sk_out[i] = best[i];
+    if (n_cached < 16) {
+        keys[n_cached] = key;
+        for (int i = 0; i < n; ++i) plans[n_cached][i] = best[i];
+        ++n_cached;
+    }
+}
+
 // The same on the split-bf16 kernels (one workgroup of 8 waves per CU, 128x128 tiles only): any 2 .. 4 problems
 // that all qualify, K-split or not — the tiles of the shorter problems fill the CUs the longest one leaves.
 static int fx_gemm_try_multi_x6(const fx_gemm_problem* p, int32_t n, fx_stream_t stream, bool* launched) {
@@ -1703,9 +1815,9 @@ static int fx_gemm_try_multi_x6(const fx_gemm_problem* p, int32_t n, fx_stream_t
     int order[FX_MULTI_MAX];
     int32_t sk[FX_MULTI_MAX];
     double wl[FX_MULTI_MAX];
+    fx_x6_plan_splits(p, n, sk);
     for (int i = 0; i < n; ++i) {
         order[i] = i;
-        sk[i] = (p[i].split_k > 1 && p[i].workspace) ? fx_splitk_rule_x6(p[i].K, p[i].split_k) : 1;
         wl[i] = (double)fx_ceil_div(p[i].K, sk[i]) + (sk[i] == 1 ? 1.0 : 0.0);     // longest workgroups first
     }
     for (int a2 = 0; a2 < n; ++a2)
