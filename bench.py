@@ -696,7 +696,7 @@ def _traffic(model, batch, world):
     if model != "DeepFM" or batch != 4096 or world != 1:
         return None, None
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:
             with open(os.path.join(here, name)) as f:
                 return json.load(f)["traffic_bytes_per_launch"], name
@@ -715,7 +715,7 @@ def _sparse_traffic(model, batch, world, kernel=None):
     if model != "DeepFM" or batch != 4096 or world != 1:
         return None
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:
             with open(os.path.join(here, name)) as f:
                 d = json.load(f)
@@ -729,7 +729,7 @@ def _sparse_traffic(model, batch, world, kernel=None):
             # does not describe it)
             if kernel + "2" in pk:
                 return pk[kernel + "2"], unit + " per launch"
-            if name.startswith("r04"):
+            if name.startswith(("r04", "r05")):
                 return pk[kernel], unit + " per launch"
             return None
         except (OSError, ValueError, KeyError):
@@ -771,7 +771,7 @@ def rooflines(m, args, world):
                                          "bf16 peak / 6 = %.1f TFLOP/s; against the fp32-MFMA peak (%.1f) the "
                                          "same figure is %.3f" % (PEAK_GEMM_TFLOPS, PEAK_FP32_MFMA_TFLOPS,
                                                                   ach / PEAK_FP32_MFMA_TFLOPS)) if X6_ON else None,
-                           "traffic": traffic if not X6_ON else None,
+                           "traffic": traffic,
                            "traffic_unit": "bytes per launch (L2 fabric requests incl. Infinity-"
                                            "Cache hits; profiles/%s)" % src if src else None,
                            "launches": g["launches"], "avg_launch_us": g["avg_us"],

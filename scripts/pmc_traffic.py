@@ -12,7 +12,7 @@ import sys
 SPARSE = ("k_sort_columns", "k_dedup_", "k_finish_catchup", "k_emb_fm_fwd", "k_emb_fm_bwd", "k_sparse_update_multi",
           "k_rs_", "k_build_keys", "k_scatter_unique", "k_catchup_rows", "k_adam_catchup", "k_sparse_adam",
           "k_emb_fused")
-GEMM = ("k_gemm_f32_pipe", "k_gemm_f32_pair", "k_gemm_f32_multi", "k_gemm_f32<")
+GEMM = ("k_gemm_f32_pipe", "k_gemm_f32_pair", "k_gemm_f32_multi", "k_gemm_f32<", "k_gemm_x6")
 
 
 def load(path, counter):
