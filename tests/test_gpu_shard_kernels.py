@@ -39,7 +39,10 @@ def _received_runs(rng, R, L, rps):
 def test_owner_fetch_rows_equals_catchup_plus_gather(R, L, rps, dims, catchup):
     """fx_owner_fetch_rows == fx_adam_catchup_rows followed by one gather per table group (the round-2
     sequence): tables, moments, row stamps and the send block bit for bit; pad entries and pad columns
-    of the block are zero; the extra zero row is cleared."""
+    of the block are zero; the extra zero row is cleared.  (Round 5: for the D = 16 (+ D = 1) tables
+    fx_adam_catchup_rows runs the quad replay — fx_catchup_quad: the same terms, summed before they meet p —
+    while the owner fetch keeps the plain replay: those cases agree to fp32 rounding, everything that is not
+    arithmetic — stamps, pad entries, pad columns — still to the bit.)"""
     rng = np.random.default_rng(R * 7919 + L)
     g = torch.Generator().manual_seed(R + L)
     idx = _received_runs(rng, R, L, rps)
@@ -78,10 +81,17 @@ def test_owner_fetch_rows_equals_catchup_plus_gather(R, L, rps, dims, catchup):
     for st, off in zip(b, offs):
         ref[:, off:off + st.D] = st.table[ii]                      # pad row of the table is zero
     torch.cuda.synchronize()
-    assert torch.equal(send, ref)
+    quad = catchup and dims[0] == 16                     # fx_catchup_quad took the reference sequence's replay
+
+    def same(x, y):
+        if not quad:
+            return torch.equal(x, y)
+        return bool(((x == 0) == (y == 0)).all()) and \
+            float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max()))
+    assert same(send, ref)
     assert float(zero_row.abs().max()) == 0.0
     for x, y in zip(a, b):
-        assert torch.equal(x.table, y.table) and torch.equal(x.m, y.m) and torch.equal(x.v, y.v)
+        assert same(x.table, y.table) and same(x.m, y.m) and same(x.v, y.v)
         assert torch.equal(x.last_step, y.last_step)
     _ = g
 
