@@ -39,6 +39,8 @@ VARIANTS = {
     "splitk1": {"FX_DW_SPLITK": "1"},          # weight gradients without split-K (one k-ordered chain)
     "lazy": {"FX_PROBE_SPARSE": "lazy"},       # (not parity: SparseAdam semantics; scale reference)
     "no_inplace": {"FX_DIN_INPLACE": "0", "FX_DLRM_INPLACE": "0"},   # the concatenating compositions of DIN / DLRM
+    "x6_off": {"FX_GEMM_BF16X6": "0"},         # round 5: every GEMM on the fp32-MFMA kernels
+    "quad_off": {"FX_CATCHUP_QUAD": "0"},      # round 5: the plain catch-up replays
 }
 
 
