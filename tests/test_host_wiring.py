@@ -541,6 +541,42 @@ def test_a_head_whose_output_is_not_the_logit_falls_back(monkeypatch):
     assert not calls
 
 
+def test_a_logit_modified_in_place_after_the_head_is_not_the_fused_logit(monkeypatch):
+    """the reference's AutoInt / DESTINE write `y_pred = self.fc(...); y_pred += self.lr_layer(X)`
+    (AutoInt.py:112-116, DESTINE.py:133-135).  The in-place add leaves the logit's storage (and `data_ptr()`) where
+    the fused head put its result, with another value in it: the loss must not take the head's loss / dlogit
+    (formed on the value before the add), the tower's backward must not take the head's gradients.  The tensor's
+    version counter tells the two apart: same loss and same gradients as without the offer."""
+    _cpu_emul.install(monkeypatch)
+    from fuxictr_amd import layers, rank_model
+    gen = torch.Generator().manual_seed(9)
+    B, K = 16, 8
+    fc = layers.MLP_Block(input_dim=K, output_dim=1, hidden_units=[12], hidden_activations="ReLU")
+    wide = torch.nn.Linear(K, 1)                       # a stock layer: nothing overwrites the head's result
+    act = rank_model.FxSigmoid()
+    x = torch.randn(B, K, generator=gen)
+    y = (torch.rand(B, 1, generator=gen) > 0.5).float()
+
+    def run(offer):
+        for p_ in list(fc.parameters()) + list(wide.parameters()):
+            p_.grad = None
+        layers._HEAD_CTX = layers._HeadCtx(lambda: y, 1.0, 0) if offer else None
+        try:
+            logit = fc(x)
+            logit += wide(x)                           # IN PLACE, after the head ran
+            loss = rank_model._bce_loss(act(logit), y)
+        finally:
+            layers._HEAD_CTX = None
+        loss.backward()
+        return [loss.detach().clone()] + [p_.grad.clone() for p_ in list(fc.parameters()) + list(wide.parameters())]
+    ref = run(False)
+    got = run(True)
+    for a_, b_ in zip(got, ref):
+        assert torch.allclose(a_, b_, rtol=1e-6, atol=1e-7), (a_, b_)
+    want = torch.nn.functional.binary_cross_entropy(torch.sigmoid(fc(x) + wide(x)).detach(), y)
+    assert abs(float(got[0]) - float(want)) <= 1e-6
+
+
 def test_dcnv2_head_masks_the_deep_columns_itself(tmp_path, monkeypatch):
     """zoo.DCNv2 `parallel`: the head reads the [cross | deep] buffer of layers._CrossDeepFn; the one-pass
     head (ops.head_train, mask_from = width of the cross part) hands back a gradient whose deep columns
