@@ -32,7 +32,7 @@ def _dev(t):
 
 # (M, N, K): >= 144 tiles of 128 x 128 (x slabs) so that fx_gemm_f32 takes the split-bf16 kernels
 X6_SHAPES = [(4096, 1024, 1024), (4096, 1024, 624), (4096, 624, 624), (4096, 624, 1024), (2000, 1160, 200),
-             (4099 - 3, 628, 68), (1536, 1536, 100)]
+             (4096, 628, 68), (4092, 628, 68), (1536, 1536, 100)]
 
 
 @pytest.mark.parametrize("M,N,K", X6_SHAPES)
@@ -55,7 +55,10 @@ def test_x6_all_layouts_against_float64(M, N, K, ta, tb):
 
 
 @pytest.mark.parametrize("M,N,K,sk", [(1024, 1024, 4096, 4), (1024, 624, 4096, 8), (624, 624, 4096, 8),
-                                      (1024, 1024, 4000, 5), (640, 1024, 4100, 3)])
+                                      (1024, 1024, 4000, 5), (640, 1024, 4100, 3),
+                                      # no K split: the row sums leave the kernel directly; slabs of one and two
+                                      # k tiles, the last one partial (the pipeline's fill is then most of the loop)
+                                      (1536, 1536, 512, 1), (2048, 1280, 200, 5), (1536, 1536, 72, 2)])
 def test_x6_weight_gradient_slabs_and_bias_gradient(M, N, K, sk):
     """dW[M, N] = dz^T x with K slabs and the fused row sums of dz^T (the bias gradient), ragged K included."""
     ops = _ops()
