@@ -109,7 +109,7 @@ struct X6Opnd {
     // load instruction I of tile t.  MASK = false: the tile lies fully inside [kbeg, kend) — uniform tile base +
     // 32-bit per-lane byte offset (the saddr form); MASK = true (the slab's last tiles, the pipeline fill):
     // elements past kend are read from clamped in-range addresses here and zeroed WHERE THEY ARE CONSUMED
-    // (split_piece<S, true>) — a select on the loaded registers right behind the load would wait for it and
+    // (mask_raw, called where the tile is split) — a select on the loaded registers right behind the load would wait for it and
     // drain the prefetch in the last iterations of every slab.
     template <int I, bool MASK>
     __device__ __forceinline__ void load_piece(int32_t t, float (&r)[8]) const {
@@ -150,20 +150,25 @@ struct X6Opnd {
     // off the conversion's result, so the work stays in the slot it was written in and the raw registers are
     // read where they are.  (s_nop 0: gfx950 wants one wait state between a VALU write and v_cvt_pk_bf16_f32
     // reading it — the compiler inserts it for its own conversions.)
-    // MASK: the staged tile was tile t of the slab and may cross kend: its elements past kend become zero
-    // before the first conversion (see load_piece).
-    template <int S, bool MASK = false>
-    __device__ __forceinline__ void split_piece(float (&r)[8], uint32_t (&pl)[3][4], int32_t t = 0) const {
-        constexpr int j = S / 3, st = S % 3;
-        if constexpr (MASK && st == 0) {
-            const int32_t k0 = kbeg + t * FX_BK + kl;
-            if constexpr (KC) {
-                if (!(k0 < kend)) { r[2 * j] = 0.f; r[2 * j + 1] = 0.f; }
-            } else {
-                if (!(k0 + 2 * j < kend)) r[2 * j] = 0.f;
-                if (!(k0 + 2 * j + 1 < kend)) r[2 * j + 1] = 0.f;
+    // The staged tile was tile t of the slab and may cross kend: its elements past kend become zero before
+    // anything consumes them (the first conversion, the fused row sums) — see load_piece.
+    __device__ __forceinline__ void mask_raw(float (&r)[8], int32_t t) const {
+        const int32_t k0 = kbeg + t * FX_BK + kl;
+        if constexpr (KC) {
+            if (!(k0 < kend)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = 0.f;
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (!(k0 + e < kend)) r[e] = 0.f;
         }
+    }
+
+    template <int S>
+    static __device__ __forceinline__ void split_piece(float (&r)[8], uint32_t (&pl)[3][4]) {
+        constexpr int j = S / 3, st = S % 3;
         uint32_t p;
         asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(r[2 * j]), "v"(r[2 * j + 1]));
         pl[st][j] = p;
@@ -287,15 +292,16 @@ __device__ __forceinline__ void fx_gemm_x6_tile(const GemmArgs& a, const int64_t
                 else if constexpr (I < X2) oa.template load_piece<I - X1, MASK>(tl, ra[P]);
                 else if constexpr (I < X3) ob.template write_piece<I - X2>(st_nxt + X6_OPER, pb);
                 else if constexpr (I < X4) {
+                    if constexpr (I == X3 && MASK) oa.mask_raw(ra[P ^ 1], tsa);
                     if constexpr (I == X3 && !A_KC) {
                         if (do_rowsum && kt + 1 < nk) {      // workgroup-uniform; tile kt + 1 is a real tile
                             const float (&r)[8] = ra[P ^ 1];
                             rs += ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
                         }
                     }
-                    oa.template split_piece<I - X3, MASK>(ra[P ^ 1], pa, tsa);
+                    OA::template split_piece<I - X3>(ra[P ^ 1], pa);
                 } else if constexpr (I < X5) oa.template write_piece<I - X4>(st_nxt, pa);
-                else if constexpr (I < X6) oa.template split_piece<6 + I - X5, MASK>(ra[P ^ 1], pa, tsa);
+                else if constexpr (I < X6) OA::template split_piece<6 + I - X5>(ra[P ^ 1], pa);
                 else oa.template write_piece<I - X6 + NWA1>(st_nxt, pa);
             };
             fx_static_for<0, 12>([&](auto mm) {
@@ -316,7 +322,8 @@ __device__ __forceinline__ void fx_gemm_x6_tile(const GemmArgs& a, const int64_t
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (DO) mfma(mm, std::integral_constant<int, 1>{});
-                ob.template split_piece<m, MASK>(rb, pb, tl);
+                if constexpr (m == 0 && MASK) ob.mask_raw(rb, tl);
+                OB::template split_piece<m>(rb, pb);
                 if constexpr (m >= 2 && m < 11)
                     frag_read(std::integral_constant<int, m - 2>{}, std::integral_constant<int, 0>{}, st_nxt);
                 __builtin_amdgcn_sched_barrier(0);
@@ -330,7 +337,8 @@ __device__ __forceinline__ void fx_gemm_x6_tile(const GemmArgs& a, const int64_t
         using FF = std::false_type;
         fx_static_for<0, OB::NL>([&](auto ii) { ob.template load_piece<decltype(ii)::value, true>(0, rb); });
         fx_static_for<0, OA::NL>([&](auto ii) { oa.template load_piece<decltype(ii)::value, true>(0, ra[0]); });
-        fx_static_for<0, 12>([&](auto ss) { ob.template split_piece<decltype(ss)::value, true>(rb, pb, 0); });
+        ob.mask_raw(rb, 0);
+        fx_static_for<0, 12>([&](auto ss) { OB::template split_piece<decltype(ss)::value>(rb, pb); });
         body(-1, P1{}, FF{}, TT{});
         // tile kt + 2 is loaded in iteration kt: plain bodies while it has all 32 k inside the slab.  Pairs in
         // the loops, the odd tail outside (a skip path inside a loop would join two "loads in flight" states
