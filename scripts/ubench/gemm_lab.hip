@@ -8,6 +8,7 @@
 //   run:    gemm_lab [suite] [--trace] [--check]      suite = tower | cross | ksweep | all
 #define FX_GEMM_LAB 1
 #include "../../fuxictr_amd/csrc/fx_gemm.hip"
+#include "../../fuxictr_amd/csrc/fx_gemm_x6.hip"     // (round 5: fx_gemm.hip dispatches into it; FX_GEMM_BF16X6=0 keeps the lab on the fp32 kernels)
 
 #include <stdarg.h>
 
