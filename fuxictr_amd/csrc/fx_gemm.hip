@@ -1733,9 +1733,10 @@ static double fx_x6_makespan(const int64_t* tiles, const int64_t* ktiles, const 
 }
 
 static void fx_x6_plan_splits(const fx_gemm_problem* p, int n, int32_t* sk_out) {
-    static FxX6PlanKey keys[16];
-    static int32_t plans[16][FX_MULTI_MAX];
-    static int n_cached = 0;
+    // (launches are issued from one host thread per process — torch's stream owner; the cache is not locked)
+    static FxX6PlanKey keys[64];
+    static int32_t plans[64][FX_MULTI_MAX];
+    static int n_cached = 0, n_next = 0;
     FxX6PlanKey key;
     memset(&key, 0, sizeof(key));
     key.n = n;
@@ -1794,11 +1795,10 @@ static void fx_x6_plan_splits(const fx_gemm_problem* p, int n, int32_t* sk_out) 
         }
     }
     for (int i = 0; i < n; ++i) sk_out[i] = best[i];
-    if (n_cached < 16) {
-        keys[n_cached] = key;
-        for (int i = 0; i < n; ++i) plans[n_cached][i] = best[i];
-        ++n_cached;
-    }
+    keys[n_next] = key;                       // (64 shape sets, oldest replaced)
+    for (int i = 0; i < n; ++i) plans[n_next][i] = best[i];
+    n_next = (n_next + 1) & 63;
+    if (n_cached < 64) ++n_cached;
 }
 
 // The same on the split-bf16 kernels (one workgroup of 8 waves per CU, 128x128 tiles only): any 2 .. 4 problems
