@@ -1423,7 +1423,7 @@ static bool fx_gemm_pipe_ok(int32_t transa, int32_t transb, const GemmArgs& a) {
 // box against the fp32-MFMA kernels (profiles/r05_gemm_x6s_lab_a.txt): 4096x1024x1024 forward 50.6 vs 86.6 us,
 // dX 52.4 vs 88.5, dW (4 slabs) 57.3 vs 91.7, 4096x624x624 29.3 vs 43.0; a 256x256x128 product loses
 // (8.4 vs 7.2 us): small outputs stay on the fp32 kernels' 64x64 tiles.
-#define FX_X6_MIN_WGS 144
+#define FX_X6_MIN_WGS 96
 static bool fx_gemm_x6_shape(int64_t M, int64_t N, int64_t K) {
     return fx_gemm_x6_enabled() && M >= 128 && N >= 128 && K >= 64;
 }
@@ -1432,8 +1432,10 @@ static bool fx_gemm_x6_ok(int32_t transa, int32_t transb, const GemmArgs& a) {
     if (!fx_gemm_x6_shape(a.M, a.N, a.K)) return false;
     if (!fx_gemm_pipe_ok(transa, transb, a) || !fx_gemm_tr_ok(a)) return false;
     if (a.epi.rowsum && !transa) return false;
-    // one 8-wave workgroup per CU at ~1.7x the fp32 kernels' per-CU rate: below ~144 tiles (0.56 of the CUs)
-    // the fp32 kernels' 64x64 tiles, which fill the chip with a quarter of the output, come out ahead
+    // one 8-wave workgroup per CU at ~1.7x the fp32 kernels' per-CU rate against 64x64 tiles that fill the chip
+    // with a quarter of the output.  Measured on one box (profiles/r05_gemm_x6_tile_threshold.txt, K = 1024
+    // forward with bias + ReLU): 128 tiles 40.5 vs 48.6 us, 96 tiles 38.6 vs 46.7, 64 tiles 36.6 vs 30.8 —
+    // the split-bf16 kernels take a launch from 96 workgroups up
     return fx_ceil_div(a.M, 128) * fx_ceil_div(a.N, 128) * a.split_k >= FX_X6_MIN_WGS;
 }
 

@@ -476,6 +476,15 @@ int main(int argc, char** argv) {
     void* h = dlopen(so, RTLD_NOW | RTLD_LOCAL);
     if (h) g_fx_gemm = (fx_gemm_f32_t)dlsym(h, "fx_gemm_f32");
     if (!g_fx_gemm) fprintf(stderr, "no libfxctr (%s): fp32-mfma column skipped\n", dlerror());
+    if (argc > 2 && !strcmp(argv[2], "thr")) {      // where do 128x128-tile launches stop paying? (fx_gemm_x6_ok's threshold)
+        bench(4096, 512, 1024, 0, 1, 1, 1, "fwd 128 tiles K1024");
+        bench(4096, 512, 384, 0, 1, 1, 1, "fwd 128 tiles K384");
+        bench(4096, 384, 1024, 0, 1, 1, 1, "fwd 96 tiles K1024");
+        bench(4096, 256, 1024, 0, 1, 1, 1, "fwd 64 tiles K1024");
+        bench(4096, 512, 1024, 0, 0, 1, 0, "dX 128 tiles");
+        bench(2048, 1024, 1024, 0, 1, 1, 1, "fwd 128 tiles (M 2048)");
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "bias")) {
         for (int pass = 0; pass < 2; ++pass) {
             g_fill_shift = pass ? 0.f : 0.5f;
