@@ -30,7 +30,7 @@ def _dev(t):
     return t.to(DEV)
 
 
-# (M, N, K): >= 144 tiles of 128 x 128 (x slabs) so that fx_gemm_f32 takes the split-bf16 kernels
+# (M, N, K): >= 96 tiles of 128 x 128 (x slabs) so that fx_gemm_f32 takes the split-bf16 kernels
 X6_SHAPES = [(4096, 1024, 1024), (4096, 1024, 624), (4096, 624, 624), (4096, 624, 1024), (2000, 1160, 200),
              (4096, 628, 68), (4092, 628, 68), (1536, 1536, 100)]
 

@@ -508,7 +508,7 @@ def test_gemm_batch_of_two_forward_problems_is_the_two_launches(M):
         torch.cuda.synchronize()
         res.append((out.cpu(), z.cpu()))
     if M == 4096:
-        # (both forms on the same kernels — round 5: the split-bf16 ones, every problem has >= 144 tiles)
+        # (both forms on the same kernels — round 5: the split-bf16 ones, every problem has >= 96 tiles)
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     # M = 1000: the batch (104 tiles of 128x128) leaves on the split-bf16 kernels, the single launches (40 and
     # 64 tiles) stay on the fp32-MFMA ones — same products, different rounding: compared through fp64 below
