@@ -28,6 +28,7 @@ FX_CLIP_MAX_PARTS = 16
 SC_STEP, SC_ERR, SC_LR, SC_BETA1, SC_BETA2, SC_EPS = 0, 1, 2, 3, 4, 5
 SC_BC1, SC_BC2S, SC_STEP_SIZE, SC_CLIP, SC_TOTAL_NORM, SC_MAX_NORM, SC_LOSS = 6, 7, 8, 9, 10, 11, 12
 SC_REG_L1, SC_REG_L2 = 13, 14
+SC_SERIES_TCAP = 15     # int32: entries of the Adam series table that follows the block (0: none)
 SC_WORDS = 16
 
 vp = C.c_void_p
@@ -88,6 +89,8 @@ SIGNATURES = {
                                         vp, vp]),
     "fx_emb_numeric_grad": (i32, [vp, i64, vp, vp, i64, i32, i32, i64, vp, vp, vp]),
     "fx_opt_begin_step": (i32, [vp, vp]),
+    "fx_adam_series_words": (i64, [i32]),
+    "fx_adam_series_build": (i32, [vp, i32, vp]),
     "fx_clip_coef": (i32, [C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
     "fx_sparse_adam": (i32, [vp, vp, vp, vp, i32, vp, vp, i64, vp, vp, vp]),
     "fx_adam_catchup": (i32, [vp, vp, vp, vp, i32, vp, vp, i64, i64, i32, vp, vp]),

@@ -73,15 +73,44 @@ static inline FxRowGeom fx_row_geom(int D) {
 // 1 - beta1 ** step (python double), step_size = lr / bias_correction1, bias_correction2_sqrt =
 // (1 - beta2 ** step) ** 0.5.  One thread of one kernel per step (fx_opt_begin_step, or fused into
 // the first launch of the de-dup).
+// torch.optim.Adam computes its scalars from the python-side doubles (lr 0.001, betas 0.9 / 0.999: the bias
+// corrections, step_size = lr / bias_correction1, the lerp weights 1 - beta) while the tensor ops multiply the
+// moments by the fp32 images of the betas.  The scalar block holds fp32 images; the double is recovered as
+// the nearest number of 6 significant decimal digits when that rounds to the same fp32.  (Round 6, found by
+// holding the exact mode to an fp64 trajectory: 1 - fl32(0.999) = 0.99998713e-3 against 1e-3 — the weight of
+// g^2 in v was 1.3e-5 low, every update 6e-6 large; 1 - 0.999^t from the fp32 image is off by the same 1.3e-5
+// for every t << 1000.)
+__device__ __forceinline__ double fx_dec_f64(float b) {
+    const double x = (double)b;
+    if (!(x > 0.0) || !(x < 1.0e30)) return x;
+    const double scale = pow(10.0, 5.0 - floor(log10(x)));
+    const double r = rint(x * scale) / scale;
+    return ((float)r == b) ? r : x;
+}
+__device__ __forceinline__ double fx_beta_f64(float b) { return fx_dec_f64(b); }
+// the weight torch hands to lerp_ / addcmul_: float(1 - beta) of the double beta
+__device__ __forceinline__ float fx_one_minus(float beta) { return (float)(1.0 - fx_dec_f64(beta)); }
+// log2 of both: lb* (fp32 image: the decay of the moments), lc* (the double: the bias corrections)
+struct FxLogs {
+    double lb1, lb2, lc1, lc2;
+};
+__device__ __forceinline__ FxLogs fx_logs_of(const fx_scalars& sc) {
+    FxLogs l;
+    l.lb1 = log2((double)sc.beta1);
+    l.lb2 = log2((double)sc.beta2);
+    l.lc1 = log2(fx_beta_f64(sc.beta1));
+    l.lc2 = log2(fx_beta_f64(sc.beta2));
+    return l;
+}
 __device__ __forceinline__ void fx_begin_step_dev(fx_scalars* sc) {
     const int t = sc->step + 1;
     sc->step = t;
-    const double b1 = (double)sc->beta1, b2 = (double)sc->beta2;
+    const double b1 = fx_beta_f64(sc->beta1), b2 = fx_beta_f64(sc->beta2);
     const double bc1 = 1.0 - pow(b1, (double)t);
     const double bc2 = 1.0 - pow(b2, (double)t);
     sc->bc1 = (float)bc1;
     sc->bc2_sqrt = (float)sqrt(bc2);
-    sc->step_size = (float)((double)sc->lr / bc1);
+    sc->step_size = (float)(fx_dec_f64(sc->lr) / bc1);
 }
 
 template <int VEC>
@@ -206,10 +235,144 @@ __device__ __forceinline__ void fx_tab_store(void* base, int bf16, int64_t off, 
 // have decayed by 0.9^j (tests: exact mode == dense Adam to 5e-6 over 330 steps).
 #define FX_REPLAY_MAX 256
 #define FX_REPLAY_WINDOW 16
+
+// ---- the Adam series table (round 6; layout and mathematics: include/fxctr.h, fx_adam_series_build) ----
+// The k missed steps of a row last updated at `last` sum to
+//     (lr m / sqrt(v)) * ( F(last; c) - (b1/sqrt(b2))^k F(last + k; c b2^(-k/2)) ),   c = eps / sqrt(v)
+// with F(t; .) read from the table: per element one sqrt, one division for 1 / sqrt(v), and per table
+// segment (one for t >= 128) a division and six fmas — instead of 3 instructions for each of up to 256
+// replayed steps.  The arithmetic of an element does not depend on how many elements a lane holds, so every
+// kernel that calls this (unique-row catch-up, owner fetch, flush) moves a row to the same bits.
+#define FX_SER_HDR 16
+#define FX_SER_SEGW 8
+#define FX_SER_ENTRYW (8 * FX_SER_SEGW)
+struct FxSeries {
+    const float* tab;      // first early entry; nullptr: no table (replay)
+    int tcap;
+};
+__device__ __forceinline__ FxSeries fx_series_of(const fx_scalars* scal, const fx_scalars& sc) {
+    FxSeries s;
+    s.tcap = sc.series_tcap;
+    s.tab = s.tcap > FX_SERIES_EARLY ? reinterpret_cast<const float*>(scal) + 16 + FX_SER_HDR : nullptr;
+    return s;
+}
+__device__ __forceinline__ const float* fx_series_entry(const FxSeries& s, int t, int& nseg) {
+    t = t < s.tcap ? t : s.tcap - 1;
+    t = t > 0 ? t : 0;
+    if (t < FX_SERIES_EARLY) {
+        const float* e = s.tab + (int64_t)t * FX_SER_ENTRYW;
+        nseg = __float_as_int(e[7]);
+        return e;
+    }
+    nseg = 1;
+    return s.tab + (int64_t)FX_SERIES_EARLY * FX_SER_ENTRYW + (int64_t)(t - FX_SERIES_EARLY) * FX_SER_SEGW;
+}
+// out[e] = F(t; c[e]) of the entry `en`
+template <int NE>
+__device__ __forceinline__ void fx_series_F(const float* en, int nseg, const float (&c)[NE], float (&out)[NE]) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) out[e] = 0.f;
+    for (int s = 0; s < nseg; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(en + s * FX_SER_SEGW);
+        const float4 b = *reinterpret_cast<const float4*>(en + s * FX_SER_SEGW + 4);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const float y = a.x / (a.x + c[e]);
+            float q = fmaf(y, b.z, b.y);
+            q = fmaf(y, q, b.x);
+            q = fmaf(y, q, a.w);
+            q = fmaf(y, q, a.z);
+            q = fmaf(y * y, q, a.y);
+            out[e] = fmaf(y, q, out[e]);
+        }
+    }
+}
+// p -= the k zero-gradient steps after `last` (k > FX_SERIES_KDIR); m, v are the row's moments AT `last`
+template <int NE>
+__device__ __forceinline__ void fx_series_move(float (&p)[NE], const float (&m)[NE], const float (&v)[NE],
+                                               int last, int k, const fx_scalars& sc, const FxSeries& ser,
+                                               const FxLogs& lg) {
+    float c[NE], scale[NE], F0[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const float r = sqrtf(v[e]);
+        const bool live = (m[e] != 0.f) && (r > 0.f);
+        const float inv = live ? 1.f / r : 0.f;
+        c[e] = live ? sc.eps * inv : 1.f;          // (a dead element: any c, scale 0)
+        scale[e] = sc.lr * m[e] * inv;
+    }
+    int ns;
+    const float* en = fx_series_entry(ser, last, ns);
+    fx_series_F<NE>(en, ns, c, F0);
+    if (k < 1024) {                                // (b1/sqrt(b2))^1024 ~ 1e-47: no tail left
+        const float rho = (float)exp2((lg.lb1 - 0.5 * lg.lb2) * (double)k);
+        const float bm = (float)exp2(-0.5 * lg.lb2 * (double)k);
+        float c2[NE], F1[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) c2[e] = c[e] * bm;
+        const float* en2 = fx_series_entry(ser, last + k, ns);
+        fx_series_F<NE>(en2, ns, c2, F1);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) F0[e] = fmaf(-rho, F1[e], F0[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) p[e] = fmaf(-scale[e], F0[e], p[e]);
+}
+
+// the k <= FX_SERIES_KDIR steps that the table does not cover (the difference of two sums would cancel), in
+// the same factored form: sum_i w_i / (g_i + c), met with p once.  The bias corrections are carried as
+// d = 1 - b^t (d' = (1 - b) + b d): 1 - b2^t is 0.001 t early in a run and b2^t rounded to fp32 first would
+// leave it with a relative error of 3e-5 / t.
+template <int NE>
+__device__ __forceinline__ void fx_short_move(float (&p)[NE], const float (&m)[NE], const float (&v)[NE],
+                                              int last, int k, const fx_scalars& sc, const FxLogs& lg) {
+    float c[NE], scale[NE], acc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const float r = sqrtf(v[e]);
+        const bool live = (m[e] != 0.f) && (r > 0.f);
+        const float inv = live ? 1.f / r : 0.f;
+        c[e] = live ? sc.eps * inv : 1.f;
+        scale[e] = sc.lr * m[e] * inv;
+        acc[e] = 0.f;
+    }
+    const float sb2 = sqrtf(sc.beta2);
+    // d = 1 - B^t of the doubles B; d' = (1 - B) + B d
+    const float e1 = (float)(1.0 - exp2(lg.lc1)), e2 = (float)(1.0 - exp2(lg.lc2));
+    float d1 = (float)(1.0 - exp2(lg.lc1 * (double)last)), d2 = (float)(1.0 - exp2(lg.lc2 * (double)last));
+    float bi = 1.f, hb = 1.f;
+    for (int i = 1; i <= k; ++i) {
+        bi *= sc.beta1;
+        hb *= sb2;
+        d1 = fmaf(sc.beta1, d1, e1);
+        d2 = fmaf(sc.beta2, d2, e2);
+        const float w = bi * __builtin_amdgcn_rcpf(d1);
+        const float g = hb * __builtin_amdgcn_rsqf(d2);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) acc[e] = fmaf(w, __builtin_amdgcn_rcpf(g + c[e]), acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) p[e] = fmaf(-scale[e], acc[e], p[e]);
+}
+
 template <int VEC>
 __device__ __forceinline__ void fx_adam_replay(float (&p)[VEC], float (&m)[VEC], float (&v)[VEC],
                                                int last, int k_steps, const fx_scalars& sc,
-                                               double lb1, double lb2) {
+                                               const FxLogs& lg, const FxSeries& ser) {
+    const double lb1 = lg.lb1, lb2 = lg.lb2;
+    if (ser.tab != nullptr) {
+        bool mv = false;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) mv |= (m[k] != 0.f);
+        if (mv) {
+            if (k_steps > FX_SERIES_KDIR) fx_series_move<VEC>(p, m, v, last, k_steps, sc, ser, lg);
+            else fx_short_move<VEC>(p, m, v, last, k_steps, sc, lg);
+        }
+        const float f1 = (float)exp2(lb1 * (double)k_steps), f2 = (float)exp2(lb2 * (double)k_steps);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { m[k] *= f1; v[k] *= f2; }
+        return;
+    }
     int kk = k_steps < FX_REPLAY_MAX ? k_steps : FX_REPLAY_MAX;
     // (round 4) The steps that cannot move p are not replayed.  A row that never had a gradient (m = 0: most
     // first touches of a large table) does not move at all.  Otherwise |u_j| shrinks by >= 8 % per step once
@@ -223,8 +386,8 @@ __device__ __forceinline__ void fx_adam_replay(float (&p)[VEC], float (&m)[VEC],
     for (int k = 0; k < VEC; ++k) moving |= (m[k] != 0.f);
     if (!moving) kk = 0;
     int done = kk;
-    float pw1 = (float)exp2(lb1 * (double)last);       // beta1^last
-    float pw2 = (float)exp2(lb2 * (double)last);
+    float pw1 = (float)exp2(lg.lc1 * (double)last);       // beta1^last
+    float pw2 = (float)exp2(lg.lc2 * (double)last);
     const float sb2 = sqrtf(sc.beta2);
     float r[VEC];
 #pragma unroll

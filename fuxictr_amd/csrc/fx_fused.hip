@@ -74,7 +74,7 @@ __device__ __forceinline__ void fx_row_load(const FxTableDev& t, int64_t row, in
 template <int VEC>
 __device__ __forceinline__ void fx_catchup_finish(const FxTableDev& t, int64_t row, int sub,
                                                   FxRowRegs<VEC>& r, const fx_scalars& sc, int upto,
-                                                  double lb1, double lb2) {
+                                                  const FxLogs& lg, const FxSeries& ser) {
     if (!r.act) return;
     const int last = r.last;
     const int k_steps = upto - last;
@@ -84,7 +84,7 @@ __device__ __forceinline__ void fx_catchup_finish(const FxTableDev& t, int64_t r
 #pragma unroll
         for (int k = 0; k < VEC; ++k) any = any || (r.m[k] != 0.f) || (r.v[k] != 0.f);
         if (any) {
-            fx_adam_replay<VEC>(r.p, r.m, r.v, last, k_steps, sc, lb1, lb2);
+            fx_adam_replay<VEC>(r.p, r.m, r.v, last, k_steps, sc, lg, ser);
             const int64_t o = row * t.D + sub * VEC;
             fx_tab_store<VEC>(t.table, t.bf16, o, r.p);
             fx_store<VEC>(t.m + o, r.m);
@@ -96,11 +96,11 @@ __device__ __forceinline__ void fx_catchup_finish(const FxTableDev& t, int64_t r
 
 template <int VEC>
 __device__ __forceinline__ void fx_catchup_row(const FxTableDev& t, int64_t row, int sub,
-                                               const fx_scalars& sc, int upto, double lb1,
-                                               double lb2) {
+                                               const fx_scalars& sc, int upto, const FxLogs& lg,
+                                               const FxSeries& ser) {
     FxRowRegs<VEC> r;
     fx_row_load<VEC>(t, row, sub, r);
-    fx_catchup_finish<VEC>(t, row, sub, r, sc, upto, lb1, lb2);
+    fx_catchup_finish<VEC>(t, row, sub, r, sc, upto, lg, ser);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -143,11 +143,12 @@ __device__ __forceinline__ bool fx_quad_any(bool x) {
 }
 
 // LR = false: the D = 16 table alone (DCNv2, DLRM, ...: models without a first-order term).
+// r0 / r1 leave with the row as it stands after the catch-up (the owner fetch of the row-sharded path sends it
+// from there: one code path, one rounding, for 1 rank and for N).
 template <bool LR>
 __device__ __forceinline__ void fx_catchup_quad(const FxTableDev& t0, const FxTableDev& t1, int64_t row, int sub,
-                                                const fx_scalars& sc, int upto, double lb1, double lb2) {
-    FxRowRegs<4> r0;
-    FxRowRegs<1> r1;
+                                                const fx_scalars& sc, int upto, const FxLogs& lg,
+                                                const FxSeries& ser, FxRowRegs<4>& r0, FxRowRegs<1>& r1) {
     fx_row_load<4, false>(t0, row, sub, r0);
     if constexpr (LR) fx_row_load<1, false>(t1, row, sub, r1);
     else { r1.p[0] = r1.m[0] = r1.v[0] = 0.f; r1.on = r1.act = false; r1.last = 0; }
@@ -157,8 +158,8 @@ __device__ __forceinline__ void fx_catchup_quad(const FxTableDev& t0, const FxTa
     if (last1 != last) {
         // the two tables were not touched together (cannot happen under one id plan): the plain replays
         r0.last = last; r1.last = last1;
-        fx_catchup_finish<4>(t0, row, sub, r0, sc, upto, lb1, lb2);
-        fx_catchup_finish<1>(t1, row, sub, r1, sc, upto, lb1, lb2);
+        fx_catchup_finish<4>(t0, row, sub, r0, sc, upto, lg, ser);
+        fx_catchup_finish<1>(t1, row, sub, r1, sc, upto, lg, ser);
         return;
     }
     if (k0 <= 0) return;                               // (the whole quad: `last` is the row's)
@@ -175,7 +176,10 @@ __device__ __forceinline__ void fx_catchup_quad(const FxTableDev& t0, const FxTa
         moving |= (me[e] != 0.f);
     }
     const int kk = k0 < FX_REPLAY_MAX ? k0 : FX_REPLAY_MAX;
-    if (fx_quad_any(moving)) {
+    if (ser.tab != nullptr && k0 > FX_SERIES_KDIR) {
+        // (round 6) the sum of the missed steps from the series table: no step loop (fx_common.h)
+        if (moving) fx_series_move<5>(pe, me, ve, last, k0, sc, ser, lg);
+    } else if (fx_quad_any(moving)) {
         float c[5], sc_e[5], acc[5];
 #pragma unroll
         for (int e = 0; e < 5; ++e) {
@@ -192,15 +196,20 @@ __device__ __forceinline__ void fx_catchup_quad(const FxTableDev& t0, const FxTa
         const float b1_4 = b1_2 * b1_2, b2_4 = b2_2 * b2_2, sb2_4 = sb2_2 * sb2_2;
         float bi = sub == 0 ? b1 : sub == 1 ? b1_2 : sub == 2 ? b1_2 * b1 : b1_4;          // b1^(sub+1)
         float sb = sub == 0 ? sb2 : sub == 1 ? sb2_2 : sub == 2 ? sb2_2 * sb2 : sb2_4;
-        float a1 = (float)exp2(lb1 * (double)(last + sub + 1));                             // b1^(t+i)
-        float a2 = (float)exp2(lb2 * (double)(last + sub + 1));
+        // the bias corrections as d = 1 - b^(t+i), advanced by d' = (1 - b^4) + b^4 d (round 6: 1 - b2^t is
+        // 0.001 t early in a run; b2^t rounded to fp32 first left it with a relative error of 3e-5 / t)
+        // (lc*: torch's python-side doubles — fx_beta_f64)
+        float d1 = (float)(1.0 - exp2(lg.lc1 * (double)(last + sub + 1)));
+        float d2 = (float)(1.0 - exp2(lg.lc2 * (double)(last + sub + 1)));
+        const float e1_4 = (float)(1.0 - exp2(4.0 * lg.lc1)), e2_4 = (float)(1.0 - exp2(4.0 * lg.lc2));
         const int nr = (kk + 3) >> 2;
         for (int q = 0; q < nr; ++q) {
             const int i = 4 * q + sub + 1;
-            float w = bi * __builtin_amdgcn_rcpf(1.f - a1);
-            const float g = sb * __builtin_amdgcn_rsqf(1.f - a2);
+            float w = bi * __builtin_amdgcn_rcpf(d1);
+            const float g = sb * __builtin_amdgcn_rsqf(d2);
             w = i <= kk ? w : 0.f;
-            bi *= b1_4; sb *= sb2_4; a1 *= b1_4; a2 *= b2_4;
+            bi *= b1_4; sb *= sb2_4;
+            d1 = fmaf(b1_4, d1, e1_4); d2 = fmaf(b2_4, d2, e2_4);
             float term[5];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -224,7 +233,7 @@ __device__ __forceinline__ void fx_catchup_quad(const FxTableDev& t0, const FxTa
     }
     // the decay of the moments over ALL missed steps, in closed form
     if (any_state) {
-        const float f1 = (float)exp2(lb1 * (double)k0), f2 = (float)exp2(lb2 * (double)k0);
+        const float f1 = (float)exp2(lg.lb1 * (double)k0), f2 = (float)exp2(lg.lb2 * (double)k0);
 #pragma unroll
         for (int e = 0; e < 5; ++e) { me[e] *= f1; ve[e] *= f2; }
     }
@@ -233,19 +242,19 @@ __device__ __forceinline__ void fx_catchup_quad(const FxTableDev& t0, const FxTa
 #pragma unroll
         for (int e = 0; e < 4; ++e) any |= (r0.m[e] != 0.f) || (r0.v[e] != 0.f);
         if (any) {
-            float po[4] = {pe[0], pe[1], pe[2], pe[3]}, mo[4] = {me[0], me[1], me[2], me[3]},
-                  vo[4] = {ve[0], ve[1], ve[2], ve[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { r0.p[e] = pe[e]; r0.m[e] = me[e]; r0.v[e] = ve[e]; }
             const int64_t o = row * t0.D + sub * 4;
-            fx_tab_store<4>(t0.table, t0.bf16, o, po);
-            fx_store<4>(t0.m + o, mo);
-            fx_store<4>(t0.v + o, vo);
+            fx_tab_store<4>(t0.table, t0.bf16, o, r0.p);
+            fx_store<4>(t0.m + o, r0.m);
+            fx_store<4>(t0.v + o, r0.v);
         }
     }
     if (r1.on && ((r1.m[0] != 0.f) || (r1.v[0] != 0.f))) {
-        float po[1] = {pe[4]}, mo[1] = {me[4]}, vo[1] = {ve[4]};
-        fx_tab_store<1>(t1.table, t1.bf16, row, po);
-        fx_store<1>(t1.m + row, mo);
-        fx_store<1>(t1.v + row, vo);
+        r1.p[0] = pe[4]; r1.m[0] = me[4]; r1.v[0] = ve[4];
+        fx_tab_store<1>(t1.table, t1.bf16, row, r1.p);
+        fx_store<1>(t1.m + row, r1.m);
+        fx_store<1>(t1.v + row, r1.v);
     }
     if (sub == 0) {
         t0.last_step[row] = upto;
@@ -260,27 +269,23 @@ static const bool fx_catchup_quad_on = []() {     // FX_CATCHUP_QUAD=0: the two 
 
 // one unique row of a de-dup result, in every table group that shares the id plan
 __device__ __forceinline__ void fx_catchup_tables(const FxTableDev* t, int n_tables, int64_t row,
-                                                  int sub, const fx_scalars& sc, int upto, double lb1,
-                                                  double lb2, bool quad = false) {
-    if (quad) {
-        fx_catchup_quad<true>(t[0], t[1], row, sub, sc, upto, lb1, lb2);
-        return;
-    }
+                                                  int sub, const fx_scalars& sc, int upto, const FxLogs& lg,
+                                                  const FxSeries& ser) {
     if (n_tables == 2 && t[0].vec == 4 && t[1].vec == 1) {
         // the D-float tables + the D=1 tables of LogisticRegression: all eight loads in flight
         FxRowRegs<4> r0;
         FxRowRegs<1> r1;
         fx_row_load<4>(t[0], row, sub, r0);
         fx_row_load<1>(t[1], row, sub, r1);
-        fx_catchup_finish<4>(t[0], row, sub, r0, sc, upto, lb1, lb2);
-        fx_catchup_finish<1>(t[1], row, sub, r1, sc, upto, lb1, lb2);
+        fx_catchup_finish<4>(t[0], row, sub, r0, sc, upto, lg, ser);
+        fx_catchup_finish<1>(t[1], row, sub, r1, sc, upto, lg, ser);
         return;
     }
     for (int i = 0; i < n_tables; ++i) {
         const FxTableDev& tb = t[i];
-        if (tb.vec == 4) fx_catchup_row<4>(tb, row, sub, sc, upto, lb1, lb2);
-        else if (tb.vec == 2) fx_catchup_row<2>(tb, row, sub, sc, upto, lb1, lb2);
-        else fx_catchup_row<1>(tb, row, sub, sc, upto, lb1, lb2);
+        if (tb.vec == 4) fx_catchup_row<4>(tb, row, sub, sc, upto, lg, ser);
+        else if (tb.vec == 2) fx_catchup_row<2>(tb, row, sub, sc, upto, lg, ser);
+        else fx_catchup_row<1>(tb, row, sub, sc, upto, lg, ser);
     }
 }
 
@@ -469,12 +474,13 @@ __global__ __launch_bounds__(256) void k_finish_catchup(FinishArgs a) {
     const int64_t n = a.B * a.C;
     fx_scalars sc;
     int upto = 0;
-    double lb1 = 0.0, lb2 = 0.0;
+    FxLogs lg{0.0, 0.0, 0.0, 0.0};
+    FxSeries ser{nullptr, 0};
     if (a.n_tables > 0) {
         sc = *a.scal;
         upto = sc.step + a.upto_offset;
-        lb1 = log2((double)sc.beta1);
-        lb2 = log2((double)sc.beta2);
+        lg = fx_logs_of(sc);
+        ser = fx_series_of(a.scal, sc);
     }
     for (int64_t i = (int64_t)blockIdx.x * ipb + (threadIdx.x >> a.group_log2); i < n;
          i += (int64_t)gridDim.x * ipb) {
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(256) void k_finish_catchup(FinishArgs a) {
             }
         }
         if (!head) continue;
-        fx_catchup_tables(a.t, a.n_tables, (int64_t)k, sub, sc, upto, lb1, lb2);
+        fx_catchup_tables(a.t, a.n_tables, (int64_t)k, sub, sc, upto, lg, ser);
     }
 }
 
@@ -1525,7 +1531,7 @@ __device__ __forceinline__ void fx_update_row(const FxTableDev& t, int64_t u, in
             float m[VEC], v[VEC];
             fx_load<VEC>(t.m + o, m);
             fx_load<VEC>(t.v + o, v);
-            const float w1 = 1.f - sc.beta1, w2 = 1.f - sc.beta2;
+            const float w1 = fx_one_minus(sc.beta1), w2 = fx_one_minus(sc.beta2);   // torch's float(1 - beta)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float gk = g[k] * sc.clip_coef;
@@ -1557,7 +1563,7 @@ __device__ __forceinline__ void fx_adam_finish(const FxTableDev& t, int64_t row,
 #pragma unroll
             for (int k = 0; k < VEC; ++k) g[k] += fx_reg_grad2(r.p[k], sc.reg_l1, sc.reg_l2);
         }
-        const float w1 = 1.f - sc.beta1, w2 = 1.f - sc.beta2;
+        const float w1 = fx_one_minus(sc.beta1), w2 = fx_one_minus(sc.beta2);   // torch's float(1 - beta)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const float gk = g[k] * sc.clip_coef;
@@ -1662,11 +1668,12 @@ __global__ __launch_bounds__(256) void k_catchup_all(FxTableDev t, int64_t total
     const int64_t rpb = 256 >> t.lanes_log2;
     const fx_scalars sc = *scal;
     const int upto = sc.step + upto_offset;
-    const double lb1 = log2((double)sc.beta1), lb2 = log2((double)sc.beta2);
+    const FxLogs lg = fx_logs_of(sc);
+    const FxSeries ser = fx_series_of(scal, sc);
     for (int64_t row = (int64_t)blockIdx.x * rpb + (threadIdx.x >> t.lanes_log2); row < total_rows;
          row += (int64_t)gridDim.x * rpb) {
         if (t.last_step[row] >= upto) continue;
-        fx_catchup_row<VEC>(t, row, sub, sc, upto, lb1, lb2);
+        fx_catchup_row<VEC>(t, row, sub, sc, upto, lg, ser);
     }
 }
 
@@ -1711,21 +1718,24 @@ __global__ __launch_bounds__(256) void k_catchup_rows(CatchRowsArgs a) {
     const int nu = *a.n_unique;
     const fx_scalars sc = *a.scal;
     const int upto = sc.step + a.upto_offset;
-    const double lb1 = log2((double)sc.beta1), lb2 = log2((double)sc.beta2);
+    const FxLogs lg = fx_logs_of(sc);
+    const FxSeries ser = fx_series_of(a.scal, sc);
     if (a.quad) {
+        FxRowRegs<4> r0;
+        FxRowRegs<1> r1;
         // (the votes inside fx_catchup_quad run over the lanes that are in it: quads past the end of the list
         // simply are not)
         if (a.quad == 1)
             for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> 2); u < nu; u += (int64_t)gridDim.x * rpb)
-                fx_catchup_quad<true>(a.t[0], a.t[1], (int64_t)a.uniq_row[u], sub, sc, upto, lb1, lb2);
+                fx_catchup_quad<true>(a.t[0], a.t[1], (int64_t)a.uniq_row[u], sub, sc, upto, lg, ser, r0, r1);
         else
             for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> 2); u < nu; u += (int64_t)gridDim.x * rpb)
-                fx_catchup_quad<false>(a.t[0], a.t[0], (int64_t)a.uniq_row[u], sub, sc, upto, lb1, lb2);
+                fx_catchup_quad<false>(a.t[0], a.t[0], (int64_t)a.uniq_row[u], sub, sc, upto, lg, ser, r0, r1);
         return;
     }
     for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.group_log2); u < nu;
          u += (int64_t)gridDim.x * rpb)
-        fx_catchup_tables(a.t, a.n_tables, (int64_t)a.uniq_row[u], sub, sc, upto, lb1, lb2);
+        fx_catchup_tables(a.t, a.n_tables, (int64_t)a.uniq_row[u], sub, sc, upto, lg, ser);
 }
 
 static int fx_launch_catchup_rows(const FxTableDev* t, int n_tables, int gl, const uint32_t* uniq_row,
@@ -1798,7 +1808,7 @@ struct OwnerFetchArgs {
     int64_t ld, n_total;
     const fx_scalars* scal;
     float* zero_row;             // zero_w floats cleared on the way (pad row of the block the rows land in)
-    int32_t n_tables, group_log2, upto_offset, catchup, used_w, zero_w;
+    int32_t n_tables, group_log2, upto_offset, catchup, used_w, zero_w, quad;
 };
 
 template <int VEC>
@@ -1811,12 +1821,12 @@ __device__ __forceinline__ void fx_owner_put(const OwnerFetchArgs& a, int ti, co
 
 template <int VEC>
 __device__ __forceinline__ void fx_owner_one(const OwnerFetchArgs& a, int ti, int64_t row, int sub,
-                                             const fx_scalars& sc, int upto, double lb1, double lb2,
-                                             uint32_t beg, uint32_t end) {
+                                             const fx_scalars& sc, int upto, const FxLogs& lg,
+                                             const FxSeries& ser, uint32_t beg, uint32_t end) {
     FxRowRegs<VEC> r;
     if (a.catchup) {
         fx_row_load<VEC>(a.t[ti], row, sub, r);
-        fx_catchup_finish<VEC>(a.t[ti], row, sub, r, sc, upto, lb1, lb2);
+        fx_catchup_finish<VEC>(a.t[ti], row, sub, r, sc, upto, lg, ser);
     } else {                                   // plain gather: only the row itself (no optimizer state)
         const int lanes = 1 << a.t[ti].lanes_log2;
         r.act = sub < lanes;
@@ -1833,12 +1843,13 @@ __global__ __launch_bounds__(256) void k_owner_fetch_rows(OwnerFetchArgs a) {
     const int nu = *a.n_unique;
     fx_scalars sc;
     int upto = 0;
-    double lb1 = 0.0, lb2 = 0.0;
+    FxLogs lg{0.0, 0.0, 0.0, 0.0};
+    FxSeries ser{nullptr, 0};
     if (a.catchup) {
         sc = *a.scal;
         upto = sc.step + a.upto_offset;
-        lb1 = log2((double)sc.beta1);
-        lb2 = log2((double)sc.beta2);
+        lg = fx_logs_of(sc);
+        ser = fx_series_of(a.scal, sc);
     }
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < a.zero_w; i += 256) a.zero_row[i] = 0.f;
@@ -1847,22 +1858,32 @@ __global__ __launch_bounds__(256) void k_owner_fetch_rows(OwnerFetchArgs a) {
     for (int64_t u = gid; u < nu; u += gstride) {
         const int64_t row = a.uniq_row[u];
         const uint32_t beg = a.seg_start[u], end = a.seg_start[u + 1];
-        if (a.catchup && a.n_tables == 2 && a.t[0].vec == 4 && a.t[1].vec == 1) {
+        if (a.quad) {
+            // the shape of k_catchup_rows' quad replay, by the same function: a row is caught up to the same
+            // bits whether its owner is this rank of N or the only rank (round 6; the plain replays below
+            // round the k <= FX_SERIES_KDIR steps differently)
+            FxRowRegs<4> r0;
+            FxRowRegs<1> r1;
+            if (a.quad == 1) fx_catchup_quad<true>(a.t[0], a.t[1], row, sub, sc, upto, lg, ser, r0, r1);
+            else fx_catchup_quad<false>(a.t[0], a.t[0], row, sub, sc, upto, lg, ser, r0, r1);
+            fx_owner_put<4>(a, 0, r0, sub, beg, end);
+            if (a.quad == 1) fx_owner_put<1>(a, 1, r1, sub, beg, end);
+        } else if (a.catchup && a.n_tables == 2 && a.t[0].vec == 4 && a.t[1].vec == 1) {
             // the D-float tables + the D=1 tables of LogisticRegression: all eight loads in flight
             FxRowRegs<4> r0;
             FxRowRegs<1> r1;
             fx_row_load<4>(a.t[0], row, sub, r0);
             fx_row_load<1>(a.t[1], row, sub, r1);
-            fx_catchup_finish<4>(a.t[0], row, sub, r0, sc, upto, lb1, lb2);
-            fx_catchup_finish<1>(a.t[1], row, sub, r1, sc, upto, lb1, lb2);
+            fx_catchup_finish<4>(a.t[0], row, sub, r0, sc, upto, lg, ser);
+            fx_catchup_finish<1>(a.t[1], row, sub, r1, sc, upto, lg, ser);
             fx_owner_put<4>(a, 0, r0, sub, beg, end);
             fx_owner_put<1>(a, 1, r1, sub, beg, end);
         } else {
             for (int ti = 0; ti < a.n_tables; ++ti) {
                 const int vec = a.t[ti].vec;
-                if (vec == 4) fx_owner_one<4>(a, ti, row, sub, sc, upto, lb1, lb2, beg, end);
-                else if (vec == 2) fx_owner_one<2>(a, ti, row, sub, sc, upto, lb1, lb2, beg, end);
-                else fx_owner_one<1>(a, ti, row, sub, sc, upto, lb1, lb2, beg, end);
+                if (vec == 4) fx_owner_one<4>(a, ti, row, sub, sc, upto, lg, ser, beg, end);
+                else if (vec == 2) fx_owner_one<2>(a, ti, row, sub, sc, upto, lg, ser, beg, end);
+                else fx_owner_one<1>(a, ti, row, sub, sc, upto, lg, ser, beg, end);
             }
         }
         if (sub == 0)                                          // pad columns of the block's rows
@@ -1910,6 +1931,8 @@ extern "C" int fx_owner_fetch_rows(const fx_row_state* tables_host, const int32_
     a.send = send; a.ld = ld; a.n_total = n_total; a.scal = scal; a.n_tables = n_tables;
     a.group_log2 = gl; a.upto_offset = upto_offset; a.catchup = catchup ? 1 : 0; a.used_w = used;
     a.zero_row = zero_row; a.zero_w = zero_w;
+    a.quad = !catchup || !fx_catchup_quad_on || gl != 2 || a.t[0].vec != 4 || a.t[0].D != 16 ? 0
+             : (n_tables == 2 && a.t[1].vec == 1 && a.t[1].D == 1) ? 1 : n_tables == 1 ? 2 : 0;
     int64_t blocks = fx_ceil_div(n_total, 256 >> gl);
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(k_owner_fetch_rows, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream), a);

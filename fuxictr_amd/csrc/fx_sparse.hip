@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(256) void k_sparse_adam(RowOptArgs a) {
     const int nu = *a.n_unique;
     const int64_t rpb = 256 >> a.lanes_log2;
     const fx_scalars sc = *a.scal;
-    const float w1 = 1.f - sc.beta1, w2 = 1.f - sc.beta2;
+    const float w1 = fx_one_minus(sc.beta1), w2 = fx_one_minus(sc.beta2);   // torch's float(1 - beta)
     for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2); u < nu;
          u += (int64_t)gridDim.x * rpb) {
         const int64_t row = a.uniq_row[u];
@@ -1309,7 +1309,8 @@ __global__ __launch_bounds__(256) void k_adam_catchup(RowOptArgs a) {
     const fx_scalars sc = *a.scal;
     const int upto = sc.step + a.upto_offset;
     const int64_t n = a.uniq_row ? (int64_t)(*a.n_unique) : a.total_rows;
-    const double lb1 = log2((double)sc.beta1), lb2 = log2((double)sc.beta2);
+    const FxLogs lg = fx_logs_of(sc);
+    const FxSeries ser = fx_series_of(a.scal, sc);
     for (int64_t u = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2); u < n;
          u += (int64_t)gridDim.x * rpb) {
         const int64_t row = a.uniq_row ? (int64_t)a.uniq_row[u] : u;
@@ -1326,7 +1327,7 @@ __global__ __launch_bounds__(256) void k_adam_catchup(RowOptArgs a) {
             for (int k = 0; k < VEC; ++k) any = any || (m[k] != 0.f) || (v[k] != 0.f);
             if (any) {
                 fx_load<VEC>(a.table + o, p);
-                fx_adam_replay<VEC>(p, m, v, last, k_steps, sc, lb1, lb2);
+                fx_adam_replay<VEC>(p, m, v, last, k_steps, sc, lg, ser);
                 fx_store<VEC>(a.table + o, p);
                 fx_store<VEC>(a.m + o, m);
                 fx_store<VEC>(a.v + o, v);
@@ -1467,7 +1468,7 @@ __global__ __launch_bounds__(256) void k_reg_dense(RowOptArgs a) {
     const int d0 = sub * VEC;
     const int64_t rpb = 256 >> a.lanes_log2;
     const fx_scalars sc = *a.scal;
-    const float w1 = 1.f - sc.beta1, w2 = 1.f - sc.beta2;
+    const float w1 = fx_one_minus(sc.beta1), w2 = fx_one_minus(sc.beta2);   // torch's float(1 - beta)
     const float scale = sc.lr * sc.clip_coef;
     for (int64_t row = (int64_t)blockIdx.x * rpb + (threadIdx.x >> a.lanes_log2); row < a.total_rows;
          row += (int64_t)gridDim.x * rpb) {
@@ -1629,7 +1630,7 @@ __global__ __launch_bounds__(256) void k_mt_adam(MtArgs a) {
     float* v = a.v[t];
     const int64_t n = a.size[t];
     const fx_scalars sc = *a.scal;
-    const float w1 = 1.f - sc.beta1, w2 = 1.f - sc.beta2;
+    const float w1 = fx_one_minus(sc.beta1), w2 = fx_one_minus(sc.beta2);   // torch's float(1 - beta)
     const int64_t stride = (int64_t)gridDim.x * 256;
     const uintptr_t al = reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                          reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v);

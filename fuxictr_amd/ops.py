@@ -5,6 +5,7 @@ into libfxctr.so.  All functions require CUDA(HIP) fp32/int32 contiguous tensors
 otherwise — there is no CPU path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -143,8 +144,26 @@ def _need_cuda(t, name):
                            "(got device %s)" % (name, t.device))
 
 
-def new_scalars(device, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.0):
-    """Allocate and initialise a device-resident fx_scalars block (16 x 4-byte words)."""
+# worst relative error of a table entry (against the directly summed series) that the catch-up accepts: the
+# replay it replaces carries ~2e-7 from its approximate reciprocals
+SERIES_MAX_ERR = 2.5e-7
+_series_cache = {}          # (device, beta1, beta2) -> (tcap, table words incl. header) of a checked table
+
+
+def series_tcap(beta1, beta2):
+    """Entries of the Adam series table: one per step until both bias corrections are 1 in fp32."""
+    import math
+    if not (0.0 < beta1 < 1.0 and 0.0 < beta2 < 1.0):
+        return 0
+    t = max(math.log(2.0 ** -26) / math.log(beta1), math.log(2.0 ** -26) / math.log(beta2))
+    t = int(math.ceil(t / 1024.0)) * 1024
+    return t if 256 <= t <= (1 << 20) else 0
+
+
+def new_scalars(device, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.0, series=False):
+    """Allocate and initialise a device-resident fx_scalars block (16 x 4-byte words).  series=True (the
+    exact-mode Adam of the tables): the block is followed, in the same allocation, by the Adam series table
+    of (beta1, beta2) — fx_adam_series_build; FX_CATCHUP_SERIES=0 leaves it out (the step-by-step replay)."""
     host = torch.zeros(_lib.SC_WORDS, dtype=torch.float32)
     host[_lib.SC_LR] = lr
     host[_lib.SC_BETA1] = beta1
@@ -152,7 +171,40 @@ def new_scalars(device, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.0)
     host[_lib.SC_EPS] = eps
     host[_lib.SC_CLIP] = 1.0
     host[_lib.SC_MAX_NORM] = max_norm
-    return host.to(device)
+    device = torch.device(device)
+    tcap = series_tcap(beta1, beta2) if series and os.environ.get("FX_CATCHUP_SERIES", "1") != "0" else 0
+    if tcap == 0 or device.type != "cuda":
+        return host.to(device)
+    lib = _lib.load()
+    words = int(lib.fx_adam_series_words(tcap))
+    buf = torch.zeros(_lib.SC_WORDS + words, dtype=torch.float32, device=device)
+    scal = buf[:_lib.SC_WORDS]              # (a view: the table lives as long as the block)
+    scal.copy_(host)
+    key = (str(device), float(host[_lib.SC_BETA1]), float(host[_lib.SC_BETA2]))      # (as fp32 holds them)
+    hit = _series_cache.get(key)
+    if hit is None:
+        check(lib.fx_adam_series_build(ptr(scal), tcap, stream_ptr(device)), "fx_adam_series_build")
+        err = float(buf[_lib.SC_WORDS + 2].item())          # one host sync per (device, betas)
+        ok = err <= SERIES_MAX_ERR
+        _series_cache[key] = (tcap, buf[_lib.SC_WORDS:].clone() if ok else None, err)
+        if not ok:
+            import logging
+            logging.warning("Adam series table for betas (%g, %g): worst entry error %.2e > %.1e - the "
+                            "exact-mode catch-up keeps the step-by-step replay", beta1, beta2, err,
+                            SERIES_MAX_ERR)
+            scal.view(torch.int32)[_lib.SC_SERIES_TCAP:_lib.SC_SERIES_TCAP + 1].fill_(0)
+    elif hit[1] is not None:
+        buf[_lib.SC_WORDS:].copy_(hit[1])
+        scal.view(torch.int32)[_lib.SC_SERIES_TCAP:_lib.SC_SERIES_TCAP + 1].fill_(tcap)
+    return scal
+
+
+def series_error(scal):
+    """Worst entry error the builder measured for the table behind `scal` (None: no table)."""
+    if int(scal.view(torch.int32)[_lib.SC_SERIES_TCAP].item()) == 0:
+        return None
+    hit = _series_cache.get((str(scal.device), float(scal[_lib.SC_BETA1].item()), float(scal[_lib.SC_BETA2].item())))
+    return None if hit is None else hit[2]
 
 
 @_timed("pack_columns", "other")

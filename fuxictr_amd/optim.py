@@ -48,7 +48,10 @@ class _NativeOptimizer(torch.optim.Optimizer):
             if self._require_cuda:
                 raise _lib.FxError("native optimizer needs parameters on the GPU (no CPU fallback)")
             self.device = params[0].device
-        self.scal = ops.new_scalars(self.device, lr=lr, beta1=betas[0], beta2=betas[1], eps=eps)
+        # exact-mode Adam sums a row's missed zero-gradient steps from the series table behind the block
+        self.scal = ops.new_scalars(self.device, lr=lr, beta1=betas[0], beta2=betas[1], eps=eps,
+                                    series=(self.kind == "adam" and sparse_update == "exact"
+                                            and bool(self._groups)))
         self._lr_dev = float(lr)
         self._max_norm = 0.0
         self._max_norm_explicit = False   # set_max_norm() was called by the user of the optimizer

@@ -56,7 +56,9 @@ typedef struct fx_scalars {
     float loss;        /* 12: scratch for the fused loss kernel */
     float reg_l1;      /* 13: embedding regularizer, l1 weight (0 = off)   rank_model.py:106-112 */
     float reg_l2;      /* 14: embedding regularizer, l2 weight: loss += l1 |p|_1 + l2/2 |p|_2^2 */
-    float pad[1];
+    int32_t series_tcap; /* 15: 0, or the entry count of the Adam series table that FOLLOWS this struct in the
+                          *     same allocation (fx_adam_series_build); the exact-mode catch-up kernels then
+                          *     sum a row's missed zero-gradient steps from it instead of replaying them */
 } fx_scalars;
 
 int fx_abi_version(void);
@@ -258,6 +260,31 @@ int fx_emb_numeric_grad(const float* dout, int64_t dout_ld, const int64_t* num_o
  * pointers, counts_host their lengths (<= 16 arrays).
  * ------------------------------------------------------------------------------------------ */
 int fx_opt_begin_step(fx_scalars* scal, fx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam series table (exact mode; torch.optim.Adam as stepped at rank_model.py:322 over rows whose
+ * gradient is zero, torch_utils.py:72-76).  Step i after a row's last update t moves an element by
+ *     u_i = lr m b1^i / (1 - b1^(t+i)) / (sqrt(v) b2^(i/2) / sqrt(1 - b2^(t+i)) + eps)
+ *         = (lr m / sqrt(v)) * w_i(t) / (g_i(t) + c),      c = eps / sqrt(v),
+ * w_i, g_i the same for every element of every row last updated at t.  The table holds, per t, the
+ * infinite sum F(t; c) = sum_{i>=1} w_i / (g_i + c) as a few segments of i, each expanded about its
+ * weighted mean g:  sum_seg = y (c0 + y^2 (c2 + y (c3 + y (c4 + y (c5 + y c6))))), y = g / (g + c)
+ * (uniformly convergent in c >= 0).  The k missed steps of a row are then
+ *     sum_{i<=k} u_i = (lr m / sqrt(v)) * ( F(t; c) - (b1/sqrt(b2))^k F(t + k; c b2^(-k/2)) ),
+ * k <= FX_SERIES_KDIR steps are still replayed one by one (the difference would cancel).
+ * Layout after the 16 words of fx_scalars: 16 header words | 128 entries x 8 segments x 8 floats
+ * (t < 128; word 7 of an entry = its segment count) | (tcap - 128) entries x 8 floats (one segment);
+ * t >= tcap reads entry tcap - 1 (both bias corrections are 1 in fp32 there).
+ * fx_adam_series_words(tcap): 4-byte words the table needs behind the struct.
+ * fx_adam_series_build: reads beta1 / beta2 from scal, fills the table (fp64 inside, fp32 out), writes
+ * the largest relative error of any entry against the directly summed series (probed over c from 0 to
+ * 100 g_1) to header word 2 and sets scal->series_tcap = tcap.  The host reads that word once and clears
+ * series_tcap if it is above its tolerance (other betas than torch's defaults may not converge).
+ * ------------------------------------------------------------------------------------------ */
+#define FX_SERIES_KDIR 12
+#define FX_SERIES_EARLY 128
+int64_t fx_adam_series_words(int32_t tcap);
+int fx_adam_series_build(fx_scalars* scal, int32_t tcap, fx_stream_t stream);
 int fx_clip_coef(const float* const* parts_host, const int64_t* counts_host, int32_t n_parts,
                  fx_scalars* scal, fx_stream_t stream);
 

@@ -12,7 +12,7 @@ from fuxictr_amd import _lib
 SC = _lib
 
 
-def new_scalars(device, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.0):
+def new_scalars(device, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.0, series=False):
     s = torch.zeros(_lib.SC_WORDS, dtype=torch.float32)
     s[SC.SC_LR], s[SC.SC_BETA1], s[SC.SC_BETA2], s[SC.SC_EPS] = lr, beta1, beta2, eps
     s[SC.SC_CLIP], s[SC.SC_MAX_NORM] = 1.0, max_norm
@@ -245,14 +245,23 @@ def emb_numeric_grad(dout, dout_ld, num_out_off, dense, D, dnum_w):
         dnum_w[j] = (dense[:, j:j + 1] * flat[idx]).sum(0)
 
 
+def _beta_f64(b32):
+    """fx_dec_f64 (csrc/fx_common.h): the python-side double behind the fp32 image of lr / a beta."""
+    x = float(b32)
+    if not (0.0 < x < 1e30):
+        return x
+    r = float("%.6g" % x)
+    return r if float(torch.tensor(r, dtype=torch.float32)) == x else x
+
+
 def opt_begin_step(scal):
     t = _step(scal) + 1
     scal.view(torch.int32)[SC.SC_STEP] = t
-    b1, b2 = float(scal[SC.SC_BETA1]), float(scal[SC.SC_BETA2])
+    b1, b2 = _beta_f64(scal[SC.SC_BETA1]), _beta_f64(scal[SC.SC_BETA2])
     bc1 = 1 - b1 ** t
     scal[SC.SC_BC1] = bc1
     scal[SC.SC_BC2S] = math.sqrt(1 - b2 ** t)
-    scal[SC.SC_STEP_SIZE] = float(scal[SC.SC_LR]) / bc1
+    scal[SC.SC_STEP_SIZE] = _beta_f64(scal[SC.SC_LR]) / bc1
 
 
 def clip_coef(parts, scal):
@@ -264,8 +273,10 @@ def clip_coef(parts, scal):
 
 def _adam(p, m, v, g, scal):
     b1, b2, eps = scal[SC.SC_BETA1], scal[SC.SC_BETA2], scal[SC.SC_EPS]
-    m += (1 - b1) * (g - m)
-    v.mul_(b2).add_((1 - b2) * g * g)
+    w1 = float(torch.tensor(1.0 - _beta_f64(b1), dtype=torch.float32))     # torch's float(1 - beta)
+    w2 = float(torch.tensor(1.0 - _beta_f64(b2), dtype=torch.float32))
+    m += w1 * (g - m)
+    v.mul_(b2).add_(w2 * g * g)
     p -= scal[SC.SC_STEP_SIZE] * (m / (v.sqrt() / scal[SC.SC_BC2S] + eps))
 
 

@@ -218,19 +218,35 @@ def _adam_ref_step(p, g, m, v, t, lr):
     O.adam_dense(p, g, m, v, t, lr)
 
 
+def _within_yardstick(native, ref32, ref64, floor, what):
+    """|native - fp64 Adam| <= max(floor, 1.5 x |torch-fp32 Adam - fp64 Adam|): the reference itself rounds p
+    at every step (k roundings of up to half an ulp each); the native path is held to being as close to the
+    exact trajectory as the reference's own fp32 stepping is, on the same rows, not to a fixed number that one
+    rounding sequence happens to meet."""
+    e_nat = (native.double() - ref64).abs().max().item()
+    e_ref = (ref32.double() - ref64).abs().max().item()
+    assert e_nat <= max(floor, 1.5 * e_ref), (what, e_nat, e_ref)
+    return e_nat, e_ref
+
+
+@pytest.mark.parametrize("series", [False, True])
 @pytest.mark.parametrize("D", [16, 1, 10])
-def test_sparse_adam_exact_mode_equals_dense_adam(D):
-    """The heart of the 'exact' claim: touched-rows-only updates + catch-up replay reproduce the
-    reference's dense Adam over the WHOLE table (rows idle for > FX_REPLAY_MAX steps included)."""
+def test_sparse_adam_exact_mode_equals_dense_adam(D, series):
+    """The heart of the 'exact' claim: touched-rows-only updates + catch-up reproduce the reference's dense
+    Adam over the WHOLE table (rows idle for > FX_REPLAY_MAX steps included) — with the step-by-step replay
+    and (series) with the Adam series table behind the scalar block.  Yardstick: the same trajectory in fp64."""
     rng = np.random.default_rng(5)
     R, lr = 400, 1e-2
     table0 = torch.randn(R, D, generator=torch.Generator().manual_seed(2))
     p_ref, m_ref, v_ref = table0.clone(), torch.zeros(R, D), torch.zeros(R, D)
+    p64, m64, v64 = table0.double(), torch.zeros(R, D, dtype=torch.float64), torch.zeros(R, D, dtype=torch.float64)
     table, m, v = _dev(table0), torch.zeros(R, D, device=DEV), torch.zeros(R, D, device=DEV)
     last = torch.zeros(R, dtype=torch.int32, device=DEV)
-    scal = ops.new_scalars(DEV, lr=lr)
+    scal = ops.new_scalars(DEV, lr=lr, series=series)
+    assert (int(scal.view(torch.int32)[_lib.SC_SERIES_TCAP].item()) > 0) == series
     ws = torch.empty(ops.dedup_workspace_bytes(64), dtype=torch.uint8, device=DEV)
     n_steps = 330
+    seen = []
     for t in range(1, n_steps + 1):
         # rows 0..9 are touched only at t = 1 and t = 320 (idle > 256 steps); others randomly
         if t in (1, 320):
@@ -246,18 +262,21 @@ def test_sparse_adam_exact_mode_equals_dense_adam(D):
         rows = dd.uniq_row[:nu].cpu().long()
         # the rows a forward would read now equal the dense-Adam table after t-1 steps
         if t in (2, 100, 320):
-            assert (table[rows.to(DEV)].cpu() - p_ref[rows]).abs().max().item() <= 2e-6
+            seen.append(_within_yardstick(table[rows.to(DEV)].cpu(), p_ref[rows], p64[rows], 2e-6, ("read", t)))
         G = torch.zeros(dd.n_max, D)
         G[:nu] = torch.randn(nu, D, generator=torch.Generator().manual_seed(t)) * 0.1
         g_dense = torch.zeros(R, D)
         g_dense[rows] = G[:nu]
         _adam_ref_step(p_ref, g_dense, m_ref, v_ref, t, lr)
+        O.adam_dense(p64, g_dense.double(), m64, v64, t, lr)
         ops.sparse_adam(table, m, v, last, D, dd, _dev(G), scal)
     ops.adam_catchup(table, m, v, last, D, None, R, 0, scal)       # flush
     assert int(last.min()) == n_steps
-    assert (table.cpu() - p_ref).abs().max().item() <= 5e-6
+    seen.append(_within_yardstick(table.cpu(), p_ref, p64, 2e-6, "flush"))
     assert (m.cpu() - m_ref).abs().max().item() <= 1e-6
     assert (v.cpu() - v_ref).abs().max().item() <= 1e-6
+    print("[exact mode] D %d series %s: |native - fp64| / |torch fp32 - fp64| at t = 2, 100, 320, flush: %s"
+          % (D, series, ", ".join("%.1e / %.1e" % s for s in seen)))
 
 
 def test_sparse_sgd_and_clip():
