@@ -90,6 +90,11 @@ def parse():
                          "the young-run figure is reported beside it (`young_run`)")
     ap.add_argument("--no-uniform", action="store_true",
                     help="skip the uniform-id measurement (`value_uniform`, SURVEY 8d: both distributions)")
+    ap.add_argument("--no-din", action="store_true",
+                    help="skip the DIN (configs[3]) sub-measurement of the default DeepFM run")
+    ap.add_argument("--long-parity-steps", type=int, default=400,
+                    help="steps of the long native-vs-oracle trajectory (`parity_full_vocab.steps_400`: c2 with "
+                         "the tables x 0.01, 131 072 hold-out rows; ~1 min); 0 skips it")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the full-vocabulary parity leg (`parity_full_vocab`: the native step against the "
                          "oracle at 33.76 M rows, same weights, same batches)")
@@ -259,6 +264,58 @@ def cpu_baseline(args, cards, n_steps):
                                             "box")}
 
 
+def reference_dataloader_rate(args, batches=24):
+    """SURVEY.md 8d "a second number *with* the reference DataLoader": samples/s the reference's OWN
+    RankDataLoader -> NpzDataLoader (rank_dataloader.py:84-101, npz_dataloader.py:35-66: per-row __getitem__,
+    default_collate, BatchCollator) hands out on this host for the c2 Criteo shape — the ceiling of ANY model
+    behind it, native or not.  Needs a reference checkout (FX_REFERENCE_ROOT, <repo>/.ref_checkout or
+    /root/reference): the GPU box of the driver has none, and the field then says so."""
+    import types
+    root = os.environ.get("FX_REFERENCE_ROOT")
+    if not root:
+        for cand in (os.path.join(ROOT, ".ref_checkout"), "/root/reference"):
+            if os.path.isdir(os.path.join(cand, "fuxictr")):
+                root = cand
+                break
+    if not root or not os.path.isdir(os.path.join(root, "fuxictr")):
+        return {"skipped": "no reference checkout on this box (the reference is a Python package and does not "
+                           "travel); builder-side figures: profiles/r05_dropin_timing.txt (host-only 0.43 - 0.54 M "
+                           "samples/s for RankDataLoader, 3.49 M end to end behind the native DeviceNpzDataLoader)"}
+    try:
+        for name in ["polars", "h5py", "keras_preprocessing", "keras_preprocessing.sequence"]:
+            sys.modules.setdefault(name, types.ModuleType(name))
+        sys.modules["keras_preprocessing.sequence"].pad_sequences = lambda *a, **k: None
+        sys.dont_write_bytecode = True
+        if root not in sys.path:
+            sys.path.insert(0, root)
+        from fuxictr.pytorch.dataloaders import RankDataLoader
+        fmap, spec = synthetic.criteo_feature_map(embedding_dim=16)
+        rng = np.random.default_rng(7)
+        big = synthetic.criteo_batch(rng, args.batch * (batches + 6), dist="powerlaw")
+        path = "/tmp/fx_ref_loader_rate_%d.npz" % os.getpid()
+        np.savez(path, **{k: np.asarray(v) for k, v in big.items()})
+        out = {"unit": "samples/sec", "by_num_workers": {},
+               "what": "host side only: the reference's RankDataLoader (npz) for the c2 shape at batch %d on "
+                       "%d host cores; a model behind it cannot be faster" % (args.batch, _host_cores())}
+        for w in (0, 8):
+            gen, _ = RankDataLoader(fmap, stage="train", train_data=path, batch_size=args.batch, shuffle=True,
+                                    num_workers=w).make_iterator()
+            it = iter(gen)
+            for _ in range(3):
+                next(it)
+            t0 = time.perf_counter()
+            n = 0
+            for _ in range(batches):
+                n += next(iter(next(it).values())).shape[0]
+            out["by_num_workers"][str(w)] = n / (time.perf_counter() - t0)
+            del it, gen
+        os.remove(path)
+        out["value"] = max(out["by_num_workers"].values())
+        return out
+    except Exception as exc:   # noqa: BLE001 - a reported sub-field must not end the run
+        return {"skipped": "reference DataLoader failed here: %s: %s" % (type(exc).__name__, exc)}
+
+
 def parity_full_vocab(case, gpu_index, steps=6, B=4096, dist="powerlaw"):
     """the native step against the oracle AT THE FULL VOCABULARY the metric is quoted on
     (33 762 603 rows; the parity tests of tests/baseline_shapes.py scale the tables x 0.01).  The native
@@ -337,6 +394,108 @@ def parity_full_vocab(case, gpu_index, steps=6, B=4096, dist="powerlaw"):
     res["max_dlogit"] = max(d0, d1)
     res["seconds"] = round(time.perf_counter() - t_begin, 1)
     del model, tr
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def parity_long_horizon(case, gpu_index, steps=400, B=4096, dist="powerlaw", vocab_scale=0.01,
+                        holdout=131072, checkpoints=(100, 200, 400)):
+    """a LONG native-vs-oracle trajectory.  The headline is timed on a state hundreds of
+    steps old (rows 1 ... 300 steps behind the optimizer), while no comparison with the oracle was longer than
+    12 steps.  Here the BASELINE shapes (tables x `vocab_scale`, so that the oracle's dense Adam over every
+    row stays affordable) train for `steps` Adam steps on power-law ids — cold rows come back after hundreds of
+    steps — through the native train_step (eager steps, hipGraph capture, replays) and through the oracle
+    (rank_model.py:307-345 / torch_utils.py:72-76 restated on ATen's CPU kernels), with the oracle's identical
+    code on ATen's GPU kernels as the same-run yardstick of how far two fp32 evaluations of the reference's
+    own algorithm drift apart.  At every checkpoint the oracle's weights are loaded into a second native
+    model (reference checkpoint keys): SAME WEIGHTS -> logits within 1e-4 and AUC / logloss within 5e-5 on
+    `holdout` teacher-labelled rows.  The oracle is the CHECKER here, never the thing measured."""
+    import tempfile
+    from sklearn.metrics import log_loss, roc_auc_score
+    from fuxictr_amd import zoo
+    from oracle import ctr_oracle as O
+    from tests import baseline_shapes as bs
+    t_begin = time.perf_counter()
+    root = tempfile.mkdtemp(prefix="fx_long_")
+    model, features, cfg, spec, cards = bs.build(case, zoo, gpu_index, root, vocab_scale=vocab_scale,
+                                                 hip_graph=True)
+    probe = bs.build(case, zoo, gpu_index, root + "_probe", vocab_scale=vocab_scale)[0]
+    dev = model.device
+    state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tr = O.OracleTrainer(cfg, state0, features, lr=1e-3, max_norm=10.0)
+    yard = O.OracleTrainer(cfg, state0, features, lr=1e-3, max_norm=10.0, device=dev)
+    teacher = bs.Teacher(features)
+    rng = np.random.default_rng(606)
+    hold = bs.make_batches(case, spec, cards, rng, B, max(1, holdout // B), dist, teacher)
+    y = np.concatenate([b["label"] for b in hold]).astype(np.float64)
+    torch.set_num_threads(min(_host_cores(), 32))
+
+    def to_dev(b):
+        return {k: v.to(dev) for k, v in bs.tb(b).items()}
+
+    def describe(lg, ref=None):
+        pr = 1.0 / (1.0 + np.exp(-lg.astype(np.float64)))
+        d = {"auc": float(roc_auc_score(y, pr)), "logloss": float(log_loss(y, pr))}
+        if ref is not None:
+            d["max_dlogit"] = float(np.abs(lg - ref).max())
+            d["mean_dlogit"] = float(np.abs(lg - ref).mean())
+        return d
+    res = {"case": case, "rows": int(sum(cards) + len(cards)) if cards else None, "steps": steps, "batch": B,
+           "id_distribution": dist, "vocab_scale": vocab_scale, "holdout_rows": int(len(y)),
+           "launch": "3 eager steps, hipGraph capture, %d replays" % max(steps - 4, 0), "checkpoints": {}}
+    model.train()
+    model._max_gradient_norm = 10.0
+    ln, lo, ly = [], [], []
+    gaps = []
+    for t in range(1, steps + 1):
+        b = bs.make_batches(case, spec, cards, rng, B, 1, dist, teacher)[0]
+        tb_ = bs.tb(b)
+        ln.append(float(model.train_step(to_dev(b)).item()))
+        lo.append(tr.train_step(tb_, tb_["label"])[0])
+        ly.append(yard.train_step(tb_, tb_["label"])[0])
+        if t in checkpoints:
+            # how far behind the optimizer the rows of this state are (the exact mode's row stamps)
+            for grp in model.optimizer._groups:
+                if grp.last_step is not None and grp.D > 1:
+                    ls = grp.last_step
+                    touched = ls[ls > 0]
+                    gaps.append({"step": t, "rows_touched": int(touched.numel()),
+                                 "behind_max": int(t - touched.min().item()),
+                                 "behind_mean": float((t - touched.float()).mean().item())})
+                    break
+            ref = np.concatenate([tr.logits(bs.tb(hb)).numpy() for hb in hold])
+            probe.load_state_dict({k: v.detach().cpu() for k, v in tr.state.items()})
+            probe.eval()
+            same = describe(np.concatenate([bs.logits_of(probe, to_dev(hb))[0] for hb in hold]), ref)
+            rf = describe(ref)
+            ck = {"reference": rf,
+                  "same_weights": {"max_dlogit": same["max_dlogit"], "dauc": abs(same["auc"] - rf["auc"]),
+                                   "dlogloss": abs(same["logloss"] - rf["logloss"])}}
+            if t == max(checkpoints):
+                # the independently trained native model is only evaluated at the END: an evaluation flushes
+                # the exact mode (every row caught up), and the point of the run is rows that are far behind
+                model.eval()
+                nat = describe(np.concatenate([bs.logits_of(model, to_dev(hb))[0] for hb in hold]), ref)
+                model.train()
+                yd = describe(np.concatenate([yard.logits(bs.tb(hb)).numpy() for hb in hold]), ref)
+                ck["independent_native"] = {"mean_dlogit": nat["mean_dlogit"], "dauc": abs(nat["auc"] - rf["auc"]),
+                                            "dlogloss": abs(nat["logloss"] - rf["logloss"])}
+                ck["independent_yardstick"] = {"mean_dlogit": yd["mean_dlogit"], "dauc": abs(yd["auc"] - rf["auc"]),
+                                               "dlogloss": abs(yd["logloss"] - rf["logloss"])}
+            res["checkpoints"][str(t)] = ck
+    model.optimizer.check_errors()
+    ln, lo, ly = np.asarray(ln), np.asarray(lo), np.asarray(ly)
+    res["row_age"] = gaps
+    res["loss_first_last"] = [float(lo[0]), float(lo[-1])]
+    res["max_dloss"] = float(np.abs(ln - lo).max())
+    res["max_dloss_yardstick"] = float(np.abs(ly - lo).max())
+    # the per-step differences by century (the trajectories of an ill-conditioned optimizer part over time)
+    res["dloss_by_100"] = [[float(np.abs(ln - lo)[i:i + 100].max()), float(np.abs(ly - lo)[i:i + 100].max())]
+                           for i in range(0, steps, 100)]
+    res["seconds"] = round(time.perf_counter() - t_begin, 1)
+    del model, probe, tr, yard
     import gc
     gc.collect()
     torch.cuda.empty_cache()
@@ -508,9 +667,11 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
     if args.probe_loss:
         probe = probe_losses(args, model, cards, spec, rank, world, dev, dist,
                              sharded=(world > 1 or world1) and not args.replicas)
-    age = max(args.age_steps, args.warmup, 20) if (not args.no_graph and not args.loader
-                                                   and not args.host_inputs) else max(args.warmup, 20)
-    n_pool = min(args.pool, max(8, age + 3 * args.steps + 40))
+    # graph mode: `age` steps bring the run to the state a training run sustains, THEN --warmup more steps, then
+    # the clock (round 6: the flag means what it says; `aged_steps` is reported beside it)
+    age = max(args.age_steps, 20) if (not args.no_graph and not args.loader
+                                      and not args.host_inputs) else max(args.warmup, 20)
+    n_pool = min(args.pool, max(8, age + max(args.warmup, 0) + 3 * args.steps + 40))
     pool = make_pool(args, rank, cards, spec, dev, n_pool)
 
     loader_iter = None
@@ -553,6 +714,7 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
             for b in pool:
                 model.prepare_batch(b)
     young = None
+    aged = 0
     try:
         # graph mode: 3 eager steps + the capture, then the host side of the pool's input casts, then replays
         # back to back right up to the clock (the chip's power management needs ~20 ms of sustained load to
@@ -581,6 +743,11 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         while step_i < warm_run:
             model.train_step(next_batch(step_i))
             step_i += 1
+        aged = step_i if model._use_graph else 0
+        if model._use_graph:
+            for _ in range(max(args.warmup, 0)):
+                model.train_step(next_batch(step_i))
+                step_i += 1
         warm_run = step_i
         sync()
     except Exception as exc:   # noqa: BLE001 — e.g. a capture problem on a software stack not seen
@@ -685,6 +852,7 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
     gc.collect()
     torch.cuda.empty_cache()
     return {"dt": dt, "dt_events": dt_events, "step_us": step_us, "warmup_run": warm_run, "young": young,
+            "aged": aged,
             "ktimes": ktimes, "launch": launch, "parallelism": parallelism,
             "cards": cards, "timing_mode": timing_mode, "rows": rows, "n_pool": n_pool,
             "probe": probe}
@@ -877,10 +1045,11 @@ def timing_detail(m, args):
         y = m["young"]
         out["young_run"] = {"ms_per_step": round(y["ms_per_step"], 4),
                             "value": args.batch * 1e3 / y["ms_per_step"],
-                            "note": "%d steps timed right after step %d of the same run (HIP events): rows "
-                                    "have few missed Adam steps to catch up yet — NOT the headline; `value` "
-                                    "is measured after %d steps" % (y["steps"], y["steps_before"],
-                                                                    m["warmup_run"])}
+                            "note": "%d steps timed right after step %d of the same run (HIP events), NOT the "
+                                    "headline; `value` is measured after %d steps.  Until round 5 a young run "
+                                    "was 4 - 6 %% faster (rows had few missed Adam steps to replay); with the Adam "
+                                    "series table (round 6) the catch-up does not depend on a row's age"
+                                    % (y["steps"], y["steps_before"], m["warmup_run"])}
     if m.get("step_us"):
         out["step_us"] = {k: (round(v, 1) if isinstance(v, float) else
                               [round(x, 1) for x in v] if isinstance(v, list) else v)
@@ -976,6 +1145,14 @@ def main():
         args2.model = "DCNv2"
         m2 = measure(args2, rank, local_rank, world, world1, dev, dist)
         second = (args2, m2)
+    fourth = None
+    if (args.model == "DeepFM" and world == 1 and not world1 and not args.no_din
+            and not args.loader and not args.host_inputs and args.zoo == "native"):
+        # configs[3]: DIN on the synthetic Taobao-shape sequence schema (seq_len 50), same protocol
+        import copy
+        args4 = copy.copy(args)
+        args4.model = "DIN"
+        fourth = (args4, measure(args4, rank, local_rank, world, world1, dev, dist))
     third = None
     if (args.model == "DeepFM" and world == 1 and not world1 and not args.no_uniform and args.dist == "powerlaw"
             and not args.loader and not args.host_inputs):
@@ -990,7 +1167,8 @@ def main():
         out = {
             "metric": "samples/sec at batch 4096, Criteo-shape DeepFM/DCNv2, 1/2/4/8 MI355X",
             "value": value, "unit": "samples/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": m["warmup_run"], "warmup_requested": args.warmup,
+            "warmup": args.warmup if m["aged"] else m["warmup_run"], "aged_steps": m["aged"],
+            "steps_before_clock": m["warmup_run"],
             "ms_per_step": 1e3 * m["dt"] / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (bf16x6 split operands, fp32 accumulate)" if X6_ON else "f32",
@@ -1030,6 +1208,14 @@ def main():
             sub.update(timing_detail(m2, args2))
             sub.update(rooflines(m2, args2, world))
             out["dcnv2"] = sub
+        if fourth is not None:
+            args4, m4 = fourth
+            sub = {"workload": workload_name(args4, m4["rows"]),
+                   "value": args.batch * args.steps / m4["dt"], "unit": "samples/sec",
+                   "ms_per_step": 1e3 * m4["dt"] / args.steps, "launch": m4["launch"]}
+            sub.update(timing_detail(m4, args4))
+            sub.update(rooflines(m4, args4, world))
+            out["din"] = sub
         if third is not None:
             m3 = third
             out["value_uniform"] = args.batch * args.steps / m3["dt"]
@@ -1045,6 +1231,15 @@ def main():
                          ("c2_deepfm",) if args.model == "DeepFM" else ("c3_dcnv2",)):
                 out["parity_full_vocab"][case] = parity_full_vocab(case, local_rank)
             out["parity_full_vocab"]["max_dlogit"] = max(v["max_dlogit"] for v in out["parity_full_vocab"].values())
+            if args.long_parity_steps > 0 and args.model == "DeepFM":
+                #  the long trajectory: tables x 0.01 so that the oracle's dense Adam is affordable
+                r = parity_long_horizon("c2_deepfm", local_rank, steps=args.long_parity_steps,
+                                        checkpoints=tuple(sorted({max(1, args.long_parity_steps // 4),
+                                                                  max(1, args.long_parity_steps // 2),
+                                                                  args.long_parity_steps})))
+                out["parity_full_vocab"]["steps_%d" % args.long_parity_steps] = r
+        if world == 1 and not world1:
+            out["reference_dataloader"] = reference_dataloader_rate(args)
         if world == 1 and not args.no_cpu_baseline and args.model in ("DeepFM", "DCNv2"):
             out["cpu_baseline"] = cpu_baseline(args, m["cards"], args.cpu_baseline_steps)
         assert out["n_gpus"] == args.gpus

@@ -10,7 +10,7 @@ if [ -n "$PYT" ]; then
   echo "pytest exit $?" | tee -a $S
   grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_$TAG.log | tail -25 | tee -a $S
   grep -E "^E  " $OUT/pytest_$TAG.log | head -30 | cut -c1-400 | tee -a $S
-  grep -E "^\[(series|quad|exact)" $OUT/pytest_$TAG.log | head -60 | tee -a $S
+  grep -E "^\[(series|quad|exact|x6 range|long horizon|baseline)" $OUT/pytest_$TAG.log | head -60 | tee -a $S
 fi
 if [ -n "$AB" ]; then
   A="${AB%%|*}"; B="${AB##*|}"

@@ -251,20 +251,16 @@ def run_parity(case, dist, model, features, cfg, spec, cards, oracle_mod, B=4096
     # native path's RMS is 0.5 - 1.5 x the yardsticks', profiles/r03_parity_sweep_summary.txt): the
     # bound is slack x that RMS (no more 10 x the same-run value).
     rms8 = _yardstick_rms(case, dist)
-    # ... scaled by how hard THIS draw is for the reference itself (round 5): the 8-seed RMS describes a typical
-    # draw; on one where the reference's own two back ends sit `hard` x further apart in logits than their
-    # 8-seed RMS (c4 uniform, seed 2019: the GPU oracle's mean |dlogit| is 1.72e-4 against an RMS of 9.0e-5) the
-    # spread of the derived metrics scales with it — any change of rounding in a kernel re-draws the native
-    # path's own position inside that spread (the split-bf16 GEMM moved its dAUC from 2e-5 to 5.9e-5 here while
-    # its mean |dlogit| stayed BELOW the GPU oracle's).
-    hard = max(1.0, yard(lambda k: res[k]["mean"]) / rms8["mean"]) if rms8["mean"] > 0 else 1.0
-    res["draw_hardness"] = hard
+    # (Round 5 multiplied the AUC / logloss bounds by a same-run "draw hardness" factor, fitted after the
+    # split-bf16 GEMM had moved one configuration's dAUC past 5e-5; round 6 removed it again — VERDICT r5 weak 1 —
+    # together with the cause of most of the native path's own spread: the Adam kernels formed their lerp
+    # weights from the fp32 images of the betas, every update 6e-6 large, profiles/r06_series_catchup_ab.txt.)
     bound = {"loss": max(loss_tol, slack * yard(lambda k: res["loss"][k])),
              "max": max(logit_tol, (slack + 1) * yard(lambda k: res[k]["max"])),
              "mean": max(0.1 * logit_tol, slack * yard(lambda k: res[k]["mean"])),
-             "auc": max(metric_tol, slack * hard * rms8["dAUC"],
+             "auc": max(metric_tol, slack * rms8["dAUC"],
                         slack * yard(lambda k: abs(res[k]["auc"] - ref["auc"]))),
-             "logloss": max(metric_tol, slack * hard * rms8["dLL"],
+             "logloss": max(metric_tol, slack * rms8["dLL"],
                             slack * yard(lambda k: abs(res[k]["logloss"] - ref["logloss"])))}
     res["bounds"] = bound
     assert res["loss"]["native"] <= bound["loss"], ("loss trajectory", res)

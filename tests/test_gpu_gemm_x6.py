@@ -191,3 +191,92 @@ def test_x6_switch_selects_other_kernels_with_the_same_results(tmp_path):
             e1 = np.linalg.norm(b - ref) / np.linalg.norm(ref)
             print("[x6 a/b] %s/%s relative L2 error vs float64: fp32-MFMA %.3e  split-bf16 %.3e" % (tag, k, e0, e1))
             assert e1 <= 1.2e-6 and e1 <= 1.25 * e0 + 1e-8, (tag, k, e0, e1)
+
+
+# ---- adversarial operand ranges: every test above draws randn ---------------------------------
+RANGE_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, %r)
+from fuxictr_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(17)
+out = {}
+M, N, K = 4096, 1024, 1024
+def run(tag, x, W, dz):
+    # forward x W^T, and the weight-gradient / input-gradient pair of the same layer (K slabs + fused row sums)
+    y = torch.empty(M, N, device=dev)
+    ops.gemm(x.to(dev), W.to(dev), y, transb=True)
+    dW, dx, rs = torch.empty(N, K, device=dev), torch.empty(M, K, device=dev), torch.empty(N, device=dev)
+    ws = torch.empty(ops.gemm_workspace_floats(N, K, 4), device=dev)
+    ops.gemm_dw_dx(dz.to(dev), x.to(dev), W.to(dev), dW, dx, split_k=4, workspace=ws, rowsum=rs)
+    out[tag + "/y"], out[tag + "/dW"], out[tag + "/dx"] = y.cpu().numpy(), dW.cpu().numpy(), dx.cpu().numpy()
+x, W, dz = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05, torch.randn(M, N, generator=g)
+np.savez(sys.argv[1] + ".in", x=x.numpy(), W=W.numpy(), dz=dz.numpy())
+for tag, sx, sw, sz in (("unit", 1.0, 1.0, 1.0), ("grad_1e-8", 1.0, 1.0, 1e-8), ("act_1e-20", 1e-20, 1.0, 1e-12),
+                        ("tiny_1e-30", 1e-30, 1.0, 1.0), ("tiny_1e-35", 1e-35, 1.0, 1.0),
+                        ("huge_1e30", 1e30, 1e5, 1e-25), ("mixed", 1e18, 1e-18, 1e-10)):
+    run(tag, x * sx, W * sw, dz * sz)
+# one Inf activation and one NaN upstream gradient: what leaves the rows / columns they touch
+xi = x.clone(); xi[7, 100] = float("inf")
+dzi = dz.clone(); dzi[11, 5] = float("nan")
+run("nonfinite", xi, W, dzi)
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_x6_operand_ranges_against_float64_and_the_fp32_kernels(tmp_path):
+    """Scales the training step really produces (mean-BCE gradients of 1e-8, activations and weights of order
+    one) and scales it never does (1e-35: the third bf16 plane of an operand is a bf16 denormal; 1e30), both
+    kernels in separate processes, both against float64.  Inf / NaN: confined to the rows and columns they
+    touch; where the fp32 chain would give Inf the split product gives NaN (0 x Inf between planes) —
+    documented in fx_gemm_x6.hip and INTEGRATION.md, asserted here."""
+    res = {}
+    for mode in ("0", "1"):
+        out = str(tmp_path / ("rng_%s.npz" % mode))
+        env = dict(os.environ)
+        env["FX_GEMM_BF16X6"] = mode
+        p = subprocess.run([sys.executable, "-c", RANGE_SCRIPT % ROOT, out], env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[mode] = np.load(out)
+    base = np.load(str(tmp_path / "rng_1.npz.in.npz"))
+    x, W, dz = (base[k].astype(np.float64) for k in ("x", "W", "dz"))
+    scales = {"unit": (1.0, 1.0, 1.0), "grad_1e-8": (1.0, 1.0, 1e-8), "act_1e-20": (1e-20, 1.0, 1e-12),
+              "tiny_1e-30": (1e-30, 1.0, 1.0), "tiny_1e-35": (1e-35, 1.0, 1.0), "huge_1e30": (1e30, 1e5, 1e-25),
+              "mixed": (1e18, 1e-18, 1e-10)}
+    # float32 images of the scaled operands are what both kernels were given
+    for tag, (sx, sw, sz) in scales.items():
+        xs = (base["x"] * np.float32(sx)).astype(np.float64)
+        Ws = (base["W"] * np.float32(sw)).astype(np.float64)
+        zs = (base["dz"] * np.float32(sz)).astype(np.float64)
+        refs = {"y": xs @ Ws.T, "dW": zs.T @ xs, "dx": zs @ Ws}
+        for k, ref in refs.items():
+            e0 = np.linalg.norm(res["0"]["%s/%s" % (tag, k)] - ref) / np.linalg.norm(ref)
+            e1 = np.linalg.norm(res["1"]["%s/%s" % (tag, k)] - ref) / np.linalg.norm(ref)
+            print("[x6 range] %-11s %-2s relative L2 error vs float64: fp32-MFMA %.3e  split-bf16 %.3e" % (tag, k, e0, e1))
+            assert np.isfinite(res["1"]["%s/%s" % (tag, k)]).all(), (tag, k)
+            if tag == "tiny_1e-35":
+                # the third plane (2^-16 of 1e-35) lies below the smallest normal bf16 (1.2e-38): if the matrix
+                # core flushes it the product keeps 16 significand bits — a documented limit far outside any
+                # training state (INTEGRATION.md); bounded here so that a change of behaviour is noticed
+                assert e1 <= 2e-5, (tag, k, e1)
+            else:
+                assert e1 <= 1.2e-6 and e1 <= 1.25 * e0 + 1e-8, (tag, k, e0, e1)
+    # non-finite operands
+    for mode in ("0", "1"):
+        y, dW, dx = (res[mode]["nonfinite/" + k] for k in ("y", "dW", "dx"))
+        assert not np.isfinite(y[7]).any() or mode == "0"            # row 7 of y saw the Inf activation
+        assert np.isfinite(np.delete(y, 7, axis=0)).all(), mode      # ... and only row 7
+        assert not np.isfinite(dx[11]).any() and np.isfinite(np.delete(dx, 11, axis=0)).all(), mode
+        # dW[n, k] = sum_m dz[m, n] x[m, k]: NaN in column n = 5 of dz -> row 5 of dW; Inf in x[7, 100] -> column 100
+        bad = ~np.isfinite(dW)
+        assert bad[5].all() and bad[:, 100].all(), mode
+        bad[5] = False
+        bad[:, 100] = False
+        assert not bad.any(), mode
+    y0, y1 = res["0"]["nonfinite/y"][7], res["1"]["nonfinite/y"][7]
+    print("[x6 range] Inf activation: fp32-MFMA row has %d Inf / %d NaN, split-bf16 row has %d Inf / %d NaN"
+          % (np.isinf(y0).sum(), np.isnan(y0).sum(), np.isinf(y1).sum(), np.isnan(y1).sum()))
+    assert np.isnan(y1).all()                                        # the documented Inf -> NaN of the split
