@@ -18,6 +18,8 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+
 // Operand tile loader for an R x 32 tile (R = 64 or 128 rows of the non-contracted dimension).
 // KC: element (r,k) at P[r*ld + k] (k contiguous) else at P[k*ld + r] (r contiguous).
 // LDS image is always k-major T[k][LD]: LD = R+1 when filled by transposing 4-byte writes
@@ -1735,10 +1737,13 @@ static double fx_x6_makespan(const int64_t* tiles, const int64_t* ktiles, const 
 }
 
 static void fx_x6_plan_splits(const fx_gemm_problem* p, int n, int32_t* sk_out) {
-    // (launches are issued from one host thread per process — torch's stream owner; the cache is not locked)
+    // (forward batches are launched from the main thread, backward ones from the autograd engine's thread: the
+    // cache is locked — ADVICE r5 — and a plan never exceeds this problem's workspace cap, see the clamp below)
     static FxX6PlanKey keys[64];
     static int32_t plans[64][FX_MULTI_MAX];
     static int n_cached = 0, n_next = 0;
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> lock(mtx);
     FxX6PlanKey key;
     memset(&key, 0, sizeof(key));
     key.n = n;
@@ -1752,7 +1757,7 @@ static void fx_x6_plan_splits(const fx_gemm_problem* p, int n, int32_t* sk_out) 
     }
     for (int c = 0; c < n_cached; ++c)
         if (keys[c] == key) {
-            for (int i = 0; i < n; ++i) sk_out[i] = plans[c][i];
+            for (int i = 0; i < n; ++i) sk_out[i] = plans[c][i] <= cap[i] ? plans[c][i] : cap[i];
             return;
         }
     static const bool planner_on = []() {     // FX_X6_PLAN=0: ~1024-deep slabs (round 5's first cut)
@@ -1796,11 +1801,23 @@ static void fx_x6_plan_splits(const fx_gemm_problem* p, int n, int32_t* sk_out) 
             if (i == n) break;
         }
     }
-    for (int i = 0; i < n; ++i) sk_out[i] = best[i];
+    for (int i = 0; i < n; ++i) sk_out[i] = best[i] <= cap[i] ? best[i] : cap[i];
     keys[n_next] = key;                       // (64 shape sets, oldest replaced)
     for (int i = 0; i < n; ++i) plans[n_next][i] = best[i];
     n_next = (n_next + 1) & 63;
     if (n_cached < 64) ++n_cached;
+}
+
+// Which slab rule a problem of a batch gets when it is launched on its own: the x6 rule (~1024-deep
+// slabs) only if the x6 kernels will really take it — enough 128x128 tiles x slabs, a fused row sum only on a
+// row-contiguous op(A); a 256x256 or 512x512 weight gradient with K = 4096 otherwise ran on the fp32 kernels'
+// 64x64 tiles with 4 slabs where their own rule gives 16 (a quarter of the chip).  (Operand alignment is checked
+// again in fx_gemm_f32; a misaligned problem only loses the better split.)
+static bool fx_batch_wants_x6(const fx_gemm_problem& q) {
+    if (!fx_gemm_x6_shape(q.M, q.N, q.K)) return false;
+    if (q.epilogue && q.epilogue->rowsum && !q.transa) return false;
+    const int32_t sk = fx_splitk_rule_x6(q.K, q.workspace ? q.split_k : 1);
+    return fx_ceil_div(q.M, 128) * fx_ceil_div(q.N, 128) * sk >= FX_X6_MIN_WGS;
 }
 
 // The same on the split-bf16 kernels (one workgroup of 8 waves per CU, 128x128 tiles only): any 2 .. 4 problems
@@ -2064,8 +2081,8 @@ extern "C" int fx_gemm_f32_batch(const fx_gemm_problem* p, int32_t n, fx_stream_
         const int rc = fx_gemm_f32(q.transa, q.transb, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C,
                                    q.ldc, q.epilogue,
                                    fx_gemm_skinny(q) ? q.split_k
-                                   : fx_gemm_x6_shape(q.M, q.N, q.K) ? fx_splitk_rule_x6(q.K, q.workspace ? q.split_k : 1)
-                                                     : fx_splitk_rule64(q.M, q.N, q.K, q.split_k),
+                                   : fx_batch_wants_x6(q) ? fx_splitk_rule_x6(q.K, q.workspace ? q.split_k : 1)
+                                                          : fx_splitk_rule64(q.M, q.N, q.K, q.split_k),
                                    q.workspace, stream);
         if (rc != FX_OK) return rc;
     }

@@ -20,6 +20,8 @@ import os
 from collections import OrderedDict
 from functools import partial  # noqa: F401  (used by eval'ed initializer strings)
 
+import weakref
+
 import torch
 from torch import nn
 
@@ -1816,12 +1818,17 @@ class _MLPFn(torch.autograd.Function):
                 # (the logit's version counter: a model that goes on to modify it IN PLACE — AutoInt.py:112-116
                 # `y_pred += self.lr_layer(X)` — hands the loss the same storage with another value; views share
                 # the counter with their base)
-                ctx.head = (dlogit, dzp, dW, db, asker, note, y, y._version)
+                # (a WEAK reference to the output: ctx -> y -> grad_fn -> ctx would be a cycle that only this
+                # node's backward breaks — a head-fused forward that is never followed by backward would keep the
+                # logit and the fused gradients alive until the cyclic GC runs; hc.result owns y)
+                ctx.head = (dlogit, dzp, dW, db, asker, note, weakref.ref(y), y._version)
                 hc.result = (y, dlogit, loss, y._version)
             else:
                 ops.gemm(h, W, y, transa=False, transb=True, bias=b, act=1 if acts[i] else 0,
                          add=out_add if (i == n - 1 and out_add is not None) else None)
-            hs.append(y)
+            # (the tower's own output is only needed by the backward as the ReLU mask of an activated last layer:
+            # otherwise it is not kept on ctx — the same cycle)
+            hs.append(y if (i < n - 1 or acts[i]) else None)
             h = y
         ctx.has_add = out_add is not None
         ctx.acts = acts
@@ -1841,12 +1848,13 @@ class _MLPFn(torch.autograd.Function):
         top = n - 1
         head_used = False
         if ctx.head is not None:
-            dlogit, dzp, dWh, dbh, asker, note, y_head, y_ver = ctx.head
+            dlogit, dzp, dWh, dbh, asker, note, y_ref, y_ver = ctx.head
+            y_head = y_ref()
             # (no second owner of dW / db: AccumulateGrad takes over a gradient it holds alone and
             # CLONES one somebody else still references — two copy launches per step)
             ctx.head = None
             if (dy.data_ptr() == dlogit.data_ptr() and dy.numel() == dlogit.numel()
-                    and y_head._version == y_ver):
+                    and y_head is not None and y_head._version == y_ver):
                 # the gradient that arrives IS the fused dlogit: the head's own gradients and the
                 # gradient below it were formed in the forward pass (ops.head_train)
                 head_used = True
