@@ -864,7 +864,7 @@ def _traffic(model, batch, world):
     if model != "DeepFM" or batch != 4096 or world != 1:
         return None, None
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:
             with open(os.path.join(here, name)) as f:
                 return json.load(f)["traffic_bytes_per_launch"], name
@@ -883,7 +883,7 @@ def _sparse_traffic(model, batch, world, kernel=None):
     if model != "DeepFM" or batch != 4096 or world != 1:
         return None
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:
             with open(os.path.join(here, name)) as f:
                 d = json.load(f)
@@ -897,7 +897,7 @@ def _sparse_traffic(model, batch, world, kernel=None):
             # does not describe it)
             if kernel + "2" in pk:
                 return pk[kernel + "2"], unit + " per launch"
-            if name.startswith(("r04", "r05")):
+            if name.startswith(("r04", "r05", "r06")):
                 return pk[kernel], unit + " per launch"
             return None
         except (OSError, ValueError, KeyError):

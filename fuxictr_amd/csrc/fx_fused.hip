@@ -1815,8 +1815,14 @@ template <int VEC>
 __device__ __forceinline__ void fx_owner_put(const OwnerFetchArgs& a, int ti, const FxRowRegs<VEC>& r,
                                              int sub, uint32_t beg, uint32_t end) {
     if (!r.on) return;
+    float v[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        // a bf16 table holds the ROUNDED row: that is what an unsharded gather would read back after the
+        // catch-up stored it, so that is what travels (the registers still hold the unrounded fp32 result)
+        v[k] = a.t[ti].bf16 ? fx_bf16_to_f32(fx_f32_to_bf16(r.p[k])) : r.p[k];
     for (uint32_t i = beg; i < end; ++i)
-        fx_store<VEC>(a.send + (int64_t)a.sorted_pos[i] * a.ld + a.off[ti] + sub * VEC, r.p);
+        fx_store<VEC>(a.send + (int64_t)a.sorted_pos[i] * a.ld + a.off[ti] + sub * VEC, v);
 }
 
 template <int VEC>
@@ -1831,7 +1837,7 @@ __device__ __forceinline__ void fx_owner_one(const OwnerFetchArgs& a, int ti, in
         const int lanes = 1 << a.t[ti].lanes_log2;
         r.act = sub < lanes;
         r.on = r.act && sub * VEC < a.t[ti].D;
-        if (r.on) fx_tab_load<VEC>(a.t[ti].table, 0, row * a.t[ti].D + sub * VEC, r.p);
+        if (r.on) fx_tab_load<VEC>(a.t[ti].table, a.t[ti].bf16, row * a.t[ti].D + sub * VEC, r.p);
     }
     fx_owner_put<VEC>(a, ti, r, sub, beg, end);
 }
@@ -1920,7 +1926,6 @@ extern "C" int fx_owner_fetch_rows(const fx_row_state* tables_host, const int32_
     if (st != FX_OK) return st;
     int used = 0;
     for (int t = 0; t < n_tables; ++t) {
-        FX_CHECK_ARG(!a.t[t].bf16, "fx_owner_fetch_rows: bf16 tables are not supported here");
         FX_CHECK_ARG(off_host[t] >= 0 && off_host[t] + a.t[t].D <= ld && off_host[t] % a.t[t].vec == 0 &&
                          ld % a.t[t].vec == 0,
                      "fx_owner_fetch_rows: table %d does not fit / align in the block", t);

@@ -213,14 +213,15 @@ class _TableGroup(object):
         if self.total_rows >= 2 ** 32 - 1:
             raise NotImplementedError("packed table with %d rows exceeds the 2^32-1 row limit "
                                       "of the sparse path" % self.total_rows)
-        if self.total_rows > 0 and self.sharded and _EMB_DTYPE != torch.float32:
-            raise NotImplementedError("emb_dtype=bf16 with shard='row' is not implemented")
         if self.total_rows > 0 and self.sharded:
             # local shard + one all-zero pad row (index rows_per_shard) that padded all-to-all
-            # slots point at; it is never part of a de-dup result, so it is never updated
+            # slots point at; it is never part of a de-dup result, so it is never updated.
+            # (round 6: `emb_dtype: bf16` shards too — the owner widens its bf16 rows into the fp32 block of
+            # the exchange, requesters read what they received exactly as an unsharded bf16 table's rows
+            # are read after widening; moments, gradients and the update arithmetic are fp32 on the owner)
             self.rows_per_shard = -(-self.total_rows // self.n_shards)
-            self.table = torch.zeros(self.rows_per_shard + 1, self.D, dtype=torch.float32,
-                                     device=self.device)
+            dt = _EMB_DTYPE if self.D > 1 else torch.float32
+            self.table = torch.zeros(self.rows_per_shard + 1, self.D, dtype=dt, device=self.device)
         elif self.total_rows > 0:
             # (the D=1 tables of LogisticRegression stay fp32: 4-byte rows gain nothing from bf16)
             dt = _EMB_DTYPE if self.D > 1 else torch.float32
@@ -404,8 +405,6 @@ class _TableGroup(object):
         fill one slot of the record (categorical columns and the positions of RAW sequences alike;
         pooled sequences keep the pooling kernels).  Row-sharded groups run the same kernels over the
         rows received from their owners (slot matrix instead of ids)."""
-        if self.sharded and self.table is not None and self.table.dtype != torch.float32:
-            return False
         return plan.n_seq == 0 and _lib.row_lanes(self.D) <= 64
 
     def dedup(self, plan, ids, inputs):
@@ -605,8 +604,7 @@ class _TableGroup(object):
         if track and not catchup:
             for p, _ in layout:                       # mixed optimizers: separate catch-up launches
                 if p.exact and p.opt_kind == "adam":
-                    ops.adam_catchup(p.table, p.m, p.v, p.last_step, p.D, sx.owner_dd,
-                                     p.rows_per_shard + 1, -1, p.scal)
+                    ops.adam_catchup_rows([p.row_state()], sx.owner_dd, -1, p.scal)     # (dtype-aware)
         ops.owner_fetch_rows([p.row_state() for p, _ in layout], [off for _, off in layout],
                              sx.owner_dd, send, catchup, self.ensure_scal(), zero_row=recv[N * cap])
         self.dist.all_to_all(send, recv=recv[:N * cap])

@@ -767,7 +767,8 @@ int fx_emb_fm_fwd(const void* table, int32_t table_dtype, int32_t D, const int32
  *   floats cleared in the same launch (the pad row of the block the received rows will land in; NULL /
  *   0 = none).  Replaces, on the owning rank, the
  *   row reads of aten::embedding (feature_embedding.py:283-291) and dense Adam's step on untouched
- *   rows (torch_utils.py:76).  fp32 tables only. */
+ *   rows (torch_utils.py:76).  fp32 or bf16 tables (table_dtype): a bf16 row travels widened to fp32, after the
+ *   rounding its stored copy went through. */
 int fx_owner_fetch_rows(const fx_row_state* tables_host, const int32_t* off_host, int32_t n_tables,
                         const uint32_t* uniq_row, const uint32_t* seg_start,
                         const uint32_t* sorted_pos, const int32_t* n_unique, int64_t n_total,

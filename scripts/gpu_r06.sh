@@ -17,7 +17,7 @@ if [ -n "$AB" ]; then
   for R in $(seq 1 $REPS); do
     for V in A B; do
       if [ $V = A ]; then E="$A"; else E="$B"; fi
-      env $E timeout 400 python bench.py --model $MODEL --steps 100 --warmup 10 --no-cpu-baseline --no-dcnv2 --no-parity --no-uniform 2>$OUT/ab_$TAG.err | head -1 > $OUT/ab_tmp.json
+      env $E timeout 400 python bench.py --model $MODEL --steps 100 --warmup 10 --no-cpu-baseline --no-dcnv2 --no-din --no-parity --no-uniform 2>$OUT/ab_$TAG.err | head -1 > $OUT/ab_tmp.json
       python - "$V [$E]" $OUT/ab_tmp.json <<'PY' | tee -a $S
 import json, sys
 try:
@@ -37,7 +37,7 @@ if [ "$TL" = "1" ]; then
   echo "== rocprofv3 kernel trace ($MODEL)" | tee -a $S
   rm -rf /tmp/prof_$TAG
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- \
-      python $REPO/bench.py --model $MODEL --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-dcnv2 --no-parity --no-uniform > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err)
+      python $REPO/bench.py --model $MODEL --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-dcnv2 --no-din --no-parity --no-uniform > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err)
   echo "rocprof exit $?" | tee -a $S
   STATS=$(ls -t $(find /tmp/prof_$TAG -name '*kernel_stats.csv') 2>/dev/null | head -1)
   if [ -n "$STATS" ]; then cp $STATS $OUT/kernel_stats_$TAG.csv; fi

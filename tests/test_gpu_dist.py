@@ -129,3 +129,21 @@ def test_eight_ranks_on_one_gpu_at_the_real_c5_shapes(dist):
           "even share of the lookups %d)" % (dist, eight["probe_loss"], fill["fullest_bucket_rows"],
                                              fill["capacity_rows"], fill["fill"], fill["even_share_of_lookups"]))
     assert 0.0 < fill["fill"] < 1.0
+
+
+def test_bf16_tables_row_sharded_over_two_ranks_reproduce_the_one_rank_losses():
+    """Round 6: `emb_dtype: bf16` with `shard: row` (it raised NotImplementedError until
+    now).  The owner widens its bf16 rows — after the rounding their stored copy went through — into the fp32
+    block of the exchange; requesters read them as an unsharded bf16 table's rows are read; moments, gradients
+    and the update arithmetic are fp32 on the owner, the updated row is rounded to nearest-even bf16.  Same
+    seeded model, same seeded GLOBAL batch: the two probe losses of the 2-rank run (both ranks on cuda:0,
+    collectives staged through gloo) equal those of the one-rank bf16 run on the whole batch."""
+    common = ["--vocab-scale", "0.01", "--steps", "3", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing",
+              "--no-dcnv2", "--no-din", "--no-parity", "--no-uniform", "--probe-loss", "--emb-dtype", "bf16"]
+    one = _bench_line(["--gpus", "1", "--probe-world", "2"] + common)
+    two = _bench_line(["--gpus", "2"] + common, env={"FX_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and "row-sharded" in two["config"]["parallelism"]
+    assert "bf16" in two["config"]["emb_dtype"]
+    for a, b in zip(one["probe_loss"], two["probe_loss"]):
+        assert abs(a - b) <= 2e-5, (one["probe_loss"], two["probe_loss"])
+    assert one["probe_loss"][0] != one["probe_loss"][1]

@@ -243,3 +243,50 @@ def test_shard_plan_slot_uniq_is_the_inverse_of_uniq_slot(N, B):
     np.testing.assert_array_equal(us[:nu], u2.numpy()[:nu])
     np.testing.assert_array_equal(su, su2.numpy())
     np.testing.assert_array_equal(lookup_slot.cpu().numpy()[valid], l2.numpy()[valid])
+
+
+@pytest.mark.parametrize("catchup", [True, False])
+def test_owner_fetch_rows_of_a_bf16_table(catchup):
+    """Round 6: the owner fetch takes bf16 tables (`emb_dtype: bf16` + `shard: row`).  What travels is the row as
+    an unsharded bf16 table would hold it after the same catch-up — rounded to nearest-even bf16, then widened —
+    so: send block == gather of the tables that fx_adam_catchup_rows left behind, bit for bit; the D = 1 table of
+    the first-order term stays fp32."""
+    R, L, rps = 4, 600, 3000
+    rng = np.random.default_rng(77)
+    idx = _received_runs(rng, R, L, rps)
+    n = R * L
+    ws = torch.empty(ops.dedup_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    odd = ops.dedup_sorted_runs(_dev(idx).view(n, 1), R, rps + 1, rps, ws)
+    scal = ops.new_scalars(DEV, lr=1e-2, series=True)
+    scal.view(torch.int32)[_lib.SC_STEP] = 399
+    ops.opt_begin_step(scal)
+
+    def make():
+        gg = torch.Generator().manual_seed(4321)
+        sts = []
+        for D, dt in ((16, torch.bfloat16), (1, torch.float32)):
+            t = torch.randn(rps + 1, D, generator=gg)
+            t[rps] = 0
+            m = torch.randn(rps + 1, D, generator=gg) * 1e-2
+            v = torch.rand(rps + 1, D, generator=gg) * 1e-3
+            last = torch.randint(0, 400, (rps + 1,), generator=gg).int()
+            sts.append(ops.RowState(_dev(t).to(dt), _dev(m), _dev(v), _dev(last), D))
+        return sts
+    a, b = make(), make()
+    send = torch.full((n, 20), 7.0, device=DEV)
+    zero_row = torch.full((20,), 3.0, device=DEV)
+    ops.owner_fetch_rows(a, [0, 16], odd, send, catchup, scal, zero_row=zero_row)
+    if catchup:
+        ops.adam_catchup_rows(b, odd, -1, scal)
+    ref = torch.zeros(n, 20, device=DEV)
+    ii = torch.from_numpy(idx.astype(np.int64)).to(DEV)
+    ref[:, 0:16] = b[0].table[ii].float()
+    ref[:, 16:17] = b[1].table[ii]
+    torch.cuda.synchronize()
+    assert torch.equal(send, ref)
+    assert float(zero_row.abs().max()) == 0.0
+    for x, y in zip(a, b):
+        assert torch.equal(x.table, y.table) and torch.equal(x.m, y.m) and torch.equal(x.v, y.v)
+        assert torch.equal(x.last_step, y.last_step)
+    if catchup:
+        assert not torch.equal(a[0].table, make()[0].table)          # rows did move
