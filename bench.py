@@ -984,7 +984,7 @@ def rooflines(m, args, world):
             "algorithmic_bytes_per_sample": per_sample, "us_per_step": us_step,
             "launches_per_step": sp["launches"] / n_inst,
             "distinct_batches_replayed": sp.get("steps", 1),
-            "per_kernel": "profiles/r05_step_timeline_%s_final.txt (rocprofv3 kernel trace of one "
+            "per_kernel": "profiles/r06_step_timeline_%s_final.txt (rocprofv3 kernel trace of one "
                           "step of the timed region)" % args.model}
         tr = _sparse_traffic(args.model, args.batch, world)
         if tr is not None:

@@ -41,6 +41,7 @@ VARIANTS = {
     "no_inplace": {"FX_DIN_INPLACE": "0", "FX_DLRM_INPLACE": "0"},   # the concatenating compositions of DIN / DLRM
     "x6_off": {"FX_GEMM_BF16X6": "0"},         # round 5: every GEMM on the fp32-MFMA kernels
     "quad_off": {"FX_CATCHUP_QUAD": "0"},      # round 5: the plain catch-up replays
+    "series_off": {"FX_CATCHUP_SERIES": "0"},  # round 6: no Adam series table (step-by-step replay of every gap)
 }
 
 
