@@ -39,7 +39,7 @@ i64 = C.c_int64
 class RowState(C.Structure):
     """struct fx_row_state"""
     _fields_ = [("table", vp), ("m", vp), ("v", vp), ("last_step", vp), ("G", vp), ("D", i32),
-                ("table_dtype", i32)]
+                ("table_dtype", i32), ("table_ld", i64), ("m_ld", i64), ("v_ld", i64), ("last_ld", i64)]
 
 
 class GemmEpilogue(C.Structure):
@@ -63,9 +63,9 @@ SIGNATURES = {
     "fx_pack_columns": (i32, [C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), i32, i64, i32, vp,
                               i64, i64, vp]),
     "fx_emb_gather_fwd": (i32, [vp, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, vp, i32, vp, i64,
-                                i64, vp, vp]),
+                                i64, vp, i64, vp]),
     "fx_emb_seq_pool_fwd": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp, i64,
-                                  vp, vp]),
+                                  vp, i64, vp]),
     "fx_dedup_workspace_bytes": (C.c_size_t, [i64]),
     "fx_dedup": (i32, [vp, i64, i64, i32, vp, vp, vp, i64, vp, C.c_size_t, vp, vp, vp, vp, vp, vp,
                        i32, i32, vp, vp]),
@@ -106,7 +106,7 @@ SIGNATURES = {
     "fx_fm_bwd": (i32, [vp, i64, i32, i32, vp, vp, i64, i32, i64, vp]),
     "fx_dot_interact_fwd": (i32, [vp, i64, i32, i32, i64, vp, i64, i32, vp]),
     "fx_dot_interact_bwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i64, vp, i64, vp]),
-    "fx_lr_fwd": (i32, [vp, vp, i64, vp, vp, i32, vp, i64, vp, i32, vp, vp, i64, vp, vp]),
+    "fx_lr_fwd": (i32, [vp, vp, i64, vp, vp, i32, vp, i64, vp, i32, vp, vp, i64, vp, i64, vp]),
     "fx_gemm_f32_batch": (i32, [C.POINTER(GemmProblem), i32, vp]),
     "fx_gemm_f32": (i32, [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64,
                           C.POINTER(GemmEpilogue), i32, vp, vp]),

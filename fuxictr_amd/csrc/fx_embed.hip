@@ -109,6 +109,7 @@ struct GatherArgs {
     int64_t B;
     fx_scalars* scal;
     int32_t D, C, Fd, lanes_log2;
+    int64_t table_ld;     // row stride of `table` in floats (D for a packed table, W inside a row record)
 };
 
 template <int VEC>
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void k_emb_gather_fwd(GatherArgs a) {
             if (id >= 0 && id < a.col_vocab[r]) {
                 if (lane_on) {
                     const int64_t row = a.col_row_base[r] + id;
-                    fx_load<VEC>(a.table + row * a.D + d0, val);
+                    fx_load<VEC>(a.table + row * a.table_ld + d0, val);
                 }
             } else if (sub == 0) {
                 atomicOr(&a.scal->err_flag, FX_FLAG_BAD_ID);
@@ -165,9 +166,10 @@ extern "C" int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* i
                                  const int32_t* col_vocab, const int64_t* col_out_off, int32_t C,
                                  const float* dense, int64_t dense_ld, const float* num_w,
                                  const int64_t* num_out_off, int32_t Fd, float* out,
-                                 int64_t out_ld, int64_t B, fx_scalars* scal,
+                                 int64_t out_ld, int64_t B, fx_scalars* scal, int64_t table_ld,
                                  fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256, "fx_emb_gather_fwd: D=%d not in [1,256]", D);
+    if (table_ld <= 0) table_ld = D;
     FX_CHECK_ARG(C >= 0 && Fd >= 0 && B >= 0, "fx_emb_gather_fwd: negative size");
     if (B == 0 || C + Fd == 0) return FX_OK;
     FX_CHECK_ARG(out && scal, "fx_emb_gather_fwd: null out/scal");
@@ -178,8 +180,10 @@ extern "C" int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* i
     const FxRowGeom g = fx_row_geom(D);
     FX_CHECK_ARG(out_ld % g.vec == 0, "fx_emb_gather_fwd: out_ld=%lld not a multiple of %d",
                  (long long)out_ld, g.vec);
+    FX_CHECK_ARG(table_ld >= D && table_ld % g.vec == 0,
+                 "fx_emb_gather_fwd: table_ld=%lld does not allow %d-wide row loads", (long long)table_ld, g.vec);
     GatherArgs a{table, ids, ids_ld, col_row_base, col_vocab, col_out_off, dense, dense_ld,
-                 num_w, num_out_off, out, out_ld, B, scal, D, C, Fd, fx_log2i(g.lanes)};
+                 num_w, num_out_off, out, out_ld, B, scal, D, C, Fd, fx_log2i(g.lanes), table_ld};
     const int64_t items = B * (int64_t)(C + Fd);
     int64_t blocks = fx_ceil_div(items, 256 / g.lanes);
     if (blocks > 256 * 32) blocks = 256 * 32;
@@ -216,6 +220,7 @@ struct SeqPoolArgs {
     int64_t B;
     fx_scalars* scal;
     int32_t D, n_seq, lanes_log2;
+    int64_t table_ld;     // row stride of `table` in floats
 };
 
 template <int VEC>
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256) void k_emb_seq_pool_fwd(SeqPoolArgs a) {
                 const int32_t id = row_ids[l];
                 if (id >= 0 && id < a.col_vocab[c0 + l]) {
                     if (lane_on)
-                        fx_load<VEC>(a.table + (a.col_row_base[c0 + l] + id) * a.D + d0, val);
+                        fx_load<VEC>(a.table + (a.col_row_base[c0 + l] + id) * a.table_ld + d0, val);
                 } else if (sub == 0) {
                     atomicOr(&a.scal->err_flag, FX_FLAG_BAD_ID);
                 }
@@ -281,8 +286,9 @@ extern "C" int fx_emb_seq_pool_fwd(const float* table, int32_t D, const int32_t*
                                    const int32_t* seq_len, const int32_t* seq_mode,
                                    const int64_t* seq_out_off, int32_t n_seq, float* out,
                                    int64_t out_ld, float* denom, int64_t B, fx_scalars* scal,
-                                   fx_stream_t stream) {
+                                   int64_t table_ld, fx_stream_t stream) {
     FX_CHECK_ARG(D >= 1 && D <= 256, "fx_emb_seq_pool_fwd: D=%d not in [1,256]", D);
+    if (table_ld <= 0) table_ld = D;
     FX_CHECK_ARG(n_seq >= 0 && B >= 0, "fx_emb_seq_pool_fwd: negative size");
     if (B == 0 || n_seq == 0) return FX_OK;
     const FxRowGeom g = fx_row_geom(D);
@@ -292,8 +298,10 @@ extern "C" int fx_emb_seq_pool_fwd(const float* table, int32_t D, const int32_t*
                      seq_out_off && out && denom && scal, "fx_emb_seq_pool_fwd: null pointer");
     FX_CHECK_ARG(out_ld % g.vec == 0, "fx_emb_seq_pool_fwd: out_ld=%lld not a multiple of %d",
                  (long long)out_ld, g.vec);
+    FX_CHECK_ARG(table_ld >= D && table_ld % g.vec == 0,
+                 "fx_emb_seq_pool_fwd: table_ld=%lld does not allow %d-wide row loads", (long long)table_ld, g.vec);
     SeqPoolArgs a{table, ids, ids_ld, col_row_base, col_vocab, seq_col0, seq_len, seq_mode,
-                  seq_out_off, out, out_ld, denom, B, scal, D, n_seq, fx_log2i(g.lanes)};
+                  seq_out_off, out, out_ld, denom, B, scal, D, n_seq, fx_log2i(g.lanes), table_ld};
     int64_t blocks = fx_ceil_div(B * (int64_t)n_seq, 4);
     if (blocks > 256 * 32) blocks = 256 * 32;
     dim3 grid((unsigned)blocks);
@@ -513,7 +521,8 @@ __global__ __launch_bounds__(256) void k_lr_fwd(const float* table1, const int32
                                                 const int32_t* col_vocab, int C,
                                                 const float* dense, int64_t dense_ld,
                                                 const float* num_w1, int Fd, const float* bias,
-                                                float* out, int64_t B, fx_scalars* scal) {
+                                                float* out, int64_t B, fx_scalars* scal,
+                                                int64_t table1_ld) {
     const int ls = threadIdx.x & 15;
     const int64_t n_iter = (B + 16 * (int64_t)gridDim.x - 1) / (16 * (int64_t)gridDim.x);
     for (int64_t it = 0; it < n_iter; ++it) {
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(256) void k_lr_fwd(const float* table1, const int32
         if (valid) {
             for (int c = ls; c < C; c += 16) {
                 const int32_t id = ids[b * ids_ld + c];
-                if (id >= 0 && id < col_vocab[c]) acc += table1[col_row_base[c] + id];
+                if (id >= 0 && id < col_vocab[c]) acc += table1[(col_row_base[c] + id) * table1_ld];
                 else atomicOr(&scal->err_flag, FX_FLAG_BAD_ID);
             }
             for (int j = ls; j < Fd; j += 16) acc = fmaf(dense[b * dense_ld + j], num_w1[j], acc);
@@ -537,8 +546,9 @@ extern "C" int fx_lr_fwd(const float* table1, const int32_t* ids, int64_t ids_ld
                          const int64_t* col_row_base, const int32_t* col_vocab, int32_t C,
                          const float* dense, int64_t dense_ld, const float* num_w1, int32_t Fd,
                          const float* bias, float* out, int64_t B, fx_scalars* scal,
-                         fx_stream_t stream) {
+                         int64_t table1_ld, fx_stream_t stream) {
     FX_CHECK_ARG(C >= 0 && Fd >= 0, "fx_lr_fwd: negative size");
+    if (table1_ld <= 0) table1_ld = 1;
     if (B <= 0) return FX_OK;
     FX_CHECK_ARG(out && scal, "fx_lr_fwd: null out/scal");
     FX_CHECK_ARG(C == 0 || (table1 && ids && col_row_base && col_vocab),
@@ -548,7 +558,7 @@ extern "C" int fx_lr_fwd(const float* table1, const int32_t* ids, int64_t ids_ld
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_lr_fwd, dim3((unsigned)blocks), dim3(256), 0, fx_hip_stream(stream),
                        table1, ids, ids_ld, col_row_base, col_vocab, (int)C, dense, dense_ld,
-                       num_w1, (int)Fd, bias, out, B, scal);
+                       num_w1, (int)Fd, bias, out, B, scal, table1_ld);
     FX_CHECK_LAUNCH();
     return FX_OK;
 }

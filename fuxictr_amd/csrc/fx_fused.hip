@@ -35,6 +35,8 @@ struct FxTableDev {
     int32_t* last_step;
     const float* G;        // update kernels only
     int32_t D, vec, lanes_log2, bf16;
+    int64_t tld, mld, vld, lld;   // row strides of table / m / v (elements) and of last_step (ints): D, D, D, 1 for
+                                  // packed arrays; all = W when the four point into one row record (round 6)
 };
 
 #define FX_MAX_TABLES 4
@@ -62,12 +64,11 @@ __device__ __forceinline__ void fx_row_load(const FxTableDev& t, int64_t row, in
     r.last = 0;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) r.p[k] = r.m[k] = r.v[k] = 0.f;
-    if (WANT_LAST && r.act) r.last = t.last_step[row];
+    if (WANT_LAST && r.act) r.last = t.last_step[row * t.lld];
     if (r.on) {
-        const int64_t o = row * t.D + d0;
-        fx_load<VEC>(t.m + o, r.m);
-        fx_load<VEC>(t.v + o, r.v);
-        fx_tab_load<VEC>(t.table, t.bf16, o, r.p);
+        fx_load<VEC>(t.m + row * t.mld + d0, r.m);
+        fx_load<VEC>(t.v + row * t.vld + d0, r.v);
+        fx_tab_load<VEC>(t.table, t.bf16, row * t.tld + d0, r.p);
     }
 }
 
@@ -85,13 +86,12 @@ __device__ __forceinline__ void fx_catchup_finish(const FxTableDev& t, int64_t r
         for (int k = 0; k < VEC; ++k) any = any || (r.m[k] != 0.f) || (r.v[k] != 0.f);
         if (any) {
             fx_adam_replay<VEC>(r.p, r.m, r.v, last, k_steps, sc, lg, ser);
-            const int64_t o = row * t.D + sub * VEC;
-            fx_tab_store<VEC>(t.table, t.bf16, o, r.p);
-            fx_store<VEC>(t.m + o, r.m);
-            fx_store<VEC>(t.v + o, r.v);
+            fx_tab_store<VEC>(t.table, t.bf16, row * t.tld + sub * VEC, r.p);
+            fx_store<VEC>(t.m + row * t.mld + sub * VEC, r.m);
+            fx_store<VEC>(t.v + row * t.vld + sub * VEC, r.v);
         }
     }
-    if (sub == 0) t.last_step[row] = upto;
+    if (sub == 0) t.last_step[row * t.lld] = upto;
 }
 
 template <int VEC>
@@ -152,8 +152,8 @@ __device__ __forceinline__ void fx_catchup_quad(const FxTableDev& t0, const FxTa
     fx_row_load<4, false>(t0, row, sub, r0);
     if constexpr (LR) fx_row_load<1, false>(t1, row, sub, r1);
     else { r1.p[0] = r1.m[0] = r1.v[0] = 0.f; r1.on = r1.act = false; r1.last = 0; }
-    const int last = t0.last_step[row];               // (same address in the four lanes: one access)
-    const int last1 = LR ? t1.last_step[row] : last;
+    const int last = t0.last_step[row * t0.lld];      // (same address in the four lanes: one access)
+    const int last1 = LR ? t1.last_step[row * t1.lld] : last;
     const int k0 = upto - last, k1 = upto - last1;
     if (last1 != last) {
         // the two tables were not touched together (cannot happen under one id plan): the plain replays
@@ -244,21 +244,20 @@ __device__ __forceinline__ void fx_catchup_quad(const FxTableDev& t0, const FxTa
         if (any) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { r0.p[e] = pe[e]; r0.m[e] = me[e]; r0.v[e] = ve[e]; }
-            const int64_t o = row * t0.D + sub * 4;
-            fx_tab_store<4>(t0.table, t0.bf16, o, r0.p);
-            fx_store<4>(t0.m + o, r0.m);
-            fx_store<4>(t0.v + o, r0.v);
+            fx_tab_store<4>(t0.table, t0.bf16, row * t0.tld + sub * 4, r0.p);
+            fx_store<4>(t0.m + row * t0.mld + sub * 4, r0.m);
+            fx_store<4>(t0.v + row * t0.vld + sub * 4, r0.v);
         }
     }
     if (r1.on && ((r1.m[0] != 0.f) || (r1.v[0] != 0.f))) {
         r1.p[0] = pe[4]; r1.m[0] = me[4]; r1.v[0] = ve[4];
-        fx_tab_store<1>(t1.table, t1.bf16, row, r1.p);
-        fx_store<1>(t1.m + row, r1.m);
-        fx_store<1>(t1.v + row, r1.v);
+        fx_tab_store<1>(t1.table, t1.bf16, row * t1.tld, r1.p);
+        fx_store<1>(t1.m + row * t1.mld, r1.m);
+        fx_store<1>(t1.v + row * t1.vld, r1.v);
     }
     if (sub == 0) {
-        t0.last_step[row] = upto;
-        if constexpr (LR) t1.last_step[row] = upto;
+        t0.last_step[row * t0.lld] = upto;
+        if constexpr (LR) t1.last_step[row * t1.lld] = upto;
     }
 }
 
@@ -526,6 +525,14 @@ static int fx_fill_tables(const fx_row_state* tables_host, int32_t n_tables, FxT
         out[t].last_step = h.last_step;
         out[t].G = h.G;
         out[t].D = h.D;
+        out[t].tld = h.table_ld > 0 ? h.table_ld : h.D;
+        out[t].mld = h.m_ld > 0 ? h.m_ld : h.D;
+        out[t].vld = h.v_ld > 0 ? h.v_ld : h.D;
+        out[t].lld = h.last_ld > 0 ? h.last_ld : 1;
+        if (out[t].tld < h.D || out[t].mld < h.D || out[t].vld < h.D) {
+            fx_set_error("%s: table %d has a row stride below D", who, t);
+            return FX_ERR_INVALID;
+        }
         out[t].bf16 = h.table_dtype == FX_BF16 ? 1 : 0;
         if (h.table_dtype != FX_F32 && h.table_dtype != FX_BF16) {
             fx_set_error("%s: table %d has table_dtype %d (FX_F32 or FX_BF16)", who, t, h.table_dtype);
@@ -1520,7 +1527,7 @@ __device__ __forceinline__ void fx_update_row(const FxTableDev& t, int64_t u, in
     const int d0 = sub * VEC;
     if (d0 < t.D) {
         float p[VEC], g[VEC];
-        const int64_t o = row * t.D + d0;
+        const int64_t o = row * t.tld + d0;
         fx_tab_load<VEC>(t.table, t.bf16, o, p);
         fx_load<VEC>(t.G + u * t.D + d0, g);
         if (sc.reg_l1 != 0.f || sc.reg_l2 != 0.f) {
@@ -1529,8 +1536,9 @@ __device__ __forceinline__ void fx_update_row(const FxTableDev& t, int64_t u, in
         }
         if constexpr (ADAM) {
             float m[VEC], v[VEC];
-            fx_load<VEC>(t.m + o, m);
-            fx_load<VEC>(t.v + o, v);
+            const int64_t om = row * t.mld + d0, ov = row * t.vld + d0;
+            fx_load<VEC>(t.m + om, m);
+            fx_load<VEC>(t.v + ov, v);
             const float w1 = fx_one_minus(sc.beta1), w2 = fx_one_minus(sc.beta2);   // torch's float(1 - beta)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
@@ -1540,8 +1548,8 @@ __device__ __forceinline__ void fx_update_row(const FxTableDev& t, int64_t u, in
                 const float denom = sqrtf(v[k]) / sc.bc2_sqrt + sc.eps;
                 p[k] = p[k] - sc.step_size * (m[k] / denom);         // param.addcdiv_
             }
-            fx_store<VEC>(t.m + o, m);
-            fx_store<VEC>(t.v + o, v);
+            fx_store<VEC>(t.m + om, m);
+            fx_store<VEC>(t.v + ov, v);
         } else {
             const float scale = sc.lr * sc.clip_coef;
 #pragma unroll
@@ -1549,7 +1557,7 @@ __device__ __forceinline__ void fx_update_row(const FxTableDev& t, int64_t u, in
         }
         fx_tab_store<VEC>(t.table, t.bf16, o, p);
     }
-    if (sub == 0 && t.last_step) t.last_step[row] = sc.step;
+    if (sub == 0 && t.last_step) t.last_step[row * t.lld] = sc.step;
 }
 
 // the Adam half of fx_update_row on registers that are already loaded
@@ -1572,12 +1580,11 @@ __device__ __forceinline__ void fx_adam_finish(const FxTableDev& t, int64_t row,
             const float denom = sqrtf(r.v[k]) / sc.bc2_sqrt + sc.eps;
             r.p[k] = r.p[k] - sc.step_size * (r.m[k] / denom);
         }
-        const int64_t o = row * t.D + sub * VEC;
-        fx_tab_store<VEC>(t.table, t.bf16, o, r.p);
-        fx_store<VEC>(t.m + o, r.m);
-        fx_store<VEC>(t.v + o, r.v);
+        fx_tab_store<VEC>(t.table, t.bf16, row * t.tld + sub * VEC, r.p);
+        fx_store<VEC>(t.m + row * t.mld + sub * VEC, r.m);
+        fx_store<VEC>(t.v + row * t.vld + sub * VEC, r.v);
     }
-    if (sub == 0 && t.last_step) t.last_step[row] = sc.step;
+    if (sub == 0 && t.last_step) t.last_step[row * t.lld] = sc.step;
 }
 
 template <bool ADAM>
@@ -1672,7 +1679,7 @@ __global__ __launch_bounds__(256) void k_catchup_all(FxTableDev t, int64_t total
     const FxSeries ser = fx_series_of(scal, sc);
     for (int64_t row = (int64_t)blockIdx.x * rpb + (threadIdx.x >> t.lanes_log2); row < total_rows;
          row += (int64_t)gridDim.x * rpb) {
-        if (t.last_step[row] >= upto) continue;
+        if (t.last_step[row * t.lld] >= upto) continue;
         fx_catchup_row<VEC>(t, row, sub, sc, upto, lg, ser);
     }
 }
@@ -1837,7 +1844,7 @@ __device__ __forceinline__ void fx_owner_one(const OwnerFetchArgs& a, int ti, in
         const int lanes = 1 << a.t[ti].lanes_log2;
         r.act = sub < lanes;
         r.on = r.act && sub * VEC < a.t[ti].D;
-        if (r.on) fx_tab_load<VEC>(a.t[ti].table, a.t[ti].bf16, row * a.t[ti].D + sub * VEC, r.p);
+        if (r.on) fx_tab_load<VEC>(a.t[ti].table, a.t[ti].bf16, row * a.t[ti].tld + sub * VEC, r.p);
     }
     fx_owner_put<VEC>(a, ti, r, sub, beg, end);
 }

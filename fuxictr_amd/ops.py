@@ -246,6 +246,14 @@ def _gather_bytes(table, D, ids, col_row_base, col_vocab, col_out_off, dense, nu
     return B * (C_ * (4 * D + 4) + Fd * 4 + (C_ + Fd) * 4 * D)
 
 
+def _row_ld(table):
+    """Row stride in elements of a [rows, D] table that may be a field of a row record (0: packed)."""
+    if table is None or table.dim() != 2:
+        return 0
+    assert table.stride(1) == 1, "table rows must be contiguous"
+    return int(table.stride(0))
+
+
 @_timed("k_emb_gather_fwd", "sparse_path", _gather_bytes)
 def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, num_w,
                    num_out_off, out, scal, n_cols=None):
@@ -258,7 +266,7 @@ def emb_gather_fwd(table, D, ids, col_row_base, col_vocab, col_out_off, dense, n
                                 ptr(col_row_base), ptr(col_vocab), ptr(col_out_off), C_,
                                 ptr(dense), 0 if dense is None else dense.stride(0), ptr(num_w),
                                 ptr(num_out_off), Fd, ptr(out), out.stride(0), B, ptr(scal),
-                                stream_ptr(out.device)), "fx_emb_gather_fwd")
+                                _row_ld(table), stream_ptr(out.device)), "fx_emb_gather_fwd")
     return out
 
 
@@ -274,7 +282,8 @@ def emb_seq_pool_fwd(table, D, ids, col_row_base, col_vocab, seq_col0, seq_len, 
     check(lib.fx_emb_seq_pool_fwd(ptr(table), D, ptr(ids), ids.stride(0), ptr(col_row_base),
                                   ptr(col_vocab), ptr(seq_col0), ptr(seq_len), ptr(seq_mode),
                                   ptr(seq_out_off), n_seq, ptr(out), out.stride(0), ptr(denom),
-                                  B, ptr(scal), stream_ptr(out.device)), "fx_emb_seq_pool_fwd")
+                                  B, ptr(scal), _row_ld(table), stream_ptr(out.device)),
+          "fx_emb_seq_pool_fwd")
     return out
 
 
@@ -577,8 +586,8 @@ def lr_fwd(table1, ids, col_row_base, col_vocab, dense, num_w1, bias, out, scal)
     check(_lib.load().fx_lr_fwd(ptr(table1), ptr(ids), 0 if ids is None else ids.stride(0),
                                 ptr(col_row_base), ptr(col_vocab), C_, ptr(dense),
                                 0 if dense is None else dense.stride(0), ptr(num_w1), Fd,
-                                ptr(bias), ptr(out), B, ptr(scal), stream_ptr(out.device)),
-          "fx_lr_fwd")
+                                ptr(bias), ptr(out), B, ptr(scal), _row_ld(table1),
+                                stream_ptr(out.device)), "fx_lr_fwd")
     return out
 
 
@@ -1043,6 +1052,11 @@ def _row_states(states):
         arr[i].G = s.G.data_ptr() if s.G is not None else None
         arr[i].D = int(s.D)
         arr[i].table_dtype = _lib.FX_BF16 if s.table.dtype == torch.bfloat16 else _lib.FX_F32
+        # row strides: 0 (packed) unless the arrays are fields of a row record
+        arr[i].table_ld = _row_ld(s.table)
+        arr[i].m_ld = _row_ld(s.m)
+        arr[i].v_ld = _row_ld(s.v)
+        arr[i].last_ld = 0 if s.last_step is None else int(s.last_step.stride(0))
     return arr
 
 

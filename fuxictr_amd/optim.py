@@ -13,10 +13,15 @@ Plain SGD is identical sparse or dense.
 The object is a torch.optim.Optimizer so `param_groups[*]["lr"]` (BaseModel.lr_decay,
 rank_model.py:221-234) and zero_grad() keep working.
 """
+import os
+
 import torch
 
 from . import _lib, ops
 from .layers import FeatureEmbeddingDict, finish_shard_backward
+
+# FX_ROW_RECORD=0 keeps table / m / v / last_step as four packed arrays (the layout of rounds 1 - 5) for A/B runs
+ROW_RECORD = os.environ.get("FX_ROW_RECORD", "1") != "0"
 
 
 class _NativeOptimizer(torch.optim.Optimizer):
@@ -91,11 +96,17 @@ class _NativeOptimizer(torch.optim.Optimizer):
         # dense_reg: every row is stepped every step, so there is nothing to catch up
         grp.exact = self.kind == "adam" and self.sparse_update == "exact" and not self.dense_reg
         grp.dense_reg = self.dense_reg
-        if self.kind == "adam" and grp.table is not None:
-            grp.m = torch.zeros_like(grp.table, dtype=torch.float32)     # fp32 state, also for
-            grp.v = torch.zeros_like(grp.table, dtype=torch.float32)     # bf16 tables
-        if (self.kind == "adam" or self.dense_reg) and grp.table is not None:
-            grp.last_step = torch.zeros(grp.table.shape[0], dtype=torch.int32, device=grp.device)
+        recorded = False
+        if grp.exact and grp.table is not None and ROW_RECORD:
+            # round 6: [p | m | v | last_step] in one record per row (fp32 tables; bf16 tables keep four arrays)
+            recorded = grp.adopt_record()
+        if not recorded:
+            grp.drop_record()
+            if self.kind == "adam" and grp.table is not None:
+                grp.m = torch.zeros_like(grp.table, dtype=torch.float32)     # fp32 state, also for
+                grp.v = torch.zeros_like(grp.table, dtype=torch.float32)     # bf16 tables
+            if (self.kind == "adam" or self.dense_reg) and grp.table is not None:
+                grp.last_step = torch.zeros(grp.table.shape[0], dtype=torch.int32, device=grp.device)
         if self.dense_reg and grp.table is not None:
             grp.reg_partials = torch.zeros(3 * _lib.FX_REG_BLOCKS, dtype=torch.float32,
                                            device=grp.device)
@@ -365,7 +376,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
             for rec in grp.pending:
                 buckets.setdefault(id(rec.dd), []).append((grp, rec))
         for items in buckets.values():
-            if len(items) == 1 and items[0][0].table.dtype == torch.float32:
+            if len(items) == 1 and items[0][0].table.dtype == torch.float32 and items[0][0].record is None:
                 self._sparse_update(*items[0])
                 continue
             # dtype-aware multi-table kernel, FX_MAX_TABLES groups per launch (a bf16 table must never

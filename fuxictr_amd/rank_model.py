@@ -860,7 +860,11 @@ class BaseModel(nn.Module):
         if hasattr(self.optimizer, "flush"):
             self.optimizer.flush()
         os.makedirs(os.path.dirname(checkpoint), exist_ok=True)
-        torch.save(self.state_dict(), self._shard_path(checkpoint))
+        # (a table inside a row record is a strided view: saved as such, torch would write the record's
+        # whole storage — moments included — so those entries are compacted first)
+        state = OrderedDict((k, v if v.is_contiguous() else v.contiguous())
+                            for k, v in self.state_dict().items())
+        torch.save(state, self._shard_path(checkpoint))
 
     def load_weights(self, checkpoint):
         self.to(self.device)

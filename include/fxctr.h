@@ -82,16 +82,18 @@ int fx_pack_columns(const void* const* cols_host, const int32_t* dtypes_host,
  * one packed table, Fd numeric columns are expanded by their nn.Linear(1,D,bias=False) weight
  * (feature_embedding.py:153-154, :280-282), everything is written straight into its final slot
  * of the per-sample output record (no stack/cat pass):
- *     out[b*out_ld + col_out_off[c] + d] = table[(col_row_base[c] + ids[b,c]) * D + d]
+ *     out[b*out_ld + col_out_off[c] + d] = table[(col_row_base[c] + ids[b,c]) * table_ld + d]
  *     out[b*out_ld + num_out_off[j] + d] = dense[b,j] * num_w[j*D + d]
  * ids outside [0, col_vocab[c]) set FX_FLAG_BAD_ID in scal->err_flag and read as a zero row.
+ * table_ld: row stride of `table` in floats (<= 0: D, a packed table; W for a table that is the
+ * first field of a [p | m | v | last_step] row record, see fx_row_state).
  * ------------------------------------------------------------------------------------------ */
 int fx_emb_gather_fwd(const float* table, int32_t D, const int32_t* ids, int64_t ids_ld,
                       const int64_t* col_row_base, const int32_t* col_vocab,
                       const int64_t* col_out_off, int32_t C, const float* dense,
                       int64_t dense_ld, const float* num_w, const int64_t* num_out_off,
                       int32_t Fd, float* out, int64_t out_ld, int64_t B, fx_scalars* scal,
-                      fx_stream_t stream);
+                      int64_t table_ld, fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pooled sequence features, forward.  Replaces the lookup of a sequence feature followed by its
@@ -113,7 +115,8 @@ int fx_emb_seq_pool_fwd(const float* table, int32_t D, const int32_t* ids, int64
                         const int64_t* col_row_base, const int32_t* col_vocab,
                         const int32_t* seq_col0, const int32_t* seq_len, const int32_t* seq_mode,
                         const int64_t* seq_out_off, int32_t n_seq, float* out, int64_t out_ld,
-                        float* denom, int64_t B, fx_scalars* scal, fx_stream_t stream);
+                        float* denom, int64_t B, fx_scalars* scal,
+                        int64_t table_ld /* row stride in floats; <= 0: D */, fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Index de-duplication for the sparse backward/update.  Builds, for the B*C lookups of a batch,
@@ -381,7 +384,8 @@ int fx_dot_interact_bwd(const float* emb, int64_t emb_ld, const float* g, int64_
 int fx_lr_fwd(const float* table1, const int32_t* ids, int64_t ids_ld,
               const int64_t* col_row_base, const int32_t* col_vocab, int32_t C,
               const float* dense, int64_t dense_ld, const float* num_w1, int32_t Fd,
-              const float* bias, float* out, int64_t B, fx_scalars* scal, fx_stream_t stream);
+              const float* bias, float* out, int64_t B, fx_scalars* scal,
+              int64_t table1_ld /* row stride of table1 in floats; <= 0: 1 */, fx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * fp32 MFMA GEMM with fused epilogue (MLP_Block / CrossNetV2 / fc layers and their backward:
@@ -734,6 +738,11 @@ typedef struct fx_row_state {
     const float* G;     /* [n_max, D] reduced gradient, update entry points only */
     int32_t D;
     int32_t table_dtype; /* FX_F32 | FX_BF16: storage of `table` only; m, v, G are fp32 */
+    /* row strides in elements of the respective array (0: packed = D, D, D, 1).  Round 6: the "row record" —
+     * one [p | m | v | last_step] record of W floats per row, `table`, `m`, `v`, `last_step` pointing at its
+     * four fields with all four strides = W — makes a row's catch-up / update ONE scattered access instead of
+     * four (scripts/ubench/row_record.hip: 13.0 -> 5.9 us for 25 K rows out of 33.76 M). */
+    int64_t table_ld, m_ld, v_ld, last_ld;
 } fx_row_state;
 
 int fx_dedup_catchup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,

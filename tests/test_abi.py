@@ -42,7 +42,7 @@ def test_argument_validation_without_gpu():
     """Entry points validate arguments before touching the device, so bad calls fail cleanly."""
     lib = _lib.load()
     st = lib.fx_emb_gather_fwd(None, 0, None, 0, None, None, None, 0, None, 0, None, None, 0,
-                               None, 0, 4, None, None)
+                               None, 0, 4, None, 0, None)
     assert st == 1 and b"D=0" in lib.fx_last_error()
     st = lib.fx_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 1, None, None)
     assert st == 1 and b"null matrix" in lib.fx_last_error()
