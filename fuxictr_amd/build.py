@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libfxctr.so")
-SOURCES = ["fx_api.cpp", "fx_embed.hip", "fx_sparse.hip", "fx_gemm.hip", "fx_gemm_x6.hip", "fx_din.hip", "fx_din_attn.hip", "fx_cin.hip", "fx_cin_mfma.hip", "fx_metrics.hip", "fx_fused.hip", "fx_sort.hip", "fx_series.hip"]
+SOURCES = ["fx_api.cpp", "fx_embed.hip", "fx_sparse.hip", "fx_gemm.hip", "fx_gemm_x6.hip", "fx_din.hip", "fx_din_attn.hip", "fx_cin.hip", "fx_cin_mfma.hip", "fx_metrics.hip", "fx_fused.hip", "fx_sort.hip", "fx_series.hip", "fx_dedup_lds.hip"]
 HEADERS = [os.path.join(CSRC, "fx_common.h"), os.path.join(CSRC, "fx_cin.h"), os.path.join(CSRC, "fx_gemm_int.h"),
            os.path.join(HERE, "..", "include", "fxctr.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

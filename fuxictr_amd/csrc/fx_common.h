@@ -52,6 +52,17 @@ int fx_dedup_columns_launch(const int32_t* ids, int64_t ids_ld, int64_t B, int32
                             uint32_t* seg_start, int32_t* n_unique, uint32_t* sorted_uid,
                             fx_scalars* begin_scal, hipStream_t s);
 
+// ---- fx_dedup_lds.hip: the bucketed in-LDS de-dup of the generic (n_shards = 1) path: rows hashed into 256
+// buckets by their low 8 bits (one stable partition pass), one workgroup sorts a bucket in LDS.  4 launches.
+// workspace: fx_dedup_buckets_bytes(n) bytes (<= fx_dedup_workspace_bytes(n)).
+size_t fx_dedup_buckets_bytes(int64_t n);
+bool fx_dedup_buckets_ok(int64_t n);      // FX_DEDUP_BUCKETS != 0 and n within the 256 x 8192 LDS capacity
+int fx_dedup_buckets_launch(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C,
+                            const int64_t* col_row_base, const int32_t* col_vocab, const int32_t* col_pad,
+                            uint32_t sentinel, void* workspace, uint32_t* sorted_key, uint32_t* sorted_pos,
+                            uint32_t* uniq_row, uint32_t* seg_start, int32_t* n_unique, uint32_t* sorted_uid,
+                            fx_scalars* begin_scal, hipStream_t s);
+
 // Row-vector geometry: a D-float row is handled by G lanes (power of two) holding VEC floats each.
 struct FxRowGeom {
     int vec;    // 4, 2 or 1

@@ -231,12 +231,20 @@ extern "C" int fx_dedup(const int32_t* ids, int64_t ids_ld, int64_t B, int32_t C
 
     int64_t blocks = fx_ceil_div(n, 256);
     if (blocks > 4096) blocks = 4096;
-    if (columns_sorted && n_shards == 1 && B <= 8192 && C <= 256) {
+    if (columns_sorted == 1 && n_shards == 1 && B <= 8192 && C <= 256) {
         // (measured in round 1: rocprim's segmented_radix_sort takes 81 us for 26 x 4096, its device
         // merge sort 57 us; one in-LDS workgroup sort per column over only the needed bits is the path)
         return fx_dedup_columns_launch(ids, ids_ld, B, C, col_row_base, col_vocab, col_pad, keys_in, scan,
                                        sorted_key, sorted_pos, uniq_row, seg_start, n_unique,
                                        sorted_uid, begin_scal, s);
+    } else if (columns_sorted == 2 && n_shards == 1 && fx_dedup_buckets_ok(n) &&
+               fx_dedup_buckets_bytes(n) <= workspace_bytes) {
+        // round 6: sequence columns that alias a table, shared tables, B > 8192 — rows hashed into 256 buckets by
+        // their low 8 bits, each bucket sorted by one workgroup in LDS (fx_dedup_lds.hip): 4 launches instead of
+        // 10; unique rows come out grouped by (row & 255, row >> 8) instead of ascending
+        return fx_dedup_buckets_launch(ids, ids_ld, B, C, col_row_base, col_vocab, col_pad, sentinel, workspace,
+                                       sorted_key, sorted_pos, uniq_row, seg_start, n_unique, sorted_uid,
+                                       begin_scal, s);
     } else {
         hipLaunchKernelGGL(k_build_keys, dim3((unsigned)blocks), dim3(256), 0, s, ids, ids_ld, n,
                            (int)C, col_row_base, col_vocab, col_pad, sentinel, (uint32_t)n_shards,

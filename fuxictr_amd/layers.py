@@ -467,9 +467,10 @@ class _TableGroup(object):
                                             device=self.device))
         # (the optimizer step's device-side opening rides in the de-dup's first launch)
         begin = self.opt.take_begin() if self.opt is not None else None
+        # (unsharded: nothing downstream needs ascending rows — sequence schemas take the bucketed in-LDS path)
         dd = ops.dedup(ids, plan.col_row_base, plan.col_vocab, plan.col_pad, self.total_rows,
                        self.dedup_ws[1], columns_sorted=plan.columns_sorted, want_uid=True,
-                       begin_scal=begin)
+                       begin_scal=begin, grouped=not self.sharded)
         if cache is not None:
             cache[ckey] = dd
         return dd

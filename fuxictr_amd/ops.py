@@ -313,16 +313,23 @@ class DedupResult(object):
 
 @_timed("dedup", "sparse_path")
 def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None,
-          n_shards=1, want_uid=False, columns_sorted=False, begin_scal=None):
+          n_shards=1, want_uid=False, columns_sorted=False, begin_scal=None, grouped=False):
+    """grouped: ascending unique rows are not needed (fx_dedup's columns_sorted = 2: the bucketed in-LDS path)."""
     lib = _lib.load()
     B, C_ = ids.shape
     if result is None:
         result = DedupResult(B * C_, C_, ids.device, want_uid=want_uid)
+    mode = 0
+    if n_shards == 1:
+        if columns_sorted and B <= 8192 and C_ <= 256:
+            mode = 1
+        elif grouped:
+            mode = 2
     check(lib.fx_dedup(ptr(ids), ids.stride(0), B, C_, ptr(col_row_base), ptr(col_vocab),
                        ptr(col_pad), total_rows, ptr(workspace), workspace.numel(),
                        ptr(result.sorted_key), ptr(result.sorted_pos), ptr(result.uniq_row),
                        ptr(result.seg_start), ptr(result.n_unique), ptr(result.sorted_uid),
-                       n_shards, 1 if (columns_sorted and n_shards == 1) else 0, ptr(begin_scal),
+                       n_shards, mode, ptr(begin_scal),
                        stream_ptr(ids.device)),
           "fx_dedup")
     return result

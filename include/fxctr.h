@@ -134,6 +134,14 @@ int fx_emb_seq_pool_fwd(const float* table, int32_t D, const int32_t* ids, int64
  * scan / scatter of the unique rows — all own kernels, no library).  In that mode padding_idx / bad-id lookups stay inside their column's key range with
  * sorted_pos = 0xFFFFFFFF ("contributes nothing"): the padding row may appear as a unique row
  * whose reduced gradient is exactly zero.
+ * columns_sorted == 2 (hint; needs n_shards = 1, B*C <= 2^21): the caller does not need ASCENDING unique rows,
+ * only every row's lookups side by side in position order and a deterministic order of the rows — sequence
+ * columns that alias their target's table (DIN), shared tables, B > 8192.  The rows are hashed into 256
+ * buckets by their low 8 bits (one stable partition pass) and every bucket is sorted by one workgroup in LDS
+ * (csrc/fx_dedup_lds.hip; a bucket of more than 8192 lookups is sorted through global memory by the same
+ * code): 4 launches instead of the generic path's 10.  sorted_key / uniq_row come out ordered by
+ * (row & 255, row >> 8); padding / bad-id lookups form the tail (key = total_rows, sorted_pos = sorted_uid =
+ * 0xFFFFFFFF).  Everything else as in the generic path.
  * This replaces the zero-filled dense [V,D] gradient + index_add of aten::embedding_dense_backward
  * (triggered at rank_model.py:320) — no dense gradient ever exists.  Deterministic.
  * Packed tables are limited to < 2^32 - 1 rows.
