@@ -813,10 +813,10 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a) {
 // result is bit for bit k_splitk_reduce's.  4096 x 1024 x 1024's weight gradient (8 slabs of 4 MB): 7.4 us
 // -> round 4's A/B in profiles/.
 template <int SK>
-__global__ __launch_bounds__(256) void k_splitk_reduce_v4(GemmArgs a) {
+__device__ __forceinline__ void fx_splitk_reduce_v4_body(const GemmArgs& a, int64_t bx, int64_t gx) {
     const int64_t total = a.M * a.N, nv = total >> 2, n4 = a.N >> 2;
     const int sk = SK > 0 ? SK : a.split_k;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = bx * 256 + threadIdx.x; i < nv; i += gx * 256) {
         const float4* w = reinterpret_cast<const float4*>(a.ws) + i;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (SK > 0) {
@@ -846,8 +846,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_v4(GemmArgs a) {
     }
     if (a.epi.rowsum) {
         const float* rs = a.ws + (int64_t)sk * total;
-        for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < a.M;
-             m += (int64_t)gridDim.x * 256) {
+        for (int64_t m = bx * 256 + threadIdx.x; m < a.M;
+             m += gx * 256) {
             float r = 0.f;
             int z = 0;
             for (; z + 8 <= sk; z += 8) {
@@ -861,6 +861,44 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_v4(GemmArgs a) {
             a.epi.rowsum[m] = r;
         }
     }
+}
+
+template <int SK>
+__global__ __launch_bounds__(256) void k_splitk_reduce_v4(GemmArgs a) {
+    fx_splitk_reduce_v4_body<SK>(a, (int64_t)blockIdx.x, (int64_t)gridDim.x);
+}
+
+// (round 6) the slab reduces of every weight gradient of ONE multi-problem GEMM launch in one launch (DCNv2's
+// cross + deep pairs: 7 reduce launches per step -> 4): workgroups [start[i], start[i + 1]) take problem i and
+// run the single-problem body on it — same sums, same order, same bits.
+struct ReduceMultiArgs {
+    GemmArgs p[FX_MULTI_MAX];
+    int32_t start[FX_MULTI_MAX + 1];
+    int32_t n;
+};
+__global__ __launch_bounds__(256) void k_splitk_reduce_v4_multi(ReduceMultiArgs ma) {
+    int i = 0;
+#pragma unroll
+    for (int q = 1; q < FX_MULTI_MAX; ++q)
+        if (q < ma.n && (int)blockIdx.x >= ma.start[q]) i = q;
+    const int64_t bx = (int64_t)blockIdx.x - ma.start[i], gx = (int64_t)ma.start[i + 1] - ma.start[i];
+    // (indexing p[] by a runtime value would copy the 200-byte argument block to scratch: select by branches)
+#define FX_RM_CASE(Q)                                                                        \
+    if (i == Q) {                                                                            \
+        const GemmArgs& a = ma.p[Q];                                                         \
+        switch (a.split_k) {                                                                 \
+            case 2: fx_splitk_reduce_v4_body<2>(a, bx, gx); break;                           \
+            case 4: fx_splitk_reduce_v4_body<4>(a, bx, gx); break;                           \
+            case 8: fx_splitk_reduce_v4_body<8>(a, bx, gx); break;                           \
+            default: fx_splitk_reduce_v4_body<0>(a, bx, gx); break;                          \
+        }                                                                                    \
+        return;                                                                              \
+    }
+    FX_RM_CASE(0)
+    FX_RM_CASE(1)
+    FX_RM_CASE(2)
+    FX_RM_CASE(3)
+#undef FX_RM_CASE
 }
 
 // many slabs over a small output (skinny weight gradients with K = B*L): EL elements x 256/EL slab
@@ -959,6 +997,41 @@ static void fx_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, s, a);
     }
+}
+
+static bool fx_splitk_reduce_is_v4(const GemmArgs& a) {
+    const int64_t total = a.M * a.N;
+    return !(a.split_k >= 32 && total <= 65536 && a.M <= 256) && fx_splitk_v4_mode() && fx_gemm_tr_ok(a) &&
+           (total & 3) == 0;
+}
+
+// every split-K problem of a multi-problem launch: one reduce launch when two or more of them take the vector
+// kernel (FX_REDUCE_MULTI=0: one launch each, as in rounds 3 - 5)
+static void fx_launch_splitk_reduces(const GemmArgs* p, int n, hipStream_t s) {
+    static const bool multi = []() {
+        const char* e = getenv("FX_REDUCE_MULTI");
+        return !(e && atoi(e) == 0);
+    }();
+    ReduceMultiArgs ma;
+    memset(&ma, 0, sizeof(ma));
+    int cnt = 0;
+    int64_t wgs = 0;
+    for (int i = 0; i < n && multi; ++i)
+        if (p[i].split_k > 1 && fx_splitk_reduce_is_v4(p[i])) {
+            int64_t blocks = fx_ceil_div((p[i].M * p[i].N) >> 2, 256);
+            if (blocks > 4096) blocks = 4096;
+            ma.p[cnt] = p[i];
+            ma.start[cnt] = (int32_t)wgs;
+            wgs += blocks;
+            ++cnt;
+        }
+    if (cnt >= 2) {
+        for (int q = cnt; q <= FX_MULTI_MAX; ++q) ma.start[q] = (int32_t)wgs;
+        ma.n = cnt;
+        hipLaunchKernelGGL(k_splitk_reduce_v4_multi, dim3((unsigned)wgs), dim3(256), 0, s, ma);
+    }
+    for (int i = 0; i < n; ++i)
+        if (p[i].split_k > 1 && !(cnt >= 2 && fx_splitk_reduce_is_v4(p[i]))) fx_launch_splitk_reduce(p[i], s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1865,11 +1938,8 @@ static int fx_gemm_try_multi_x6(const fx_gemm_problem* p, int32_t n, fx_stream_t
     hipStream_t s = fx_hip_stream(stream);
     const int rc = fx_gemm_x6_launch_multi(ma, wgs, s);
     if (rc != FX_OK) return rc;
-    for (int oi = 0; oi < n; ++oi)
-        if (ma.p[oi].split_k > 1) {
-            fx_launch_splitk_reduce(ma.p[oi], s);
-            FX_CHECK_LAUNCH();
-        }
+    fx_launch_splitk_reduces(ma.p, n, s);
+    FX_CHECK_LAUNCH();
     *launched = true;
     return FX_OK;
 }
@@ -1931,11 +2001,8 @@ static int fx_gemm_try_multi(const fx_gemm_problem* p, int32_t n, fx_stream_t st
     hipStream_t s = fx_hip_stream(stream);
     hipLaunchKernelGGL(k_gemm_f32_multi, dim3((unsigned)wgs), dim3(256), 0, s, ma);
     FX_CHECK_LAUNCH();
-    for (int oi = 0; oi < n; ++oi)
-        if (ma.p[oi].split_k > 1) {
-            fx_launch_splitk_reduce(ma.p[oi], s);
-            FX_CHECK_LAUNCH();
-        }
+    fx_launch_splitk_reduces(ma.p, n, s);
+    FX_CHECK_LAUNCH();
     *launched = true;
     return FX_OK;
 }
