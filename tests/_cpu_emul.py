@@ -1,7 +1,10 @@
 """TEST INFRASTRUCTURE: torch-CPU emulation of the libfxctr entry points, with the same
 signatures as fuxictr_amd.ops.  tests/test_host_wiring.py monkeypatches it in so the HOST logic
 (layer bookkeeping, autograd wiring, optimizer sequencing, BaseModel loop) can be exercised in the
-GPU-less build container.  It is never importable from the product package."""
+GPU-less build container.  It is never importable from the product package.
+It is a SECOND implementation of every kernel's contract: the CPU tests that run on it validate the host
+wiring, not the HIP code — the kernels themselves are held to the oracle / numpy / fp64 restatements by the
+`-m gpu` tests, which call through the C-ABI."""
 import math
 
 import numpy as np
