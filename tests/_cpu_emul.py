@@ -76,7 +76,8 @@ class DedupResult(object):
 
 
 def dedup(ids, col_row_base, col_vocab, col_pad, total_rows, workspace, result=None,
-          n_shards=1, want_uid=False, columns_sorted=False, begin_scal=None):
+          n_shards=1, want_uid=False, columns_sorted=False, begin_scal=None, grouped=False):
+    # (grouped: the caller accepts any deterministic grouping of the rows; ascending is one)
     if begin_scal is not None:
         opt_begin_step(begin_scal)
     B, C = ids.shape
