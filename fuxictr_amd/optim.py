@@ -22,16 +22,6 @@ from .layers import FeatureEmbeddingDict, finish_shard_backward
 
 # FX_ROW_RECORD=0 keeps table / m / v / last_step as four packed arrays (the layout of rounds 1 - 5) for A/B runs
 ROW_RECORD = os.environ.get("FX_ROW_RECORD", "1") != "0"
-# FX_FORK_UPDATE=0: the tables' row updates after the dense update on the one stream (rounds 1 - 5)
-FORK_UPDATE = os.environ.get("FX_FORK_UPDATE", "1") != "0"
-
-
-class _NullCtx(object):
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *a):
-        return False
 
 
 class _NativeOptimizer(torch.optim.Optimizer):
@@ -377,38 +367,14 @@ class _NativeOptimizer(torch.optim.Optimizer):
             # all-reduced table part
             parts.append(tsq)
         ops.clip_coef(parts, self.scal)
+        if ps:
+            self._dense_update(ps, gs)
         # table groups that were reduced against the SAME de-dup result (the D=16 tables and the D=1
         # tables of LogisticRegression) are updated by one launch
         buckets = {}
         for grp in self._groups:
             for rec in grp.pending:
                 buckets.setdefault(id(rec.dd), []).append((grp, rec))
-        # (round 6) the dense update (HBM-bound: 28 B per tower parameter) and the row updates of the tables
-        # (latency-bound: ~1.5 workgroups per CU) depend on nothing but the clip coefficient and touch disjoint
-        # memory: the row updates run on a side stream beside the dense update — two parallel branches of the
-        # captured step — and join before anything else is launched (FX_FORK_UPDATE=0: one after the other)
-        fork = (FORK_UPDATE and bool(ps) and bool(buckets) and self.dist is None and not self.dense_reg
-                and self.device.type == "cuda")
-        if fork:
-            main = torch.cuda.current_stream(self.device)
-            if getattr(self, "_update_stream", None) is None:
-                self._update_stream = torch.cuda.Stream(self.device)
-            self._update_stream.wait_stream(main)
-        if ps:
-            self._dense_update(ps, gs)
-        with (torch.cuda.stream(self._update_stream) if fork else _NullCtx()):
-            self._sparse_updates(buckets)
-        if fork:
-            main.wait_stream(self._update_stream)
-        for grp in self._groups:
-            if self.dense_reg and grp.table is not None:
-                ops.reg_dense_update(grp.table, grp.m, grp.v, grp.last_step, grp.D,
-                                     self.kind == "adam", self.scal)
-            grp.pending = []
-            grp.num_grad = None
-        return None
-
-    def _sparse_updates(self, buckets):
         for items in buckets.values():
             if len(items) == 1 and items[0][0].table.dtype == torch.float32 and items[0][0].record is None:
                 self._sparse_update(*items[0])
@@ -419,6 +385,13 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 part = items[i:i + _lib.FX_MAX_TABLES]
                 ops.sparse_update_multi(self.kind, [g.row_state(G=r.G) for g, r in part],
                                         part[0][1].dd, self.scal)
+        for grp in self._groups:
+            if self.dense_reg and grp.table is not None:
+                ops.reg_dense_update(grp.table, grp.m, grp.v, grp.last_step, grp.D,
+                                     self.kind == "adam", self.scal)
+            grp.pending = []
+            grp.num_grad = None
+        return None
 
     # -- checkpoint / resume (the reference saves weights only) ------------------
     def state_dict(self):

@@ -50,13 +50,13 @@ def test_400_steps_against_the_oracle(case):
 def test_c4_din_400_steps_against_the_oracle():
     """c4 (DIN, 50-position click sequence aliasing adgroup_id, Dice attention) over the same horizon: the id
     plan that takes the bucketed in-LDS de-dup (round 6) and, with it, the row record and the series catch-up —
-    400 steps at B = 1024 (the oracle's attention on the CPU is what bounds the batch), rows up to 399 steps
-    behind, same bounds as above."""
+    400 steps at B = 1024 (the oracle's attention on the CPU is what bounds the batch), rows more than 200 steps
+    behind (the x 0.01 tables are small: every row returns within ~ 240 steps), same bounds as above."""
     import bench
-    r = bench.parity_long_horizon("c4_din", 0, steps=400, B=1024, holdout=32768, checkpoints=(100, 200, 400))
+    r = bench.parity_long_horizon("c4_din", 0, steps=400, B=1024, checkpoints=(100, 200, 400))
     print("[long horizon] c4_din: %s" % json.dumps(r))
-    assert r["steps"] == 400 and r["holdout_rows"] >= 32768
-    assert max(g["behind_max"] for g in r["row_age"]) >= 300, r["row_age"]
+    assert r["steps"] == 400 and r["holdout_rows"] >= 131072
+    assert max(g["behind_max"] for g in r["row_age"]) >= 200, r["row_age"]
     for t in ("100", "200", "400"):
         s = r["checkpoints"][t]["same_weights"]
         assert s["max_dlogit"] <= 1e-4 and s["dauc"] < 5e-5 and s["dlogloss"] < 5e-5, (t, s)
