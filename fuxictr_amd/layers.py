@@ -1402,6 +1402,8 @@ class FeatureEmbeddingDict(nn.Module):
 
     # -- optimizer hooks --------------------------------------------------------------------
     def table_groups(self):
+        for grp in self._groups.values():
+            grp.owner = weakref.ref(self)     # (a deep copy of the module carries the original's weak reference)
         return list(self._groups.values())
 
     def table_parameters(self):
