@@ -42,6 +42,8 @@ VARIANTS = {
     "x6_off": {"FX_GEMM_BF16X6": "0"},         # round 5: every GEMM on the fp32-MFMA kernels
     "quad_off": {"FX_CATCHUP_QUAD": "0"},      # round 5: the plain catch-up replays
     "series_off": {"FX_CATCHUP_SERIES": "0"},  # round 6: no Adam series table (step-by-step replay of every gap)
+    "buckets_off": {"FX_DEDUP_BUCKETS": "0"},  # round 6: sequence schemas on the device-wide radix sort (ascending rows)
+    "record_off": {"FX_ROW_RECORD": "0"},      # round 6: table / m / v / last_step as four packed arrays
 }
 
 
