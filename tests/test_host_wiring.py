@@ -661,3 +661,64 @@ def test_relu_note_is_ignored_when_the_buffer_has_a_second_consumer(monkeypatch)
     assert n_ref1 == 1 and n_got1 == 0                 # sole consumer: the head's gradient is read in place
     for a_, b_ in zip(got1, ref1):
         assert torch.allclose(a_, b_, atol=1e-6, rtol=1e-6)
+
+
+def test_row_record_host_logic(tmp_path, monkeypatch):
+    """Round 6's row record on the emulated kernels: with an exact-mode Adam attached, table / m / v / last_step
+    of every fp32 table group are column ranges of ONE [rows, W] record, the per-feature Parameters are views of
+    it, state_dict keys / values are the reference's, save_weights writes compact tables, a dtype change of the
+    module goes back to four packed arrays — and the training trajectory still is the golden one (the layout
+    moves no bit)."""
+    import os
+    from fuxictr_amd import optim
+    from fuxictr_amd.layers import _TableGroup
+    g = Golden("deepfm_adam")
+    assert [_TableGroup.record_width(d) for d in (1, 4, 8, 10, 16, 32, 64)] == [4, 16, 28, 32, 64, 128, 224]
+    model = _build(g, tmp_path, monkeypatch)
+    groups = [grp for grp in model.optimizer._groups if grp.table is not None]
+    assert groups and all(grp.record is not None for grp in groups)
+    for grp in groups:
+        W = _TableGroup.record_width(grp.D)
+        assert grp.record.shape == (grp.table.shape[0], W)
+        assert grp.table.data_ptr() == grp.record.data_ptr() and grp.table.stride(0) == W
+        assert grp.m.stride(0) == W and grp.v.stride(0) == W
+        assert grp.last_step.dtype == torch.int32 and grp.last_step.stride(0) == W
+        assert float(grp.m.abs().sum()) == 0.0 and int(grp.last_step.abs().sum()) == 0
+    # the Parameters alias the record: writing one shows in the group's table
+    sd = model.state_dict()
+    key = [k for k in sd if ".embedding_layers." in k and sd[k].dim() == 2 and sd[k].shape[1] > 1][0]
+    before = sd[key][1].clone()
+    sd[key][1] += 1.0
+    grp16 = [grp for grp in groups if grp.D > 1][0]
+    assert any(torch.equal(grp16.table[r], before + 1.0) for r in range(grp16.table.shape[0]))
+    sd[key][1] -= 1.0
+    # the golden trajectory on the record layout, then the same without it
+    model.train()
+    losses = [float(model.train_step(tb(g.batches[i])).item()) for i in range(g.meta["steps"])]
+    np.testing.assert_allclose(losses, g.expect["loss"], atol=2e-5)
+    monkeypatch.setattr(optim, "ROW_RECORD", False)
+    packed = _build(g, tmp_path / "packed", monkeypatch)
+    assert all(grp.record is None for grp in packed.optimizer._groups)
+    packed.train()
+    losses_p = [float(packed.train_step(tb(g.batches[i])).item()) for i in range(g.meta["steps"])]
+    # (ATen's CPU kernels — the emulation — are not layout-invariant to the last bit: strided and packed
+    # operands take different vector paths; the HIP kernels are, tests/test_gpu_row_record.py holds them to
+    # torch.equal)
+    np.testing.assert_allclose(losses, losses_p, rtol=0, atol=1e-6)
+    for mdl in (model, packed):               # both layouts end at the reference's weights
+        mdl.optimizer.flush()                 # (exact mode: rows a late batch did not touch are caught up now)
+        sd1 = mdl.state_dict()
+        for k, ref in g.state1.items():
+            assert_weights_close(sd1[k].numpy(), ref, g.meta["lr"], g.meta["steps"], k)
+    # compact checkpoints
+    pa, pb = str(tmp_path / "a" / "m.model"), str(tmp_path / "b" / "m.model")
+    model.save_weights(pa)
+    packed.save_weights(pb)
+    assert abs(os.path.getsize(pa) - os.path.getsize(pb)) < 65536
+    # a dtype change leaves the record layout (it is fp32 by construction) and keeps the values
+    ref = {k: v.clone() for k, v in model.state_dict().items()}
+    model.double()
+    assert all(grp.record is None for grp in groups)
+    for k, v in model.state_dict().items():
+        assert v.dtype == torch.float64 or not v.is_floating_point()
+        assert torch.equal(v.float(), ref[k].float()), k
