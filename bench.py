@@ -764,6 +764,12 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         sync()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
+    # (the HIP events behind torch's Event objects are created at their FIRST record: 0.03 - 0.3 ms of host time
+    # that used to fall inside the clock — profiles/r06_soak_and_step_count.txt.  One record before the
+    # bracket's synchronise creates them; the GPU is idle again when the clock starts.)
+    ev0.record()
+    ev1.record()
+    sync()
     t0 = time.perf_counter()
     ev0.record()                 # on the launch stream (torch's current stream): first launch ...
     for _ in range(args.steps):
