@@ -732,13 +732,18 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
             sync()
             y0 = torch.cuda.Event(enable_timing=True)
             y1 = torch.cuda.Event(enable_timing=True)
+            y0.record()                      # (created here; recorded again below)
+            y1.record()
+            model.train_step(next_batch(step_i))     # the same bracket as the headline's: see below
+            step_i += 1
+            sync()
             y0.record()
             for _ in range(args.steps):
                 model.train_step(next_batch(step_i))
                 step_i += 1
             y1.record()
             sync()
-            young = {"ms_per_step": y0.elapsed_time(y1) / args.steps, "steps_before": 20,
+            young = {"ms_per_step": y0.elapsed_time(y1) / args.steps, "steps_before": 21,
                      "steps": args.steps}
         while step_i < warm_run:
             model.train_step(next_batch(step_i))
@@ -764,11 +769,17 @@ def measure(args, rank, local_rank, world, world1, dev, dist):
         sync()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
-    # (the HIP events behind torch's Event objects are created at their FIRST record: 0.03 - 0.3 ms of host time
-    # that used to fall inside the clock — profiles/r06_soak_and_step_count.txt.  One record before the
-    # bracket's synchronise creates them; the GPU is idle again when the clock starts.)
+    # (the HIP events behind torch's Event objects are created at their first record: done before the clock)
     ev0.record()
     ev1.record()
+    # One more UNTIMED step between two synchronises: the first launch after a LONG blocking synchronise (the one
+    # that drained the warm phase) costs the launching thread 0.1 - 1.2 ms (measured: 1.16 ms for the first
+    # train_step of the DIN leg, 39 us with this step in front; profiles/r06_soak_and_step_count.txt) — host wake-up,
+    # not GPU work, and it used to sit inside a 9 - 14 ms clock.  The clock still starts right after a barrier +
+    # torch.cuda.synchronize(); the step is counted in `steps_before_clock`.
+    model.train_step(next_batch(step_i))
+    step_i += 1
+    warm_run += 1
     sync()
     t0 = time.perf_counter()
     ev0.record()                 # on the launch stream (torch's current stream): first launch ...
